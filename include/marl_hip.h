@@ -1,0 +1,178 @@
+/* marl_hip.h - C ABI of the MI355X (gfx950) hot path for Skylarking/MARL.
+ *
+ * The reference has no FFI layer (it is pure Python/PyTorch); the functions below are what a
+ * binding for its hot path would call, one per fused torch-op sequence.
+ * Each entry cites the reference code it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless typed otherwise; row-major; sizes in elements
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises, allocates or frees
+ *   - return value: 0 on success, otherwise a hipError_t
+ *   - workspaces are caller-provided; *_workspace() gives the byte count
+ *   - (B,T,N,*) arrays are episode-major: row = (b*T + t)*N + n
+ */
+#ifndef MARL_HIP_H
+#define MARL_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Virtual row-major matrix [M,K] = [dense0 | dense1 | nhot one-hot blocks | agent-id block].
+ * Replaces the th.cat([...]) input builders: controller/share_params.py:84-112,
+ * network/mixer.py:151-153 (QPLEX [s|actions]), :380,:386 (QTRAN [h|u], [s|enc]), :416.
+ * Row remap (rpe != 0): source row = (row / rpe) * bs + (row % rpe) + off, and a row whose
+ * (row % rpe) + off < 0 reads as zero / "no action" (used for (T+1)-slot episode storage and
+ * for the one-step-shifted last action). */
+typedef struct {
+  const float* p0; long ld0; int k0;        /* dense segment 0, k0 columns */
+  const float* p1; long ld1; int k1;        /* dense segment 1 */
+  const int* idx; int nhot; int hot_w;      /* column j*hot_w + idx[row*nhot + j] = 1 (idx < 0: none) */
+  int nid;                                  /* column (row % nid) = 1 */
+  const float* m0; long ldm0;               /* optional relu gate on segment 0: v * (m0 > 0) */
+  long rpe0, bs0, off0;                     /* row remap for p0 (and m0) */
+  long rpei, bsi, offi;                     /* row remap for idx */
+} marl_src_t;
+
+/* Batched ("grouped") launches over equally shaped problems whose operands sit at a constant
+ * element stride (QPLEX's 10 attention heads, network/mixer.py:117-145). 0 = shared operand. */
+typedef struct {
+  int groups;
+  long gs_x0, gs_x1, gs_w, gs_b, gs_y, gs_m0;
+} marl_group_t;
+
+/* RNNQNet parameters (network/q_network.py:12-14), torch layouts. */
+typedef struct {
+  const float *fc1_w, *fc1_b;   /* (H,I), (H)   */
+  const float *w_ih, *w_hh;     /* (3H,H) gate order r,z,n */
+  const float *b_ih, *b_hh;     /* (3H) */
+  const float *fc2_w, *fc2_b;   /* (A,H), (A) */
+  int H;                        /* must be 64 */
+} marl_agent_weights_t;
+
+/* ---- dense layers on the fp32 matrix cores (gemm.hip) ---------------------------------------
+ * Y = act(X W^T + b) [+ beta*Y].  Replaces every nn.Linear(+ReLU) on the path
+ * (network/mixer.py:37-55,117-145,200-206,365-375,399-409).  w_kmajor=1 reads W as [K][N]
+ * so the same kernel computes dX = dY W (autograd of nn.Linear wrt input). act: 0 none, 1 relu. */
+int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_kmajor, const float* bias,
+                float* Y, long ldy, int M, int N, int K, int act, float beta,
+                const marl_group_t* grp, void* stream);
+/* dW += G^T X, db += colsum(G) with G = dY * (Yact > 0 if Yact). Fixed-order slab reduction.
+ * In grp: gs_y = dY stride, gs_m0 = Yact stride, gs_w / gs_b = dW / db strides. */
+int marl_linear_wgrad(const float* dY, long lddy, const float* Yact, long ldya, const marl_src_t* x,
+                      float* dW, long lddw, float* db, int M, int N, int K,
+                      const marl_group_t* grp, float* ws, size_t ws_bytes, void* stream);
+size_t marl_linear_wgrad_workspace(int M, int N, int K, int groups);
+int marl_wgrad_slabs(int M);
+
+/* ---- agent (agent.hip) ----------------------------------------------------------------------
+ * T-step unroll of RNNQNet over B*N rows in ONE launch.  Replaces SharedMAC.get_current_q_values /
+ * get_next_q_values (controller/share_params.py:125-168) incl. _build_inputs (:84-112), and with
+ * T=1 the network call of SharedMAC.choose_action (:37-63).
+ *   obs   : row (b,t,n) at obs + ((b*obs_bs) + (t+obs_t0)*N + n)*O        (obs_bs = rows/episode)
+ *   ufed  : int32 action fed back at step t: ufed[b*u_bs + (t+u_t0)*N + n]; none if t+u_t0 < 0,
+ *           value < 0 or ufed == NULL (one-hot of zeros, share_params.py:96-100)
+ *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
+ *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = 6 planes (B,T,N,64)
+ *   [hprev,x,r,z,n,hn] for the backward pass or NULL */
+int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
+                          const int* ufed, long u_bs, int u_t0, const float* h0, float* q, float* hs,
+                          float* h_last, float* saved, int B, int T, int N, int O, int A,
+                          int last_action, int reuse_network, void* stream);
+/* BPTT delta pass (autograd of the unroll above; q_learner.py:171 loss.backward()).
+ *   dq (B,T,N,A) gradient on q; dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
+ *   dgate (B,T,N,256) = d r_pre | d z_pre | d n_pre | d(W_hn h + b_hn);  dxp (B,T,N,64) = d fc1 pre-act
+ * Weight gradients follow as marl_linear_wgrad reductions over these. */
+int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const float* dhs,
+                          const float* saved, float* dgate, float* dxp, float* dh0,
+                          int B, int T, int N, int A, void* stream);
+
+/* ---- per-row kernels (mixers.hip) -----------------------------------------------------------*/
+/* out[row] = q[row,idx[row]] (th.gather, q_learner.py:100,114); idx < 0 -> 0 */
+int marl_q_gather(const float* q, const int* idx, float* out, long rows, int A, void* stream);
+/* q[avail==0] = mask_val; max / first-index argmax over actions (q_learner.py:105,112-117,125-127;
+ * qtran_learner.py:104-113). avail may be NULL. out_max / out_arg may be NULL. */
+int marl_q_masked_max(const float* q, const float* avail, float mask_val, float* out_max, int* out_arg,
+                      long rows, int A, void* stream);
+/* dq = 0; dq[row,idx1[row]] += g1[row/gdiv]; dq[row,idx2[row]] += g2[row/gdiv] (idx2/g2 may be
+ * NULL): autograd of gather / max (+ of the sum over agents when gdiv = N). */
+int marl_q_scatter(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,
+                   long rows, int A, int gdiv, void* stream);
+/* out[r,d] = sum_n in[r,n,d]   (VDNMixer, mixer.py:15-16 with D=1; QTRAN .sum(dim=-2), :384,:414) */
+int marl_agent_sum(const float* in, float* out, long rows, int N, int D, void* stream);
+/* out[r,n,d] = in[r,d] (+ out if accumulate): autograd of the sum above */
+int marl_agent_bcast(const float* in, float* out, long rows, int N, int D, int accumulate, void* stream);
+
+/* QMixMixer.forward after the hypernet layers (mixer.py:64-80).  hy row = [w1raw (N*E, agent-major)
+ * | b1 (E) | w2raw (E) | relu(hyper_b2.0) (E)], b2 = hyper_b2.2 output. */
+int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* q, float* q_tot,
+                      long rows, int N, int E, void* stream);
+/* its autograd: fills dhy[w1raw|b1|w2raw] (the 4th block is written by the caller), db2, dq */
+int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
+                      float* db2, float* dq, long rows, int N, int E, void* stream);
+
+/* QPLEX (DMAQer.forward + calc_v/calc_adv, mixer.py:211-288; DMAQ_SI_Weight tail :158-169).
+ *  wv row = [w_raw (N) | v (N)] (outputs of hyper_w_final.2 / V.2);
+ *  heads = key (rows,K,1) | agents (rows,K,N) | action (rows,K,N) raw extractor outputs.
+ *  out: v_tot, a_tot (either may be NULL).  max_q NULL => is_v only. */
+int marl_qplex_mix_fwd(const float* w_raw, const float* v, const float* q, const float* max_q,
+                       const float* key, const float* ag, const float* ac, float* v_tot, float* a_tot,
+                       float* lam_out, long rows, int N, int K, int weighted_head, int minus_one,
+                       void* stream);
+/* autograd for q_tot = v_tot + a_tot given g = dL/dq_tot: dq (N), dw_raw, dv, dkey, dag, dac */
+int marl_qplex_mix_bwd(const float* w_raw, const float* q, const float* max_q, const float* key,
+                       const float* ag, const float* ac, const float* g, float* dq, float* dw_raw,
+                       float* dv, float* dkey, float* dag, float* dac, long rows, int N, int K,
+                       int weighted_head, int minus_one, void* stream);
+
+/* TD target + masked squared error (q_learner.py:165-168).  Writes the UN-normalised gradient
+ * dq_tot = -2 mask^2 td and out2 = {sum (mask td)^2, sum mask}; the 1/sum(mask) factor is applied
+ * in the optimizer so that data-parallel ranks can all-reduce numerators. */
+int marl_td_loss(const float* q_tot, const float* q_tot_tgt, const float* r, const float* term,
+                 const float* padded, float gamma, float* dq_tot, float* out2, float* ws, long rows,
+                 void* stream);
+/* QTRAN-base losses (qtran_learner.py:121-152). out4 = {l_td, l_opt, l_nopt numerators, sum mask};
+ * gradients un-normalised: d_jq (joint_q_evals), d_v, d_qsum_opt, d_qsum_nopt. */
+int marl_qtran_loss(const float* jq, const float* jq_tgt, const float* v, const float* jq_hat,
+                    const float* qsum_opt, const float* qsum_nopt, const float* r, const float* term,
+                    const float* padded, float gamma, float lam_opt, float lam_nopt, float* d_jq,
+                    float* d_v, float* d_qsum_opt, float* d_qsum_nopt, float* out4, float* ws, long rows,
+                    void* stream);
+size_t marl_loss_workspace(long rows);
+
+/* ---- optimizer (optim.hip): clip_grad_norm_ + RMSprop / Adam on ONE flat buffer -------------
+ * (q_learner.py:42-47,170-173; torch defaults).  g is the un-normalised gradient; den points to
+ * sum(mask) on the device (NULL = 1).  sumsq[0] receives sum g^2 (before scaling). */
+int marl_grad_sumsq(const float* g, long n, float* sumsq, float* ws, void* stream);
+size_t marl_sumsq_workspace(long n);
+int marl_rmsprop_step(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps,
+                      float clip, const float* sumsq, const float* den, void* stream);
+int marl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                   float beta2, float eps, float bc1, float bc2_sqrt, float clip, const float* sumsq,
+                   const float* den, void* stream);
+
+/* ---- rollout (rollout.hip) ------------------------------------------------------------------
+ * epsilon-greedy action choice of SharedMAC.choose_action (share_params.py:66-70), batched:
+ * explore iff u01(hash(rseed,EXPLORE,env,tg,n)) < eps, then the floor(u01(hash(..PICK..))*n_avail)-th
+ * available action, else first-index argmax of avail-masked q.  act_out[e*act_es + n]; envs with
+ * alive[e]==0 get -1. tg[e] = per-env global step id (NULL: tg0). */
+int marl_select_actions(const float* q, const float* avail, long avail_es, const int* alive, float eps,
+                        unsigned rseed, int env0, const int* tg, int tg0, int* act_out, long act_es,
+                        int E, int N, int A, void* stream);
+/* Synthetic SMAC-shaped environment (stands in for StarCraft II, main.py:16-20).
+ * Episode storage is (T+1)-slot: obs (E,T+1,N,O), state (E,T+1,S), avail (E,T+1,N,A). */
+int marl_synth_lengths(unsigned seed, int env0, int episode, int* len, int* won, int E, int T, void* stream);
+int marl_synth_observe(unsigned seed, int env0, int episode, int t, const int* len, float* obs,
+                       float* state, float* avail, int E, int T, int N, int O, int S, int A, void* stream);
+/* reward / terminated / padded for step t given act (E,N) (rollout.py:86-96,122-133 for padding);
+ * u (E,T,N) int32 gets the action or -1 on padding. alive_out[e] = (t+1 < len[e]) */
+int marl_synth_step(unsigned seed, int env0, int episode, int t, const int* len, const int* act,
+                    int* u, float* r, float* term, float* padded, int* alive_next, int E, int T, int N, int A,
+                    void* stream);
+
+const char* marl_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,505 @@
+// Persistent GRU-agent unroll kernels for gfx950 (reference network/q_network.py:16-21,
+// controller/share_params.py:84-168).  One launch runs all T steps.
+//
+// Decomposition (MI355X-first, not one-thread-per-row):
+//   * a workgroup owns a block of (episode, agent) rows = RT tiles of 16 rows and keeps them
+//     for the whole unroll; 4 compute waves + 1 loader wave (320 threads);
+//   * compute wave w owns hidden units [16w, 16w+16): its slice of W_ih / W_hh / W_2 lives in
+//     VGPRs for the whole kernel as MFMA B-fragments (fc1's slice lives in LDS because its K
+//     depends on the map), so the only per-step operand traffic is the activation tiles in LDS;
+//   * all products run on v_mfma_f32_16x16x4_f32 (exact fp32, the fp32 roofline of the chip);
+//   * the loader wave streams the next step's observation tile HBM -> LDS while the gates run and
+//     synthesises the one-hot(last action) / agent-id columns, so HBM latency never sits on the
+//     recurrent critical path;
+//   * GRU pointwise math is done on the accumulator (D) layout in registers; activations that the
+//     backward pass needs are written once, coalesced per 16-lane group.
+#include "common.h"
+#include "../../include/marl_hip.h"
+
+namespace {
+
+constexpr int H = 64;
+constexpr int HS = H + 4;      // LDS row stride of 64-wide tiles (floats); +4 spreads banks
+constexpr int NT = 320;        // threads per workgroup
+
+struct FwdArgs {
+  const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;
+  const float* obs;       // row (b,t,n) at (b*obs_bs + (t+obs_t0)*N + n)*O
+  long obs_bs; int obs_t0;
+  const int* ufed;        // action fed back at step t: ufed[b*u_bs + (t+u_t0)*N + n]; <0 / t+u_t0<0 = none
+  long u_bs; int u_t0;
+  const float* h0;        // (B*N,64) or null (zeros)
+  float* q;               // (B,T,N,A)
+  float* hs;              // (B,T,N,64) or null
+  float* h_last;          // (B*N,64) or null
+  float* saved;           // [6][B,T,N,64]: hprev,x,r,z,n,hn  or null
+  int B, T, N, O, A, I, KC, RT;
+  int has_act, has_id;
+  long R;                 // B*N rows
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int AC>
+__global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = lane & 15;
+  const int rows = a.RT * 16;
+  const int KP = a.KC * 16, KS = KP + 4;
+  // LDS carve (all offsets multiples of 4 floats)
+  float* W1s = smem;                                  // [4][KC][64] f32x4
+  float* In = W1s + 4 * a.KC * 64 * 4;                // [rows][KS]
+  float* Xt = In + rows * KS;                         // [rows][HS]
+  float* Ha = Xt + rows * HS;                         // [rows][HS] x2
+  float* Hb = Ha + rows * HS;
+  long* rowbase = reinterpret_cast<long*>(Hb + rows * HS);   // [rows]: (b*T*N + n), -1 if row invalid
+  long* rowb = rowbase + rows;                               // [rows]: b
+
+  const long row0 = (long)blockIdx.x * rows;
+  for (int r = tid; r < rows; r += NT) {
+    long rho = row0 + r;
+    long v = -1;
+    long b = 0;
+    if (rho < a.R) { b = rho / a.N; int n = (int)(rho % a.N); v = b * a.T * a.N + n; }
+    rowbase[r] = v;
+    rowb[r] = b;
+  }
+  const long tstride = a.N;   // rows per time step within an episode
+
+  // ---- stage weights: fc1 slice -> LDS fragments; GRU / fc2 slices -> registers
+  f32x4 wih[3][4], whh[3][4], w2[AC][4];
+  float bias_r = 0, bias_z = 0, bias_in = 0, bias_hn = 0, bias1 = 0, bias2[AC];
+  if (wave < 4) {
+    const int j = 16 * wave + m;
+    for (int c = 0; c < a.KC; ++c) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = 16 * c + 4 * q + i;
+        v[i] = k < a.I ? a.W1[(long)j * a.I + k] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(W1s + ((wave * a.KC + c) * 64 + lane) * 4) = v;
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        wih[g][c] = *reinterpret_cast<const f32x4*>(a.Wih + (long)(g * H + j) * H + 16 * c + 4 * q);
+        whh[g][c] = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + j) * H + 16 * c + 4 * q);
+      }
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      int arow = 16 * ac + m; if (arow >= a.A) arow = a.A - 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        w2[ac][c] = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
+      bias2[ac] = a.b2[arow];
+    }
+    bias1 = a.b1[j];
+    bias_r = a.bih[j] + a.bhh[j];
+    bias_z = a.bih[H + j] + a.bhh[H + j];
+    bias_in = a.bih[2 * H + j];
+    bias_hn = a.bhh[2 * H + j];
+  }
+  __syncthreads();   // rowbase visible
+
+  // ---- initial hidden tile
+  for (int e = tid; e < rows * H; e += NT) {
+    int r = e / H, k = e % H;
+    long rho = row0 + r;
+    Ha[r * HS + k] = (a.h0 && rho < a.R) ? a.h0[rho * H + k] : 0.f;
+  }
+
+  // loader: build the input tile [obs | onehot(ufed) | id | 0-pad] for step t into buf
+  auto load_inputs = [&](int t, float* buf) {
+    const int O = a.O;
+    for (int e = lane; e < rows * KP; e += 64) {
+      const int r = e / KP, k = e - r * KP;
+      const long rb = rowbase[r];
+      float v = 0.f;
+      if (rb >= 0) {
+        const int n = (int)(rb % a.N);   // rb = b*T*N + n and T*N is a multiple of N
+        const long b = rowb[r];
+        if (k < O) v = a.obs[(b * a.obs_bs + (long)(t + a.obs_t0) * a.N + n) * O + k];
+        else if (a.has_act && k < O + a.A) {
+          int u = -1;
+          if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[b * a.u_bs + (long)(t + a.u_t0) * a.N + n];
+          v = (u == k - O) ? 1.f : 0.f;
+        } else if (a.has_id && k < a.I) {
+          v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
+        }
+      }
+      buf[r * KS + k] = v;
+    }
+  };
+  if (wave == 4) load_inputs(0, In);
+  __syncthreads();
+
+  const long plane = (long)a.B * a.T * a.N * H;   // one saved array
+  float* Hp = Ha;
+  float* Hn = Hb;
+  for (int t = 0; t < a.T; ++t) {
+    if (wave < 4) {
+      // ---------------- phase 1: x = relu(fc1(in))  (two row tiles in flight)
+      const int j = 16 * wave + m;
+      for (int rt = 0; rt < a.RT; rt += 2) {
+        const bool two = rt + 1 < a.RT;
+        f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
+        const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
+        const float* in1 = in0 + 16 * KS;
+        const float* wf = W1s + (wave * a.KC * 64 + lane) * 4;
+        for (int c = 0; c < a.KC; ++c) {
+          f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
+          f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
+          acc0 = mfma16x4(a0, bv, acc0);
+          if (two) {
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
+            acc1 = mfma16x4(a1, bv, acc1);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = rt * 16 + 4 * q + i;
+          const float x0 = fmaxf(acc0[i], 0.f);
+          Xt[r * HS + j] = x0;
+          const long rb = rowbase[r];
+          if (a.saved && rb >= 0) a.saved[plane + (rb + (long)t * tstride) * H + j] = x0;
+          if (two) {
+            const float x1 = fmaxf(acc1[i], 0.f);
+            Xt[(r + 16) * HS + j] = x1;
+            const long rb1 = rowbase[r + 16];
+            if (a.saved && rb1 >= 0) a.saved[plane + (rb1 + (long)t * tstride) * H + j] = x1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 4) {
+      // the input tile was consumed by phase 1; refill it for step t+1 while the gates run
+      if (t + 1 < a.T) load_inputs(t + 1, In);
+    } else {
+      // ---------------- phase 2: GRU gates + pointwise update
+      const int j = 16 * wave + m;
+      for (int rt = 0; rt < a.RT; ++rt) {
+        f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
+        f32x4 az = {bias_z, bias_z, bias_z, bias_z};
+        f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
+        f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
+        const float* xr = Xt + (rt * 16 + m) * HS + 4 * q;
+        const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
+          ahn = mfma16x4(ah, whh[2][c], ahn);
+          ar = mfma16x4(ah, whh[0][c], ar);
+          az = mfma16x4(ah, whh[1][c], az);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = rt * 16 + 4 * q + i;
+          const float hp = Hp[r * HS + j];
+          const float rg = sigmoidf_(ar[i]);
+          const float zg = sigmoidf_(az[i]);
+          const float ng = tanhf_(ain[i] + rg * ahn[i]);
+          const float hn = (1.f - zg) * ng + zg * hp;
+          Hn[r * HS + j] = hn;
+          const long rb = rowbase[r];
+          if (rb >= 0) {
+            const long off = (rb + (long)t * tstride) * H + j;
+            if (a.hs) a.hs[off] = hn;
+            if (a.saved) {
+              a.saved[off] = hp;
+              a.saved[2 * plane + off] = rg;
+              a.saved[3 * plane + off] = zg;
+              a.saved[4 * plane + off] = ng;
+              a.saved[5 * plane + off] = ahn[i];
+            }
+            if (a.h_last && t == a.T - 1) a.h_last[(row0 + r) * H + j] = hn;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < 4) {
+      // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the waves)
+      for (int rt = wave; rt < a.RT; rt += 4) {
+        f32x4 acc[AC];
+#pragma unroll
+        for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
+        const float* hr = Hn + (rt * 16 + m) * HS + 4 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+#pragma unroll
+          for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
+        }
+#pragma unroll
+        for (int ac = 0; ac < AC; ++ac) {
+          const int col = 16 * ac + m;
+          if (col < a.A) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const long rb = rowbase[rt * 16 + 4 * q + i];
+              if (rb >= 0) a.q[(rb + (long)t * tstride) * a.A + col] = acc[ac][i];
+            }
+          }
+        }
+      }
+    }
+    float* tmp = Hp; Hp = Hn; Hn = tmp;
+    // no barrier here: phase 1 of t+1 reads In (refilled before the 2nd barrier above) and writes Xt
+    // (last read before it); Hn of step t is only re-written in phase 2 of t+2, two barriers later.
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward through time, delta part: per step computes the gate pre-activation gradients and
+// dx_pre, carries dh; weight gradients are then plain reductions (marl_linear_wgrad).
+struct BwdArgs {
+  const float *Wih, *Whh, *W2;
+  const float* dq;        // (B,T,N,A)
+  const float* dhs;       // (B,T,N,64) external gradient on hs[t], or null
+  const float* saved;     // [6][B,T,N,64]
+  float* dgate;           // (B,T,N,256): d r_pre | d z_pre | d n_pre | d hn  (hn = W_hn h + b_hn)
+  float* dxp;             // (B,T,N,64): gradient at fc1 pre-activation
+  float* dh0;             // (B*N,64) gradient wrt the initial hidden state, or null
+  int B, T, N, A, RT;
+  long R;
+};
+
+constexpr int DGS = 256 + 4;
+
+template <int AC>
+__global__ __launch_bounds__(NT, 2) void agent_bwd_kernel(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = lane & 15;
+  const int rows = a.RT * 16;
+  constexpr int QP = AC * 16, QS = QP + 4;
+  float* DG = smem;                         // [rows][DGS]
+  float* DQ0 = DG + rows * DGS;             // [rows][QS] x2
+  float* DQ1 = DQ0 + rows * QS;
+  float* CAR = DQ1 + rows * QS;             // [rows][HS] carried dh (each wave touches its own columns)
+  long* rowbase = reinterpret_cast<long*>(CAR + rows * HS);
+
+  const long row0 = (long)blockIdx.x * rows;
+  for (int r = tid; r < rows; r += NT) {
+    long rho = row0 + r;
+    long v = -1;
+    if (rho < a.R) { long b = rho / a.N; int n = (int)(rho % a.N); v = b * a.T * a.N + n; }
+    rowbase[r] = v;
+  }
+  for (int e = tid; e < rows * HS; e += NT) CAR[e] = 0.f;
+  const long tstride = a.N;
+  const long plane = (long)a.B * a.T * a.N * H;
+
+  // B-fragments of the TRANSPOSED products: lane (q,m) holds W[k = 16c+4q+i][col 16w+m]
+  f32x4 whhT[12], wihT[12], w2T[AC];
+  if (wave < 4) {
+    const int j = 16 * wave + m;
+#pragma unroll
+    for (int c = 0; c < 12; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * c + 4 * q + i;
+        whhT[c][i] = a.Whh[(long)k * H + j];
+        wihT[c][i] = a.Wih[(long)k * H + j];
+      }
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * ac + 4 * q + i;
+        w2T[ac][i] = k < a.A ? a.W2[(long)k * H + j] : 0.f;
+      }
+  }
+  __syncthreads();
+
+  auto load_dq = [&](int t, float* buf) {
+    for (int e = lane; e < rows * QP; e += 64) {
+      const int r = e / QP, k = e - r * QP;
+      const long rb = rowbase[r];
+      float v = 0.f;
+      if (rb >= 0 && k < a.A) v = a.dq[(rb + (long)t * tstride) * a.A + k];
+      buf[r * QS + k] = v;
+    }
+  };
+  if (wave == 4) load_dq(a.T - 1, DQ0);
+  __syncthreads();
+
+  int par = 0;
+  for (int t = a.T - 1; t >= 0; --t, par ^= 1) {
+    float* DQ = par ? DQ1 : DQ0;
+    float* DQn = par ? DQ0 : DQ1;
+    if (wave == 4) {
+      if (t > 0) load_dq(t - 1, DQn);
+    } else {
+      // ---------------- phase B: dh = carry + dhs + dq W2 ; gate gradients
+      const int j = 16 * wave + m;
+      for (int rt = 0; rt < a.RT; ++rt) {
+        f32x4 dh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+        const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
+#pragma unroll
+        for (int ac = 0; ac < AC; ++ac) {
+          f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
+          dh = mfma16x4(av, w2T[ac], dh);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = rt * 16 + 4 * q + i;
+          const long rb = rowbase[r];
+          float drp = 0.f, dzp = 0.f, dnp = 0.f, dhn = 0.f, dcar = 0.f;
+          if (rb >= 0) {
+            const long off = (rb + (long)t * tstride) * H + j;
+            float d = dh[i];
+            if (a.dhs) d += a.dhs[off];
+            const float hp = a.saved[off];
+            const float rg = a.saved[2 * plane + off];
+            const float zg = a.saved[3 * plane + off];
+            const float ng = a.saved[4 * plane + off];
+            const float hn = a.saved[5 * plane + off];
+            const float dn = d * (1.f - zg);
+            const float dz = d * (hp - ng);
+            dcar = d * zg;
+            dnp = dn * (1.f - ng * ng);
+            dzp = dz * zg * (1.f - zg);
+            drp = dnp * hn * rg * (1.f - rg);
+            dhn = dnp * rg;
+            float* dg = a.dgate + (rb + (long)t * tstride) * 256 + j;
+            dg[0] = drp; dg[64] = dzp; dg[128] = dnp; dg[192] = dhn;
+          }
+          float* l = DG + r * DGS + j;
+          l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
+          CAR[r * HS + j] = dcar;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < 4) {
+      // ---------------- phase C: dh_prev = z*dh + [drp,dzp,dhn] W_hh ; dx = [drp,dzp,dnp] W_ih
+      const int j = 16 * wave + m;
+      for (int rt = 0; rt < a.RT; ++rt) {
+        f32x4 dhp, dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dhp[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+        const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+          f32x4 ai = *reinterpret_cast<const f32x4*>(gr + 16 * c);              // drp|dzp|dnp
+          dx = mfma16x4(ai, wihT[c], dx);
+          f32x4 ah = c < 8 ? ai : *reinterpret_cast<const f32x4*>(gr + 192 + 16 * (c - 8));  // drp|dzp|dhn
+          dhp = mfma16x4(ah, whhT[c], dhp);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = rt * 16 + 4 * q + i;
+          const long rb = rowbase[r];
+          CAR[r * HS + j] = dhp[i];
+          if (rb >= 0) {
+            const long off = (rb + (long)t * tstride) * H + j;
+            const float x = a.saved[plane + off];
+            a.dxp[off] = x > 0.f ? dx[i] : 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (a.dh0 && wave < 4) {
+    const int j = 16 * wave + m;
+    for (int r = 4 * q; r < rows; r += 16)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rowbase[r + i] >= 0) a.dh0[(row0 + r + i) * H + j] = CAR[(r + i) * HS + j];
+  }
+}
+
+// choose row tiles per workgroup: fill 256 CUs, keep LDS within budget
+inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap) {
+  const long tiles = (R + 15) / 16;
+  const size_t budget = 160 * 1024;
+  int rt_max = (int)((budget - fixed_bytes) / (bytes_per_row * 16));
+  if (rt_max > rt_cap) rt_max = rt_cap;
+  if (rt_max < 1) rt_max = 1;
+  int rt = (int)((tiles + 255) / 256);
+  if (rt < 1) rt = 1;
+  if (rt > rt_max) rt = rt_max;
+  return rt;
+}
+
+}  // namespace
+
+extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
+                                     const int* ufed, long u_bs, int u_t0, const float* h0, float* q,
+                                     float* hs, float* h_last, float* saved, int B, int T, int N, int O,
+                                     int A, int last_action, int reuse_network, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
+  FwdArgs a;
+  a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
+  a.W2 = w->fc2_w; a.b2 = w->fc2_b;
+  a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
+  a.B = B; a.T = T; a.N = N; a.O = O; a.A = A;
+  a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
+  a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
+  a.KC = (a.I + 15) / 16;
+  a.R = (long)B * N;
+  const int KS = a.KC * 16 + 4;
+  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 16;
+  const size_t fixed = (size_t)4 * a.KC * 64 * 16;
+  a.RT = pick_rt(a.R, per_row, fixed, 8);
+  const size_t lds = fixed + per_row * a.RT * 16;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  const long rows = a.RT * 16;
+  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(NT);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (A <= 16) {
+    e = hipFuncSetAttribute((const void*)agent_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((agent_fwd_kernel<1>), grid, block, lds, s, a);
+  } else {
+    e = hipFuncSetAttribute((const void*)agent_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((agent_fwd_kernel<2>), grid, block, lds, s, a);
+  }
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const float* dhs,
+                                     const float* saved, float* dgate, float* dxp, float* dh0,
+                                     int B, int T, int N, int A, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
+  BwdArgs a;
+  a.Wih = w->w_ih; a.Whh = w->w_hh; a.W2 = w->fc2_w;
+  a.dq = dq; a.dhs = dhs; a.saved = saved; a.dgate = dgate; a.dxp = dxp; a.dh0 = dh0;
+  a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
+  const int AC = A <= 16 ? 1 : 2;
+  const int QS = AC * 16 + 4;
+  const size_t per_row = (size_t)(DGS + 2 * QS + HS) * 4 + 8;
+  a.RT = pick_rt(a.R, per_row, 0, 8);
+  const size_t lds = per_row * a.RT * 16;
+  const long rows = a.RT * 16;
+  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(NT);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (AC == 1) {
+    e = hipFuncSetAttribute((const void*)agent_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((agent_bwd_kernel<1>), grid, block, lds, s, a);
+  } else {
+    e = hipFuncSetAttribute((const void*)agent_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((agent_bwd_kernel<2>), grid, block, lds, s, a);
+  }
+  MARL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,88 @@
+// Shared device helpers for the gfx950 kernels (wave64, fp32 MFMA 16x16x4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MARL_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D = A(16x4) * B(4x16) + C, exact f32 (v_mfma_f32_16x16x4_f32).
+// lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]; D reg r: D[row 4*(l>>4)+r][col l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// K-permutation trick: a k-chunk of 16 is consumed as 4 MFMA steps; at step i lane (q=l>>4)
+// supplies element k0+4q+i for BOTH operands, so each lane's 4 operands are 16 contiguous bytes.
+__device__ __forceinline__ f32x4 mfma16x4(const f32x4& a, const f32x4& b, f32x4 c) {
+  c = mfma16(a[0], b[0], c);
+  c = mfma16(a[1], b[1], c);
+  c = mfma16(a[2], b[2], c);
+  c = mfma16(a[3], b[3], c);
+  return c;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // 1 - 2/(e^{2x}+1): saturates cleanly, abs error ~1e-7
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Virtual row-major matrix [M, K] = [dense0 | dense1 | nhot one-hot blocks | agent-id block].
+// Lets GEMMs consume concatenations ([h|onehot(u)], [s|enc], [s|joint one-hot], [obs|u|id])
+// without materialising them.
+struct ConcatSrc {
+  const float* p0; long ld0; int k0;        // dense segment 0 (k0 columns)
+  const float* p1; long ld1; int k1;        // dense segment 1
+  const int* idx; int nhot; int hot_w;      // one-hot blocks: column j*hot_w + idx[row*nhot+j] is 1
+  int nid;                                  // identity block: column (row % nid) is 1
+  const float* m0; long ldm0;               // optional gate on segment 0: value * (m0 > 0)
+  long rpe0, bs0, off0;                     // row remap of p0/m0: (row/rpe)*bs + row%rpe + off
+  long rpei, bsi, offi;                     // row remap of idx; (row%rpe)+off < 0 reads "none"
+};
+
+__device__ __forceinline__ long remap_row(long row, long rpe, long bs, long off, bool& valid) {
+  valid = true;
+  if (rpe == 0) return row;
+  const long e = row / rpe, w = row - e * rpe + off;
+  valid = w >= 0;
+  return e * bs + w;
+}
+
+__device__ __forceinline__ float concat_elem(const ConcatSrc& s, long row, int k) {
+  if (k < s.k0) {
+    bool ok;
+    const long r0 = remap_row(row, s.rpe0, s.bs0, s.off0, ok);
+    if (!ok) return 0.f;
+    float v = s.p0[r0 * s.ld0 + k];
+    if (s.m0) v = s.m0[r0 * s.ldm0 + k] > 0.f ? v : 0.f;
+    return v;
+  }
+  k -= s.k0;
+  if (k < s.k1) return s.p1[row * s.ld1 + k];
+  k -= s.k1;
+  int hw = s.nhot * s.hot_w;
+  if (k < hw) {
+    int j = k / s.hot_w;
+    bool ok;
+    const long ri = remap_row(row, s.rpei, s.bsi, s.offi, ok);
+    if (!ok) return 0.f;
+    int a = s.idx[ri * s.nhot + j];
+    return (a == k - j * s.hot_w) ? 1.f : 0.f;
+  }
+  k -= hw;
+  if (k < s.nid) return ((int)(row % s.nid) == k) ? 1.f : 0.f;
+  return 0.f;
+}
+
+__host__ __device__ inline int concat_width(const ConcatSrc& s) { return s.k0 + s.k1 + s.nhot * s.hot_w + s.nid; }
+
+#define MARL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,395 @@
+// Per-row kernels of the learner: action-value selection, agent sums, the QMIX and QPLEX mixing
+// epilogues (after their hypernet GEMMs) and the TD / QTRAN losses.  HBM-bound elementwise work:
+// coalesced over the row axis, reductions by wave shuffles, deterministic two-stage sums.
+#include "common.h"
+#include "../../include/marl_hip.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int nblk(long n, int cap = 65535 * 16) {
+  long b = (n + TPB - 1) / TPB;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ void q_gather_kernel(const float* q, const int* idx, float* out, long rows, int A) {
+  for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
+    const int a = idx[r];
+    out[r] = a >= 0 ? q[r * A + a] : 0.f;
+  }
+}
+
+__global__ void q_masked_max_kernel(const float* q, const float* avail, float mask_val, float* out_max,
+                                    int* out_arg, long rows, int A) {
+  for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
+    float best = 0.f;
+    int arg = 0;
+    for (int a = 0; a < A; ++a) {
+      float v = q[r * A + a];
+      if (avail && avail[r * A + a] == 0.f) v = mask_val;
+      if (a == 0 || v > best) { best = v; arg = a; }   // strict >: first index wins ties (torch)
+    }
+    if (out_max) out_max[r] = best;
+    if (out_arg) out_arg[r] = arg;
+  }
+}
+
+__global__ void q_scatter_kernel(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,
+                                 long rows, int A, int gdiv) {
+  for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
+    const int a1 = idx1 ? idx1[r] : -1;
+    const int a2 = idx2 ? idx2[r] : -1;
+    const float v1 = g1 ? g1[r / gdiv] : 0.f;
+    const float v2 = g2 ? g2[r / gdiv] : 0.f;
+    for (int a = 0; a < A; ++a) {
+      float v = 0.f;
+      if (a == a1) v += v1;
+      if (a == a2) v += v2;
+      dq[r * A + a] = v;
+    }
+  }
+}
+
+__global__ void agent_sum_kernel(const float* in, float* out, long rows, int N, int D) {
+  const long total = rows * D;
+  for (long e = (long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long)gridDim.x * TPB) {
+    const long r = e / D;
+    const int d = (int)(e - r * D);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += in[(r * N + n) * D + d];
+    out[e] = s;
+  }
+}
+
+__global__ void agent_bcast_kernel(const float* in, float* out, long rows, int N, int D, int acc) {
+  const long total = rows * N * D;
+  for (long e = (long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long)gridDim.x * TPB) {
+    const long rn = e / D;
+    const int d = (int)(e - rn * D);
+    const long r = rn / N;
+    const float v = in[r * D + d];
+    out[e] = acc ? out[e] + v : v;
+  }
+}
+
+// ---- QMIX: 32 lanes per row (lane = embed unit e), two rows per wave ---------------------------
+__global__ void qmix_mix_fwd_kernel(const float* hy, long ldh, const float* b2, const float* q, float* q_tot,
+                                    long rows, int N, int E) {
+  const int half = (threadIdx.x & 63) >> 5, l = threadIdx.x & 31;
+  const long wave_id = ((long)blockIdx.x * TPB + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * TPB) >> 6;
+  for (long r2 = wave_id; r2 * 2 < rows; r2 += nwaves) {
+    const long r = r2 * 2 + half;
+    float part = 0.f;
+    if (r < rows) {
+      const float* h = hy + r * ldh;
+      for (int e = l; e < E; e += 32) {
+        float a = h[N * E + e];                                  // b1
+        for (int n = 0; n < N; ++n) a += q[r * N + n] * fabsf(h[n * E + e]);
+        const float hid = a > 0.f ? a : (__expf(a) - 1.f);       // elu, alpha = 1
+        part += hid * fabsf(h[N * E + E + e]);
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (r < rows && l == 0) q_tot[r] = part + b2[r];
+  }
+}
+
+__global__ void qmix_mix_bwd_kernel(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
+                                    float* db2, float* dq, long rows, int N, int E) {
+  const int half = (threadIdx.x & 63) >> 5, l = threadIdx.x & 31;
+  const long wave_id = ((long)blockIdx.x * TPB + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * TPB) >> 6;
+  for (long r2 = wave_id; r2 * 2 < rows; r2 += nwaves) {
+    const long r = r2 * 2 + half;
+    const bool ok = r < rows;
+    const float g = ok ? dq_tot[r] : 0.f;
+    float dqn[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) dqn[n] = 0.f;
+    if (ok) {
+      const float* h = hy + r * ldh;
+      float* dh = dhy + r * ldh;
+      for (int e = l; e < E; e += 32) {
+        float a = h[N * E + e];
+        for (int n = 0; n < N; ++n) a += q[r * N + n] * fabsf(h[n * E + e]);
+        const float ex = __expf(a);
+        const float hid = a > 0.f ? a : ex - 1.f;
+        const float w2r = h[N * E + E + e];
+        const float sgn2 = w2r > 0.f ? 1.f : (w2r < 0.f ? -1.f : 0.f);
+        dh[N * E + E + e] = g * hid * sgn2;                       // d w2raw
+        const float dpre = g * fabsf(w2r) * (a > 0.f ? 1.f : ex);
+        dh[N * E + e] = dpre;                                     // d b1
+        for (int n = 0; n < N; ++n) {
+          const float w1r = h[n * E + e];
+          const float sgn1 = w1r > 0.f ? 1.f : (w1r < 0.f ? -1.f : 0.f);
+          dh[n * E + e] = q[r * N + n] * dpre * sgn1;             // d w1raw
+          if (n < 16) dqn[n] += fabsf(w1r) * dpre;
+        }
+      }
+    }
+    for (int n = 0; n < N && n < 16; ++n) {
+      float v = dqn[n];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (ok && l == 0) dq[r * N + n] = v;
+    }
+    if (ok && l == 0) db2[r] = g;
+  }
+}
+
+// ---- QPLEX --------------------------------------------------------------------------------------
+__global__ void qplex_mix_fwd_kernel(const float* w_raw, const float* v, const float* q, const float* max_q,
+                                     const float* key, const float* ag, const float* ac, float* v_tot,
+                                     float* a_tot, float* lam_out, long rows, int N, int K, int weighted,
+                                     int minus_one) {
+  for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
+    float vt = 0.f, at = 0.f;
+    for (int i = 0; i < N; ++i) {
+      const float w = fabsf(w_raw[r * N + i]) + 1e-10f;
+      const float qi = q[r * N + i];
+      const float qt = weighted ? w * qi + v[r * N + i] : qi;
+      vt += qt;
+      if (max_q) {
+        const float mi = max_q[r * N + i];
+        const float mt = weighted ? w * mi + v[r * N + i] : mi;
+        float lam = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float kk = fabsf(key[r * K + k]) + 1e-10f;
+          lam += kk * sigmoidf_(ag[(r * K + k) * N + i]) * sigmoidf_(ac[(r * K + k) * N + i]);
+        }
+        if (lam_out) lam_out[r * N + i] = lam;
+        at += (qt - mt) * (minus_one ? lam - 1.f : lam);
+      }
+    }
+    if (v_tot) v_tot[r] = vt;
+    if (a_tot && max_q) a_tot[r] = at;
+  }
+}
+
+__global__ void qplex_mix_bwd_kernel(const float* w_raw, const float* q, const float* max_q, const float* key,
+                                     const float* ag, const float* ac, const float* g, float* dq, float* dw_raw,
+                                     float* dv, float* dkey, float* dag, float* dac, long rows, int N, int K,
+                                     int weighted, int minus_one) {
+  for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
+    const float gr = g[r];
+    for (int k = 0; k < K; ++k) dkey[r * K + k] = 0.f;
+    for (int i = 0; i < N; ++i) {
+      const float wr = w_raw[r * N + i];
+      const float w = fabsf(wr) + 1e-10f;
+      const float qi = q[r * N + i];
+      // v_tot path (adv is detached in the reference: mixer.py:237)
+      dq[r * N + i] = weighted ? gr * w : gr;
+      dw_raw[r * N + i] = weighted ? gr * qi * (wr > 0.f ? 1.f : (wr < 0.f ? -1.f : 0.f)) : 0.f;
+      dv[r * N + i] = weighted ? gr : 0.f;
+      // a_tot path: only lambda gets gradient
+      const float mi = max_q[r * N + i];
+      const float adv = weighted ? (w * qi - w * mi) : (qi - mi);
+      const float dlam = gr * adv;
+      for (int k = 0; k < K; ++k) {
+        const float kr = key[r * K + k];
+        const float kk = fabsf(kr) + 1e-10f;
+        const float sa = sigmoidf_(ag[(r * K + k) * N + i]);
+        const float sc = sigmoidf_(ac[(r * K + k) * N + i]);
+        dkey[r * K + k] += dlam * sa * sc * (kr > 0.f ? 1.f : (kr < 0.f ? -1.f : 0.f));
+        dag[(r * K + k) * N + i] = dlam * kk * sc * sa * (1.f - sa);
+        dac[(r * K + k) * N + i] = dlam * kk * sa * sc * (1.f - sc);
+      }
+    }
+  }
+}
+
+// ---- deterministic two-stage sums ------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void block_partials(float (&v)[NV], float* ws) {
+  __shared__ float sh[NV][TPB / 64];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float s = wave_sum(v[i]);
+    if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float s = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) s += sh[threadIdx.x][w];
+    ws[(long)blockIdx.x * NV + threadIdx.x] = s;
+  }
+}
+
+__global__ void finish_sums_kernel(const float* ws, int nblocks, int nv, float* out) {
+  __shared__ float sh[TPB];
+  for (int i = 0; i < nv; ++i) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += TPB) s += ws[(long)b * nv + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = sh[0];
+    __syncthreads();
+  }
+}
+
+__global__ void td_loss_kernel(const float* q_tot, const float* q_tgt, const float* r, const float* term,
+                               const float* padded, float gamma, float* dq_tot, float* ws, long rows) {
+  float acc[2] = {0.f, 0.f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < rows; i += (long)gridDim.x * TPB) {
+    const float mask = 1.f - padded[i];
+    const float target = r[i] + gamma * q_tgt[i] * (1.f - term[i]);
+    const float td = target - q_tot[i];
+    const float mtd = mask * td;
+    acc[0] += mtd * mtd;
+    acc[1] += mask;
+    dq_tot[i] = -2.f * mask * mtd;
+  }
+  block_partials<2>(acc, ws);
+}
+
+__global__ void qtran_loss_kernel(const float* jq, const float* jq_tgt, const float* v, const float* jq_hat,
+                                  const float* qs_opt, const float* qs_nopt, const float* r, const float* term,
+                                  const float* padded, float gamma, float lam_opt, float lam_nopt, float* d_jq,
+                                  float* d_v, float* d_qs_opt, float* d_qs_nopt, float* ws, long rows) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < rows; i += (long)gridDim.x * TPB) {
+    const float mask = 1.f - padded[i];
+    const float y = r[i] + gamma * jq_tgt[i] * (1.f - term[i]);
+    const float td = (jq[i] - y) * mask;
+    const float opt = (qs_opt[i] - jq_hat[i] + v[i]) * mask;
+    float nraw = qs_nopt[i] - jq[i] + v[i];
+    nraw = nraw < 0.f ? nraw : 0.f;
+    const float nopt = nraw * mask;
+    acc[0] += td * td; acc[1] += opt * opt; acc[2] += nopt * nopt; acc[3] += mask;
+    d_jq[i] = 2.f * mask * td;
+    const float go = lam_opt * 2.f * mask * opt, gn = lam_nopt * 2.f * mask * nopt;
+    d_v[i] = go + gn;
+    d_qs_opt[i] = go;
+    d_qs_nopt[i] = gn;
+  }
+  block_partials<4>(acc, ws);
+}
+
+inline int loss_blocks(long rows) {
+  long b = (rows + TPB - 1) / TPB;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int marl_q_gather(const float* q, const int* idx, float* out, long rows, int A, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(q_gather_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, q, idx, out, rows, A);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_q_masked_max(const float* q, const float* avail, float mask_val, float* out_max, int* out_arg,
+                                 long rows, int A, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(q_masked_max_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, q, avail, mask_val,
+                     out_max, out_arg, rows, A);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_q_scatter(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,
+                              long rows, int A, int gdiv, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(q_scatter_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, dq, idx1, g1, idx2, g2,
+                     rows, A, gdiv < 1 ? 1 : gdiv);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_agent_sum(const float* in, float* out, long rows, int N, int D, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(agent_sum_kernel, dim3(nblk(rows * D)), dim3(TPB), 0, (hipStream_t)stream, in, out, rows, N, D);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_agent_bcast(const float* in, float* out, long rows, int N, int D, int accumulate, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(agent_bcast_kernel, dim3(nblk(rows * N * D)), dim3(TPB), 0, (hipStream_t)stream, in, out, rows,
+                     N, D, accumulate);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* q, float* q_tot, long rows,
+                                 int N, int E, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(qmix_mix_fwd_kernel, dim3(nblk((rows + 1) / 2 * 64, 8192)), dim3(TPB), 0, (hipStream_t)stream,
+                     hy, ldh, b2, q, q_tot, rows, N, E);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
+                                 float* db2, float* dq, long rows, int N, int E, void* stream) {
+  if (rows <= 0) return 0;
+  if (N > 16) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(qmix_mix_bwd_kernel, dim3(nblk((rows + 1) / 2 * 64, 8192)), dim3(TPB), 0, (hipStream_t)stream,
+                     hy, ldh, q, dq_tot, dhy, db2, dq, rows, N, E);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_qplex_mix_fwd(const float* w_raw, const float* v, const float* q, const float* max_q,
+                                  const float* key, const float* ag, const float* ac, float* v_tot, float* a_tot,
+                                  float* lam_out, long rows, int N, int K, int weighted_head, int minus_one,
+                                  void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(qplex_mix_fwd_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, w_raw, v, q, max_q,
+                     key, ag, ac, v_tot, a_tot, lam_out, rows, N, K, weighted_head, minus_one);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_qplex_mix_bwd(const float* w_raw, const float* q, const float* max_q, const float* key,
+                                  const float* ag, const float* ac, const float* g, float* dq, float* dw_raw,
+                                  float* dv, float* dkey, float* dag, float* dac, long rows, int N, int K,
+                                  int weighted_head, int minus_one, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(qplex_mix_bwd_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, w_raw, q, max_q, key,
+                     ag, ac, g, dq, dw_raw, dv, dkey, dag, dac, rows, N, K, weighted_head, minus_one);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t marl_loss_workspace(long rows) { return (size_t)1024 * 4 * sizeof(float); }
+
+extern "C" int marl_td_loss(const float* q_tot, const float* q_tot_tgt, const float* r, const float* term,
+                            const float* padded, float gamma, float* dq_tot, float* out2, float* ws, long rows,
+                            void* stream) {
+  if (rows <= 0) return 0;
+  const int nb = loss_blocks(rows);
+  hipLaunchKernelGGL(td_loss_kernel, dim3(nb), dim3(TPB), 0, (hipStream_t)stream, q_tot, q_tot_tgt, r, term, padded,
+                     gamma, dq_tot, ws, rows);
+  MARL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, (const float*)ws, nb, 2, out2);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_qtran_loss(const float* jq, const float* jq_tgt, const float* v, const float* jq_hat,
+                               const float* qsum_opt, const float* qsum_nopt, const float* r, const float* term,
+                               const float* padded, float gamma, float lam_opt, float lam_nopt, float* d_jq,
+                               float* d_v, float* d_qsum_opt, float* d_qsum_nopt, float* out4, float* ws, long rows,
+                               void* stream) {
+  if (rows <= 0) return 0;
+  const int nb = loss_blocks(rows);
+  hipLaunchKernelGGL(qtran_loss_kernel, dim3(nb), dim3(TPB), 0, (hipStream_t)stream, jq, jq_tgt, v, jq_hat, qsum_opt,
+                     qsum_nopt, r, term, padded, gamma, lam_opt, lam_nopt, d_jq, d_v, d_qsum_opt, d_qsum_nopt, ws,
+                     rows);
+  MARL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, (const float*)ws, nb, 4, out4);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}

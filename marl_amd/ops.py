@@ -1,0 +1,245 @@
+"""Thin Python wrappers over the C ABI: torch tensors in, raw device pointers out.
+
+torch is used only for device memory and the stream handle (plumbing); every computation
+below is a hand-written HIP kernel from marl_amd/csrc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, check
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda, "expected a CUDA float32 tensor"
+    return t
+
+
+def _i32(t):
+    assert t.dtype == torch.int32 and t.is_cuda, "expected a CUDA int32 tensor"
+    return t
+
+
+class Workspace:
+    """Grow-only scratch buffers keyed by name (no allocation in steady state)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, nbytes, device):
+        n = (int(nbytes) + 3) // 4
+        b = self.bufs.get(name)
+        if b is None or b.numel() < n or b.device != device:
+            b = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+            self.bufs[name] = b
+        return b
+
+
+WS = Workspace()
+
+
+def src(x0=None, x1=None, idx=None, nhot=0, hot_w=0, nid=0, gate=None, remap0=None, remapi=None, k0=None):
+    """Build a marl_src_t.  x0/x1: 2-D (rows, k) float32 views with unit inner stride."""
+    s = MarlSrc()
+    keep = []
+    if x0 is not None:
+        _f32(x0); assert x0.dim() == 2 and x0.stride(1) == 1
+        s.p0, s.ld0, s.k0 = x0.data_ptr(), x0.stride(0), (x0.shape[1] if k0 is None else k0)
+        keep.append(x0)
+    if x1 is not None:
+        _f32(x1); assert x1.dim() == 2 and x1.stride(1) == 1
+        s.p1, s.ld1, s.k1 = x1.data_ptr(), x1.stride(0), x1.shape[1]
+        keep.append(x1)
+    if idx is not None:
+        _i32(idx)
+        s.idx, s.nhot, s.hot_w = idx.data_ptr(), nhot, hot_w
+        keep.append(idx)
+    s.nid = nid
+    if gate is not None:
+        _f32(gate); assert gate.dim() == 2 and gate.stride(1) == 1
+        s.m0, s.ldm0 = gate.data_ptr(), gate.stride(0)
+        keep.append(gate)
+    if remap0 is not None:
+        s.rpe0, s.bs0, s.off0 = remap0
+    if remapi is not None:
+        s.rpei, s.bsi, s.offi = remapi
+    s._keep = keep
+    return s
+
+
+def src_width(s):
+    return s.k0 + s.k1 + s.nhot * s.hot_w + s.nid
+
+
+def group(groups, x0=0, x1=0, w=0, b=0, y=0, m0=0):
+    return MarlGroup(groups, x0, x1, w, b, y, m0)
+
+
+def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, grp=None):
+    """Y[M,N] = act(X W^T + b) (+beta*Y).  W: (N,K) view, or (K,N) when w_kmajor."""
+    lib = _lib.load()
+    if ldw is None:
+        ldw = W.stride(0) if W.dim() == 2 else (N if w_kmajor else K)
+    ldy = Y.stride(0) if Y.dim() == 2 else N
+    assert src_width(x) == K, (src_width(x), K)
+    check(lib.marl_linear(C.byref(x), _p(_f32(W)), ldw, 1 if w_kmajor else 0, _p(bias), _p(_f32(Y)), ldy,
+                          M, N, K, act, float(beta), C.byref(grp) if grp is not None else None, _stream()),
+          "marl_linear")
+
+
+def linear_wgrad(dY, x, dW, db, M, N, K, Yact=None, grp=None, lddw=None):
+    """dW[N,K] += (dY * (Yact>0))^T X ; db[N] += column sums."""
+    lib = _lib.load()
+    g = grp.groups if grp is not None else 1
+    nbytes = lib.marl_linear_wgrad_workspace(M, N, K, g)
+    ws = WS.get("wgrad", nbytes, dY.device)
+    if lddw is None:
+        lddw = dW.stride(0) if dW.dim() == 2 else K
+    assert src_width(x) == K, (src_width(x), K)
+    check(lib.marl_linear_wgrad(_p(_f32(dY)), dY.stride(0) if dY.dim() == 2 else N,
+                                _p(Yact), (Yact.stride(0) if Yact.dim() == 2 else N) if Yact is not None else 0,
+                                C.byref(x), _p(_f32(dW)), lddw, _p(db), M, N, K,
+                                C.byref(grp) if grp is not None else None, _p(ws), ws.numel() * 4, _stream()),
+          "marl_linear_wgrad")
+
+
+def agent_weights(params):
+    """params: dict name -> tensor with RNNQNet keys."""
+    w = MarlAgentWeights()
+    w.fc1_w, w.fc1_b = params["fc1.weight"].data_ptr(), params["fc1.bias"].data_ptr()
+    w.w_ih, w.w_hh = params["rnn.weight_ih"].data_ptr(), params["rnn.weight_hh"].data_ptr()
+    w.b_ih, w.b_hh = params["rnn.bias_ih"].data_ptr(), params["rnn.bias_hh"].data_ptr()
+    w.fc2_w, w.fc2_b = params["fc2.weight"].data_ptr(), params["fc2.bias"].data_ptr()
+    w.H = params["rnn.weight_hh"].shape[1]
+    for k in ("fc1.weight", "rnn.weight_ih", "rnn.weight_hh", "fc2.weight"):
+        assert params[k].is_contiguous() and params[k].dtype == torch.float32 and params[k].is_cuda
+    w._keep = params
+    return w
+
+
+def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
+                     B, T, N, O, A, last_action=True, reuse_network=True):
+    lib = _lib.load()
+    check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(h0),
+                                    _p(_f32(q)), _p(hs), _p(h_last), _p(saved), B, T, N, O, A,
+                                    1 if last_action else 0, 1 if reuse_network else 0, _stream()),
+          "marl_agent_unroll_fwd")
+
+
+def agent_unroll_bwd(w, dq, dhs, saved, dgate, dxp, dh0, B, T, N, A):
+    lib = _lib.load()
+    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)), _p(dhs), _p(_f32(saved)), _p(_f32(dgate)),
+                                    _p(_f32(dxp)), _p(dh0), B, T, N, A, _stream()), "marl_agent_unroll_bwd")
+
+
+def q_gather(q, idx, out, rows, A):
+    check(_lib.load().marl_q_gather(_p(_f32(q)), _p(_i32(idx)), _p(_f32(out)), rows, A, _stream()), "marl_q_gather")
+
+
+def q_masked_max(q, avail, mask_val, out_max, out_arg, rows, A):
+    check(_lib.load().marl_q_masked_max(_p(_f32(q)), _p(avail), float(mask_val), _p(out_max), _p(out_arg), rows, A,
+                                        _stream()), "marl_q_masked_max")
+
+
+def q_scatter(dq, idx1, g1, idx2, g2, rows, A, gdiv=1):
+    check(_lib.load().marl_q_scatter(_p(_f32(dq)), _p(idx1), _p(g1), _p(idx2), _p(g2), rows, A, gdiv, _stream()),
+          "marl_q_scatter")
+
+
+def agent_sum(inp, out, rows, N, D):
+    check(_lib.load().marl_agent_sum(_p(_f32(inp)), _p(_f32(out)), rows, N, D, _stream()), "marl_agent_sum")
+
+
+def agent_bcast(inp, out, rows, N, D, accumulate=False):
+    check(_lib.load().marl_agent_bcast(_p(_f32(inp)), _p(_f32(out)), rows, N, D, 1 if accumulate else 0, _stream()),
+          "marl_agent_bcast")
+
+
+def qmix_mix_fwd(hy, b2, q, q_tot, rows, N, E):
+    check(_lib.load().marl_qmix_mix_fwd(_p(_f32(hy)), hy.stride(0), _p(_f32(b2)), _p(_f32(q)), _p(_f32(q_tot)), rows,
+                                        N, E, _stream()), "marl_qmix_mix_fwd")
+
+
+def qmix_mix_bwd(hy, q, dq_tot, dhy, db2, dq, rows, N, E):
+    assert dhy.stride(0) == hy.stride(0)
+    check(_lib.load().marl_qmix_mix_bwd(_p(_f32(hy)), hy.stride(0), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dhy)),
+                                        _p(_f32(db2)), _p(_f32(dq)), rows, N, E, _stream()), "marl_qmix_mix_bwd")
+
+
+def qplex_mix_fwd(w_raw, v, q, max_q, key, ag, ac, v_tot, a_tot, lam_out, rows, N, K, weighted, minus_one):
+    check(_lib.load().marl_qplex_mix_fwd(_p(w_raw), _p(v), _p(q), _p(max_q), _p(key), _p(ag), _p(ac), _p(v_tot),
+                                         _p(a_tot), _p(lam_out), rows, N, K, int(weighted), int(minus_one), _stream()),
+          "marl_qplex_mix_fwd")
+
+
+def qplex_mix_bwd(w_raw, q, max_q, key, ag, ac, g, dq, dw_raw, dv, dkey, dag, dac, rows, N, K, weighted, minus_one):
+    check(_lib.load().marl_qplex_mix_bwd(_p(w_raw), _p(q), _p(max_q), _p(key), _p(ag), _p(ac), _p(g), _p(dq),
+                                         _p(dw_raw), _p(dv), _p(dkey), _p(dag), _p(dac), rows, N, K, int(weighted),
+                                         int(minus_one), _stream()), "marl_qplex_mix_bwd")
+
+
+def td_loss(q_tot, q_tgt, r, term, padded, gamma, dq_tot, out2, rows):
+    lib = _lib.load()
+    ws = WS.get("loss", lib.marl_loss_workspace(rows), q_tot.device)
+    check(lib.marl_td_loss(_p(_f32(q_tot)), _p(_f32(q_tgt)), _p(_f32(r)), _p(_f32(term)), _p(_f32(padded)),
+                           float(gamma), _p(_f32(dq_tot)), _p(_f32(out2)), _p(ws), rows, _stream()), "marl_td_loss")
+
+
+def qtran_loss(jq, jq_tgt, v, jq_hat, qs_opt, qs_nopt, r, term, padded, gamma, lam_opt, lam_nopt,
+               d_jq, d_v, d_qso, d_qsn, out4, rows):
+    lib = _lib.load()
+    ws = WS.get("loss", lib.marl_loss_workspace(rows), jq.device)
+    check(lib.marl_qtran_loss(_p(jq), _p(jq_tgt), _p(v), _p(jq_hat), _p(qs_opt), _p(qs_nopt), _p(r), _p(term),
+                              _p(padded), float(gamma), float(lam_opt), float(lam_nopt), _p(d_jq), _p(d_v), _p(d_qso),
+                              _p(d_qsn), _p(out4), _p(ws), rows, _stream()), "marl_qtran_loss")
+
+
+def grad_sumsq(g, n, out1):
+    lib = _lib.load()
+    ws = WS.get("sumsq", lib.marl_sumsq_workspace(n), g.device)
+    check(lib.marl_grad_sumsq(_p(_f32(g)), n, _p(_f32(out1)), _p(ws), _stream()), "marl_grad_sumsq")
+
+
+def rmsprop_step(p, g, sq, n, lr, alpha, eps, clip, sumsq, den):
+    check(_lib.load().marl_rmsprop_step(_p(_f32(p)), _p(_f32(g)), _p(_f32(sq)), n, float(lr), float(alpha), float(eps),
+                                        float(clip), _p(sumsq), _p(den), _stream()), "marl_rmsprop_step")
+
+
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2s, clip, sumsq, den):
+    check(_lib.load().marl_adam_step(_p(_f32(p)), _p(_f32(g)), _p(_f32(m)), _p(_f32(v)), n, float(lr), float(b1),
+                                     float(b2), float(eps), float(bc1), float(bc2s), float(clip), _p(sumsq), _p(den),
+                                     _stream()), "marl_adam_step")
+
+
+def select_actions(q, avail, avail_es, alive, eps, rseed, env0, tg, tg0, act_out, act_es, E, N, A):
+    check(_lib.load().marl_select_actions(_p(_f32(q)), _p(_f32(avail)), avail_es, _p(alive), float(eps),
+                                          int(rseed) & 0xFFFFFFFF, env0, _p(tg), tg0, _p(_i32(act_out)), act_es,
+                                          E, N, A, _stream()), "marl_select_actions")
+
+
+def synth_lengths(seed, env0, episode, length, won, E, T):
+    check(_lib.load().marl_synth_lengths(int(seed) & 0xFFFFFFFF, env0, episode, _p(_i32(length)), _p(won), E, T,
+                                         _stream()), "marl_synth_lengths")
+
+
+def synth_observe(seed, env0, episode, t, length, obs, state, avail, E, T, N, O, S, A):
+    check(_lib.load().marl_synth_observe(int(seed) & 0xFFFFFFFF, env0, episode, t, _p(_i32(length)), _p(_f32(obs)),
+                                         _p(_f32(state)), _p(_f32(avail)), E, T, N, O, S, A, _stream()),
+          "marl_synth_observe")
+
+
+def synth_step(seed, env0, episode, t, length, act, u, r, term, padded, alive_next, E, T, N, A):
+    check(_lib.load().marl_synth_step(int(seed) & 0xFFFFFFFF, env0, episode, t, _p(_i32(length)), _p(_i32(act)),
+                                      _p(_i32(u)), _p(_f32(r)), _p(_f32(term)), _p(_f32(padded)), _p(alive_next),
+                                      E, T, N, A, _stream()), "marl_synth_step")
