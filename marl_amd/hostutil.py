@@ -1,0 +1,134 @@
+"""Host-side plumbing shared by the network / learner mirrors: flat parameter storage,
+a dense-layer helper that maps an nn.Linear onto the HIP kernels, and the device batch."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def require_cuda(what="the MARL hot path"):
+    if not torch.cuda.is_available():
+        raise RuntimeError("%s runs only on the MI355X HIP kernels (no CPU fallback); "
+                           "torch.cuda.is_available() is False" % what)
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class FlatParams:
+    """One contiguous fp32 device buffer (and one gradient buffer) behind a list of nn.Parameters.
+
+    The optimizer kernel, the gradient all-reduce and target-network sync then touch a single
+    buffer each.  Parameters keep their names/shapes, so state_dict()/deepcopy work as in torch.
+    """
+
+    def __init__(self, params, device, with_grad=True):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device) if with_grad else None
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = self.flat[off:off + k].view(p.shape)
+            if with_grad:
+                p.grad = self.grad[off:off + k].view(p.shape)
+            self.offsets.append(off)
+            off += k
+        self.n = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def flatten_module(module: nn.Module, device, with_grad=False):
+    fp = FlatParams(list(module.parameters()), device, with_grad=with_grad)
+    module._flat = fp
+    return fp
+
+
+class Lin:
+    """An nn.Linear (weight (N,K), bias (N)) driven through marl_linear / marl_linear_wgrad."""
+
+    def __init__(self, weight, bias):
+        self.w, self.b = weight, bias
+        self.N, self.K = weight.shape
+
+    def fwd(self, x, Y, M, act=0, beta=0.0):
+        ops.linear(x, self.w.data, self.b.data if self.b is not None else None, Y, M, self.N, self.K, act=act, beta=beta)
+
+    def bwd_x(self, dY, dX, M, Yact=None, beta=0.0):
+        """dX[M,K] (=|+=) (dY * relu'(Yact)) W"""
+        ops.linear(ops.src(dY, gate=Yact), self.w.data, None, dX, M, self.K, self.N, beta=beta, w_kmajor=True)
+
+    def wgrad(self, dY, x, M, Yact=None):
+        ops.linear_wgrad(dY, x, self.w.grad, self.b.grad if self.b is not None else None, M, self.N, self.K, Yact=Yact)
+
+
+def lin_of(module: nn.Linear):
+    return Lin(module.weight, module.bias)
+
+
+def to_dev(x, device, dtype=torch.float32):
+    """numpy / torch (any device, any dtype) -> contiguous device tensor of dtype."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x)).to(device=device, dtype=dtype).contiguous()
+
+
+def onehot_to_index(u_onehot):
+    """(…,A) one-hot or all-zero rows -> int32 index, -1 for all-zero rows (padding / t=0)."""
+    s = u_onehot.sum(-1)
+    idx = u_onehot.argmax(-1).to(torch.int32)
+    return torch.where(s > 0, idx, torch.full_like(idx, -1)).contiguous()
+
+
+class DeviceBatch:
+    """Kernel-ready view of the 11-key episode dict (reference rollout.py:135-146).
+
+    obs is addressed as (tensor, rows-per-episode, t0) so that (T+1)-slot storage serves both the
+    current (t0=0) and next (t0=1) passes without materialising o_next.
+    """
+
+    def __init__(self):
+        self.extra = {}
+
+    @staticmethod
+    def first_terminated_len(term, episode_limit):
+        """get_max_episode_len (algorithm/q_learner.py:49-66) on device: max over episodes of the first
+        terminated index + 1; episodes that never terminate are ignored; 0 -> episode_limit."""
+        t = (term.reshape(term.shape[0], -1)[:, :episode_limit] == 1)
+        anyt = t.any(dim=1)
+        first = t.to(torch.int32).argmax(dim=1) + 1
+        m = int(torch.where(anyt, first, torch.zeros_like(first)).max().item()) if t.shape[0] > 0 else 0
+        return m if m > 0 else episode_limit
+
+    @classmethod
+    def from_dict(cls, batch, args, device, T=None):
+        self = cls()
+        N, O, S, A = args.n_agents, args.obs_shape, args.state_shape, args.n_actions
+        term_full = to_dev(batch["terminated"], device)
+        if T is None:
+            T = cls.first_terminated_len(term_full, args.episode_limit)
+        B = term_full.shape[0]
+        self.B, self.T, self.N, self.O, self.S, self.A = B, T, N, O, S, A
+        cut = lambda k, dt=torch.float32: to_dev(batch[k][:, :T], device, dt)
+        o, o_next = cut("o"), cut("o_next")
+        self.o_cur = (o, T * N, 0)
+        self.o_next = (o_next, T * N, 0)
+        self.s = cut("s").view(B * T, S)
+        self.s_next = cut("s_next").view(B * T, S)
+        self.u_act = cut("u", torch.int32).view(B, T, N)
+        if "u_idx" in batch:
+            self.u_fed = cut("u_idx", torch.int32).view(B, T, N)
+        else:
+            self.u_fed = onehot_to_index(cut("u_onehot")).view(B, T, N)
+        self.r = cut("r").view(B * T)
+        self.term = term_full[:, :T].contiguous().view(B * T)
+        self.padded = cut("padded").view(B * T)
+        self.avail = cut("avail_u").view(B * T * N, A)
+        self.avail_next = cut("avail_u_next").view(B * T * N, A)
+        return self

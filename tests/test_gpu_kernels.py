@@ -1,0 +1,433 @@
+"""Kernel-level parity: every C-ABI entry point vs the CPU oracle / plain torch-CPU fp32.
+Needs a real MI355X: ``pytest -m gpu``.  Tolerances: 1e-4 absolute on O(1) fp32 values
+(north_star), tighter where the arithmetic is short."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import seeded, nets, rollout as orl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from marl_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def cu(x, dev, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to(dtype).to(dev).contiguous()
+
+
+def close(a, b, atol=1e-4, rtol=1e-4, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=atol, rtol=rtol, err_msg=msg)
+
+
+# ------------------------------------------------------------------------------------- dense
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 120, 0), (37, 11, 64, 1), (129, 1, 33, 0), (16, 70, 7, 1),
+                                       (2050, 64, 176, 1)])
+def test_linear_fwd(dev, M, N, K, act):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    X, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+    ref = F.linear(X, W, b)
+    if act:
+        ref = torch.relu(ref)
+    Xd, Wd, bd = cu(X, dev), cu(W, dev), cu(b, dev)
+    Y = torch.full((M, N), 7.0, device=dev)
+    ops.linear(ops.src(Xd), Wd, bd, Y, M, N, K, act=act)
+    close(Y, ref, 2e-4)
+    # dX = dY W through the k-major path, with relu gate and accumulate
+    Yact = torch.randn(M, N, generator=g)
+    dY = torch.randn(M, N, generator=g)
+    base = torch.randn(M, K, generator=g)
+    refdx = base + (dY * (Yact > 0)) @ W
+    dX = cu(base, dev)
+    ops.linear(ops.src(cu(dY, dev), gate=cu(Yact, dev)), Wd, None, dX, M, K, N, beta=1.0, w_kmajor=True)
+    close(dX, refdx, 3e-4)
+
+
+def test_linear_concat_and_groups(dev):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, K0, K1, NH, HW, NID = 75, 20, 9, 3, 4, 5
+    x0, x1 = torch.randn(M, K0, generator=g), torch.randn(M, K1, generator=g)
+    idx = torch.randint(-1, HW, (M, NH), generator=g)
+    oh = torch.zeros(M, NH, HW)
+    for j in range(NH):
+        v = idx[:, j] >= 0
+        oh[v, j, idx[v, j]] = 1
+    eye = torch.eye(NID)[torch.arange(M) % NID]
+    Xfull = torch.cat([x0, x1, oh.reshape(M, -1), eye], 1)
+    K = Xfull.shape[1]
+    W, b = torch.randn(13, K, generator=g), torch.randn(13, generator=g)
+    Y = torch.empty(M, 13, device=dev)
+    s = ops.src(cu(x0, dev), cu(x1, dev), cu(idx, dev, torch.int32), NH, HW, NID)
+    ops.linear(s, cu(W, dev), cu(b, dev), Y, M, 13, K)
+    close(Y, F.linear(Xfull, W, b), 2e-4)
+    # weight gradient of the same virtual input
+    dY = torch.randn(M, 13, generator=g)
+    dW, db = torch.zeros(13, K, device=dev), torch.zeros(13, device=dev)
+    ops.linear_wgrad(cu(dY, dev), s, dW, db, M, 13, K)
+    close(dW, dY.t() @ Xfull, 3e-4)
+    close(db, dY.sum(0), 3e-4)
+    # grouped: 4 heads, shared input, strided weights inside one flat buffer, strided output columns
+    G, N, Kg = 4, 6, 40
+    X = torch.randn(M, Kg, generator=g)
+    per = N * Kg + N
+    flat = torch.randn(G * per, generator=g)
+    fd = cu(flat, dev)
+    Y = torch.zeros(M, G * N, device=dev)
+    grp = ops.group(G, w=per, b=per, y=N)
+    ops.linear(ops.src(cu(X, dev)), fd[:N * Kg].view(N, Kg), fd[N * Kg:per], Y, M, N, Kg, act=1, grp=grp)
+    for k in range(G):
+        Wk, bk = flat[k * per:k * per + N * Kg].view(N, Kg), flat[k * per + N * Kg:(k + 1) * per]
+        close(Y[:, k * N:(k + 1) * N], torch.relu(F.linear(X, Wk, bk)), 2e-4, msg="group %d" % k)
+    # grouped wgrad with relu gate
+    dYg = torch.randn(M, G * N, generator=g)
+    gflat = torch.zeros(G * per, device=dev)
+    ops.linear_wgrad(cu(dYg, dev), ops.src(cu(X, dev)), gflat[:N * Kg].view(N, Kg), gflat[N * Kg:per], M, N, Kg,
+                     Yact=Y, grp=ops.group(G, w=per, b=per, y=N, m0=N))
+    Yc = Y.cpu()
+    for k in range(G):
+        Gk = dYg[:, k * N:(k + 1) * N] * (Yc[:, k * N:(k + 1) * N] > 0)
+        close(gflat[k * per:k * per + N * Kg].view(N, Kg), Gk.t() @ X, 3e-4)
+        close(gflat[k * per + N * Kg:(k + 1) * per], Gk.sum(0), 3e-4)
+
+
+def test_wgrad_large_rows_and_remap(dev):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, T, N, O = 6, 50, 5, 24            # (T+1)-slot storage read through the row remap
+    store = torch.randn(B, T + 1, N, O, generator=g)
+    u = torch.randint(-1, 7, (B, T, N), generator=g)
+    dY = torch.randn(B * T * N, 64, generator=g)
+    for t0, uoff in ((0, -1), (1, 0)):
+        xs = store[:, t0:t0 + T].reshape(B * T * N, O)
+        up = torch.full((B, T, N), -1, dtype=torch.long)
+        if uoff == -1:
+            up[:, 1:] = u[:, :-1]
+        else:
+            up = u.clone()
+        oh = torch.zeros(B * T * N, 7)
+        flat = up.reshape(-1)
+        oh[flat >= 0, flat[flat >= 0]] = 1
+        Xfull = torch.cat([xs, oh, torch.eye(N)[torch.arange(B * T * N) % N]], 1)
+        K = Xfull.shape[1]
+        s = ops.src(cu(store.reshape(-1, O), dev), idx=cu(u.reshape(-1, 1), dev, torch.int32), nhot=1, hot_w=7, nid=N,
+                    remap0=(T * N, (T + 1) * N, t0 * N), remapi=(T * N, T * N, uoff * N))
+        dW, db = torch.zeros(64, K, device=dev), torch.zeros(64, device=dev)
+        ops.linear_wgrad(cu(dY, dev), s, dW, db, B * T * N, 64, K)
+        close(dW, dY.t() @ Xfull, 2e-3, 1e-3)
+        Y = torch.empty(B * T * N, 10, device=dev)
+        W = torch.randn(10, K, generator=g)
+        ops.linear(s, cu(W, dev), None, Y, B * T * N, 10, K)
+        close(Y, Xfull @ W.t(), 3e-4)
+
+
+# ------------------------------------------------------------------------------------- agent
+def _agent_case(shape, B, T, dev, seed=0, with_h0=False):
+    args = seeded.make_args(shape, "qmix", episode_limit=T)
+    p_np = seeded.seeded_state(seeded.agent_param_shapes(args), seed=11 + seed, scale=2.0)
+    rng = np.random.default_rng(seed)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    obs = rng.standard_normal((B, T, N, O)).astype(np.float32)
+    ufed = rng.integers(-1, A, size=(B, T, N))
+    h0 = rng.standard_normal((B * N, 64)).astype(np.float32) * 0.5 if with_h0 else None
+    return args, p_np, obs, ufed, h0
+
+
+def _oracle_unroll(args, p_np, obs, ufed, h0, requires_grad=False):
+    p = {k: torch.tensor(v, requires_grad=requires_grad) for k, v in p_np.items()}
+    B, T, N, O = obs.shape
+    A = args.n_actions
+    oh = np.zeros((B, T, N, A), np.float32)
+    bb, tt, nn = np.nonzero(ufed >= 0)
+    oh[bb, tt, nn, ufed[bb, tt, nn]] = 1
+    h = torch.zeros(B * N, 64) if h0 is None else torch.tensor(h0)
+    q, hs, hl = nets.agent_unroll(p, torch.tensor(obs), torch.tensor(oh), h)
+    return p, q, hs, hl
+
+
+@pytest.mark.parametrize("shape,B,T,with_h0", [("2s3z", 7, 5, False), ("2s3z", 70, 3, True), ("matrix", 9, 1, False),
+                                               ("3s5z", 5, 4, True), ("MMM2", 4, 3, False)])
+def test_agent_unroll_fwd(dev, shape, B, T, with_h0):
+    from marl_amd import ops
+    args, p_np, obs, ufed, h0 = _agent_case(shape, B, T, dev, with_h0=with_h0)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    with torch.no_grad():
+        _, q_ref, hs_ref, hl_ref = _oracle_unroll(args, p_np, obs, ufed, h0)
+    pd = {k: cu(v, dev) for k, v in p_np.items()}
+    w = ops.agent_weights(pd)
+    q = torch.empty(B, T, N, A, device=dev)
+    hs = torch.empty(B, T, N, 64, device=dev)
+    hl = torch.empty(B * N, 64, device=dev)
+    saved = torch.empty(6, B, T, N, 64, device=dev)
+    ops.agent_unroll_fwd(w, cu(obs, dev), T * N, 0, cu(ufed, dev, torch.int32), T * N, 0,
+                         cu(h0, dev) if h0 is not None else None, q, hs, hl, saved, B, T, N, O, A)
+    close(q, q_ref, 1e-4, msg="q")
+    close(hs, hs_ref, 1e-4, msg="hs")
+    close(hl, hl_ref, 1e-4, msg="h_last")
+    # saved plane 0 is the hidden state fed INTO each step
+    hprev = torch.cat([(torch.zeros(B, 1, N, 64) if h0 is None else torch.tensor(h0).view(B, 1, N, 64)), hs_ref[:, :-1]], 1)
+    close(saved[0], hprev, 1e-4, msg="hprev")
+
+
+def test_agent_unroll_shifted_storage(dev):
+    """(T+1)-slot observation storage + one-step shifted last action == the o / o_next passes."""
+    from marl_amd import ops
+    B, T = 5, 4
+    args, p_np, _, _, _ = _agent_case("2s3z", B, T, dev)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    rng = np.random.default_rng(3)
+    store = rng.standard_normal((B, T + 1, N, O)).astype(np.float32)
+    u = rng.integers(-1, A, size=(B, T, N))
+    pd = {k: cu(v, dev) for k, v in p_np.items()}
+    w = ops.agent_weights(pd)
+    sd, ud = cu(store, dev), cu(u, dev, torch.int32)
+    for t0, ut0 in ((0, -1), (1, 0)):
+        ufed = np.full((B, T, N), -1)
+        if ut0 == -1:
+            ufed[:, 1:] = u[:, :-1]
+        else:
+            ufed = u
+        with torch.no_grad():
+            _, q_ref, hs_ref, _ = _oracle_unroll(args, p_np, store[:, t0:t0 + T], ufed, None)
+        q = torch.empty(B, T, N, A, device=dev)
+        ops.agent_unroll_fwd(w, sd, (T + 1) * N, t0, ud, T * N, ut0, None, q, None, None, None, B, T, N, O, A)
+        close(q, q_ref, 1e-4)
+
+
+@pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6)])
+def test_agent_unroll_bwd(dev, shape, B, T):
+    """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll."""
+    from marl_amd import ops
+    args, p_np, obs, ufed, h0 = _agent_case(shape, B, T, dev, seed=1)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    I = O + A + N
+    p, q_ref, hs_ref, _ = _oracle_unroll(args, p_np, obs, ufed, None, requires_grad=True)
+    g = torch.Generator().manual_seed(2)
+    dq = torch.randn(B, T, N, A, generator=g)
+    dhs = torch.randn(B, T, N, 64, generator=g) * 0.3
+    ((q_ref * dq).sum() + (hs_ref * dhs).sum()).backward()
+
+    pd = {k: cu(v, dev) for k, v in p_np.items()}
+    w = ops.agent_weights(pd)
+    q = torch.empty(B, T, N, A, device=dev)
+    hs = torch.empty(B, T, N, 64, device=dev)
+    saved = torch.empty(6, B, T, N, 64, device=dev)
+    obs_d, u_d = cu(obs, dev), cu(ufed, dev, torch.int32)
+    ops.agent_unroll_fwd(w, obs_d, T * N, 0, u_d, T * N, 0, None, q, hs, None, saved, B, T, N, O, A)
+    dgate = torch.empty(B, T, N, 256, device=dev)
+    dxp = torch.empty(B, T, N, 64, device=dev)
+    dq_d = cu(dq, dev)
+    ops.agent_unroll_bwd(w, dq_d, cu(dhs, dev), saved, dgate, dxp, None, B, T, N, A)
+    M = B * T * N
+    grads = {k: torch.zeros_like(v) for k, v in pd.items()}
+    dg2 = dgate.view(M, 256)
+    ops.linear_wgrad(dg2[:, :192], ops.src(saved[1].view(M, 64)), grads["rnn.weight_ih"], grads["rnn.bias_ih"], M, 192, 64)
+    ops.linear_wgrad(dg2[:, :128], ops.src(saved[0].view(M, 64)), grads["rnn.weight_hh"][:128], grads["rnn.bias_hh"][:128], M, 128, 64)
+    ops.linear_wgrad(dg2[:, 192:], ops.src(saved[0].view(M, 64)), grads["rnn.weight_hh"][128:], grads["rnn.bias_hh"][128:], M, 64, 64)
+    ops.linear_wgrad(dq_d.view(M, A), ops.src(hs.view(M, 64)), grads["fc2.weight"], grads["fc2.bias"], M, A, 64)
+    ops.linear_wgrad(dxp.view(M, 64), ops.src(obs_d.view(M, O), idx=u_d.view(M, 1), nhot=1, hot_w=A, nid=N),
+                     grads["fc1.weight"], grads["fc1.bias"], M, 64, I)
+    for k in p:
+        ref = p[k].grad
+        scale = max(1.0, float(ref.abs().max()))
+        close(grads[k] / scale, ref / scale, 2e-4, 1e-3, msg=k)
+
+
+# ------------------------------------------------------------------------------------- per-row
+def test_select_kernels(dev):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    R, A = 1000, 11
+    q = torch.randn(R, A, generator=g)
+    q[5, 3] = q[5, 7] = 9.0        # tie -> first index
+    avail = (torch.rand(R, A, generator=g) < 0.7).float()
+    avail[:, 0] = 1
+    idx = torch.randint(0, A, (R,), generator=g)
+    qd, ad, idd = cu(q, dev), cu(avail, dev), cu(idx, dev, torch.int32)
+    out = torch.empty(R, device=dev)
+    ops.q_gather(qd, idd, out, R, A)
+    close(out, q.gather(1, idx[:, None]).squeeze(1), 0, 0)
+    qm = q.clone(); qm[avail == 0] = -9999999.0
+    mx, am = torch.empty(R, device=dev), torch.empty(R, dtype=torch.int32, device=dev)
+    ops.q_masked_max(qd, ad, -9999999.0, mx, am, R, A)
+    close(mx, qm.max(1)[0], 0, 0)
+    assert (am.cpu().long() == qm.argmax(1)).all()
+    g1, g2 = torch.randn(R // 5, generator=g), torch.randn(R // 5, generator=g)
+    dq = torch.empty(R, A, device=dev)
+    ops.q_scatter(dq, idd, cu(g1, dev), am, cu(g2, dev), R, A, gdiv=5)
+    ref = torch.zeros(R, A)
+    ref[torch.arange(R), idx] += g1.repeat_interleave(5)
+    ref[torch.arange(R), qm.argmax(1)] += g2.repeat_interleave(5)
+    close(dq, ref, 1e-6)
+    x = torch.randn(40, 5, 7, generator=g)
+    s = torch.empty(40, 7, device=dev)
+    ops.agent_sum(cu(x, dev), s, 40, 5, 7)
+    close(s, x.sum(1), 1e-5)
+    bc = cu(x, dev)
+    ops.agent_bcast(s, bc, 40, 5, 7, accumulate=True)
+    close(bc, x + x.sum(1, keepdim=True), 1e-5)
+
+
+def test_qmix_mix(dev):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(6)
+    R, N, E = 333, 5, 32
+    Wd = N * E + 3 * E
+    hy = torch.randn(R, Wd, generator=g, requires_grad=True)
+    b2 = torch.randn(R, generator=g, requires_grad=True)
+    q = torch.randn(R, N, generator=g, requires_grad=True)
+    w1 = hy[:, :N * E].abs().view(R, N, E)
+    hid = F.elu((q.unsqueeze(2) * w1).sum(1) + hy[:, N * E:N * E + E])
+    qt = (hid * hy[:, N * E + E:N * E + 2 * E].abs()).sum(1) + b2
+    gq = torch.randn(R, generator=g)
+    (qt * gq).sum().backward()
+    hyd, qd = cu(hy.detach(), dev), cu(q.detach(), dev)
+    out = torch.empty(R, device=dev)
+    ops.qmix_mix_fwd(hyd, cu(b2.detach(), dev), qd, out, R, N, E)
+    close(out, qt, 1e-4)
+    dhy = torch.zeros(R, Wd, device=dev)
+    db2, dq = torch.empty(R, device=dev), torch.empty(R, N, device=dev)
+    ops.qmix_mix_bwd(hyd, qd, cu(gq, dev), dhy, db2, dq, R, N, E)
+    close(dhy[:, :N * E + 2 * E], hy.grad[:, :N * E + 2 * E], 1e-4)
+    close(db2, b2.grad, 1e-6)
+    close(dq, q.grad, 1e-4)
+
+
+def test_qplex_mix(dev):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(7)
+    R, N, K = 257, 5, 10
+    t = lambda *s: torch.randn(*s, generator=g, requires_grad=True)
+    w_raw, v, q, key, ag, ac = t(R, N), t(R, N), t(R, N), t(R, K), t(R, K, N), t(R, K, N)
+    mx = q.detach() + torch.rand(R, N, generator=g)
+    w = w_raw.abs() + 1e-10
+    qt = w * q + v
+    mt = w * mx + v
+    lam = ((key.abs() + 1e-10).unsqueeze(2) * torch.sigmoid(ag) * torch.sigmoid(ac)).sum(1)
+    v_tot = qt.sum(1)
+    a_tot = ((qt - mt).detach() * (lam - 1)).sum(1)
+    gq = torch.randn(R, generator=g)
+    ((v_tot + a_tot) * gq).sum().backward()
+    d = lambda x: cu(x.detach(), dev)
+    vt, at, lo = torch.empty(R, device=dev), torch.empty(R, device=dev), torch.empty(R, N, device=dev)
+    ops.qplex_mix_fwd(d(w_raw), d(v), d(q), d(mx), d(key), d(ag), d(ac), vt, at, lo, R, N, K, True, True)
+    close(vt, v_tot, 1e-4); close(at, a_tot, 1e-4); close(lo, lam, 1e-4)
+    outs = [torch.empty_like(d(x)) for x in (q, w_raw, v, key, ag, ac)]
+    ops.qplex_mix_bwd(d(w_raw), d(q), d(mx), d(key), d(ag), d(ac), cu(gq, dev), *outs, R, N, K, True, True)
+    for o, ref in zip(outs, (q, w_raw, v, key, ag, ac)):
+        close(o, ref.grad, 1e-4)
+
+
+def test_losses_and_optimizer(dev):
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(8)
+    R = 5000
+    qt, qg, r = torch.randn(R, generator=g), torch.randn(R, generator=g), torch.randn(R, generator=g)
+    term = (torch.rand(R, generator=g) < 0.1).float()
+    pad = (torch.rand(R, generator=g) < 0.2).float()
+    mask = 1 - pad
+    td = (r + 0.99 * qg * (1 - term)) - qt
+    out2, dqt = torch.empty(2, device=dev), torch.empty(R, device=dev)
+    ops.td_loss(cu(qt, dev), cu(qg, dev), cu(r, dev), cu(term, dev), cu(pad, dev), 0.99, dqt, out2, R)
+    close(out2, torch.stack([((mask * td) ** 2).sum(), mask.sum()]), rtol=1e-5, atol=1e-3)
+    close(dqt, -2 * mask * td, 1e-5)
+    # qtran
+    jq, jt, v, jh, so, sn = [torch.randn(R, generator=g) for _ in range(6)]
+    jq.requires_grad_(True); v.requires_grad_(True); so.requires_grad_(True); sn.requires_grad_(True)
+    y = r + 0.99 * jt * (1 - term)
+    l_td = (((jq - y) * mask) ** 2).sum()
+    l_opt = (((so - jh + v) * mask) ** 2).sum()
+    l_nopt = (((sn - jq.detach() + v).clamp(max=0) * mask) ** 2).sum()
+    (l_td + 1.0 * l_opt + 1.0 * l_nopt).backward()
+    d = lambda x: cu(x.detach(), dev)
+    outs = [torch.empty(R, device=dev) for _ in range(4)]
+    out4 = torch.empty(4, device=dev)
+    ops.qtran_loss(d(jq), d(jt), d(v), d(jh), d(so), d(sn), cu(r, dev), cu(term, dev), cu(pad, dev), 0.99, 1.0, 1.0,
+                   *outs, out4, R)
+    close(out4, torch.stack([l_td, l_opt, l_nopt, mask.sum()]).detach(), rtol=1e-5, atol=1e-2)
+    for o, ref in zip(outs, (jq, v, so, sn)):
+        close(o, ref.grad, 1e-5)
+    # optimizer: clip + RMSprop / Adam against torch.optim on the normalised gradient
+    n = 70001
+    for kind in ("RMS", "Adam"):
+        p0 = torch.randn(n, generator=g)
+        pt = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.RMSprop([pt], lr=5e-4) if kind == "RMS" else torch.optim.Adam([pt], lr=5e-4)
+        pd = cu(p0, dev)
+        s1, s2 = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        den = cu(np.array([37.0]), dev)
+        sumsq = torch.empty(1, device=dev)
+        for step in range(1, 4):
+            graw = torch.randn(n, generator=g) * (50.0 if step == 1 else 0.5)
+            pt.grad = graw / 37.0
+            torch.nn.utils.clip_grad_norm_([pt], 10)
+            opt.step()
+            gd = cu(graw, dev)
+            ops.grad_sumsq(gd, n, sumsq)
+            if kind == "RMS":
+                ops.rmsprop_step(pd, gd, s1, n, 5e-4, 0.99, 1e-8, 10, sumsq, den)
+            else:
+                ops.adam_step(pd, gd, s1, s2, n, 5e-4, 0.9, 0.999, 1e-8, 1 - 0.9 ** step, (1 - 0.999 ** step) ** 0.5,
+                              10, sumsq, den)
+            close(pd, pt.detach(), 2e-6, 1e-5, msg="%s step %d" % (kind, step))
+
+
+def test_rollout_kernels_match_numpy_env(dev):
+    from marl_amd import ops
+    E, T, N, O, S, A = 9, 6, 5, 80, 120, 11
+    sy = orl.SynthSMAC(N, O, S, A, T, seed=5)
+    env = np.arange(3, 3 + E)
+    length = torch.empty(E, dtype=torch.int32, device=dev)
+    won = torch.empty(E, dtype=torch.int32, device=dev)
+    ops.synth_lengths(5, 3, 2, length, won, E, T)
+    L = sy.length(env, np.full(E, 2))
+    assert (length.cpu().numpy() == L).all()
+    assert (won.cpu().numpy().astype(bool) == sy.won(env, np.full(E, 2))).all()
+    obs = torch.empty(E, T + 1, N, O, device=dev); st = torch.empty(E, T + 1, S, device=dev)
+    av = torch.empty(E, T + 1, N, A, device=dev)
+    u = torch.empty(E, T, N, dtype=torch.int32, device=dev)
+    r, term, pad = (torch.empty(E, T, device=dev) for _ in range(3))
+    alive = torch.ones(E, dtype=torch.int32, device=dev)
+    act = torch.empty(E, N, dtype=torch.int32, device=dev)
+    rng = np.random.default_rng(0)
+    for t in range(T + 1):
+        ops.synth_observe(5, 3, 2, t, length, obs, st, av, E, T, N, O, S, A)
+        live = (t <= L)
+        ro = sy.obs(env, np.full(E, 2), t) * live[:, None, None]
+        np.testing.assert_array_equal(obs[:, t].cpu().numpy(), ro.astype(np.float32))
+        np.testing.assert_array_equal(st[:, t].cpu().numpy(), (sy.state(env, np.full(E, 2), t) * live[:, None]).astype(np.float32))
+        ra = sy.avail(env, np.full(E, 2), t) * live[:, None, None]
+        np.testing.assert_array_equal(av[:, t].cpu().numpy(), ra.astype(np.float32))
+        if t == T:
+            break
+        # epsilon-greedy selection vs the numpy formula
+        q = rng.standard_normal((E, N, A)).astype(np.float32)
+        ops.select_actions(cu(q, dev), av[:, t], (T + 1) * N * A, alive, 0.4, 77, 3, None, 2 * (T + 1) + t, act, N, E, N, A)
+        a_t = ra
+        qm = q.copy(); qm[a_t == 0] = -np.inf
+        tg = np.full((E, 1), 2 * (T + 1) + t)
+        explore = orl.u01(orl.key(77, orl.ST_EXPLORE, env[:, None], tg, np.arange(N)[None])) < np.float32(0.4)
+        nav = a_t.sum(-1).astype(np.int64)
+        k = np.floor(orl.u01(orl.key(77, orl.ST_PICK, env[:, None], tg, np.arange(N)[None])) * nav.astype(np.float32)).astype(np.int64)
+        k = np.minimum(k, np.maximum(nav - 1, 0))
+        pick = (np.cumsum(a_t, -1) <= k[..., None]).sum(-1)
+        ref_act = np.where(explore, pick, qm.argmax(-1))
+        got = act.cpu().numpy()
+        al = alive.cpu().numpy().astype(bool)
+        assert (got[al] == ref_act[al]).all()
+        assert (got[~al] == -1).all()
+        ops.synth_step(5, 3, 2, t, length, act, u, r, term, pad, alive, E, T, N, A)
+        rr = sy.reward(env, np.full(E, 2), t, np.where(got < 0, 0, got))
+        livet = t < L
+        np.testing.assert_array_equal(r[:, t].cpu().numpy(), np.where(livet, rr, 0).astype(np.float32))
+        np.testing.assert_array_equal(pad[:, t].cpu().numpy(), (~livet).astype(np.float32))
+        np.testing.assert_array_equal(term[:, t].cpu().numpy(), np.where(livet, (t + 1 >= L), 1).astype(np.float32))
+        assert (alive.cpu().numpy() == (t + 1 < L)).all()
