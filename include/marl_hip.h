@@ -88,8 +88,10 @@ int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const 
                           int B, int T, int N, int A, void* stream);
 
 /* ---- per-row kernels (mixers.hip) -----------------------------------------------------------*/
-/* out[row] = q[row,idx[row]] (th.gather, q_learner.py:100,114); idx < 0 -> 0 */
-int marl_q_gather(const float* q, const int* idx, float* out, long rows, int A, void* stream);
+/* out[row] = q[row,idx[row]] (th.gather, q_learner.py:100,114); idx < 0 -> 0.  With avail != NULL the
+ * value read is the masked one: avail[row,idx]==0 ? mask_val : q (q_learner.py:105 then :114). */
+int marl_q_gather(const float* q, const int* idx, const float* avail, float mask_val, float* out,
+                  long rows, int A, void* stream);
 /* q[avail==0] = mask_val; max / first-index argmax over actions (q_learner.py:105,112-117,125-127;
  * qtran_learner.py:104-113). avail may be NULL. out_max / out_arg may be NULL. */
 int marl_q_masked_max(const float* q, const float* avail, float mask_val, float* out_max, int* out_arg,
@@ -98,6 +100,8 @@ int marl_q_masked_max(const float* q, const float* avail, float mask_val, float*
  * NULL): autograd of gather / max (+ of the sum over agents when gdiv = N). */
 int marl_q_scatter(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,
                    long rows, int A, int gdiv, void* stream);
+/* out = a + b (q_tot = v_tot + a_tot, q_learner.py:135,154) */
+int marl_vec_add(const float* a, const float* b, float* out, long n, void* stream);
 /* out[r,d] = sum_n in[r,n,d]   (VDNMixer, mixer.py:15-16 with D=1; QTRAN .sum(dim=-2), :384,:414) */
 int marl_agent_sum(const float* in, float* out, long rows, int N, int D, void* stream);
 /* out[r,n,d] = in[r,d] (+ out if accumulate): autograd of the sum above */

@@ -48,9 +48,10 @@ SIGNATURES = {
     "marl_wgrad_slabs": (I, [I]),
     "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, P, I, I, I, I, P]),
-    "marl_q_gather": (I, [P, P, P, L, I, P]),
+    "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),
     "marl_q_masked_max": (I, [P, P, F, P, P, L, I, P]),
     "marl_q_scatter": (I, [P, P, P, P, P, L, I, I, P]),
+    "marl_vec_add": (I, [P, P, P, L, P]),
     "marl_agent_sum": (I, [P, P, L, I, I, P]),
     "marl_agent_bcast": (I, [P, P, L, I, I, I, P]),
     "marl_qmix_mix_fwd": (I, [P, L, P, P, P, L, I, I, P]),

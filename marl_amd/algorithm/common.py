@@ -1,0 +1,149 @@
+"""Shared machinery of the two learners: flat parameter/gradient storage with a statistics
+tail, the fused clip+optimizer wrapper, the agent backward pass and data-parallel reduction."""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..hostutil import FlatParams
+
+MASK_BIG = -9999999.0        # reference algorithm/q_learner.py:105,112,126 ; qtran_learner.py:106
+MASK_QTRAN_EVAL = -999999.0  # reference algorithm/qtran_learner.py:105
+N_STATS = 4                  # tail of the gradient buffer: loss numerators + sum(mask)
+
+
+class FlatView:
+    """A slice of a FlatParams buffer that belongs to one module (for single-copy target sync)."""
+
+    def __init__(self, flat, params, start):
+        self.params = list(params)
+        self.n = sum(p.numel() for p in self.params)
+        self.flat = flat[start:start + self.n]
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+
+
+class LearnerParams(FlatParams):
+    """All trainable parameters of a learner in ONE buffer; the gradient buffer carries N_STATS
+    extra floats so that gradients and loss statistics travel in a single all-reduce."""
+
+    def __init__(self, params, device):
+        params = list(params)
+        super().__init__(params, device, with_grad=False)
+        self.gradx = torch.zeros(self.n + N_STATS, dtype=torch.float32, device=device)
+        self.grad = self.gradx[:self.n]
+        self.stats = self.gradx[self.n:]
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.gradx.zero_()
+
+
+class FusedOptimizer:
+    """clip_grad_norm_ + RMSprop / Adam (torch defaults; reference q_learner.py:42-47,170-173) as
+    two kernel launches over the flat buffer.  ``step(den)`` divides the gradient by den[0]
+    (= global sum(mask)) inside the kernel."""
+
+    def __init__(self, flat: LearnerParams, kind, lr, clip):
+        if kind not in ("RMS", "Adam"):
+            raise ValueError("optimizer {} not recognised.".format(kind))
+        self.flat, self.kind, self.lr, self.clip = flat, kind, lr, clip
+        dev = flat.flat.device
+        self.s1 = torch.zeros(flat.n, device=dev)
+        self.s2 = torch.zeros(flat.n, device=dev) if kind == "Adam" else None
+        self.sumsq = torch.zeros(1, device=dev)
+        self.t = 0
+        self.param_groups = [{"params": flat.params, "lr": lr}]
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self, den=None):
+        f = self.flat
+        self.t += 1
+        ops.grad_sumsq(f.grad, f.n, self.sumsq)
+        if self.kind == "RMS":
+            ops.rmsprop_step(f.flat, f.grad, self.s1, f.n, self.lr, 0.99, 1e-8, self.clip, self.sumsq, den)
+        else:
+            ops.adam_step(f.flat, f.grad, self.s1, self.s2, f.n, self.lr, 0.9, 0.999, 1e-8,
+                          1.0 - 0.9 ** self.t, (1.0 - 0.999 ** self.t) ** 0.5, self.clip, self.sumsq, den)
+
+    def state_dict(self):
+        return {"kind": self.kind, "t": self.t, "s1": self.s1.cpu(), "s2": None if self.s2 is None else self.s2.cpu()}
+
+    def load_state_dict(self, sd):
+        self.t = sd["t"]
+        self.s1.copy_(sd["s1"])
+        if self.s2 is not None and sd["s2"] is not None:
+            self.s2.copy_(sd["s2"])
+
+
+class Scratch:
+    def __init__(self):
+        self.d = {}
+
+    def get(self, name, shape, device, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.d.get(key)
+        if t is None or t.device != device:
+            t = torch.empty(*shape, dtype=dtype, device=device)
+            self.d[key] = t
+        return t
+
+
+def agent_backward(mac, db, which, saved, hs, dq, dhs, buf):
+    """BPTT of the eval unroll: delta kernel, then the five weight-gradient reductions
+    (autograd of controller/share_params.py:125-146 + network/q_network.py:16-21)."""
+    args = mac.args
+    B, T, N, A, O = db.B, db.T, db.N, db.A, db.O
+    H = args.rnn_hidden_dim
+    M = B * T * N
+    dev = dq.device
+    dgate = buf.get("dgate", (B, T, N, 4 * H), dev)
+    dxp = buf.get("dxp", (B, T, N, H), dev)
+    w = mac.agent.weights()
+    ops.agent_unroll_bwd(w, dq, dhs, saved, dgate, dxp, None, B, T, N, A)
+    ag = mac.agent
+    dg = dgate.view(M, 4 * H)
+    hprev, x = saved[0].view(M, H), saved[1].view(M, H)
+    ops.linear_wgrad(dg[:, :3 * H], ops.src(x), ag.rnn.weight_ih.grad, ag.rnn.bias_ih.grad, M, 3 * H, H)
+    ops.linear_wgrad(dg[:, :2 * H], ops.src(hprev), ag.rnn.weight_hh.grad[:2 * H], ag.rnn.bias_hh.grad[:2 * H], M, 2 * H, H)
+    ops.linear_wgrad(dg[:, 3 * H:], ops.src(hprev), ag.rnn.weight_hh.grad[2 * H:], ag.rnn.bias_hh.grad[2 * H:], M, H, H)
+    ops.linear_wgrad(dq.view(M, A), ops.src(hs.view(M, H)), ag.fc2.weight.grad, ag.fc2.bias.grad, M, A, H)
+    obs, obs_bs, obs_t0 = db.o_cur if which == "cur" else db.o_next
+    remap0 = None if (obs_bs == T * N and obs_t0 == 0) else (T * N, obs_bs, obs_t0 * N)
+    kw = {}
+    if args.last_action:
+        kw.update(idx=db.u_fed.reshape(-1, 1), nhot=1, hot_w=A, remapi=(T * N, db.u_bs, (-1 if which == "cur" else 0) * N))
+    xin = ops.src(obs.reshape(-1, O), nid=N if args.reuse_network else 0, remap0=remap0, **kw)
+    I = O + (A if args.last_action else 0) + (N if args.reuse_network else 0)
+    ops.linear_wgrad(dxp.view(M, H), xin, ag.fc1.weight.grad, ag.fc1.bias.grad, M, H, I)
+
+
+class GradReducer:
+    """Data-parallel exchange step: ONE all-reduce(sum) of [gradients | loss numerators | sum(mask)]
+    over RCCL/xGMI (SURVEY 8e exactness rule: un-normalised numerators are summed, the division by
+    the GLOBAL sum(mask) happens afterwards in the optimizer kernel)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def allreduce_(self, flat_with_stats):
+        if self.enabled:
+            self.dist.all_reduce(flat_with_stats, op=self.dist.ReduceOp.SUM, group=self.group)
+        return flat_with_stats
+
+    def max_int(self, value, device):
+        """global max of a host integer (used for the global max_episode_len)."""
+        if not self.enabled:
+            return value
+        t = torch.tensor([value], dtype=torch.int64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())

@@ -14,10 +14,13 @@ inline int nblk(long n, int cap = 65535 * 16) {
   return (int)b;
 }
 
-__global__ void q_gather_kernel(const float* q, const int* idx, float* out, long rows, int A) {
+__global__ void q_gather_kernel(const float* q, const int* idx, const float* avail, float mask_val, float* out,
+                                long rows, int A) {
   for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
     const int a = idx[r];
-    out[r] = a >= 0 ? q[r * A + a] : 0.f;
+    float v = 0.f;
+    if (a >= 0) v = (avail && avail[r * A + a] == 0.f) ? mask_val : q[r * A + a];
+    out[r] = v;
   }
 }
 
@@ -50,6 +53,10 @@ __global__ void q_scatter_kernel(float* dq, const int* idx1, const float* g1, co
       dq[r * A + a] = v;
     }
   }
+}
+
+__global__ void vec_add_kernel(const float* a, const float* b, float* out, long n) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) out[i] = a[i] + b[i];
 }
 
 __global__ void agent_sum_kernel(const float* in, float* out, long rows, int N, int D) {
@@ -282,9 +289,11 @@ inline int loss_blocks(long rows) {
 
 }  // namespace
 
-extern "C" int marl_q_gather(const float* q, const int* idx, float* out, long rows, int A, void* stream) {
+extern "C" int marl_q_gather(const float* q, const int* idx, const float* avail, float mask_val, float* out,
+                             long rows, int A, void* stream) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(q_gather_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, q, idx, out, rows, A);
+  hipLaunchKernelGGL(q_gather_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, q, idx, avail, mask_val,
+                     out, rows, A);
   MARL_CHECK_LAUNCH();
   return 0;
 }
@@ -303,6 +312,13 @@ extern "C" int marl_q_scatter(float* dq, const int* idx1, const float* g1, const
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(q_scatter_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, dq, idx1, g1, idx2, g2,
                      rows, A, gdiv < 1 ? 1 : gdiv);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_vec_add(const float* a, const float* b, float* out, long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(vec_add_kernel, dim3(nblk(n, 4096)), dim3(TPB), 0, (hipStream_t)stream, a, b, out, n);
   MARL_CHECK_LAUNCH();
   return 0;
 }

@@ -126,6 +126,7 @@ class DeviceBatch:
             self.u_fed = cut("u_idx", torch.int32).view(B, T, N)
         else:
             self.u_fed = onehot_to_index(cut("u_onehot")).view(B, T, N)
+        self.u_bs = T * N
         self.r = cut("r").view(B * T)
         self.term = term_full[:, :T].contiguous().view(B * T)
         self.padded = cut("padded").view(B * T)

@@ -1,0 +1,515 @@
+"""Mixing networks (mirror of reference network/mixer.py) on the HIP kernels.
+
+Each class keeps the reference's constructor signature, parameter names (state_dict keys) and
+``forward`` signature; ``hip_forward`` / ``hip_backward`` are what the learners call: explicit
+forward with saved activations, then an explicit backward that accumulates into ``p.grad``
+(views of the learner's flat gradient buffer).  No torch autograd anywhere.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..hostutil import Lin, lin_of, require_cuda, to_dev, onehot_to_index
+
+
+class _Scratch:
+    """Cached device buffers keyed by (name, shape)."""
+
+    def __init__(self):
+        self.d = {}
+
+    def get(self, name, shape, device, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.d.get(key)
+        if t is None or t.device != device:
+            t = torch.empty(*shape, dtype=dtype, device=device)
+            self.d[key] = t
+        return t
+
+
+def _mlp(dims, sizes):
+    """nn.Sequential(Linear, ReLU, Linear, ...) with the reference's index names 0,2,4."""
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i < len(sizes) - 2:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers) if len(layers) > 1 else layers[0]
+
+
+def _linears(seq):
+    return [m for m in (seq if isinstance(seq, nn.Sequential) else [seq]) if isinstance(m, nn.Linear)]
+
+
+# =====================================================================================
+class VDNMixer(nn.Module):
+    """reference network/mixer.py:9-16."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self._s = _Scratch()
+
+    def hip_forward(self, q, s, rows, ctx=None, tag="e"):
+        out = self._s.get("qtot" + tag, (rows,), q.device)
+        ops.agent_sum(q, out, rows, self.args.n_agents, 1)
+        return out
+
+    def hip_backward(self, ctx, dq_tot, rows):
+        dq = self._s.get("dq", (rows, self.args.n_agents), dq_tot.device)
+        ops.agent_bcast(dq_tot, dq, rows, self.args.n_agents, 1)
+        return dq
+
+    def forward(self, q_values, states=None):
+        dev = require_cuda("VDNMixer")
+        B = q_values.shape[0]
+        q = to_dev(q_values, dev).reshape(-1, self.args.n_agents)
+        return self.hip_forward(q, None, q.shape[0]).clone().view(B, -1, 1)
+
+
+# =====================================================================================
+class QMixMixer(nn.Module):
+    """reference network/mixer.py:21-80 (hypernetwork-generated monotonic mixer)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        S, N, E, HH = args.state_shape, args.n_agents, args.qmix_hidden_dim, args.hyper_hidden_dim
+        if args.two_hyper_layers:
+            self.hyper_w1 = _mlp(None, [S, HH, N * E])
+            self.hyper_w2 = _mlp(None, [S, HH, E])
+        else:
+            self.hyper_w1 = nn.Linear(S, N * E)
+            self.hyper_w2 = nn.Linear(S, E)
+        self.hyper_b1 = nn.Linear(S, E)
+        self.hyper_b2 = _mlp(None, [S, E, 1])
+        self._s = _Scratch()
+
+    def hip_forward(self, q, s, rows, ctx=None, tag="e"):
+        a = self.args
+        N, E, HH = a.n_agents, a.qmix_hidden_dim, a.hyper_hidden_dim
+        dev = q.device
+        wid = N * E + 3 * E
+        hy = self._s.get("hy" + tag, (rows, wid), dev)
+        b2 = self._s.get("b2" + tag, (rows, 1), dev)
+        qtot = self._s.get("qtot" + tag, (rows,), dev)
+        xs = ops.src(s)
+        hw1 = hw2 = None
+        if a.two_hyper_layers:
+            hw1 = self._s.get("hw1" + tag, (rows, HH), dev)
+            hw2 = self._s.get("hw2" + tag, (rows, HH), dev)
+            l10, l12 = _linears(self.hyper_w1)
+            l20, l22 = _linears(self.hyper_w2)
+            lin_of(l10).fwd(xs, hw1, rows, act=1)
+            lin_of(l12).fwd(ops.src(hw1), hy[:, :N * E], rows)
+            lin_of(l20).fwd(xs, hw2, rows, act=1)
+            lin_of(l22).fwd(ops.src(hw2), hy[:, N * E + E:N * E + 2 * E], rows)
+        else:
+            lin_of(self.hyper_w1).fwd(xs, hy[:, :N * E], rows)
+            lin_of(self.hyper_w2).fwd(xs, hy[:, N * E + E:N * E + 2 * E], rows)
+        lin_of(self.hyper_b1).fwd(xs, hy[:, N * E:N * E + E], rows)
+        b20, b22 = _linears(self.hyper_b2)
+        lin_of(b20).fwd(xs, hy[:, N * E + 2 * E:], rows, act=1)
+        lin_of(b22).fwd(ops.src(hy[:, N * E + 2 * E:]), b2, rows)
+        ops.qmix_mix_fwd(hy, b2, q, qtot, rows, N, E)
+        if ctx is not None:
+            ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2)
+        return qtot
+
+    def hip_backward(self, ctx, dq_tot, rows):
+        a = self.args
+        N, E, HH = a.n_agents, a.qmix_hidden_dim, a.hyper_hidden_dim
+        hy, q, s = ctx["hy"], ctx["q"], ctx["s"]
+        dev = q.device
+        dhy = self._s.get("dhy", hy.shape, dev)
+        db2 = self._s.get("db2", (rows, 1), dev)
+        dq = self._s.get("dq", (rows, N), dev)
+        ops.qmix_mix_bwd(hy, q, dq_tot, dhy, db2, dq, rows, N, E)
+        xs = ops.src(s)
+        hb, dhb = hy[:, N * E + 2 * E:], dhy[:, N * E + 2 * E:]
+        b20, b22 = _linears(self.hyper_b2)
+        lin_of(b22).wgrad(db2, ops.src(hb), rows)
+        lin_of(b22).bwd_x(db2, dhb, rows)
+        lin_of(b20).wgrad(dhb, xs, rows, Yact=hb)
+        lin_of(self.hyper_b1).wgrad(dhy[:, N * E:N * E + E], xs, rows)
+        if a.two_hyper_layers:
+            for seq, hbuf, cols in ((self.hyper_w1, ctx["hw1"], slice(0, N * E)),
+                                    (self.hyper_w2, ctx["hw2"], slice(N * E + E, N * E + 2 * E))):
+                l0, l2 = _linears(seq)
+                lin_of(l2).wgrad(dhy[:, cols], ops.src(hbuf), rows)
+                dh = self._s.get("dhw", (rows, HH), dev)
+                lin_of(l2).bwd_x(dhy[:, cols], dh, rows)
+                lin_of(l0).wgrad(dh, xs, rows, Yact=hbuf)
+        else:
+            lin_of(self.hyper_w1).wgrad(dhy[:, :N * E], xs, rows)
+            lin_of(self.hyper_w2).wgrad(dhy[:, N * E + E:N * E + 2 * E], xs, rows)
+        return dq
+
+    def forward(self, q_values, states):
+        dev = require_cuda("QMixMixer")
+        self.to(dev)
+        B = q_values.shape[0]
+        q = to_dev(q_values, dev).reshape(-1, self.args.n_agents)
+        s = to_dev(states, dev).reshape(-1, self.args.state_shape)
+        return self.hip_forward(q, s, q.shape[0]).clone().view(B, -1, 1)
+
+
+# =====================================================================================
+class DMAQ_SI_Weight(nn.Module):
+    """lambda-net of QPLEX (reference network/mixer.py:85-171): num_kernel heads x
+    {key, agents, action} extractors."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.n_agents, self.n_actions = args.n_agents, args.n_actions
+        self.state_dim = int(np.prod(args.state_shape))
+        self.action_dim = args.n_agents * args.n_actions
+        self.state_action_dim = self.state_dim + self.action_dim
+        self.num_kernel = args.num_kernel
+        nl = getattr(args, "adv_hypernet_layers", 1)
+        if nl not in (1, 2, 3):
+            raise Exception("Error setting number of adv hypernet layers.")
+        AE = args.adv_hypernet_embed
+        hid = [AE] * (nl - 1)
+        self.key_extractors = nn.ModuleList()
+        self.agents_extractors = nn.ModuleList()
+        self.action_extractors = nn.ModuleList()
+        for _ in range(self.num_kernel):
+            self.key_extractors.append(_mlp(None, [self.state_dim] + hid + [1]))
+            self.agents_extractors.append(_mlp(None, [self.state_dim] + hid + [self.n_agents]))
+            self.action_extractors.append(_mlp(None, [self.state_action_dim] + hid + [self.n_agents]))
+
+    def families(self):
+        return (("key", self.key_extractors, 1), ("ag", self.agents_extractors, self.n_agents),
+                ("ac", self.action_extractors, self.n_agents))
+
+    def forward(self, states, actions):
+        raise RuntimeError("DMAQ_SI_Weight is evaluated inside DMAQer.hip_forward (fused lambda-net path)")
+
+
+def _head_stride(mods, attr):
+    """element stride between consecutive heads' tensors if uniform (flat parameter buffer), else None."""
+    ts = [getattr(m, attr) for m in mods]
+    if len(ts) == 1:
+        return 0
+    d = [(ts[i + 1].data_ptr() - ts[i].data_ptr()) for i in range(len(ts) - 1)]
+    if any(x != d[0] for x in d) or d[0] % 4 != 0 or d[0] <= 0:
+        return None
+    return d[0] // 4
+
+
+class DMAQer(nn.Module):
+    """QPLEX duplex dueling mixer (reference network/mixer.py:173-288)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.n_agents, self.n_actions = args.n_agents, args.n_actions
+        self.state_dim = int(np.prod(args.state_shape))
+        self.action_dim = args.n_agents * args.n_actions
+        self.state_action_dim = self.state_dim + self.action_dim + 1
+        self.embed_dim = args.mixing_embed_dim
+        HE = args.hypernet_embed
+        self.hyper_w_final = _mlp(None, [self.state_dim, HE, self.n_agents])
+        self.V = _mlp(None, [self.state_dim, HE, self.n_agents])
+        self.si_weight = DMAQ_SI_Weight(args)
+        self._s = _Scratch()
+
+    # ---- grouped dense layer over the K heads of one extractor family
+    def _layer(self, mods, li, x, x_gs, Y, y_gs, rows, act):
+        lins = [_linears(m)[li] for m in mods]
+        K = len(lins)
+        gw, gb = _head_stride(lins, "weight"), _head_stride(lins, "bias")
+        N_, K_ = lins[0].weight.shape
+        if gw is not None and gb is not None:
+            grp = ops.group(K, x0=x_gs, w=gw, b=gb, y=y_gs)
+            ops.linear(x, lins[0].weight.data, lins[0].bias.data, Y, rows, N_, K_, act=act, grp=grp)
+        else:   # parameters not in one flat buffer: one launch per head
+            for k, l in enumerate(lins):
+                xk = x if x_gs == 0 else ops.src(self._xview(x, k, x_gs, K_))
+                ops.linear(xk, l.weight.data, l.bias.data, Y[:, k * y_gs:(k + 1) * y_gs], rows, N_, K_, act=act)
+
+    @staticmethod
+    def _xview(x, k, gs, width):
+        t = x._keep[0]
+        return t[:, k * gs:k * gs + width]
+
+    def _lambda_fwd(self, s, u_idx, rows, tag, keep):
+        """raw head outputs key (rows,K), ag (rows,K,N), ac (rows,K,N) + hidden activations."""
+        a = self.args
+        K, AE, N, A = a.num_kernel, a.adv_hypernet_embed, a.n_agents, a.n_actions
+        dev = s.device
+        outs = {}
+        xs = ops.src(s)
+        xsa = ops.src(s, idx=u_idx.view(rows, N), nhot=N, hot_w=A)
+        for name, mods, nout in self.si_weight.families():
+            x_in = xsa if name == "ac" else xs
+            nl = len(_linears(mods[0]))
+            hs = []
+            cur, cur_gs = x_in, 0
+            for li in range(nl - 1):
+                hbuf = self._s.get("%s_h%d%s" % (name, li, tag), (rows, K * AE), dev)
+                self._layer(mods, li, cur, cur_gs, hbuf, AE, rows, act=1)
+                hs.append(hbuf)
+                cur, cur_gs = ops.src(hbuf, k0=AE), AE
+            out = self._s.get("%s_out%s" % (name, tag), (rows, K * nout), dev)
+            self._layer(mods, nl - 1, cur, cur_gs, out, nout, rows, act=0)
+            outs[name] = out
+            if keep is not None:
+                keep[name + "_h"] = hs
+        return outs
+
+    def hip_forward(self, q, s, rows, u_idx=None, max_q=None, ctx=None, tag="e"):
+        """q (rows,N) chosen Qs; returns (v_tot, a_tot) - a_tot None when max_q is None (is_v only).
+        u_idx (rows*N) int32 actions whose one-hot feeds the action extractors."""
+        a = self.args
+        N, K, HE = a.n_agents, a.num_kernel, a.hypernet_embed
+        dev = q.device
+        xs = ops.src(s)
+        w0, w2 = _linears(self.hyper_w_final)
+        v0, v2 = _linears(self.V)
+        hw = self._s.get("hw" + tag, (rows, HE), dev)
+        hv = self._s.get("hv" + tag, (rows, HE), dev)
+        w_raw = self._s.get("wraw" + tag, (rows, N), dev)
+        v = self._s.get("v" + tag, (rows, N), dev)
+        lin_of(w0).fwd(xs, hw, rows, act=1)
+        lin_of(w2).fwd(ops.src(hw), w_raw, rows)
+        lin_of(v0).fwd(xs, hv, rows, act=1)
+        lin_of(v2).fwd(ops.src(hv), v, rows)
+        v_tot = self._s.get("vtot" + tag, (rows,), dev)
+        a_tot = lam = None
+        heads = {}
+        if max_q is not None:
+            heads = self._lambda_fwd(s, u_idx, rows, tag, ctx)
+            a_tot = self._s.get("atot" + tag, (rows,), dev)
+            lam = self._s.get("lam" + tag, (rows, N), dev)
+        ops.qplex_mix_fwd(w_raw, v, q, max_q, heads.get("key"), heads.get("ag"), heads.get("ac"), v_tot, a_tot, lam,
+                          rows, N, K, a.weighted_head, a.is_minus_one)
+        if ctx is not None:
+            ctx.update(q=q, s=s, u_idx=u_idx, max_q=max_q, hw=hw, hv=hv, w_raw=w_raw, v=v, heads=heads, lam=lam)
+        return v_tot, a_tot
+
+    def hip_backward(self, ctx, g, rows):
+        """g = dL/d(v_tot + a_tot) (rows).  Returns dq (rows,N); accumulates parameter grads."""
+        a = self.args
+        N, K, AE, A, HE = a.n_agents, a.num_kernel, a.adv_hypernet_embed, a.n_actions, a.hypernet_embed
+        s, q = ctx["s"], ctx["q"]
+        dev = q.device
+        heads = ctx["heads"]
+        dq = self._s.get("dq", (rows, N), dev)
+        dw_raw = self._s.get("dwraw", (rows, N), dev)
+        dv = self._s.get("dv", (rows, N), dev)
+        douts = {"key": self._s.get("dkey", (rows, K), dev), "ag": self._s.get("dag", (rows, K * N), dev),
+                 "ac": self._s.get("dac", (rows, K * N), dev)}
+        ops.qplex_mix_bwd(ctx["w_raw"], q, ctx["max_q"], heads["key"], heads["ag"], heads["ac"], g, dq, dw_raw, dv,
+                          douts["key"], douts["ag"], douts["ac"], rows, N, K, a.weighted_head, a.is_minus_one)
+        xs = ops.src(s)
+        # transformation nets
+        for seq, hbuf, dout in ((self.hyper_w_final, ctx["hw"], dw_raw), (self.V, ctx["hv"], dv)):
+            l0, l2 = _linears(seq)
+            lin_of(l2).wgrad(dout, ops.src(hbuf), rows)
+            dh = self._s.get("dh_t", (rows, HE), dev)
+            lin_of(l2).bwd_x(dout, dh, rows)
+            lin_of(l0).wgrad(dh, xs, rows, Yact=hbuf)
+        # lambda-net, family by family, heads batched
+        xsa = ops.src(s, idx=ctx["u_idx"].view(rows, N), nhot=N, hot_w=A)
+        for name, mods, nout in self.si_weight.families():
+            x_in = xsa if name == "ac" else xs
+            hs = ctx[name + "_h"]
+            nl = len(_linears(mods[0]))
+            dcur, dcur_gs, gate = douts[name], nout, None
+            for li in range(nl - 1, -1, -1):
+                lins = [_linears(m)[li] for m in mods]
+                gw, gb = _head_stride(lins, "weight"), _head_stride(lins, "bias")
+                N_, K_ = lins[0].weight.shape
+                if li > 0:
+                    xin, xin_gs = ops.src(hs[li - 1], k0=K_), AE
+                else:
+                    xin, xin_gs = x_in, 0
+                assert gw is not None and gb is not None, "QPLEX heads must live in one flat parameter buffer"
+                ggw = _head_stride(lins, "weight")
+                grp = ops.group(K, x0=xin_gs, w=ggw, b=gb, y=dcur_gs, m0=dcur_gs)
+                # gradient buffers follow the parameter layout (views of the learner's flat grad)
+                ops.linear_wgrad(dcur, xin, lins[0].weight.grad, lins[0].bias.grad, rows, N_, K_, Yact=gate, grp=grp)
+                if li > 0:
+                    dprev = self._s.get("dh_%s%d" % (name, li), (rows, K * AE), dev)
+                    gx = ops.group(K, x0=dcur_gs, w=gw, y=AE, m0=dcur_gs)
+                    ops.linear(ops.src(dcur, gate=gate, k0=N_), lins[0].weight.data, None, dprev, rows, K_, N_,
+                               w_kmajor=True, grp=gx)
+                    dcur, dcur_gs, gate = dprev, AE, hs[li - 1]
+        return dq
+
+    def forward(self, agent_qs, states, actions=None, max_q_i=None, is_v=False):
+        dev = require_cuda("DMAQer")
+        self.to(dev)
+        bs = agent_qs.shape[0]
+        N = self.n_agents
+        q = to_dev(agent_qs, dev).reshape(-1, N)
+        s = to_dev(states, dev).reshape(-1, self.state_dim)
+        rows = q.shape[0]
+        if is_v:
+            v_tot, _ = self.hip_forward(q, s, rows, tag="f")
+            return v_tot.clone().view(bs, -1, 1)
+        u_idx = onehot_to_index(to_dev(actions, dev).reshape(rows, N, self.n_actions)).reshape(-1)
+        mq = to_dev(max_q_i, dev).reshape(-1, N)
+        _, a_tot = self.hip_forward(q, s, rows, u_idx=u_idx, max_q=mq, tag="f")
+        return a_tot.clone().view(bs, -1, 1)
+
+
+# =====================================================================================
+class QtranQBase(nn.Module):
+    """QTRAN-base joint action-value network (reference network/mixer.py:355-388)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        ae = args.rnn_hidden_dim + args.n_actions
+        self.hidden_action_encoding = _mlp(None, [ae, ae, ae])
+        q_in = args.state_shape + args.n_actions + args.rnn_hidden_dim
+        self.q = _mlp(None, [q_in, args.qtran_hidden_dim, args.qtran_hidden_dim, 1])
+        self._s = _Scratch()
+
+    def hip_forward(self, s, hidden, u_idx, BT, ctx=None, tag="e"):
+        """s (BT,S); hidden (BT*N,H); u_idx (BT*N) int32 -> joint q (BT)."""
+        a = self.args
+        N, H, A, Q = a.n_agents, a.rnn_hidden_dim, a.n_actions, a.qtran_hidden_dim
+        R, ae = BT * N, H + A
+        dev = s.device
+        e0, e2 = _linears(self.hidden_action_encoding)
+        q0, q2, q4 = _linears(self.q)
+        x_ha = ops.src(hidden, idx=u_idx.view(R, 1), nhot=1, hot_w=A)
+        e1 = self._s.get("e1" + tag, (R, ae), dev)
+        e2b = self._s.get("e2" + tag, (R, ae), dev)
+        esum = self._s.get("esum" + tag, (BT, ae), dev)
+        y1 = self._s.get("y1" + tag, (BT, Q), dev)
+        y2 = self._s.get("y2" + tag, (BT, Q), dev)
+        out = self._s.get("out" + tag, (BT, 1), dev)
+        lin_of(e0).fwd(x_ha, e1, R, act=1)
+        lin_of(e2).fwd(ops.src(e1), e2b, R)
+        ops.agent_sum(e2b, esum, BT, N, ae)
+        x_q = ops.src(s, esum)
+        lin_of(q0).fwd(x_q, y1, BT, act=1)
+        lin_of(q2).fwd(ops.src(y1), y2, BT, act=1)
+        lin_of(q4).fwd(ops.src(y2), out, BT)
+        if ctx is not None:
+            ctx.update(s=s, hidden=hidden, u_idx=u_idx, e1=e1, esum=esum, y1=y1, y2=y2)
+        return out.view(BT)
+
+    def hip_backward(self, ctx, d_out, BT, dhidden, accumulate):
+        """d_out (BT). Adds/writes the gradient wrt hidden into dhidden (BT*N,H)."""
+        a = self.args
+        N, H, A, Q, S = a.n_agents, a.rnn_hidden_dim, a.n_actions, a.qtran_hidden_dim, a.state_shape
+        R, ae = BT * N, H + A
+        dev = d_out.device
+        e0, e2 = _linears(self.hidden_action_encoding)
+        q0, q2, q4 = _linears(self.q)
+        s, hidden, u_idx, e1, esum, y1, y2 = (ctx[k] for k in ("s", "hidden", "u_idx", "e1", "esum", "y1", "y2"))
+        g = d_out.view(BT, 1)
+        dy2 = self._s.get("dy2", (BT, Q), dev)
+        dy1 = self._s.get("dy1", (BT, Q), dev)
+        desum = self._s.get("desum", (BT, ae), dev)
+        de2 = self._s.get("de2", (R, ae), dev)
+        de1 = self._s.get("de1", (R, ae), dev)
+        lin_of(q4).wgrad(g, ops.src(y2), BT)
+        lin_of(q4).bwd_x(g, dy2, BT)
+        lin_of(q2).wgrad(dy2, ops.src(y1), BT, Yact=y2)
+        lin_of(q2).bwd_x(dy2, dy1, BT, Yact=y2)
+        lin_of(q0).wgrad(dy1, ops.src(s, esum), BT, Yact=y1)
+        Lin(q0.weight.data[:, S:], None).bwd_x(dy1, desum, BT, Yact=y1)     # only the enc columns need a gradient
+        ops.agent_bcast(desum, de2, BT, N, ae)
+        x_ha = ops.src(hidden, idx=u_idx.view(R, 1), nhot=1, hot_w=A)
+        lin_of(e2).wgrad(de2, ops.src(e1), R)
+        lin_of(e2).bwd_x(de2, de1, R)
+        lin_of(e0).wgrad(de1, x_ha, R, Yact=e1)
+        Lin(e0.weight.data[:, :H], None).bwd_x(de1, dhidden, R, Yact=e1, beta=1.0 if accumulate else 0.0)
+
+    def forward(self, state, hidden_states, actions):
+        dev = require_cuda("QtranQBase")
+        self.to(dev)
+        B, T, N, A = actions.shape
+        s = to_dev(state, dev).reshape(B * T, -1)
+        h = to_dev(hidden_states, dev).reshape(B * T * N, -1)
+        u_idx = onehot_to_index(to_dev(actions, dev)).reshape(-1)
+        return self.hip_forward(s, h, u_idx, B * T, tag="f").clone().view(B * T, 1)
+
+
+class QtranQAlt(nn.Module):
+    """Name kept for import compatibility (reference network/mixer.py:295-351).  The reference's
+    qtran_alt path raises at run time (out of scope), so this is not implemented."""
+
+    def __init__(self, args):
+        super().__init__()
+        raise NotImplementedError("qtran_alt is broken in the reference and is not part of the hot path")
+
+
+class QtranV(nn.Module):
+    """QTRAN state-value network (reference network/mixer.py:392-418)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        H = args.rnn_hidden_dim
+        self.hidden_encoding = _mlp(None, [H, H, H])
+        self.v = _mlp(None, [args.state_shape + H, args.qtran_hidden_dim, args.qtran_hidden_dim, 1])
+        self._s = _Scratch()
+
+    def hip_forward(self, s, hidden, BT, ctx=None, tag="e"):
+        a = self.args
+        N, H, Q = a.n_agents, a.rnn_hidden_dim, a.qtran_hidden_dim
+        R = BT * N
+        dev = s.device
+        e0, e2 = _linears(self.hidden_encoding)
+        v0, v2, v4 = _linears(self.v)
+        e1 = self._s.get("e1" + tag, (R, H), dev)
+        e2b = self._s.get("e2" + tag, (R, H), dev)
+        esum = self._s.get("esum" + tag, (BT, H), dev)
+        y1 = self._s.get("y1" + tag, (BT, Q), dev)
+        y2 = self._s.get("y2" + tag, (BT, Q), dev)
+        out = self._s.get("out" + tag, (BT, 1), dev)
+        lin_of(e0).fwd(ops.src(hidden), e1, R, act=1)
+        lin_of(e2).fwd(ops.src(e1), e2b, R)
+        ops.agent_sum(e2b, esum, BT, N, H)
+        lin_of(v0).fwd(ops.src(s, esum), y1, BT, act=1)
+        lin_of(v2).fwd(ops.src(y1), y2, BT, act=1)
+        lin_of(v4).fwd(ops.src(y2), out, BT)
+        if ctx is not None:
+            ctx.update(s=s, hidden=hidden, e1=e1, esum=esum, y1=y1, y2=y2)
+        return out.view(BT)
+
+    def hip_backward(self, ctx, d_out, BT, dhidden, accumulate):
+        a = self.args
+        N, H, Q, S = a.n_agents, a.rnn_hidden_dim, a.qtran_hidden_dim, a.state_shape
+        R = BT * N
+        dev = d_out.device
+        e0, e2 = _linears(self.hidden_encoding)
+        v0, v2, v4 = _linears(self.v)
+        s, hidden, e1, esum, y1, y2 = (ctx[k] for k in ("s", "hidden", "e1", "esum", "y1", "y2"))
+        g = d_out.view(BT, 1)
+        dy2 = self._s.get("dy2", (BT, Q), dev)
+        dy1 = self._s.get("dy1", (BT, Q), dev)
+        desum = self._s.get("desum", (BT, H), dev)
+        de2 = self._s.get("de2", (R, H), dev)
+        de1 = self._s.get("de1", (R, H), dev)
+        lin_of(v4).wgrad(g, ops.src(y2), BT)
+        lin_of(v4).bwd_x(g, dy2, BT)
+        lin_of(v2).wgrad(dy2, ops.src(y1), BT, Yact=y2)
+        lin_of(v2).bwd_x(dy2, dy1, BT, Yact=y2)
+        lin_of(v0).wgrad(dy1, ops.src(s, esum), BT, Yact=y1)
+        Lin(v0.weight.data[:, S:], None).bwd_x(dy1, desum, BT, Yact=y1)
+        ops.agent_bcast(desum, de2, BT, N, H)
+        lin_of(e2).wgrad(de2, ops.src(e1), R)
+        lin_of(e2).bwd_x(de2, de1, R)
+        lin_of(e0).wgrad(de1, ops.src(hidden), R, Yact=e1)
+        lin_of(e0).bwd_x(de1, dhidden, R, Yact=e1, beta=1.0 if accumulate else 0.0)
+
+    def forward(self, state, hidden):
+        dev = require_cuda("QtranV")
+        self.to(dev)
+        B, T, N, _ = hidden.shape
+        s = to_dev(state, dev).reshape(B * T, -1)
+        h = to_dev(hidden, dev).reshape(B * T * N, -1)
+        return self.hip_forward(s, h, B * T, tag="f").clone().view(B * T, 1)

@@ -143,8 +143,9 @@ def agent_unroll_bwd(w, dq, dhs, saved, dgate, dxp, dh0, B, T, N, A):
                                     _p(_f32(dxp)), _p(dh0), B, T, N, A, _stream()), "marl_agent_unroll_bwd")
 
 
-def q_gather(q, idx, out, rows, A):
-    check(_lib.load().marl_q_gather(_p(_f32(q)), _p(_i32(idx)), _p(_f32(out)), rows, A, _stream()), "marl_q_gather")
+def q_gather(q, idx, out, rows, A, avail=None, mask_val=0.0):
+    check(_lib.load().marl_q_gather(_p(_f32(q)), _p(_i32(idx)), _p(avail), float(mask_val), _p(_f32(out)), rows, A,
+                                    _stream()), "marl_q_gather")
 
 
 def q_masked_max(q, avail, mask_val, out_max, out_arg, rows, A):
@@ -155,6 +156,10 @@ def q_masked_max(q, avail, mask_val, out_max, out_arg, rows, A):
 def q_scatter(dq, idx1, g1, idx2, g2, rows, A, gdiv=1):
     check(_lib.load().marl_q_scatter(_p(_f32(dq)), _p(idx1), _p(g1), _p(idx2), _p(g2), rows, A, gdiv, _stream()),
           "marl_q_scatter")
+
+
+def vec_add(a, b, out, n):
+    check(_lib.load().marl_vec_add(_p(_f32(a)), _p(_f32(b)), _p(_f32(out)), n, _stream()), "marl_vec_add")
 
 
 def agent_sum(inp, out, rows, N, D):
