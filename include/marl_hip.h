@@ -72,13 +72,15 @@ int marl_wgrad_slabs(int M);
  *   obs   : row (b,t,n) at obs + ((b*obs_bs) + (t+obs_t0)*N + n)*O        (obs_bs = rows/episode)
  *   ufed  : int32 action fed back at step t: ufed[b*u_bs + (t+u_t0)*N + n]; none if t+u_t0 < 0,
  *           value < 0 or ufed == NULL (one-hot of zeros, share_params.py:96-100)
+ *   ep_len: per-episode int32 length or NULL; observations of steps t >= ep_len[b] read as zeros
+ *           (the zero padding rollout.py:122-133 writes, needed when obs is (T+1)-slot storage)
  *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
  *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = 6 planes (B,T,N,64)
  *   [hprev,x,r,z,n,hn] for the backward pass or NULL */
 int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
-                          const int* ufed, long u_bs, int u_t0, const float* h0, float* q, float* hs,
-                          float* h_last, float* saved, int B, int T, int N, int O, int A,
-                          int last_action, int reuse_network, void* stream);
+                          const int* ufed, long u_bs, int u_t0, const int* ep_len, const float* h0,
+                          float* q, float* hs, float* h_last, float* saved, int B, int T, int N, int O,
+                          int A, int last_action, int reuse_network, void* stream);
 /* BPTT delta pass (autograd of the unroll above; q_learner.py:171 loss.backward()).
  *   dq (B,T,N,A) gradient on q; dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
  *   dgate (B,T,N,256) = d r_pre | d z_pre | d n_pre | d(W_hn h + b_hn);  dxp (B,T,N,64) = d fc1 pre-act

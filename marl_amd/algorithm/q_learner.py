@@ -17,6 +17,7 @@ import torch
 
 from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
+from ..rollout import EpisodeBatch
 from ..network.mixer import VDNMixer, QMixMixer, DMAQer
 from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer)
 
@@ -95,13 +96,13 @@ class QLearner:
         u_act = db.u_act.reshape(-1)
 
         # eval current-Q unroll (keeps activations), target next-Q unroll
-        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved, h0=None)
-        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None, h0=None)
+        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved, h0=None, ep_len=db.ep_len)
+        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None, h0=None, ep_len=db.ep_len)
         ops.q_gather(q_evals, u_act, q_chosen, R, A)
         cur_max = None
         if a.double_q:
             # quirk Q1: no init_hidden between the two eval passes (reference :96-110)
-            self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last)
+            self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last, ep_len=db.ep_len)
             cur_max = g("cur_max", (R,), torch.int32)
             ops.q_masked_max(q_en, db.avail_next, MASK_BIG, None, cur_max, R, A)
             ops.q_gather(q_tgt, cur_max, q_tgt_chosen, R, A, avail=db.avail_next, mask_val=MASK_BIG)
@@ -113,7 +114,7 @@ class QLearner:
         if a.alg == 'qplex':
             max_q = g("max_q", (R,))
             ops.q_masked_max(q_evals, db.avail, MASK_BIG, max_q, None, R, A)
-            v_tot, a_tot = self.mixer.hip_forward(qc, db.s, BT, u_idx=db.u_fed.reshape(-1), max_q=max_q.view(BT, N), ctx=ctx)
+            v_tot, a_tot = self.mixer.hip_forward(qc, db.s, BT, u_idx=db.u_taken.reshape(-1), max_q=max_q.view(BT, N), ctx=ctx)
             q_tot = g("q_tot", (BT,))
             ops.vec_add(v_tot, a_tot, q_tot, BT)
             if a.double_q:
@@ -143,6 +144,9 @@ class QLearner:
     def train(self, batch, train_step):
         if isinstance(batch, DeviceBatch):
             db = batch
+        elif isinstance(batch, EpisodeBatch) and batch.record is not None:
+            T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit)
+            db = DeviceBatch.from_record(batch.record, self.args, T=self.reducer.max_int(T, self.device))
         else:
             T = None
             if self.reducer.enabled:   # shards must agree on T

@@ -16,6 +16,7 @@ import torch
 
 from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
+from ..rollout import EpisodeBatch
 from ..network.mixer import QtranQBase, QtranQAlt, QtranV, QMixMixer
 from .common import (MASK_BIG, MASK_QTRAN_EVAL, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward,
                      GradReducer)
@@ -85,10 +86,10 @@ class QTRANLearner:
         q_tgt, hs_tgt = g("q_tgt", (B, T, N, A)), g("hs_tgt", (B, T, N, H))
         (oc, oc_bs, oc_t0), (on, on_bs, on_t0) = db.o_cur, db.o_next
         u_act = db.u_act.reshape(-1)
-        u_taken = db.u_fed.reshape(-1)          # one-hot(u) with zeros on padding (batch['u_onehot'])
+        u_taken = db.u_taken.reshape(-1)          # one-hot(u) with zeros on padding (batch['u_onehot'])
 
-        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved, h0=None)
-        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None, h0=None)
+        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved, h0=None, ep_len=db.ep_len)
+        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None, h0=None, ep_len=db.ep_len)
 
         # local greedy actions (reference :103-114): eval clone masked with -999999, targets with -9999999
         opt_eval, opt_tgt = g("opt_eval", (R,), torch.int32), g("opt_tgt", (R,), torch.int32)
@@ -126,6 +127,9 @@ class QTRANLearner:
     def train(self, batch, train_step):
         if isinstance(batch, DeviceBatch):
             db = batch
+        elif isinstance(batch, EpisodeBatch) and batch.record is not None:
+            T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit)
+            db = DeviceBatch.from_record(batch.record, self.args, T=self.reducer.max_int(T, self.device))
         else:
             T = None
             if self.reducer.enabled:

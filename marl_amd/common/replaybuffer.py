@@ -1,0 +1,86 @@
+"""ReplayBuffer (mirror of reference common/replaybuffer.py:5-80).
+
+Two storage modes, chosen by what is stored first:
+  * host   - the reference's 11 float64 numpy arrays (for plain dict episodes),
+  * device - (T+1)-slot EpisodeRecord on HBM for episodes produced by the batched rollout:
+             o/o_next, s/s_next and avail_u/avail_u_next are stored once.
+Ring-index arithmetic (``_get_storage_idx``) and uniform sampling WITH replacement via
+``np.random.randint`` are the reference's (quirk Q13).
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+import torch
+
+from ..env.synthetic_smac import EpisodeRecord
+from ..rollout import EpisodeBatch
+
+
+class ReplayBuffer:
+    def __init__(self, args):
+        self.args = args
+        self.n_actions = args.n_actions
+        self.n_agents = args.n_agents
+        self.state_shape = args.state_shape
+        self.obs_shape = args.obs_shape
+        self.size = args.buffer_size
+        self.episode_limit = args.episode_limit
+        self.current_idx = 0
+        self.current_size = 0
+        self.buffers = None          # host mode: dict of numpy arrays (allocated lazily)
+        self.record = None           # device mode: EpisodeRecord with `size` episodes
+        self.lock = threading.Lock()
+
+    def _alloc_host(self):
+        T, N, O, S, A, n = self.episode_limit, self.n_agents, self.obs_shape, self.state_shape, self.n_actions, self.size
+        e = np.empty
+        self.buffers = {'o': e([n, T, N, O]), 'u': e([n, T, N, 1]), 's': e([n, T, S]), 'r': e([n, T, 1]),
+                        'o_next': e([n, T, N, O]), 's_next': e([n, T, S]), 'avail_u': e([n, T, N, A]),
+                        'avail_u_next': e([n, T, N, A]), 'u_onehot': e([n, T, N, A]), 'padded': e([n, T, 1]),
+                        'terminated': e([n, T, 1])}
+
+    def store_episode(self, episode_batch):
+        rec = getattr(episode_batch, "record", None)
+        batch_size = rec.E if rec is not None else episode_batch['o'].shape[0]
+        with self.lock:
+            idxs = self._get_storage_idx(inc=batch_size)
+            if rec is not None and self.buffers is None:
+                if self.record is None:
+                    self.record = EpisodeRecord(self.size, rec.T, rec.N, rec.O, rec.S, rec.A, rec.obs.device)
+                idx_t = torch.as_tensor(np.atleast_1d(idxs), dtype=torch.long, device=rec.obs.device)
+                rec.copy_into(self.record, idx_t)
+                return
+            if self.record is not None:
+                raise ValueError("this ReplayBuffer holds device records; store EpisodeBatch objects")
+            if self.buffers is None:
+                self._alloc_host()
+            src = episode_batch.numpy() if isinstance(episode_batch, EpisodeBatch) else episode_batch
+            for k in self.buffers:
+                v = src[k]
+                self.buffers[k][idxs] = v.cpu().numpy() if isinstance(v, torch.Tensor) else v
+
+    def sample(self, batch_size):
+        idx = np.random.randint(0, self.current_size, batch_size)
+        if self.record is not None:
+            idx_t = torch.as_tensor(idx, dtype=torch.long, device=self.record.obs.device)
+            return EpisodeBatch(self.record.index_select(idx_t))
+        return {k: self.buffers[k][idx] for k in self.buffers}
+
+    def _get_storage_idx(self, inc=None):
+        inc = inc or 1
+        if self.current_idx + inc <= self.size:
+            idx = np.arange(self.current_idx, self.current_idx + inc)
+            self.current_idx += inc
+        elif self.current_idx < self.size:
+            overflow = inc - (self.size - self.current_idx)
+            idx = np.concatenate([np.arange(self.current_idx, self.size), np.arange(0, overflow)])
+            self.current_idx = overflow
+        else:
+            idx = np.arange(0, inc)
+            self.current_idx = inc
+        self.current_size = min(self.size, self.current_size + inc)
+        if inc == 1:
+            idx = idx[0]
+        return idx

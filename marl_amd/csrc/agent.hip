@@ -28,6 +28,7 @@ struct FwdArgs {
   long obs_bs; int obs_t0;
   const int* ufed;        // action fed back at step t: ufed[b*u_bs + (t+u_t0)*N + n]; <0 / t+u_t0<0 = none
   long u_bs; int u_t0;
+  const int* ep_len;      // per-episode length or null: observations of steps t >= ep_len[b] read as zero
   const float* h0;        // (B*N,64) or null (zeros)
   float* q;               // (B,T,N,A)
   float* hs;              // (B,T,N,64) or null
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
       if (rb >= 0) {
         const int n = (int)(rb % a.N);   // rb = b*T*N + n and T*N is a multiple of N
         const long b = rowb[r];
-        if (k < O) v = a.obs[(b * a.obs_bs + (long)(t + a.obs_t0) * a.N + n) * O + k];
+        if (k < O) {
+          if (!a.ep_len || t < a.ep_len[b]) v = a.obs[(b * a.obs_bs + (long)(t + a.obs_t0) * a.N + n) * O + k];
+        }
         else if (a.has_act && k < O + a.A) {
           int u = -1;
           if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[b * a.u_bs + (long)(t + a.u_t0) * a.N + n];
@@ -436,15 +439,15 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap)
 }  // namespace
 
 extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
-                                     const int* ufed, long u_bs, int u_t0, const float* h0, float* q,
-                                     float* hs, float* h_last, float* saved, int B, int T, int N, int O,
-                                     int A, int last_action, int reuse_network, void* stream) {
+                                     const int* ufed, long u_bs, int u_t0, const int* ep_len, const float* h0,
+                                     float* q, float* hs, float* h_last, float* saved, int B, int T, int N,
+                                     int O, int A, int last_action, int reuse_network, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
   FwdArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
-  a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
+  a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.ep_len = ep_len; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
   a.B = B; a.T = T; a.N = N; a.O = O; a.A = A;
   a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);

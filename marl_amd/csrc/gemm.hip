@@ -67,11 +67,17 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 
   const int K = a.K;
   const int kfull = VEC ? (K & ~15) : 0;
+  long asrc[2];   // source rows of dense segment 0 after the (T+1)-slot remap (vector path only)
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    bool ok;
+    asrc[r] = remap_row(arow[r], x.rpe0, x.bs0, x.off0, ok);
+  }
   for (int k0 = 0; k0 < kfull; k0 += 16) {   // vector path: 16 B per lane per operand
     const int kk = k0 + 4 * q;
     f32x4 av[2], bv[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) av[r] = *reinterpret_cast<const f32x4*>(x.p0 + arow[r] * x.ld0 + kk);
+    for (int r = 0; r < 2; ++r) av[r] = *reinterpret_cast<const f32x4*>(x.p0 + asrc[r] * x.ld0 + kk);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c < ct_used) {
@@ -288,7 +294,7 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
   a.groups = grp ? grp->groups : 1;
   a.gs_x0 = grp ? grp->gs_x0 : 0; a.gs_x1 = grp ? grp->gs_x1 : 0; a.gs_w = grp ? grp->gs_w : 0;
   a.gs_b = grp ? grp->gs_b : 0; a.gs_y = grp ? grp->gs_y : 0; a.gs_m0 = grp ? grp->gs_m0 : 0;
-  bool vec = a.x.k0 >= 16 && !a.x.m0 && a.x.rpe0 == 0 && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
+  bool vec = a.x.k0 >= 16 && !a.x.m0 && (a.x.rpe0 == 0 || a.x.off0 >= 0) && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
   if (!w_kmajor) vec = vec && (ldw % 4 == 0) && aligned16(W) && (a.gs_w % 4 == 0);
   // the vector loop only covers whole 16-chunks that lie inside dense segment 0
   LinArgs av = a;

@@ -95,6 +95,7 @@ class DeviceBatch:
 
     def __init__(self):
         self.extra = {}
+        self.ep_len = None      # per-episode lengths when obs is (T+1)-slot storage
 
     @staticmethod
     def first_terminated_len(term, episode_limit):
@@ -127,9 +128,37 @@ class DeviceBatch:
         else:
             self.u_fed = onehot_to_index(cut("u_onehot")).view(B, T, N)
         self.u_bs = T * N
+        self.u_taken = self.u_fed
         self.r = cut("r").view(B * T)
         self.term = term_full[:, :T].contiguous().view(B * T)
         self.padded = cut("padded").view(B * T)
         self.avail = cut("avail_u").view(B * T * N, A)
         self.avail_next = cut("avail_u_next").view(B * T * N, A)
+        return self
+
+    @classmethod
+    def from_record(cls, rec, args, T=None):
+        """Zero-copy view of a device EpisodeRecord ((T+1)-slot storage): observations are read in
+        place for both passes; only the small per-step arrays are re-packed when T < episode_limit."""
+        self = cls()
+        E, Ta, N, O, S, A = rec.E, rec.T, rec.N, rec.O, rec.S, rec.A
+        if T is None:
+            T = cls.first_terminated_len(rec.term, args.episode_limit)
+        self.B, self.T, self.N, self.O, self.S, self.A = E, T, N, O, S, A
+        self.o_cur = (rec.obs, (Ta + 1) * N, 0)
+        self.o_next = (rec.obs, (Ta + 1) * N, 1)
+        self.ep_len = rec.length
+        st2 = rec.state.view(E * (Ta + 1), S)
+        self.s = ops.Rows(st2, (T, Ta + 1, 0))
+        self.s_next = ops.Rows(st2, (T, Ta + 1, 1))
+        self.u_fed = rec.u
+        self.u_bs = Ta * N
+        cutc = lambda x: x[:, :T].contiguous()
+        self.u_taken = cutc(rec.u)
+        self.u_act = self.u_taken.clamp(min=0)
+        self.r, self.term, self.padded = cutc(rec.r).view(-1), cutc(rec.term).view(-1), cutc(rec.padded).view(-1)
+        t_idx = torch.arange(T, device=rec.obs.device)[None, :, None, None]
+        live = t_idx < rec.length[:, None, None, None]
+        self.avail = torch.where(live, rec.avail[:, :T], torch.zeros((), device=rec.obs.device)).reshape(E * T * N, A)
+        self.avail_next = rec.avail[:, 1:T + 1].reshape(E * T * N, A)
         return self

@@ -49,10 +49,20 @@ class Workspace:
 WS = Workspace()
 
 
+class Rows:
+    """A 2-D row source read through a row remap (rpe, bs, off) - e.g. the (T+1)-slot state storage."""
+
+    def __init__(self, t, remap):
+        self.t, self.remap = t, remap
+        self.device = t.device
+
+
 def src(x0=None, x1=None, idx=None, nhot=0, hot_w=0, nid=0, gate=None, remap0=None, remapi=None, k0=None):
-    """Build a marl_src_t.  x0/x1: 2-D (rows, k) float32 views with unit inner stride."""
+    """Build a marl_src_t.  x0/x1: 2-D (rows, k) float32 views with unit inner stride (x0 may be Rows)."""
     s = MarlSrc()
     keep = []
+    if isinstance(x0, Rows):
+        x0, remap0 = x0.t, x0.remap
     if x0 is not None:
         _f32(x0); assert x0.dim() == 2 and x0.stride(1) == 1
         s.p0, s.ld0, s.k0 = x0.data_ptr(), x0.stride(0), (x0.shape[1] if k0 is None else k0)
@@ -129,9 +139,9 @@ def agent_weights(params):
 
 
 def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
-                     B, T, N, O, A, last_action=True, reuse_network=True):
+                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None):
     lib = _lib.load()
-    check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(h0),
+    check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len), _p(h0),
                                     _p(_f32(q)), _p(hs), _p(h_last), _p(saved), B, T, N, O, A,
                                     1 if last_action else 0, 1 if reuse_network else 0, _stream()),
           "marl_agent_unroll_fwd")
