@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s and learner updates/s of the MARL hot path on MI355X.
+
+One "step" = the reference runner's inner iteration (runner.py:85-98) at scale: batched rollout of
+the rank's envs for T lock-steps -> ReplayBuffer.store_episode -> sample -> one learner.train().
+Workload (BASELINE.json metric): QMIX, synthetic 2s3z shape (N=5, O=80, S=120, A=11, T=120),
+4096 envs GLOBAL, split over the ranks (strong scaling); gradients all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHAPES = {"2s3z": (5, 80, 120, 11, 120), "3s5z": (8, 128, 216, 14, 150), "MMM2": (10, 176, 322, 18, 120)}
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_args(alg, shape, T):
+    from marl_amd.common.arguments import get_mixer_args
+    N, O, S, A, T0 = SHAPES[shape]
+    a = types.SimpleNamespace(alg=alg, map=shape, n_agents=N, obs_shape=O, state_shape=S, n_actions=A,
+                              episode_limit=T or T0, last_action=True, reuse_network=True, gamma=0.99,
+                              optimizer="RMS", cuda=True, RTW=False, load_model=False, model_dir="./model",
+                              result_dir="./result", replay_dir="", n_episodes=1, evaluate_epoch=0, seed=123)
+    get_mixer_args(a)
+    return a
+
+
+def agent_flops(a):
+    I = a.obs_shape + a.n_actions + a.n_agents
+    H = a.rnn_hidden_dim
+    return 2 * I * H + 12 * H * H + 2 * H * a.n_actions       # SURVEY 8d F_a
+
+
+def cpu_baseline(alg, shape, T, envs, budget_s):
+    """The CPU oracle (port of the reference path, pinned by the golden vectors) on a bounded sample
+    of the same workload, timed on this box's host cores."""
+    from oracle import seeded, learners, rollout as orl
+    cores = min(os.cpu_count() or 1, 16)     # torch-CPU oversubscribes badly beyond ~16 threads on these small ops
+    torch.set_num_threads(cores)
+    args = seeded.make_args(shape, alg, episode_limit=T)
+    agent = seeded.seeded_state(seeded.agent_param_shapes(args), seed=11)
+    mshapes = seeded.mixer_param_shapes(args)
+    mixer = seeded.seeded_state(mshapes, seed=12) if mshapes else {}
+    st = learners.LearnerState(args, agent, mixer)
+    N, O, S, A = args.n_agents, args.obs_shape, args.state_shape, args.n_actions
+    sy = orl.SynthSMAC(N, O, S, A, T, seed=1)
+    sy.length = lambda env, ep: np.full(len(np.atleast_1d(env)), T, dtype=np.int64)
+    t0 = time.time()
+    ep, _, _, steps, _ = orl.batched_rollout(agent, args, sy, envs, 0.5, rseed=0)
+    t_roll = time.time() - t0
+    t0 = time.time()
+    learners.train(st, ep, 0)
+    t_train = time.time() - t0
+    reps = 1
+    while (time.time() - t0) < budget_s * 0.5 and reps < 3:
+        learners.train(st, ep, reps)
+        reps += 1
+    t_train = (time.time() - t0) / reps
+    # the reference's actual serial rollout (one env, one agent at a time), a few episodes
+    t0 = time.time()
+    _, _, _, ssteps, _ = orl.serial_rollout(agent, args, orl.SerialSynthEnv(sy), 2, 0.5)
+    t_serial = time.time() - t0
+    return {"value": steps / (t_roll + t_train), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%s %s: %d envs x T=%d batched CPU rollout + %d oracle train() calls; serial reference-style "
+                      "rollout of 2 episodes" % (alg, shape, envs, T, reps),
+            "learner_updates_per_sec": 1.0 / t_train, "learner_transitions_per_sec": envs * T / t_train,
+            "batched_rollout_env_steps_per_sec": steps / t_roll, "serial_rollout_env_steps_per_sec": ssteps / t_serial}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=4096, help="GLOBAL number of parallel envs / episodes per update")
+    ap.add_argument("--alg", default="qmix")
+    ap.add_argument("--shape", default="2s3z")
+    ap.add_argument("--T", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=32)
+    ap.add_argument("--leg-iters", type=int, default=3, help="iterations of the separately timed learner / rollout legs")
+    o = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == o.gpus, "launch with torch.distributed.run --nproc-per-node %d" % o.gpus
+
+    from marl_amd import ops
+    from marl_amd.controller.share_params import SharedMAC
+    from marl_amd.algorithm.q_learner import QLearner
+    from marl_amd.algorithm.qtran_learner import QTRANLearner
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.common.replaybuffer import ReplayBuffer
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+
+    args = make_args(o.alg, o.shape, o.T)
+    T, N = args.episode_limit, args.n_agents
+    E = o.envs // world                      # envs / episodes per rank
+    args.buffer_size = 2 * E
+    args.batch_size = E
+    torch.manual_seed(0)                     # identical random-init weights on every rank
+    mac = SharedMAC(args)
+    learner = QTRANLearner(mac, args) if o.alg.startswith("qtran") else QLearner(mac, args)
+    env = SyntheticSMACEnv(E, N, args.obs_shape, args.state_shape, args.n_actions, T, seed=1, env0=rank * E,
+                           fixed_length=True)
+    worker = RolloutWorker(env, mac, args)
+    buf = ReplayBuffer(args)
+    np.random.seed(1 + rank)
+
+    # HIP-event timing of the dominant kernel (the persistent agent unroll, 3 launches per update)
+    ev_pairs = []
+    orig_fwd = ops.agent_unroll_fwd
+    timing = {"on": False}
+
+    def timed_fwd(*a, **k):
+        if timing["on"] and a[13] > 1:       # T > 1: learner unrolls only
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_fwd(*a, **k)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        else:
+            orig_fwd(*a, **k)
+    ops.agent_unroll_fwd = timed_fwd
+
+    train_steps = [0]
+
+    def one_step():
+        episodes, _, _, steps = worker.generate_episodes(E)
+        buf.store_episode(episodes)
+        batch = buf.sample(min(buf.current_size, args.batch_size))
+        loss = learner.train(batch, train_steps[0])
+        train_steps[0] += 1
+        return steps, loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(o.warmup):
+        one_step()
+    barrier()
+    timing["on"] = True
+    t0 = time.perf_counter()
+    env_steps = 0
+    for _ in range(o.steps):
+        s, loss = one_step()
+        env_steps += s
+    barrier()
+    dt = time.perf_counter() - t0
+    timing["on"] = False
+    tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tsum = tt.clone()
+        torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+        dt, env_steps = float(tmax[0]), float(tsum[1])
+    kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+
+    # separately timed legs (after the contract's timed region): learner-only and rollout-only
+    batch = buf.sample(E)
+    barrier(); t1 = time.perf_counter()
+    for i in range(o.leg_iters):
+        learner.train(batch, 10 ** 6 + i)
+    barrier(); t_learn = (time.perf_counter() - t1) / o.leg_iters
+    barrier(); t1 = time.perf_counter()
+    rs = 0
+    for i in range(o.leg_iters):
+        rs += worker.generate_episodes(E)[3]
+    barrier(); t_roll = (time.perf_counter() - t1) / o.leg_iters
+
+    if rank == 0:
+        fl = agent_flops(args) * E * N * T                 # algorithmic FLOP of one unroll launch
+        avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
+            "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s_%s_T%d_envs%d" % (o.alg, o.shape, T, o.envs), "alg": o.alg, "shape": o.shape,
+                       "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
+                       "n_actions": args.n_actions, "episode_limit": T, "global_envs": o.envs, "envs_per_gpu": E,
+                       "parallelism": "dp%d" % world,
+                       "step": "batched rollout (T lock-steps) + replay store/sample + 1 learner.train()"},
+            "learner_updates_per_sec": 1.0 / t_learn,
+            "learner_transitions_per_sec": o.envs * T / t_learn,
+            "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
+            "last_loss": loss,
+            "roofline": {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
+                         "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
+                         "traffic": None, "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "flop_per_launch": fl},
+        }
+        if not o.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(o.alg, o.shape, T, o.cpu_envs, budget_s=20)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,8 +36,15 @@ struct FwdArgs {
   float* saved;           // [6][B,T,N,64]: hprev,x,r,z,n,hn  or null
   int B, T, N, O, A, I, KC, RT;
   int has_act, has_id;
+  int vload;              // obs rows are 16-B aligned multiples of 4 floats: vector prefetch path
   long R;                 // B*N rows
 };
+
+// workgroup barrier that only drains LDS traffic: global stores (saved activations) and the loader's
+// prefetch loads stay in flight across it (a __syncthreads() would wait vmcnt(0) every time)
+#define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr int NLD = 32;        // float4 registers the loader wave keeps in flight (one step's obs tile)
 
 // ---------------------------------------------------------------------------------------------
 template <int AC>
@@ -54,24 +61,140 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
   float* Ha = Xt + rows * HS;                         // [rows][HS] x2
   float* Hb = Ha + rows * HS;
   long* rowbase = reinterpret_cast<long*>(Hb + rows * HS);   // [rows]: (b*T*N + n), -1 if row invalid
-  long* rowb = rowbase + rows;                               // [rows]: b
+  long* rowobs = rowbase + rows;                             // [rows]: (b*obs_bs + n) * O
+  long* rowu = rowobs + rows;                                // [rows]: b*u_bs + n
+  int* rown = reinterpret_cast<int*>(rowu + rows);           // [rows]: n
+  int* rowlen = rown + rows;                                 // [rows]: episode length (INT_MAX if none)
 
   const long row0 = (long)blockIdx.x * rows;
   for (int r = tid; r < rows; r += NT) {
     long rho = row0 + r;
-    long v = -1;
-    long b = 0;
-    if (rho < a.R) { b = rho / a.N; int n = (int)(rho % a.N); v = b * a.T * a.N + n; }
+    long v = -1, b = 0;
+    int n = 0;
+    if (rho < a.R) { b = rho / a.N; n = (int)(rho % a.N); v = b * a.T * a.N + n; }
     rowbase[r] = v;
-    rowb[r] = b;
+    rowobs[r] = (b * a.obs_bs + n) * a.O;
+    rowu[r] = b * a.u_bs + n;
+    rown[r] = n;
+    rowlen[r] = (a.ep_len && rho < a.R) ? a.ep_len[b] : 0x7fffffff;
   }
   const long tstride = a.N;   // rows per time step within an episode
+  // ---- initial hidden tile
+  for (int e = tid; e < rows * H; e += NT) {
+    int r = e / H, k = e % H;
+    long rho = row0 + r;
+    Ha[r * HS + k] = (a.h0 && rho < a.R) ? a.h0[rho * H + k] : 0.f;
+  }
+  __syncthreads();   // row tables + hidden tile visible
 
+  if (wave == 4) {
+    // =================== loader wave: streams obs(t+1) HBM -> registers -> LDS, one step ahead ========
+    const int O = a.O;
+    if (a.vload) {
+      const int O4 = O >> 2, n4 = rows * O4;
+      const float invO4 = 1.0f / (float)O4;
+      f32x4 pf[NLD];
+      int pu[2];
+      auto issue = [&](int t) {
+        const long toff = (long)(t + a.obs_t0) * a.N * O;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          int e = lane + 64 * i;
+          asm volatile("" : "+v"(e));     // keep the per-element address math inside the step (no hoisting -> no spills)
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (e < n4) {
+            const int r = (int)(((float)e + 0.5f) * invO4);
+            const int k4 = e - r * O4;
+            if (rowbase[r] >= 0 && t < rowlen[r])
+              v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + toff + 4 * k4);
+          }
+          pf[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = lane + 64 * j;
+          int u = -1;
+          if (r < rows && rowbase[r] >= 0 && a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
+          pu[j] = u;
+        }
+      };
+      auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          int e = lane + 64 * i;
+          asm volatile("" : "+v"(e));
+          if (e < n4) {
+            const int r = (int)(((float)e + 0.5f) * invO4);
+            const int k4 = e - r * O4;
+            *reinterpret_cast<f32x4*>(In + r * KS + 4 * k4) = pf[i];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = lane + 64 * j;
+          if (r < rows) {
+            const bool ok = rowbase[r] >= 0;
+            const int n = rown[r];
+            for (int k = O; k < KP; ++k) {
+              float v = 0.f;
+              if (ok) {
+                if (a.has_act && k < O + a.A) v = (pu[j] == k - O) ? 1.f : 0.f;
+                else if (a.has_id && k >= a.I - a.N && k < a.I) v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
+              }
+              In[r * KS + k] = v;
+            }
+          }
+        }
+      };
+      issue(0);
+      commit();
+      if (a.T > 1) issue(1);
+      WG_BARRIER();
+      for (int t = 0; t < a.T; ++t) {
+        WG_BARRIER();                       // phase 1 of step t has consumed the input tile
+        if (t + 1 < a.T) {
+          commit();
+          if (t + 2 < a.T) issue(t + 2);
+        }
+        WG_BARRIER();
+      }
+    } else {
+      // generic path (obs width not a multiple of 4 / unaligned): element loads, no run-ahead
+      auto load_inputs = [&](int t) {
+        for (int e = lane; e < rows * KP; e += 64) {
+          const int r = e / KP, k = e - r * KP;
+          float v = 0.f;
+          if (rowbase[r] >= 0) {
+            if (k < O) {
+              if (t < rowlen[r]) v = a.obs[rowobs[r] + (long)(t + a.obs_t0) * a.N * O + k];
+            } else if (a.has_act && k < O + a.A) {
+              int u = -1;
+              if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
+              v = (u == k - O) ? 1.f : 0.f;
+            } else if (a.has_id && k >= a.I - a.N && k < a.I) {
+              v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
+            }
+          }
+          In[r * KS + k] = v;
+        }
+      };
+      load_inputs(0);
+      WG_BARRIER();
+      for (int t = 0; t < a.T; ++t) {
+        WG_BARRIER();
+        if (t + 1 < a.T) load_inputs(t + 1);
+        WG_BARRIER();
+      }
+    }
+    return;
+  }
+
+  // =================== compute waves ===================================================================
   // ---- stage weights: fc1 slice -> LDS fragments; GRU / fc2 slices -> registers
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
-  float bias_r = 0, bias_z = 0, bias_in = 0, bias_hn = 0, bias1 = 0, bias2[AC];
-  if (wave < 4) {
-    const int j = 16 * wave + m;
+  float bias_r, bias_z, bias_in, bias_hn, bias1, bias2[AC];
+  const int j = 16 * wave + m;
+  {
     for (int c = 0; c < a.KC; ++c) {
       f32x4 v;
 #pragma unroll
@@ -102,153 +225,108 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
     bias_in = a.bih[2 * H + j];
     bias_hn = a.bhh[2 * H + j];
   }
-  __syncthreads();   // rowbase visible
-
-  // ---- initial hidden tile
-  for (int e = tid; e < rows * H; e += NT) {
-    int r = e / H, k = e % H;
-    long rho = row0 + r;
-    Ha[r * HS + k] = (a.h0 && rho < a.R) ? a.h0[rho * H + k] : 0.f;
-  }
-
-  // loader: build the input tile [obs | onehot(ufed) | id | 0-pad] for step t into buf
-  auto load_inputs = [&](int t, float* buf) {
-    const int O = a.O;
-    for (int e = lane; e < rows * KP; e += 64) {
-      const int r = e / KP, k = e - r * KP;
-      const long rb = rowbase[r];
-      float v = 0.f;
-      if (rb >= 0) {
-        const int n = (int)(rb % a.N);   // rb = b*T*N + n and T*N is a multiple of N
-        const long b = rowb[r];
-        if (k < O) {
-          if (!a.ep_len || t < a.ep_len[b]) v = a.obs[(b * a.obs_bs + (long)(t + a.obs_t0) * a.N + n) * O + k];
-        }
-        else if (a.has_act && k < O + a.A) {
-          int u = -1;
-          if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[b * a.u_bs + (long)(t + a.u_t0) * a.N + n];
-          v = (u == k - O) ? 1.f : 0.f;
-        } else if (a.has_id && k < a.I) {
-          v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
-        }
-      }
-      buf[r * KS + k] = v;
-    }
-  };
-  if (wave == 4) load_inputs(0, In);
-  __syncthreads();
+  WG_BARRIER();   // input tile of step 0 is in LDS
 
   const long plane = (long)a.B * a.T * a.N * H;   // one saved array
   float* Hp = Ha;
   float* Hn = Hb;
   for (int t = 0; t < a.T; ++t) {
-    if (wave < 4) {
-      // ---------------- phase 1: x = relu(fc1(in))  (two row tiles in flight)
-      const int j = 16 * wave + m;
-      for (int rt = 0; rt < a.RT; rt += 2) {
-        const bool two = rt + 1 < a.RT;
-        f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
-        const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
-        const float* in1 = in0 + 16 * KS;
-        const float* wf = W1s + (wave * a.KC * 64 + lane) * 4;
-        for (int c = 0; c < a.KC; ++c) {
-          f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
-          f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
-          acc0 = mfma16x4(a0, bv, acc0);
-          if (two) {
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
-            acc1 = mfma16x4(a1, bv, acc1);
-          }
+    // ---------------- phase 1: x = relu(fc1(in))  (two row tiles in flight)
+    for (int rt = 0; rt < a.RT; rt += 2) {
+      const bool two = rt + 1 < a.RT;
+      f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
+      const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
+      const float* in1 = in0 + 16 * KS;
+      const float* wf = W1s + (wave * a.KC * 64 + lane) * 4;
+      for (int c = 0; c < a.KC; ++c) {
+        f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
+        acc0 = mfma16x4(a0, bv, acc0);
+        if (two) {
+          f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
+          acc1 = mfma16x4(a1, bv, acc1);
         }
+      }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = rt * 16 + 4 * q + i;
-          const float x0 = fmaxf(acc0[i], 0.f);
-          Xt[r * HS + j] = x0;
-          const long rb = rowbase[r];
-          if (a.saved && rb >= 0) a.saved[plane + (rb + (long)t * tstride) * H + j] = x0;
-          if (two) {
-            const float x1 = fmaxf(acc1[i], 0.f);
-            Xt[(r + 16) * HS + j] = x1;
-            const long rb1 = rowbase[r + 16];
-            if (a.saved && rb1 >= 0) a.saved[plane + (rb1 + (long)t * tstride) * H + j] = x1;
-          }
+      for (int i = 0; i < 4; ++i) {
+        const int r = rt * 16 + 4 * q + i;
+        const float x0 = fmaxf(acc0[i], 0.f);
+        Xt[r * HS + j] = x0;
+        const long rb = rowbase[r];
+        if (a.saved && rb >= 0) a.saved[plane + (rb + (long)t * tstride) * H + j] = x0;
+        if (two) {
+          const float x1 = fmaxf(acc1[i], 0.f);
+          Xt[(r + 16) * HS + j] = x1;
+          const long rb1 = rowbase[r + 16];
+          if (a.saved && rb1 >= 0) a.saved[plane + (rb1 + (long)t * tstride) * H + j] = x1;
         }
       }
     }
-    __syncthreads();
-    if (wave == 4) {
-      // the input tile was consumed by phase 1; refill it for step t+1 while the gates run
-      if (t + 1 < a.T) load_inputs(t + 1, In);
-    } else {
-      // ---------------- phase 2: GRU gates + pointwise update
-      const int j = 16 * wave + m;
-      for (int rt = 0; rt < a.RT; ++rt) {
-        f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
-        f32x4 az = {bias_z, bias_z, bias_z, bias_z};
-        f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
-        f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
-        const float* xr = Xt + (rt * 16 + m) * HS + 4 * q;
-        const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+    WG_BARRIER();
+    // ---------------- phase 2: GRU gates + pointwise update
+    for (int rt = 0; rt < a.RT; ++rt) {
+      f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
+      f32x4 az = {bias_z, bias_z, bias_z, bias_z};
+      f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
+      f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
+      const float* xr = Xt + (rt * 16 + m) * HS + 4 * q;
+      const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-          ar = mfma16x4(ax, wih[0][c], ar);
-          az = mfma16x4(ax, wih[1][c], az);
-          ain = mfma16x4(ax, wih[2][c], ain);
-          ahn = mfma16x4(ah, whh[2][c], ahn);
-          ar = mfma16x4(ah, whh[0][c], ar);
-          az = mfma16x4(ah, whh[1][c], az);
-        }
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+        ar = mfma16x4(ax, wih[0][c], ar);
+        az = mfma16x4(ax, wih[1][c], az);
+        ain = mfma16x4(ax, wih[2][c], ain);
+        ahn = mfma16x4(ah, whh[2][c], ahn);
+        ar = mfma16x4(ah, whh[0][c], ar);
+        az = mfma16x4(ah, whh[1][c], az);
+      }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = rt * 16 + 4 * q + i;
-          const float hp = Hp[r * HS + j];
-          const float rg = sigmoidf_(ar[i]);
-          const float zg = sigmoidf_(az[i]);
-          const float ng = tanhf_(ain[i] + rg * ahn[i]);
-          const float hn = (1.f - zg) * ng + zg * hp;
-          Hn[r * HS + j] = hn;
-          const long rb = rowbase[r];
-          if (rb >= 0) {
-            const long off = (rb + (long)t * tstride) * H + j;
-            if (a.hs) a.hs[off] = hn;
-            if (a.saved) {
-              a.saved[off] = hp;
-              a.saved[2 * plane + off] = rg;
-              a.saved[3 * plane + off] = zg;
-              a.saved[4 * plane + off] = ng;
-              a.saved[5 * plane + off] = ahn[i];
-            }
-            if (a.h_last && t == a.T - 1) a.h_last[(row0 + r) * H + j] = hn;
+      for (int i = 0; i < 4; ++i) {
+        const int r = rt * 16 + 4 * q + i;
+        const float hp = Hp[r * HS + j];
+        const float rg = sigmoidf_(ar[i]);
+        const float zg = sigmoidf_(az[i]);
+        const float ng = tanhf_(ain[i] + rg * ahn[i]);
+        const float hn = (1.f - zg) * ng + zg * hp;
+        Hn[r * HS + j] = hn;
+        const long rb = rowbase[r];
+        if (rb >= 0) {
+          const long off = (rb + (long)t * tstride) * H + j;
+          if (a.hs) a.hs[off] = hn;
+          if (a.saved) {
+            a.saved[off] = hp;
+            a.saved[2 * plane + off] = rg;
+            a.saved[3 * plane + off] = zg;
+            a.saved[4 * plane + off] = ng;
+            a.saved[5 * plane + off] = ahn[i];
           }
+          if (a.h_last && t == a.T - 1) a.h_last[(row0 + r) * H + j] = hn;
         }
       }
     }
-    __syncthreads();
-    if (wave < 4) {
-      // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the waves)
-      for (int rt = wave; rt < a.RT; rt += 4) {
-        f32x4 acc[AC];
+    WG_BARRIER();
+    // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the waves)
+    for (int rt = wave; rt < a.RT; rt += 4) {
+      f32x4 acc[AC];
 #pragma unroll
-        for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
-        const float* hr = Hn + (rt * 16 + m) * HS + 4 * q;
+      for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
+      const float* hr = Hn + (rt * 16 + m) * HS + 4 * q;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
 #pragma unroll
-          for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
-        }
+        for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
+      }
 #pragma unroll
-        for (int ac = 0; ac < AC; ++ac) {
-          const int col = 16 * ac + m;
-          if (col < a.A) {
+      for (int ac = 0; ac < AC; ++ac) {
+        const int col = 16 * ac + m;
+        if (col < a.A) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const long rb = rowbase[rt * 16 + 4 * q + i];
-              if (rb >= 0) a.q[(rb + (long)t * tstride) * a.A + col] = acc[ac][i];
-            }
+          for (int i = 0; i < 4; ++i) {
+            const long rb = rowbase[rt * 16 + 4 * q + i];
+            if (rb >= 0) a.q[(rb + (long)t * tstride) * a.A + col] = acc[ac][i];
           }
         }
       }
@@ -454,9 +532,15 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.KC = (a.I + 15) / 16;
   a.R = (long)B * N;
   const int KS = a.KC * 16 + 4;
-  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 16;
+  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;
   const size_t fixed = (size_t)4 * a.KC * 64 * 16;
-  a.RT = pick_rt(a.R, per_row, fixed, 8);
+  a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
+  int rt_cap = 8;
+  if (a.vload) {   // the loader keeps one step's obs tile (rows * O/4 float4) in NLD*64 registers
+    int cap2 = (NLD * 64) / (16 * (O / 4));
+    if (cap2 < 1) { a.vload = 0; } else if (cap2 < rt_cap) rt_cap = cap2;
+  }
+  a.RT = pick_rt(a.R, per_row, fixed, rt_cap);
   const size_t lds = fixed + per_row * a.RT * 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const long rows = a.RT * 16;
