@@ -105,10 +105,12 @@ def clip_and_step(state: LearnerState, grads: dict):
 # ---------------------------------------------------------------------------------
 # QLearner.train  (algorithm/q_learner.py:68-179)
 # ---------------------------------------------------------------------------------
-def q_forward(state: LearnerState, batch, want=None):
-    """Forward of the VDN/QMIX/QPLEX loss.  Returns (loss, dict of intermediates)."""
+def q_forward(state: LearnerState, batch, want=None, T=None):
+    """Forward of the VDN/QMIX/QPLEX loss.  Returns (loss, dict of intermediates).
+    ``T`` overrides get_max_episode_len (data-parallel shards must agree on it)."""
     args = state.args
-    T = max_episode_len(batch["terminated"], args.episode_limit)
+    if T is None:
+        T = max_episode_len(batch["terminated"], args.episode_limit)
     bt = to_tensors(batch, T)
     B, N, H = bt["o"].shape[0], args.n_agents, args.rnn_hidden_dim
     s, u, r, s_next = bt["s"], bt["u"], bt["r"], bt["s_next"]
@@ -168,7 +170,7 @@ def q_forward(state: LearnerState, batch, want=None):
     td = targets.detach() - q_tot
     mtd = mask * td
     loss = (mtd ** 2).sum() / mask.sum()
-    inter.update(q_tot=q_tot, q_tot_target=q_tot_tgt, loss=loss)
+    inter.update(q_tot=q_tot, q_tot_target=q_tot_tgt, loss=loss, num=(mtd ** 2).sum(), den=mask.sum())
     return loss, inter
 
 
