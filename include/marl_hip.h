@@ -81,12 +81,23 @@ int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long 
                           const int* ufed, long u_bs, int u_t0, const int* ep_len, const float* h0,
                           float* q, float* hs, float* h_last, float* saved, int B, int T, int N, int O,
                           int A, int last_action, int reuse_network, void* stream);
-/* BPTT delta pass (autograd of the unroll above; q_learner.py:171 loss.backward()).
+/* Gradient destinations of the recurrent / output layers (accumulated into, torch layouts). */
+typedef struct {
+  float *w_ih, *w_hh;           /* (3H,H) */
+  float *b_ih, *b_hh;           /* (3H)   */
+  float *fc2_w, *fc2_b;         /* (A,H), (A) */
+} marl_agent_grads_t;
+
+/* BPTT (autograd of the unroll above; q_learner.py:171 loss.backward()), fused: per step the delta
+ * pass AND the weight-gradient reductions of W_ih, W_hh, W_2 and their biases (in-register
+ * accumulators, one partial slab per workgroup in `ws`, fixed-order reduce => reproducible).
  *   dq (B,T,N,A) gradient on q; dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
- *   dgate (B,T,N,256) = d r_pre | d z_pre | d n_pre | d(W_hn h + b_hn);  dxp (B,T,N,64) = d fc1 pre-act
- * Weight gradients follow as marl_linear_wgrad reductions over these. */
+ *   saved, hs: outputs of the forward pass;  dxp (B,T,N,64) = gradient at the fc1 pre-activation
+ * The fc1 gradient follows as ONE marl_linear_wgrad over dxp and the virtual input [obs|u|id]. */
+size_t marl_agent_bwd_workspace(int B, int N, int A);
 int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const float* dhs,
-                          const float* saved, float* dgate, float* dxp, float* dh0,
+                          const float* saved, const float* hs, float* dxp, float* dh0,
+                          const marl_agent_grads_t* g, float* ws, size_t ws_bytes,
                           int B, int T, int N, int A, void* stream);
 
 /* ---- per-row kernels (mixers.hip) -----------------------------------------------------------*/

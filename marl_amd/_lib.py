@@ -31,6 +31,11 @@ class MarlGroup(C.Structure):
                 ("gs_b", C.c_long), ("gs_y", C.c_long), ("gs_m0", C.c_long)]
 
 
+class MarlAgentGrads(C.Structure):
+    _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
+                ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
+
+
 class MarlAgentWeights(C.Structure):
     _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("w_ih", C.c_void_p), ("w_hh", C.c_void_p),
                 ("b_ih", C.c_void_p), ("b_hh", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
@@ -39,6 +44,7 @@ class MarlAgentWeights(C.Structure):
 
 P, I, L, F, U, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size_t
 SRC, GRP, AW = C.POINTER(MarlSrc), C.POINTER(MarlGroup), C.POINTER(MarlAgentWeights)
+AG = C.POINTER(MarlAgentGrads)
 
 # name -> (restype, argtypes); must list every symbol of include/marl_hip.h
 SIGNATURES = {
@@ -47,7 +53,8 @@ SIGNATURES = {
     "marl_linear_wgrad_workspace": (SZ, [I, I, I, I]),
     "marl_wgrad_slabs": (I, [I]),
     "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
-    "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, P, I, I, I, I, P]),
+    "marl_agent_bwd_workspace": (SZ, [I, I, I]),
+    "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),
     "marl_q_masked_max": (I, [P, P, F, P, P, L, I, P]),
     "marl_q_scatter": (I, [P, P, P, P, P, L, I, I, P]),

@@ -17,13 +17,13 @@ class FlatView:
 
     def __init__(self, flat, params, start):
         self.params = list(params)
-        self.n = sum(p.numel() for p in self.params)
-        self.flat = flat[start:start + self.n]
         self.offsets = []
         off = 0
         for p in self.params:
             self.offsets.append(off)
-            off += p.numel()
+            off += (p.numel() + 3) // 4 * 4      # same 16-byte alignment rule as FlatParams
+        self.n = off
+        self.flat = flat[start:start + self.n]
 
 
 class LearnerParams(FlatParams):
@@ -96,24 +96,21 @@ class Scratch:
 
 
 def agent_backward(mac, db, which, saved, hs, dq, dhs, buf):
-    """BPTT of the eval unroll: delta kernel, then the five weight-gradient reductions
+    """BPTT of the eval unroll: the fused kernel (delta pass + W_ih/W_hh/W_2 gradients), then the
+    fc1 weight gradient as one reduction over the virtual input [obs | one-hot(u_{t-1}) | agent id]
     (autograd of controller/share_params.py:125-146 + network/q_network.py:16-21)."""
     args = mac.args
     B, T, N, A, O = db.B, db.T, db.N, db.A, db.O
     H = args.rnn_hidden_dim
     M = B * T * N
     dev = dq.device
-    dgate = buf.get("dgate", (B, T, N, 4 * H), dev)
     dxp = buf.get("dxp", (B, T, N, H), dev)
     w = mac.agent.weights()
-    ops.agent_unroll_bwd(w, dq, dhs, saved, dgate, dxp, None, B, T, N, A)
     ag = mac.agent
-    dg = dgate.view(M, 4 * H)
-    hprev, x = saved[0].view(M, H), saved[1].view(M, H)
-    ops.linear_wgrad(dg[:, :3 * H], ops.src(x), ag.rnn.weight_ih.grad, ag.rnn.bias_ih.grad, M, 3 * H, H)
-    ops.linear_wgrad(dg[:, :2 * H], ops.src(hprev), ag.rnn.weight_hh.grad[:2 * H], ag.rnn.bias_hh.grad[:2 * H], M, 2 * H, H)
-    ops.linear_wgrad(dg[:, 3 * H:], ops.src(hprev), ag.rnn.weight_hh.grad[2 * H:], ag.rnn.bias_hh.grad[2 * H:], M, H, H)
-    ops.linear_wgrad(dq.view(M, A), ops.src(hs.view(M, H)), ag.fc2.weight.grad, ag.fc2.bias.grad, M, A, H)
+    grads = {"rnn.weight_ih": ag.rnn.weight_ih.grad, "rnn.weight_hh": ag.rnn.weight_hh.grad,
+             "rnn.bias_ih": ag.rnn.bias_ih.grad, "rnn.bias_hh": ag.rnn.bias_hh.grad,
+             "fc2.weight": ag.fc2.weight.grad, "fc2.bias": ag.fc2.bias.grad}
+    ops.agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, None, grads, B, T, N, A)
     obs, obs_bs, obs_t0 = db.o_cur if which == "cur" else db.o_next
     remap0 = None if (obs_bs == T * N and obs_t0 == 0) else (T * N, obs_bs, obs_t0 * N)
     kw = {}

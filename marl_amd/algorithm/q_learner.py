@@ -59,9 +59,8 @@ class QLearner:
         self.target_mixer.to(dev)
         self.eval_net.agent.to(dev)
         self._flat = LearnerParams(self.params, dev)
-        n_agent = sum(p.numel() for p in self.eval_net.agent.parameters())
         self.eval_net.agent._flat = FlatView(self._flat.flat, self.eval_net.agent.parameters(), 0)
-        self.mixer._flat = FlatView(self._flat.flat, self.mixer.parameters(), n_agent)
+        self.mixer._flat = FlatView(self._flat.flat, self.mixer.parameters(), self.eval_net.agent._flat.n)
         self.eval_net._dev = dev
         self.target_net._dev = dev
         self.target_net.agent.to(dev)

@@ -338,166 +338,294 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward through time, delta part: per step computes the gate pre-activation gradients and
-// dx_pre, carries dh; weight gradients are then plain reductions (marl_linear_wgrad).
+// Backward through time, fully fused: per step the delta pass (dh carry, gate gradients, dx) AND
+// the weight-gradient reductions of W_ih, W_hh, W_2 and their biases.  4 waves, one per SIMD
+// (up to 512 VGPRs): wave w keeps its B-fragments of W_ih^T / W_hh^T / W_2^T and 100 accumulator
+// registers of dW for the whole kernel.  The accumulator (D) layout of two tiles over the same 16
+// rows IS the (A^T, B) operand pair of v_mfma_f32_16x16x4, so dW += G^T X needs no LDS at all; the
+// saved activations are software-pipelined one row tile ahead straight into registers.
 struct BwdArgs {
   const float *Wih, *Whh, *W2;
   const float* dq;        // (B,T,N,A)
   const float* dhs;       // (B,T,N,64) external gradient on hs[t], or null
   const float* saved;     // [6][B,T,N,64]
-  float* dgate;           // (B,T,N,256): d r_pre | d z_pre | d n_pre | d hn  (hn = W_hn h + b_hn)
+  const float* hs;        // (B,T,N,64) hidden after each step (for dW_2)
   float* dxp;             // (B,T,N,64): gradient at fc1 pre-activation
   float* dh0;             // (B*N,64) gradient wrt the initial hidden state, or null
+  float* ws;              // [n_wg][slab]: dW_ih | dW_hh | dW_2 | db_ih | db_hh | db_2 partials
   int B, T, N, A, RT;
   long R;
 };
 
 constexpr int DGS = 256 + 4;
+constexpr int BNT = 256;
+constexpr int NQ = 16;
+
+struct Pre {            // one row tile of saved activations in accumulator layout
+  f32x4 hp_all[4], x_all[4];
+  f32x4 r, z, n, hn, dhs, ht;
+};
+
+__device__ __forceinline__ f32x4 pick4(const f32x4 (&v)[4], int w) {
+  f32x4 o = v[0];
+  if (w == 1) o = v[1];
+  if (w == 2) o = v[2];
+  if (w == 3) o = v[3];
+  return o;
+}
+
+__host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + (long)A * 64 + 2 * 192 + A; }
 
 template <int AC>
-__global__ __launch_bounds__(NT, 2) void agent_bwd_kernel(BwdArgs a) {
+__global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
   const int rows = a.RT * 16;
   constexpr int QP = AC * 16, QS = QP + 4;
-  float* DG = smem;                         // [rows][DGS]
+  float* DG = smem;                         // [rows][DGS]  drp|dzp|dnp|dhn (A operand of phase C)
   float* DQ0 = DG + rows * DGS;             // [rows][QS] x2
   float* DQ1 = DQ0 + rows * QS;
   float* CAR = DQ1 + rows * QS;             // [rows][HS] carried dh (each wave touches its own columns)
-  long* rowbase = reinterpret_cast<long*>(CAR + rows * HS);
+  float* XM = CAR + rows * HS;              // [rows][HS] x (own columns) for the relu gate of phase C
+  long* rowbase = reinterpret_cast<long*>(XM + rows * HS);
 
   const long row0 = (long)blockIdx.x * rows;
-  for (int r = tid; r < rows; r += NT) {
+  for (int r = tid; r < rows; r += BNT) {
     long rho = row0 + r;
     long v = -1;
     if (rho < a.R) { long b = rho / a.N; int n = (int)(rho % a.N); v = b * a.T * a.N + n; }
     rowbase[r] = v;
   }
-  for (int e = tid; e < rows * HS; e += NT) CAR[e] = 0.f;
+  for (int e = tid; e < rows * HS; e += BNT) CAR[e] = 0.f;
   const long tstride = a.N;
   const long plane = (long)a.B * a.T * a.N * H;
+  const int j = 16 * wave + m;
 
   // B-fragments of the TRANSPOSED products: lane (q,m) holds W[k = 16c+4q+i][col 16w+m]
   f32x4 whhT[12], wihT[12], w2T[AC];
-  if (wave < 4) {
-    const int j = 16 * wave + m;
 #pragma unroll
-    for (int c = 0; c < 12; ++c)
+  for (int c = 0; c < 12; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = 16 * c + 4 * q + i;
-        whhT[c][i] = a.Whh[(long)k * H + j];
-        wihT[c][i] = a.Wih[(long)k * H + j];
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int k = 16 * c + 4 * q + i;
+      whhT[c][i] = a.Whh[(long)k * H + j];
+      wihT[c][i] = a.Wih[(long)k * H + j];
+    }
 #pragma unroll
-    for (int ac = 0; ac < AC; ++ac)
+  for (int ac = 0; ac < AC; ++ac)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = 16 * ac + 4 * q + i;
-        w2T[ac][i] = k < a.A ? a.W2[(long)k * H + j] : 0.f;
-      }
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int k = 16 * ac + 4 * q + i;
+      w2T[ac][i] = k < a.A ? a.W2[(long)k * H + j] : 0.f;
+    }
+  f32x4 accIH[3][4], accHH[3][4], accW2[AC];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { accIH[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; accHH[g][c] = accIH[g][c]; }
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac) accW2[ac] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_hn = 0.f, sb2[AC];
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac) sb2[ac] = 0.f;
   __syncthreads();
 
-  auto load_dq = [&](int t, float* buf) {
-    for (int e = lane; e < rows * QP; e += 64) {
-      const int r = e / QP, k = e - r * QP;
-      const long rb = rowbase[r];
-      float v = 0.f;
-      if (rb >= 0 && k < a.A) v = a.dq[(rb + (long)t * tstride) * a.A + k];
-      buf[r * QS + k] = v;
-    }
+  // one row tile of saved activations, loaded in accumulator layout into NAMED registers
+  // (a struct returned from a lambda ended up in scratch memory)
+#define LOAD_PRE(HP, XA, HPO_, XO_, R_, Z_, N_, HN_, DHS_, HT_, tt, rr, en)                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+    const long rb_ = rowbase[(rr) * 16 + 4 * q + i];                                                     \
+    const bool ok_ = (en) && rb_ >= 0;                                                                   \
+    const long off_ = ok_ ? (rb_ + (long)(tt) * tstride) * H : 0;                                        \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+      HP[c][i] = ok_ ? a.saved[off_ + 16 * c + m] : 0.f;                                                 \
+      XA[c][i] = ok_ ? a.saved[plane + off_ + 16 * c + m] : 0.f;                                         \
+    }                                                                                                    \
+    HPO_[i] = ok_ ? a.saved[off_ + j] : 0.f;          /* own 16 columns (a runtime pick from HP[] would go to scratch) */ \
+    XO_[i] = ok_ ? a.saved[plane + off_ + j] : 0.f;                                                      \
+    R_[i] = ok_ ? a.saved[2 * plane + off_ + j] : 0.f;                                                   \
+    Z_[i] = ok_ ? a.saved[3 * plane + off_ + j] : 0.f;                                                   \
+    N_[i] = ok_ ? a.saved[4 * plane + off_ + j] : 0.f;                                                   \
+    HN_[i] = ok_ ? a.saved[5 * plane + off_ + j] : 0.f;                                                  \
+    HT_[i] = ok_ ? a.hs[off_ + j] : 0.f;                                                                 \
+    DHS_[i] = (ok_ && a.dhs) ? a.dhs[off_ + j] : 0.f;                                                    \
+  }
+  auto dq_elem = [&](int t, int e) -> float {
+    const int r = e / QP, k = e - r * QP;
+    const long rb = rowbase[r];
+    return (rb >= 0 && k < a.A) ? a.dq[(rb + (long)t * tstride) * a.A + k] : 0.f;
   };
-  if (wave == 4) load_dq(a.T - 1, DQ0);
+
+  for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
+  f32x4 c_hp[4], c_x[4], c_hpo, c_xo, c_r, c_z, c_n, c_hn, c_dhs, c_ht;
+  LOAD_PRE(c_hp, c_x, c_hpo, c_xo, c_r, c_z, c_n, c_hn, c_dhs, c_ht, a.T - 1, 0, true)
   __syncthreads();
 
   int par = 0;
   for (int t = a.T - 1; t >= 0; --t, par ^= 1) {
     float* DQ = par ? DQ1 : DQ0;
     float* DQn = par ? DQ0 : DQ1;
-    if (wave == 4) {
-      if (t > 0) load_dq(t - 1, DQn);
-    } else {
-      // ---------------- phase B: dh = carry + dhs + dq W2 ; gate gradients
-      const int j = 16 * wave + m;
-      for (int rt = 0; rt < a.RT; ++rt) {
-        f32x4 dh;
+    float dqpre[NQ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
-        const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + BNT * i;
+      dqpre[i] = (t > 0 && e < rows * QP) ? dq_elem(t - 1, e) : 0.f;
+    }
+    // ---------------- phase B: dh = carry + dhs + dq W2 ; gate gradients ; dW accumulation
+    for (int rt = 0; rt < a.RT; ++rt) {
+      int tn = t, rn = rt + 1;
+      if (rn >= a.RT) { rn = 0; tn = t - 1; }
+      f32x4 n_hp[4], n_x[4], n_hpo, n_xo, n_r, n_z, n_n, n_hn, n_dhs, n_ht;     // next row tile, in flight during this one
+      LOAD_PRE(n_hp, n_x, n_hpo, n_xo, n_r, n_z, n_n, n_hn, n_dhs, n_ht, (tn < 0 ? 0 : tn), rn, (tn >= 0))
+      f32x4 dh;
 #pragma unroll
-        for (int ac = 0; ac < AC; ++ac) {
-          f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
-          dh = mfma16x4(av, w2T[ac], dh);
-        }
+      for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+      const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = rt * 16 + 4 * q + i;
-          const long rb = rowbase[r];
-          float drp = 0.f, dzp = 0.f, dnp = 0.f, dhn = 0.f, dcar = 0.f;
-          if (rb >= 0) {
-            const long off = (rb + (long)t * tstride) * H + j;
-            float d = dh[i];
-            if (a.dhs) d += a.dhs[off];
-            const float hp = a.saved[off];
-            const float rg = a.saved[2 * plane + off];
-            const float zg = a.saved[3 * plane + off];
-            const float ng = a.saved[4 * plane + off];
-            const float hn = a.saved[5 * plane + off];
-            const float dn = d * (1.f - zg);
-            const float dz = d * (hp - ng);
-            dcar = d * zg;
-            dnp = dn * (1.f - ng * ng);
-            dzp = dz * zg * (1.f - zg);
-            drp = dnp * hn * rg * (1.f - rg);
-            dhn = dnp * rg;
-            float* dg = a.dgate + (rb + (long)t * tstride) * 256 + j;
-            dg[0] = drp; dg[64] = dzp; dg[128] = dnp; dg[192] = dhn;
-          }
-          float* l = DG + r * DGS + j;
-          l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
-          CAR[r * HS + j] = dcar;
-        }
+      for (int ac = 0; ac < AC; ++ac) {
+        f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
+        dh = mfma16x4(av, w2T[ac], dh);
+      }
+      const f32x4 hpo = c_hpo, xo = c_xo;          // this wave's own 16 columns of h_prev / x
+      f32x4 g_r, g_z, g_n, g_hn;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = rt * 16 + 4 * q + i;
+        const float d = dh[i] + c_dhs[i];
+        const float rg = c_r[i], zg = c_z[i], ng = c_n[i];
+        const float dn = d * (1.f - zg);
+        const float dz = d * (hpo[i] - ng);
+        const float dnp = dn * (1.f - ng * ng);
+        const float dzp = dz * zg * (1.f - zg);
+        const float drp = dnp * c_hn[i] * rg * (1.f - rg);
+        const float dhn = dnp * rg;
+        g_r[i] = drp; g_z[i] = dzp; g_n[i] = dnp; g_hn[i] = dhn;
+        float* l = DG + r * DGS + j;
+        l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
+        CAR[r * HS + j] = d * zg;
+        XM[r * HS + j] = xo[i];
+        sb_r += drp; sb_z += dzp; sb_n += dnp; sb_hn += dhn;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        accIH[0][c] = mfma16x4(g_r, c_x[c], accIH[0][c]);
+        accIH[1][c] = mfma16x4(g_z, c_x[c], accIH[1][c]);
+        accIH[2][c] = mfma16x4(g_n, c_x[c], accIH[2][c]);
+        accHH[0][c] = mfma16x4(g_r, c_hp[c], accHH[0][c]);
+        accHH[1][c] = mfma16x4(g_z, c_hp[c], accHH[1][c]);
+        accHH[2][c] = mfma16x4(g_hn, c_hp[c], accHH[2][c]);
+      }
+#pragma unroll
+      for (int ac = 0; ac < AC; ++ac) {
+        f32x4 dqf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dqf[i] = DQ[(rt * 16 + 4 * q + i) * QS + 16 * ac + m];
+        accW2[ac] = mfma16x4(dqf, c_ht, accW2[ac]);
+        sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { c_hp[c] = n_hp[c]; c_x[c] = n_x[c]; }
+      c_hpo = n_hpo; c_xo = n_xo; c_r = n_r; c_z = n_z; c_n = n_n; c_hn = n_hn; c_dhs = n_dhs; c_ht = n_ht;
+    }
+    WG_BARRIER();
+    // ---------------- phase C: dh_prev = z*dh + [drp,dzp,dhn] W_hh ; dx = [drp,dzp,dnp] W_ih
+    for (int rt = 0; rt < a.RT; ++rt) {
+      f32x4 dhp, dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dhp[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+      const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        f32x4 ai = *reinterpret_cast<const f32x4*>(gr + 16 * c);              // drp|dzp|dnp
+        dx = mfma16x4(ai, wihT[c], dx);
+        f32x4 ah = c < 8 ? ai : *reinterpret_cast<const f32x4*>(gr + 192 + 16 * (c - 8));  // drp|dzp|dhn
+        dhp = mfma16x4(ah, whhT[c], dhp);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = rt * 16 + 4 * q + i;
+        const long rb = rowbase[r];
+        CAR[r * HS + j] = dhp[i];
+        if (rb >= 0) a.dxp[(rb + (long)t * tstride) * H + j] = XM[r * HS + j] > 0.f ? dx[i] : 0.f;
       }
     }
-    __syncthreads();
-    if (wave < 4) {
-      // ---------------- phase C: dh_prev = z*dh + [drp,dzp,dhn] W_hh ; dx = [drp,dzp,dnp] W_ih
-      const int j = 16 * wave + m;
-      for (int rt = 0; rt < a.RT; ++rt) {
-        f32x4 dhp, dx = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dhp[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
-        const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
-#pragma unroll
-        for (int c = 0; c < 12; ++c) {
-          f32x4 ai = *reinterpret_cast<const f32x4*>(gr + 16 * c);              // drp|dzp|dnp
-          dx = mfma16x4(ai, wihT[c], dx);
-          f32x4 ah = c < 8 ? ai : *reinterpret_cast<const f32x4*>(gr + 192 + 16 * (c - 8));  // drp|dzp|dhn
-          dhp = mfma16x4(ah, whhT[c], dhp);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = rt * 16 + 4 * q + i;
-          const long rb = rowbase[r];
-          CAR[r * HS + j] = dhp[i];
-          if (rb >= 0) {
-            const long off = (rb + (long)t * tstride) * H + j;
-            const float x = a.saved[plane + off];
-            a.dxp[off] = x > 0.f ? dx[i] : 0.f;
-          }
-        }
+      for (int i = 0; i < NQ; ++i) {
+        const int e = tid + BNT * i;
+        if (e < rows * QP) DQn[(e / QP) * QS + (e % QP)] = dqpre[i];
       }
     }
-    __syncthreads();
+    WG_BARRIER();
   }
-  if (a.dh0 && wave < 4) {
-    const int j = 16 * wave + m;
+  if (a.dh0) {
     for (int r = 4 * q; r < rows; r += 16)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (rowbase[r + i] >= 0) a.dh0[(row0 + r + i) * H + j] = CAR[(r + i) * HS + j];
+  }
+  // ---- this workgroup's partial weight gradients -> slab (summed in fixed order by the reduce kernel)
+  float* slab = a.ws + (long)blockIdx.x * bwd_slab_floats(a.A);
+  float* s_ih = slab;
+  float* s_hh = slab + 192 * 64;
+  float* s_w2 = slab + 2 * 192 * 64;
+  float* s_bih = s_w2 + (long)a.A * 64;
+  float* s_bhh = s_bih + 192;
+  float* s_b2 = s_bhh + 192;
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = g * 64 + 16 * wave + 4 * q + i;     // gate row of W (output unit)
+        s_ih[row * 64 + 16 * c + m] = accIH[g][c][i];
+        s_hh[row * 64 + 16 * c + m] = accHH[g][c][i];
+      }
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int arow = 16 * ac + 4 * q + i;
+      if (arow < a.A) s_w2[arow * 64 + j] = accW2[ac][i];
+    }
+  // bias sums: add the 4 lane groups (rows) together, lane group 0 writes
+  auto red4 = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+  sb_r = red4(sb_r); sb_z = red4(sb_z); sb_n = red4(sb_n); sb_hn = red4(sb_hn);
+  if (q == 0) {
+    s_bih[j] = sb_r; s_bih[64 + j] = sb_z; s_bih[128 + j] = sb_n;
+    s_bhh[j] = sb_r; s_bhh[64 + j] = sb_z; s_bhh[128 + j] = sb_hn;
+  }
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac) {
+    const float v = red4(sb2[ac]);
+    if (wave == 0 && q == 0 && 16 * ac + m < a.A) s_b2[16 * ac + m] = v;
+  }
+}
+
+struct BwdRedArgs {
+  const float* ws; int nwg; int A;
+  float *dWih, *dWhh, *dW2, *dbih, *dbhh, *db2;
+};
+
+__global__ void agent_bwd_reduce_kernel(BwdRedArgs a) {
+  const long slab = bwd_slab_floats(a.A);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < a.nwg; ++w) s += a.ws[(long)w * slab + e];
+    long k = e;
+    if (k < 192 * 64) { a.dWih[k] += s; continue; }
+    k -= 192 * 64;
+    if (k < 192 * 64) { a.dWhh[k] += s; continue; }
+    k -= 192 * 64;
+    if (k < (long)a.A * 64) { a.dW2[k] += s; continue; }
+    k -= (long)a.A * 64;
+    if (k < 192) { a.dbih[k] += s; continue; }
+    k -= 192;
+    if (k < 192) { a.dbhh[k] += s; continue; }
+    k -= 192;
+    a.db2[k] += s;
   }
 }
 
@@ -560,22 +688,41 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   return 0;
 }
 
+static int bwd_rt(long R, int A) {
+  const int AC = A <= 16 ? 1 : 2;
+  const int QS = AC * 16 + 4;
+  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 8;
+  int cap = (NQ * BNT) / (16 * AC * 16);      // dq prefetch registers cover rows*QP elements
+  if (cap > 8) cap = 8;
+  return pick_rt(R, per_row, 0, cap);
+}
+
+extern "C" size_t marl_agent_bwd_workspace(int B, int N, int A) {
+  const long R = (long)B * N;
+  const int rt = bwd_rt(R, A);
+  const long nwg = (R + rt * 16 - 1) / (rt * 16);
+  return (size_t)nwg * bwd_slab_floats(A) * sizeof(float);
+}
+
 extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const float* dhs,
-                                     const float* saved, float* dgate, float* dxp, float* dh0,
+                                     const float* saved, const float* hs, float* dxp, float* dh0,
+                                     const marl_agent_grads_t* g, float* ws, size_t ws_bytes,
                                      int B, int T, int N, int A, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
+  if (ws_bytes < marl_agent_bwd_workspace(B, N, A)) return (int)hipErrorInvalidValue;
   BwdArgs a;
   a.Wih = w->w_ih; a.Whh = w->w_hh; a.W2 = w->fc2_w;
-  a.dq = dq; a.dhs = dhs; a.saved = saved; a.dgate = dgate; a.dxp = dxp; a.dh0 = dh0;
+  a.dq = dq; a.dhs = dhs; a.saved = saved; a.hs = hs; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
-  const size_t per_row = (size_t)(DGS + 2 * QS + HS) * 4 + 8;
-  a.RT = pick_rt(a.R, per_row, 0, 8);
+  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 8;
+  a.RT = bwd_rt(a.R, A);
   const size_t lds = per_row * a.RT * 16;
   const long rows = a.RT * 16;
-  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(NT);
+  const unsigned nwg = (unsigned)((a.R + rows - 1) / rows);
+  dim3 grid(nwg), block(BNT);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (AC == 1) {
@@ -587,6 +734,12 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((agent_bwd_kernel<2>), grid, block, lds, s, a);
   }
+  MARL_CHECK_LAUNCH();
+  BwdRedArgs r;
+  r.ws = ws; r.nwg = (int)nwg; r.A = A;
+  r.dWih = g->w_ih; r.dWhh = g->w_hh; r.dW2 = g->fc2_w; r.dbih = g->b_ih; r.dbhh = g->b_hh; r.db2 = g->fc2_b;
+  const long slab = bwd_slab_floats(A);
+  hipLaunchKernelGGL(agent_bwd_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }

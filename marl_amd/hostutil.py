@@ -25,19 +25,22 @@ class FlatParams:
 
     def __init__(self, params, device, with_grad=True):
         self.params = list(params)
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(n, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=device) if with_grad else None
-        off = 0
+        # every tensor starts on a 16-byte boundary (float4 operand loads); the padding floats are
+        # zero and stay zero (zero gradient -> no optimizer movement)
         self.offsets = []
+        off = 0
         for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        n = off
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device) if with_grad else None
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
             p.data = self.flat[off:off + k].view(p.shape)
             if with_grad:
                 p.grad = self.grad[off:off + k].view(p.shape)
-            self.offsets.append(off)
-            off += k
         self.n = n
 
     def zero_grad(self):

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, check
+from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, check
 
 
 def _p(t):
@@ -147,10 +147,19 @@ def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last
           "marl_agent_unroll_fwd")
 
 
-def agent_unroll_bwd(w, dq, dhs, saved, dgate, dxp, dh0, B, T, N, A):
+def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A):
+    """grads: dict name -> gradient tensor for rnn.weight_ih/hh, rnn.bias_ih/hh, fc2.weight/bias (accumulated)."""
     lib = _lib.load()
-    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)), _p(dhs), _p(_f32(saved)), _p(_f32(dgate)),
-                                    _p(_f32(dxp)), _p(dh0), B, T, N, A, _stream()), "marl_agent_unroll_bwd")
+    g = MarlAgentGrads()
+    g.w_ih, g.w_hh = grads["rnn.weight_ih"].data_ptr(), grads["rnn.weight_hh"].data_ptr()
+    g.b_ih, g.b_hh = grads["rnn.bias_ih"].data_ptr(), grads["rnn.bias_hh"].data_ptr()
+    g.fc2_w, g.fc2_b = grads["fc2.weight"].data_ptr(), grads["fc2.bias"].data_ptr()
+    for v in grads.values():
+        assert v.is_contiguous() and v.dtype == torch.float32 and v.is_cuda
+    ws = WS.get("agent_bwd", lib.marl_agent_bwd_workspace(B, N, A), dq.device)
+    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)), _p(dhs), _p(_f32(saved)), _p(_f32(hs)), _p(_f32(dxp)),
+                                    _p(dh0), C.byref(g), _p(ws), ws.numel() * 4, B, T, N, A, _stream()),
+          "marl_agent_unroll_bwd")
 
 
 def q_gather(q, idx, out, rows, A, avail=None, mask_val=0.0):

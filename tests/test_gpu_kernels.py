@@ -222,17 +222,13 @@ def test_agent_unroll_bwd(dev, shape, B, T):
     saved = torch.empty(6, B, T, N, 64, device=dev)
     obs_d, u_d = cu(obs, dev), cu(ufed, dev, torch.int32)
     ops.agent_unroll_fwd(w, obs_d, T * N, 0, u_d, T * N, 0, None, q, hs, None, saved, B, T, N, O, A)
-    dgate = torch.empty(B, T, N, 256, device=dev)
     dxp = torch.empty(B, T, N, 64, device=dev)
     dq_d = cu(dq, dev)
-    ops.agent_unroll_bwd(w, dq_d, cu(dhs, dev), saved, dgate, dxp, None, B, T, N, A)
     M = B * T * N
     grads = {k: torch.zeros_like(v) for k, v in pd.items()}
-    dg2 = dgate.view(M, 256)
-    ops.linear_wgrad(dg2[:, :192], ops.src(saved[1].view(M, 64)), grads["rnn.weight_ih"], grads["rnn.bias_ih"], M, 192, 64)
-    ops.linear_wgrad(dg2[:, :128], ops.src(saved[0].view(M, 64)), grads["rnn.weight_hh"][:128], grads["rnn.bias_hh"][:128], M, 128, 64)
-    ops.linear_wgrad(dg2[:, 192:], ops.src(saved[0].view(M, 64)), grads["rnn.weight_hh"][128:], grads["rnn.bias_hh"][128:], M, 64, 64)
-    ops.linear_wgrad(dq_d.view(M, A), ops.src(hs.view(M, 64)), grads["fc2.weight"], grads["fc2.bias"], M, A, 64)
+    ops.agent_unroll_bwd(w, dq_d, cu(dhs, dev), saved, hs, dxp, None,
+                         {k: grads[k] for k in ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh",
+                                                "fc2.weight", "fc2.bias")}, B, T, N, A)
     ops.linear_wgrad(dxp.view(M, 64), ops.src(obs_d.view(M, O), idx=u_d.view(M, 1), nhot=1, hot_w=A, nid=N),
                      grads["fc1.weight"], grads["fc1.bias"], M, 64, I)
     for k in p:

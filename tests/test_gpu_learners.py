@@ -138,10 +138,11 @@ def test_checkpoint_roundtrip(tmp_path):
     import os
     os.rename(learner.model_dir + "/0_rnn_net_params.pkl", learner.model_dir + "/rnn_net_params.pkl")
     os.rename(learner.model_dir + "/0_mixer_net_params.pkl", learner.model_dir + "/mixer_net_params.pkl")
-    before = learner._flat.flat.clone()
-    learner._flat.flat.add_(1.0)
+    before = [p.detach().clone() for p in learner.params]
+    for p in learner.params:
+        p.data.add_(1.0)
     learner.load_models()
-    assert torch.equal(before, learner._flat.flat)
+    assert all(torch.equal(b, p.detach()) for b, p in zip(before, learner.params))
     sd = torch.load(learner.model_dir + "/rnn_net_params.pkl")
     assert set(sd) == {"fc1.weight", "fc1.bias", "rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh",
                        "fc2.weight", "fc2.bias"}
