@@ -40,17 +40,24 @@ struct FwdArgs {
   long R;                 // B*N rows
 };
 
-// workgroup barrier that only drains LDS traffic: global stores (saved activations) and the loader's
+// workgroup barrier that only drains LDS traffic: global stores (saved activations) and the
 // prefetch loads stay in flight across it (a __syncthreads() would wait vmcnt(0) every time)
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-constexpr int NLD = 32;        // float4 registers the loader wave keeps in flight (one step's obs tile)
+constexpr int FNT = 512;       // 8 waves: two teams of 4, two waves per SIMD
+constexpr int NLDW = 4;        // float4 prefetch registers per thread (one step's obs tile per workgroup)
 
 // ---------------------------------------------------------------------------------------------
+// 8 compute waves = 2 teams x 4 hidden-unit slices.  Team k owns row tiles k, k+2, ...; both teams
+// keep the same weight fragments in registers.  Two waves share each SIMD, so one wave's pointwise
+// GRU math / LDS waits / global stores overlap the other's MFMAs (measured with one wave per SIMD:
+// MFMA pipe 40 % busy, 28 % of wave time parked, 30 % VALU).  Every thread also carries 1/512 of the
+// NEXT step's observation tile in 4 float4 registers, issued a full step ahead.
 template <int AC>
-__global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int team = wave >> 2, ws = wave & 3;
   const int q = lane >> 4, m = lane & 15;
   const int rows = a.RT * 16;
   const int KP = a.KC * 16, KS = KP + 4;
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
   int* rowlen = rown + rows;                                 // [rows]: episode length (INT_MAX if none)
 
   const long row0 = (long)blockIdx.x * rows;
-  for (int r = tid; r < rows; r += NT) {
+  for (int r = tid; r < rows; r += FNT) {
     long rho = row0 + r;
     long v = -1, b = 0;
     int n = 0;
@@ -79,130 +86,99 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
     rowlen[r] = (a.ep_len && rho < a.R) ? a.ep_len[b] : 0x7fffffff;
   }
   const long tstride = a.N;   // rows per time step within an episode
-  // ---- initial hidden tile
-  for (int e = tid; e < rows * H; e += NT) {
+  for (int e = tid; e < rows * H; e += FNT) {       // initial hidden tile
     int r = e / H, k = e % H;
     long rho = row0 + r;
     Ha[r * HS + k] = (a.h0 && rho < a.R) ? a.h0[rho * H + k] : 0.f;
   }
   __syncthreads();   // row tables + hidden tile visible
 
-  if (wave == 4) {
-    // =================== loader wave: streams obs(t+1) HBM -> registers -> LDS, one step ahead ========
-    const int O = a.O;
-    if (a.vload) {
-      const int O4 = O >> 2, n4 = rows * O4;
-      const float invO4 = 1.0f / (float)O4;
-      f32x4 pf[NLD];
-      int pu[2];
-      auto issue = [&](int t) {
-        const long toff = (long)(t + a.obs_t0) * a.N * O;
+  // ---- input tile [obs | onehot(ufed) | id | 0-pad]
+  const int O = a.O;
+  const int O4 = O >> 2, n4 = rows * O4;
+  const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
+  f32x4 pf[NLDW];
+  int pu = -1;
+  auto issue = [&](int t) {           // start the loads of step t's observations (vector path)
+    const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          int e = lane + 64 * i;
-          asm volatile("" : "+v"(e));     // keep the per-element address math inside the step (no hoisting -> no spills)
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (e < n4) {
-            const int r = (int)(((float)e + 0.5f) * invO4);
-            const int k4 = e - r * O4;
-            if (rowbase[r] >= 0 && t < rowlen[r])
-              v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + toff + 4 * k4);
-          }
-          pf[i] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int r = lane + 64 * j;
-          int u = -1;
-          if (r < rows && rowbase[r] >= 0 && a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
-          pu[j] = u;
-        }
-      };
-      auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          int e = lane + 64 * i;
-          asm volatile("" : "+v"(e));
-          if (e < n4) {
-            const int r = (int)(((float)e + 0.5f) * invO4);
-            const int k4 = e - r * O4;
-            *reinterpret_cast<f32x4*>(In + r * KS + 4 * k4) = pf[i];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int r = lane + 64 * j;
-          if (r < rows) {
-            const bool ok = rowbase[r] >= 0;
-            const int n = rown[r];
-            for (int k = O; k < KP; ++k) {
-              float v = 0.f;
-              if (ok) {
-                if (a.has_act && k < O + a.A) v = (pu[j] == k - O) ? 1.f : 0.f;
-                else if (a.has_id && k >= a.I - a.N && k < a.I) v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
-              }
-              In[r * KS + k] = v;
-            }
-          }
-        }
-      };
-      issue(0);
-      commit();
-      if (a.T > 1) issue(1);
-      WG_BARRIER();
-      for (int t = 0; t < a.T; ++t) {
-        WG_BARRIER();                       // phase 1 of step t has consumed the input tile
-        if (t + 1 < a.T) {
-          commit();
-          if (t + 2 < a.T) issue(t + 2);
-        }
-        WG_BARRIER();
+    for (int i = 0; i < NLDW; ++i) {
+      int e = tid + FNT * i;
+      asm volatile("" : "+v"(e));     // keep the address math inside the step (no hoisting -> no spills)
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < n4) {
+        const int r = (int)(((float)e + 0.5f) * invO4);
+        const int k4 = e - r * O4;
+        if (rowbase[r] >= 0 && t < rowlen[r])
+          v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + toff + 4 * k4);
       }
-    } else {
-      // generic path (obs width not a multiple of 4 / unaligned): element loads, no run-ahead
-      auto load_inputs = [&](int t) {
-        for (int e = lane; e < rows * KP; e += 64) {
-          const int r = e / KP, k = e - r * KP;
-          float v = 0.f;
-          if (rowbase[r] >= 0) {
-            if (k < O) {
-              if (t < rowlen[r]) v = a.obs[rowobs[r] + (long)(t + a.obs_t0) * a.N * O + k];
-            } else if (a.has_act && k < O + a.A) {
-              int u = -1;
-              if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
-              v = (u == k - O) ? 1.f : 0.f;
-            } else if (a.has_id && k >= a.I - a.N && k < a.I) {
-              v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
-            }
-          }
-          In[r * KS + k] = v;
-        }
-      };
-      load_inputs(0);
-      WG_BARRIER();
-      for (int t = 0; t < a.T; ++t) {
-        WG_BARRIER();
-        if (t + 1 < a.T) load_inputs(t + 1);
-        WG_BARRIER();
+      pf[i] = v;
+    }
+    int u = -1;
+    if (tid < rows && rowbase[tid] >= 0 && a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[tid] + (long)(t + a.u_t0) * a.N];
+    pu = u;
+  };
+  auto commit = [&]() {               // registers -> LDS tile, plus the synthesised one-hot / id columns
+#pragma unroll
+    for (int i = 0; i < NLDW; ++i) {
+      int e = tid + FNT * i;
+      asm volatile("" : "+v"(e));
+      if (e < n4) {
+        const int r = (int)(((float)e + 0.5f) * invO4);
+        const int k4 = e - r * O4;
+        *reinterpret_cast<f32x4*>(In + r * KS + 4 * k4) = pf[i];
       }
     }
-    return;
-  }
+    if (tid < rows) {
+      const int r = tid;
+      const bool ok = rowbase[r] >= 0;
+      const int n = rown[r];
+      for (int k = O; k < KP; ++k) {
+        float v = 0.f;
+        if (ok) {
+          if (a.has_act && k < O + a.A) v = (pu == k - O) ? 1.f : 0.f;
+          else if (a.has_id && k >= a.I - a.N && k < a.I) v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
+        }
+        In[r * KS + k] = v;
+      }
+    }
+  };
+  auto load_generic = [&](int t) {    // element loads, no run-ahead (obs width not a multiple of 4 / unaligned)
+    for (int e = tid; e < rows * KP; e += FNT) {
+      const int r = e / KP, k = e - r * KP;
+      float v = 0.f;
+      if (rowbase[r] >= 0) {
+        if (k < O) {
+          if (t < rowlen[r]) v = a.obs[rowobs[r] + (long)(t + a.obs_t0) * a.N * O + k];
+        } else if (a.has_act && k < O + a.A) {
+          int u = -1;
+          if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
+          v = (u == k - O) ? 1.f : 0.f;
+        } else if (a.has_id && k >= a.I - a.N && k < a.I) {
+          v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
+        }
+      }
+      In[r * KS + k] = v;
+    }
+  };
+  if (a.vload) { issue(0); commit(); if (a.T > 1) issue(1); }
+  else load_generic(0);
 
-  // =================== compute waves ===================================================================
-  // ---- stage weights: fc1 slice -> LDS fragments; GRU / fc2 slices -> registers
+  // ---- stage weights: fc1 slice -> LDS fragments (team 0 writes, both teams read); GRU / fc2 -> registers
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
   float bias_r, bias_z, bias_in, bias_hn, bias1, bias2[AC];
-  const int j = 16 * wave + m;
+  const int j = 16 * ws + m;
   {
-    for (int c = 0; c < a.KC; ++c) {
-      f32x4 v;
+    if (team == 0) {
+      for (int c = 0; c < a.KC; ++c) {
+        f32x4 v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = 16 * c + 4 * q + i;
-        v[i] = k < a.I ? a.W1[(long)j * a.I + k] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+          int k = 16 * c + 4 * q + i;
+          v[i] = k < a.I ? a.W1[(long)j * a.I + k] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(W1s + ((ws * a.KC + c) * 64 + lane) * 4) = v;
       }
-      *reinterpret_cast<f32x4*>(W1s + ((wave * a.KC + c) * 64 + lane) * 4) = v;
     }
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -225,19 +201,19 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
     bias_in = a.bih[2 * H + j];
     bias_hn = a.bhh[2 * H + j];
   }
-  WG_BARRIER();   // input tile of step 0 is in LDS
+  WG_BARRIER();   // input tile of step 0 and the fc1 fragments are in LDS
 
   const long plane = (long)a.B * a.T * a.N * H;   // one saved array
   float* Hp = Ha;
   float* Hn = Hb;
   for (int t = 0; t < a.T; ++t) {
-    // ---------------- phase 1: x = relu(fc1(in))  (two row tiles in flight)
-    for (int rt = 0; rt < a.RT; rt += 2) {
-      const bool two = rt + 1 < a.RT;
+    // ---------------- phase 1: x = relu(fc1(in))  (two of the team's row tiles in flight)
+    for (int rt = team; rt < a.RT; rt += 4) {
+      const bool two = rt + 2 < a.RT;
       f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
       const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
-      const float* in1 = in0 + 16 * KS;
-      const float* wf = W1s + (wave * a.KC * 64 + lane) * 4;
+      const float* in1 = in0 + 32 * KS;
+      const float* wf = W1s + (ws * a.KC * 64 + lane) * 4;
       for (int c = 0; c < a.KC; ++c) {
         f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
         f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
@@ -256,15 +232,20 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
         if (a.saved && rb >= 0) a.saved[plane + (rb + (long)t * tstride) * H + j] = x0;
         if (two) {
           const float x1 = fmaxf(acc1[i], 0.f);
-          Xt[(r + 16) * HS + j] = x1;
-          const long rb1 = rowbase[r + 16];
+          Xt[(r + 32) * HS + j] = x1;
+          const long rb1 = rowbase[r + 32];
           if (a.saved && rb1 >= 0) a.saved[plane + (rb1 + (long)t * tstride) * H + j] = x1;
         }
       }
     }
     WG_BARRIER();
+    // the input tile has been consumed: refill it for step t+1, start the loads of step t+2
+    if (t + 1 < a.T) {
+      if (a.vload) { commit(); if (t + 2 < a.T) issue(t + 2); }
+      else load_generic(t + 1);
+    }
     // ---------------- phase 2: GRU gates + pointwise update
-    for (int rt = 0; rt < a.RT; ++rt) {
+    for (int rt = team; rt < a.RT; rt += 2) {
       f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
       f32x4 az = {bias_z, bias_z, bias_z, bias_z};
       f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
@@ -307,8 +288,8 @@ __global__ __launch_bounds__(NT, 2) void agent_fwd_kernel(FwdArgs a) {
       }
     }
     WG_BARRIER();
-    // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the waves)
-    for (int rt = wave; rt < a.RT; rt += 4) {
+    // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the 8 waves)
+    for (int rt = wave; rt < a.RT; rt += 8) {
       f32x4 acc[AC];
 #pragma unroll
       for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
@@ -664,15 +645,15 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const size_t fixed = (size_t)4 * a.KC * 64 * 16;
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
-  if (a.vload) {   // the loader keeps one step's obs tile (rows * O/4 float4) in NLD*64 registers
-    int cap2 = (NLD * 64) / (16 * (O / 4));
+  if (a.vload) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW*512 registers
+    int cap2 = (NLDW * FNT) / (16 * (O / 4));
     if (cap2 < 1) { a.vload = 0; } else if (cap2 < rt_cap) rt_cap = cap2;
   }
   a.RT = pick_rt(a.R, per_row, fixed, rt_cap);
   const size_t lds = fixed + per_row * a.RT * 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const long rows = a.RT * 16;
-  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(NT);
+  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(FNT);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (A <= 16) {
