@@ -83,6 +83,38 @@ __device__ __forceinline__ float concat_elem(const ConcatSrc& s, long row, int k
   return 0.f;
 }
 
+// Two-stage form for inner loops: the row-dependent part (remaps) once per row, then cheap per-column reads.
+struct ConcatRow { long r0, ri, row; bool ok0, oki; };
+
+__device__ __forceinline__ ConcatRow concat_row(const ConcatSrc& s, long row) {
+  ConcatRow c;
+  c.row = row;
+  c.r0 = remap_row(row, s.rpe0, s.bs0, s.off0, c.ok0);
+  c.ri = remap_row(row, s.rpei, s.bsi, s.offi, c.oki);
+  return c;
+}
+
+__device__ __forceinline__ float concat_at(const ConcatSrc& s, const ConcatRow& c, int k) {
+  if (k < s.k0) {
+    if (!c.ok0) return 0.f;
+    float v = s.p0[c.r0 * s.ld0 + k];
+    if (s.m0) v = s.m0[c.r0 * s.ldm0 + k] > 0.f ? v : 0.f;
+    return v;
+  }
+  k -= s.k0;
+  if (k < s.k1) return s.p1[c.row * s.ld1 + k];
+  k -= s.k1;
+  const int hw = s.nhot * s.hot_w;
+  if (k < hw) {
+    if (!c.oki) return 0.f;
+    const int j = k / s.hot_w;
+    return (s.idx[c.ri * s.nhot + j] == k - j * s.hot_w) ? 1.f : 0.f;
+  }
+  k -= hw;
+  if (k < s.nid) return ((int)(c.row % s.nid) == k) ? 1.f : 0.f;
+  return 0.f;
+}
+
 __host__ __device__ inline int concat_width(const ConcatSrc& s) { return s.k0 + s.k1 + s.nhot * s.hot_w + s.nid; }
 
 #define MARL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -190,46 +190,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const long t_begin = (long)blockIdx.x * per;
   long t_end = t_begin + per; if (t_end > tiles) t_end = tiles;
 
+  // operand tiles of row tile tt in accumulator layout; rows past M and columns past N / K+1 read zero
+#define WG_LOAD_TILE(GV, XV, tt, en)                                                                    \
+  {                                                                                                      \
+    const long r0_ = (tt) * 16 + 4 * q;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+      const long row = r0_ + i;                                                                          \
+      const bool okr = (en) && row < a.M;                                                                \
+      const ConcatRow cr = concat_row(x, okr ? row : 0);                                                 \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                 \
+        float v = 0.f;                                                                                   \
+        if (nt < nt_used) {                                                                              \
+          const int n = n0 + nt * 16 + m;                                                                \
+          if (okr && n < a.N) {                                                                          \
+            v = G[row * a.ldg + n];                                                                      \
+            if (Ya) v = Ya[row * a.ldya + n] > 0.f ? v : 0.f;                                            \
+          }                                                                                              \
+        }                                                                                                \
+        GV[nt][i] = v;                                                                                   \
+      }                                                                                                  \
+      _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) {                                                 \
+        float v = 0.f;                                                                                   \
+        if (kt < kt_used) {                                                                              \
+          const int k = k0 + kt * 16 + m;                                                                \
+          if (okr) {                                                                                     \
+            if (k < a.K) v = concat_at(x, cr, k);                                                        \
+            else if (k == a.K) v = 1.f;        /* virtual ones column => bias gradient */                \
+          }                                                                                              \
+        }                                                                                                \
+        XV[kt][i] = v;                                                                                   \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  // (a register double-buffer of the next tile was tried: it halves occupancy (266 regs) and was 1.5x slower;
+  //  two resident workgroups per CU hide the load latency better)
   for (long t = t_begin + wave; t < t_end; t += 4) {
-    const long r0 = t * 16 + 4 * q;
-    f32x4 gv[4], xv[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      if (nt < nt_used) {
-        const int n = n0 + nt * 16 + m;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const long row = r0 + i;
-          float v = 0.f;
-          if (row < a.M && n < a.N) {
-            v = G[row * a.ldg + n];
-            if (Ya) v = Ya[row * a.ldya + n] > 0.f ? v : 0.f;
-          }
-          gv[nt][i] = v;
-        }
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt < kt_used) {
-        const int k = k0 + kt * 16 + m;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const long row = r0 + i;
-          float v = 0.f;
-          if (row < a.M) {
-            if (k < a.K) v = concat_elem(x, row, k);
-            else if (k == a.K) v = 1.f;        // virtual ones column => bias gradient
-          }
-          xv[kt][i] = v;
-        }
-      }
-    }
+    f32x4 gA[4], xA[4];
+    WG_LOAD_TILE(gA, xA, t, true)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
-        if (nt < nt_used && kt < kt_used) acc[nt][kt] = mfma16x4(gv[nt], xv[kt], acc[nt][kt]);
+        if (nt < nt_used && kt < kt_used) acc[nt][kt] = mfma16x4(gA[nt], xA[kt], acc[nt][kt]);
   }
 
   // cross-wave reduction of the 64x64 tile through LDS, then one slab partial per block
