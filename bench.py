@@ -199,6 +199,10 @@ def main():
 
     if rank == 0:
         fl = agent_flops(args) * E * N * T                 # algorithmic FLOP of one unroll launch
+        traffic = None                                     # HBM bytes/launch from the committed PMC passes (same workload only)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_agent.json")
+        if os.path.exists(pmc) and (o.alg, o.shape, o.envs, world, T) == ("qmix", "2s3z", 4096, 1, 120):
+            traffic = json.load(open(pmc))["agent_fwd_kernel"]["avg_hbm_bytes_per_launch"]
         avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         ach = fl / (avg_ms * 1e-3) / 1e12
         out = {
@@ -216,7 +220,8 @@ def main():
             "last_loss": loss,
             "roofline": {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
                          "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
-                         "traffic": None, "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
+                         "separate passes; profiles/r01_pmc_agent.json)", "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
                          "flop_per_launch": fl},
         }
         if not o.no_cpu_baseline:
