@@ -71,11 +71,11 @@ def cpu_baseline(alg, shape, T, envs, budget_s):
     t_train = (time.time() - t0) / reps
     # the reference's actual serial rollout (one env, one agent at a time), a few episodes
     t0 = time.time()
-    _, _, _, ssteps, _ = orl.serial_rollout(agent, args, orl.SerialSynthEnv(sy), 2, 0.5)
+    _, _, _, ssteps, _ = orl.serial_rollout(agent, args, orl.SerialSynthEnv(sy), 8, 0.5)
     t_serial = time.time() - t0
     return {"value": steps / (t_roll + t_train), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%s %s: %d envs x T=%d batched CPU rollout + %d oracle train() calls; serial reference-style "
-                      "rollout of 2 episodes" % (alg, shape, envs, T, reps),
+                      "rollout of 8 episodes" % (alg, shape, envs, T, reps),
             "learner_updates_per_sec": 1.0 / t_train, "learner_transitions_per_sec": envs * T / t_train,
             "batched_rollout_env_steps_per_sec": steps / t_roll, "serial_rollout_env_steps_per_sec": ssteps / t_serial}
 
@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=32)
+    ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--leg-iters", type=int, default=3, help="iterations of the separately timed learner / rollout legs")
     o = ap.parse_args()
 

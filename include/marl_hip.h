@@ -187,6 +187,12 @@ int marl_synth_step(unsigned seed, int env0, int episode, int t, const int* len,
                     int* u, float* r, float* term, float* padded, int* alive_next, int E, int T, int N, int A,
                     void* stream);
 
+/* select + step + observe(t+1) of the synthetic env in ONE launch per lock-step (same arithmetic as the
+ * three calls above; q is the (E,N,A) output of the T=1 agent unroll). */
+int marl_synth_fused_step(unsigned seed, unsigned rseed, int env0, int episode, int t, float eps, const int* len,
+                          const float* q, float* obs, float* state, float* avail, int* u, float* r, float* term,
+                          float* padded, int E, int T, int N, int O, int S, int A, void* stream);
+
 const char* marl_hip_version(void);
 
 #ifdef __cplusplus

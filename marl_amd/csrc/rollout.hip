@@ -101,7 +101,82 @@ __global__ void synth_step_kernel(unsigned seed, int env0, int episode, int t, c
   padded[(long)e * T + t] = live ? 0.f : 1.f;
   if (alive_next) alive_next[e] = (t + 1 < L) ? 1 : 0;
 }
+// One launch per lock-step for the synthetic env: epsilon-greedy choice (same rule as select_kernel),
+// env step (reward / terminated / padded / u) and the observation of slot t+1.  One block per env.
+__global__ void synth_fused_step_kernel(unsigned seed, unsigned rseed, int env0, int episode, int t, float eps,
+                                        const int* len, const float* q, float* obs, float* state, float* avail,
+                                        int* u, float* r, float* term, float* padded, int E, int T, int N, int O,
+                                        int S, int A) {
+  __shared__ int act[64];
+  const int e = blockIdx.x;
+  const int L = len[e];
+  const bool live = t < L;
+  const unsigned env = (unsigned)(env0 + e), tg = (unsigned)(episode * (T + 1) + t);
+  if (threadIdx.x < N) {
+    const int n = threadIdx.x;
+    int arg = -1;
+    if (live) {
+      const float* qa = q + ((long)e * N + n) * A;
+      const float* av = avail + (((long)e * (T + 1) + t) * N + n) * A;
+      float best = 0.f; int navail = 0;
+      for (int a = 0; a < A; ++a) {
+        if (av[a] == 0.f) continue;
+        ++navail;
+        if (arg < 0 || qa[a] > best) { best = qa[a]; arg = a; }
+      }
+      if (arg < 0) arg = 0;
+      const bool explore = u01(hkey(rseed, ST_EXPLORE, env, tg, (unsigned)n)) < eps;
+      if (explore && navail > 0) {
+        int k = (int)floorf(u01(hkey(rseed, ST_PICK, env, tg, (unsigned)n)) * (float)navail);
+        if (k > navail - 1) k = navail - 1;
+        int c = 0;
+        for (int a = 0; a < A; ++a) {
+          if (av[a] == 0.f) continue;
+          if (c == k) { arg = a; break; }
+          ++c;
+        }
+      }
+    }
+    act[n] = arg;
+    u[((long)e * T + t) * N + n] = arg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    if (live)
+      for (int n = 0; n < N; ++n) acc = acc + (u01(hkey(seed, ST_REWARD, env, tg, (unsigned)(n * A + act[n]))) - 0.5f);
+    r[(long)e * T + t] = live ? acc * (1.0f / (float)N) : 0.f;
+    term[(long)e * T + t] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
+    padded[(long)e * T + t] = live ? 0.f : 1.f;
+  }
+  // observation of slot t+1 (zeros once the episode is over; slot L is the final observation)
+  const int t1 = t + 1;
+  const bool live1 = t1 <= L;
+  const unsigned tg1 = tg + 1u;
+  float* o = obs + ((long)e * (T + 1) + t1) * N * O;
+  for (int i = threadIdx.x; i < N * O; i += TPB) o[i] = live1 ? 2.0f * u01(hkey(seed, ST_OBS, env, tg1, (unsigned)i)) - 1.0f : 0.f;
+  float* sp = state + ((long)e * (T + 1) + t1) * S;
+  for (int i = threadIdx.x; i < S; i += TPB) sp[i] = live1 ? 2.0f * u01(hkey(seed, ST_STATE, env, tg1, (unsigned)i)) - 1.0f : 0.f;
+  float* ap = avail + ((long)e * (T + 1) + t1) * N * A;
+  for (int i = threadIdx.x; i < N * A; i += TPB) {
+    float v = 0.f;
+    if (live1) v = (i % A == 0 || u01(hkey(seed, ST_AVAIL, env, tg1, (unsigned)i)) < 0.7f) ? 1.f : 0.f;
+    ap[i] = v;
+  }
+}
 }  // namespace
+
+extern "C" int marl_synth_fused_step(unsigned seed, unsigned rseed, int env0, int episode, int t, float eps,
+                                     const int* len, const float* q, float* obs, float* state, float* avail, int* u,
+                                     float* r, float* term, float* padded, int E, int T, int N, int O, int S, int A,
+                                     void* stream) {
+  if (E <= 0) return 0;
+  if (N > 64) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(synth_fused_step_kernel, dim3(E), dim3(TPB), 0, (hipStream_t)stream, seed, rseed, env0, episode,
+                     t, eps, len, q, obs, state, avail, u, r, term, padded, E, T, N, O, S, A);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int marl_select_actions(const float* q, const float* avail, long avail_es, const int* alive, float eps,
                                    unsigned rseed, int env0, const int* tg, int tg0, int* act_out, long act_es,

@@ -267,3 +267,10 @@ def synth_step(seed, env0, episode, t, length, act, u, r, term, padded, alive_ne
     check(_lib.load().marl_synth_step(int(seed) & 0xFFFFFFFF, env0, episode, t, _p(_i32(length)), _p(_i32(act)),
                                       _p(_i32(u)), _p(_f32(r)), _p(_f32(term)), _p(_f32(padded)), _p(alive_next),
                                       E, T, N, A, _stream()), "marl_synth_step")
+
+
+def synth_fused_step(seed, rseed, env0, episode, t, eps, length, q, obs, state, avail, u, r, term, padded, E, T, N, O, S, A):
+    check(_lib.load().marl_synth_fused_step(int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode, t, float(eps),
+                                            _p(_i32(length)), _p(_f32(q)), _p(_f32(obs)), _p(_f32(state)), _p(_f32(avail)),
+                                            _p(_i32(u)), _p(_f32(r)), _p(_f32(term)), _p(_f32(padded)), E, T, N, O, S, A,
+                                            _stream()), "marl_synth_fused_step")

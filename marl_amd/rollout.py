@@ -121,15 +121,19 @@ class RolloutWorker:
         if a.epsilon_anneal_scale == 'episode':
             epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
         w = mac.agent.weights()
+        fused = hasattr(env, "fused_step") and not getattr(self, "no_fused_env", False)
         env.observe(0, rec)
         for t in range(T):
             # agent step = the unroll kernel with T=1 reading slot t of the record in place
             ops.agent_unroll_fwd(w, rec.obs, (T + 1) * N, t, rec.u, T * N, t - 1, h, q, None, h, None,
                                  E, 1, N, O, A, a.last_action, a.reuse_network)
-            ops.select_actions(q, rec.avail[:, t], (T + 1) * N * A, alive, epsilon, self.rseed, env.env0, None,
-                               env.global_step(t), act, N, E, N, A)
-            env.step(t, act, rec, alive)
-            env.observe(t + 1, rec)
+            if fused:
+                env.fused_step(t, q, epsilon, self.rseed, rec)
+            else:
+                ops.select_actions(q, rec.avail[:, t], (T + 1) * N * A, alive, epsilon, self.rseed, env.env0, None,
+                                   env.global_step(t), act, N, E, N, A)
+                env.step(t, act, rec, alive)
+                env.observe(t + 1, rec)
             if a.epsilon_anneal_scale == 'step':
                 epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
         if not evaluate:
