@@ -75,8 +75,8 @@ int marl_wgrad_slabs(int M);
  *   ep_len: per-episode int32 length or NULL; observations of steps t >= ep_len[b] read as zeros
  *           (the zero padding rollout.py:122-133 writes, needed when obs is (T+1)-slot storage)
  *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
- *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = 6 planes (B,T,N,64)
- *   [hprev,x,r,z,n,hn] for the backward pass or NULL */
+ *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = [T][B*N][6][64] floats
+ *   (time-major; per row-step the 6 vectors hprev,x,r,z,n,hn) for the backward pass or NULL */
 int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                           const int* ufed, long u_bs, int u_t0, const int* ep_len, const float* h0,
                           float* q, float* hs, float* h_last, float* saved, int B, int T, int N, int O,

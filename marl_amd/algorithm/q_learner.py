@@ -87,7 +87,7 @@ class QLearner:
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T
         g = lambda name, shape, dt=torch.float32: self._buf.get(name, shape, dev, dt)
-        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", (6, B, T, N, H))
+        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", (T, B * N, 6, H))
         h_last, h_scr = g("h_last", (B * N, H)), g("h_scr", (B * N, H))
         q_tgt, q_en = g("q_tgt", (B, T, N, A)), g("q_en", (B, T, N, A))
         q_chosen, q_tgt_chosen = g("q_chosen", (R,)), g("q_tgt_chosen", (R,))

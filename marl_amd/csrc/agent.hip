@@ -33,7 +33,7 @@ struct FwdArgs {
   float* q;               // (B,T,N,A)
   float* hs;              // (B,T,N,64) or null
   float* h_last;          // (B*N,64) or null
-  float* saved;           // [6][B,T,N,64]: hprev,x,r,z,n,hn  or null
+  float* saved;           // [T][B*N][6][64]: hprev,x,r,z,n,hn per row-step (time-major), or null
   int B, T, N, O, A, I, KC, RT;
   int has_act, has_id;
   int vload;              // obs rows are 16-B aligned multiples of 4 floats: vector prefetch path
@@ -53,7 +53,13 @@ constexpr int NLDW = 4;        // float4 prefetch registers per thread (one step
 // GRU math / LDS waits / global stores overlap the other's MFMAs (measured with one wave per SIMD:
 // MFMA pipe 40 % busy, 28 % of wave time parked, 30 % VALU).  Every thread also carries 1/512 of the
 // NEXT step's observation tile in 4 float4 registers, issued a full step ahead.
-template <int AC>
+// store helpers: uniform base pointer (SGPR pair) + 32-bit byte offset -> saddr-form global stores,
+// one v_lshl_add per element instead of 64-bit address arithmetic per store
+__device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+template <int AC, bool SAVE>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,31 +73,34 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   float* Xt = In + rows * KS;                         // [rows][HS]
   float* Ha = Xt + rows * HS;                         // [rows][HS] x2
   float* Hb = Ha + rows * HS;
-  long* rowbase = reinterpret_cast<long*>(Hb + rows * HS);   // [rows]: (b*T*N + n), -1 if row invalid
-  long* rowobs = rowbase + rows;                             // [rows]: (b*obs_bs + n) * O
+  long* rowobs = reinterpret_cast<long*>(Hb + rows * HS);    // [rows]: (b*obs_bs + n) * O
   long* rowu = rowobs + rows;                                // [rows]: b*u_bs + n
-  int* rown = reinterpret_cast<int*>(rowu + rows);           // [rows]: n
+  int* rowidx = reinterpret_cast<int*>(rowu + rows);         // [rows]: output row b*T*N + n
+  int* rown = rowidx + rows;                                 // [rows]: n
   int* rowlen = rown + rows;                                 // [rows]: episode length (INT_MAX if none)
+  int* rowrho = rowlen + rows;                               // [rows]: b*N + n
 
+  // Rows past the end of the batch (last workgroup only) are CLAMPED to the last valid row: they load
+  // the same inputs, compute the same values and store them to the same addresses, so no per-lane
+  // validity predicate is needed anywhere in the step loop.
   const long row0 = (long)blockIdx.x * rows;
   for (int r = tid; r < rows; r += FNT) {
     long rho = row0 + r;
-    long v = -1, b = 0;
-    int n = 0;
-    if (rho < a.R) { b = rho / a.N; n = (int)(rho % a.N); v = b * a.T * a.N + n; }
-    rowbase[r] = v;
+    if (rho > a.R - 1) rho = a.R - 1;
+    const long b = rho / a.N;
+    const int n = (int)(rho % a.N);
+    rowidx[r] = (int)(b * a.T * a.N + n);
     rowobs[r] = (b * a.obs_bs + n) * a.O;
     rowu[r] = b * a.u_bs + n;
     rown[r] = n;
-    rowlen[r] = (a.ep_len && rho < a.R) ? a.ep_len[b] : 0x7fffffff;
+    rowlen[r] = a.ep_len ? a.ep_len[b] : 0x7fffffff;
+    rowrho[r] = (int)rho;
   }
-  const long tstride = a.N;   // rows per time step within an episode
+  __syncthreads();
   for (int e = tid; e < rows * H; e += FNT) {       // initial hidden tile
     int r = e / H, k = e % H;
-    long rho = row0 + r;
-    Ha[r * HS + k] = (a.h0 && rho < a.R) ? a.h0[rho * H + k] : 0.f;
+    Ha[r * HS + k] = a.h0 ? a.h0[(long)rowrho[r] * H + k] : 0.f;
   }
-  __syncthreads();   // row tables + hidden tile visible
 
   // ---- input tile [obs | onehot(ufed) | id | 0-pad]
   const int O = a.O;
@@ -109,13 +118,12 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       if (e < n4) {
         const int r = (int)(((float)e + 0.5f) * invO4);
         const int k4 = e - r * O4;
-        if (rowbase[r] >= 0 && t < rowlen[r])
-          v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + toff + 4 * k4);
+        if (t < rowlen[r]) v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + toff + 4 * k4);
       }
       pf[i] = v;
     }
     int u = -1;
-    if (tid < rows && rowbase[tid] >= 0 && a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[tid] + (long)(t + a.u_t0) * a.N];
+    if (tid < rows && a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[tid] + (long)(t + a.u_t0) * a.N];
     pu = u;
   };
   auto commit = [&]() {               // registers -> LDS tile, plus the synthesised one-hot / id columns
@@ -131,14 +139,11 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     }
     if (tid < rows) {
       const int r = tid;
-      const bool ok = rowbase[r] >= 0;
       const int n = rown[r];
       for (int k = O; k < KP; ++k) {
         float v = 0.f;
-        if (ok) {
-          if (a.has_act && k < O + a.A) v = (pu == k - O) ? 1.f : 0.f;
-          else if (a.has_id && k >= a.I - a.N && k < a.I) v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
-        }
+        if (a.has_act && k < O + a.A) v = (pu == k - O) ? 1.f : 0.f;
+        else if (a.has_id && k >= a.I - a.N && k < a.I) v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
         In[r * KS + k] = v;
       }
     }
@@ -147,16 +152,14 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     for (int e = tid; e < rows * KP; e += FNT) {
       const int r = e / KP, k = e - r * KP;
       float v = 0.f;
-      if (rowbase[r] >= 0) {
-        if (k < O) {
-          if (t < rowlen[r]) v = a.obs[rowobs[r] + (long)(t + a.obs_t0) * a.N * O + k];
-        } else if (a.has_act && k < O + a.A) {
-          int u = -1;
-          if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
-          v = (u == k - O) ? 1.f : 0.f;
-        } else if (a.has_id && k >= a.I - a.N && k < a.I) {
-          v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
-        }
+      if (k < O) {
+        if (t < rowlen[r]) v = a.obs[rowobs[r] + (long)(t + a.obs_t0) * a.N * O + k];
+      } else if (a.has_act && k < O + a.A) {
+        int u = -1;
+        if (a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[r] + (long)(t + a.u_t0) * a.N];
+        v = (u == k - O) ? 1.f : 0.f;
+      } else if (a.has_id && k >= a.I - a.N && k < a.I) {
+        v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
       }
       In[r * KS + k] = v;
     }
@@ -203,10 +206,15 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   }
   WG_BARRIER();   // input tile of step 0 and the fc1 fragments are in LDS
 
-  const long plane = (long)a.B * a.T * a.N * H;   // one saved array
+  // uniform base pointers of the per-step outputs; per-element offsets are 32-bit byte offsets
+  // saved activations: [T][R][6][64] (time-major, the 6 planes of one row-step contiguous): one base
+  // pointer per step + a per-row 32-bit offset; the plane is an immediate offset of the store
+  const unsigned jb = (unsigned)j * 4u;
   float* Hp = Ha;
   float* Hn = Hb;
   for (int t = 0; t < a.T; ++t) {
+    const unsigned trow = (unsigned)t * (unsigned)a.N;
+    float* const svt = SAVE ? a.saved + (long)t * a.R * (6 * H) : nullptr;
     // ---------------- phase 1: x = relu(fc1(in))  (two of the team's row tiles in flight)
     for (int rt = team; rt < a.RT; rt += 4) {
       const bool two = rt + 2 < a.RT;
@@ -223,18 +231,31 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
           acc1 = mfma16x4(a1, bv, acc1);
         }
       }
+      const int r0 = rt * 16 + 4 * q;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = rt * 16 + 4 * q + i;
-        const float x0 = fmaxf(acc0[i], 0.f);
-        Xt[r * HS + j] = x0;
-        const long rb = rowbase[r];
-        if (a.saved && rb >= 0) a.saved[plane + (rb + (long)t * tstride) * H + j] = x0;
-        if (two) {
-          const float x1 = fmaxf(acc1[i], 0.f);
-          Xt[(r + 32) * HS + j] = x1;
-          const long rb1 = rowbase[r + 32];
-          if (a.saved && rb1 >= 0) a.saved[plane + (rb1 + (long)t * tstride) * H + j] = x1;
+        acc0[i] = fmaxf(acc0[i], 0.f);
+        Xt[(r0 + i) * HS + j] = acc0[i];
+      }
+      if (SAVE) {
+        const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
+        st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc0[0]);
+        st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc0[1]);
+        st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc0[2]);
+        st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc0[3]);
+      }
+      if (two) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc1[i] = fmaxf(acc1[i], 0.f);
+          Xt[(r0 + 32 + i) * HS + j] = acc1[i];
+        }
+        if (SAVE) {
+          const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0 + 32);
+          st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc1[0]);
+          st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc1[1]);
+          st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc1[2]);
+          st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc1[3]);
         }
       }
     }
@@ -245,6 +266,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       else load_generic(t + 1);
     }
     // ---------------- phase 2: GRU gates + pointwise update
+    const bool last = (t == a.T - 1) && a.h_last;
     for (int rt = team; rt < a.RT; rt += 2) {
       f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
       f32x4 az = {bias_z, bias_z, bias_z, bias_z};
@@ -263,28 +285,35 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         ar = mfma16x4(ah, whh[0][c], ar);
         az = mfma16x4(ah, whh[1][c], az);
       }
+      const int r0 = rt * 16 + 4 * q;
+      f32x4 vhp, vr, vz, vn, vh;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = rt * 16 + 4 * q + i;
-        const float hp = Hp[r * HS + j];
-        const float rg = sigmoidf_(ar[i]);
-        const float zg = sigmoidf_(az[i]);
-        const float ng = tanhf_(ain[i] + rg * ahn[i]);
-        const float hn = (1.f - zg) * ng + zg * hp;
-        Hn[r * HS + j] = hn;
-        const long rb = rowbase[r];
-        if (rb >= 0) {
-          const long off = (rb + (long)t * tstride) * H + j;
-          if (a.hs) a.hs[off] = hn;
-          if (a.saved) {
-            a.saved[off] = hp;
-            a.saved[2 * plane + off] = rg;
-            a.saved[3 * plane + off] = zg;
-            a.saved[4 * plane + off] = ng;
-            a.saved[5 * plane + off] = ahn[i];
-          }
-          if (a.h_last && t == a.T - 1) a.h_last[(row0 + r) * H + j] = hn;
-        }
+        vhp[i] = Hp[(r0 + i) * HS + j];
+        vr[i] = sigmoidf_(ar[i]);
+        vz[i] = sigmoidf_(az[i]);
+        vn[i] = tanhf_(ain[i] + vr[i] * ahn[i]);
+        vh[i] = (1.f - vz[i]) * vn[i] + vz[i] * vhp[i];
+        Hn[(r0 + i) * HS + j] = vh[i];
+      }
+      if (a.hs) {
+        const int4 ri = *reinterpret_cast<const int4*>(rowidx + r0);
+        st32(a.hs, ((unsigned)ri.x + trow) * 256u + jb, vh[0]); st32(a.hs, ((unsigned)ri.y + trow) * 256u + jb, vh[1]);
+        st32(a.hs, ((unsigned)ri.z + trow) * 256u + jb, vh[2]); st32(a.hs, ((unsigned)ri.w + trow) * 256u + jb, vh[3]);
+      }
+      const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
+      if (SAVE) {
+        const unsigned e0 = (unsigned)rr.x * 1536u + jb, e1 = (unsigned)rr.y * 1536u + jb;
+        const unsigned e2 = (unsigned)rr.z * 1536u + jb, e3 = (unsigned)rr.w * 1536u + jb;
+        st32(svt, e0, vhp[0]); st32(svt, e1, vhp[1]); st32(svt, e2, vhp[2]); st32(svt, e3, vhp[3]);
+        st32(svt, e0 + 512u, vr[0]); st32(svt, e1 + 512u, vr[1]); st32(svt, e2 + 512u, vr[2]); st32(svt, e3 + 512u, vr[3]);
+        st32(svt, e0 + 768u, vz[0]); st32(svt, e1 + 768u, vz[1]); st32(svt, e2 + 768u, vz[2]); st32(svt, e3 + 768u, vz[3]);
+        st32(svt, e0 + 1024u, vn[0]); st32(svt, e1 + 1024u, vn[1]); st32(svt, e2 + 1024u, vn[2]); st32(svt, e3 + 1024u, vn[3]);
+        st32(svt, e0 + 1280u, ahn[0]); st32(svt, e1 + 1280u, ahn[1]); st32(svt, e2 + 1280u, ahn[2]); st32(svt, e3 + 1280u, ahn[3]);
+      }
+      if (last) {
+        st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
+        st32(a.h_last, (unsigned)rr.z * 256u + jb, vh[2]); st32(a.h_last, (unsigned)rr.w * 256u + jb, vh[3]);
       }
     }
     WG_BARRIER();
@@ -300,15 +329,17 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
       }
+      const int4 ri = *reinterpret_cast<const int4*>(rowidx + rt * 16 + 4 * q);
+      const unsigned A4 = (unsigned)a.A * 4u;
 #pragma unroll
       for (int ac = 0; ac < AC; ++ac) {
         const int col = 16 * ac + m;
         if (col < a.A) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const long rb = rowbase[rt * 16 + 4 * q + i];
-            if (rb >= 0) a.q[(rb + (long)t * tstride) * a.A + col] = acc[ac][i];
-          }
+          const unsigned cb = (unsigned)col * 4u;
+          st32(a.q, ((unsigned)ri.x + trow) * A4 + cb, acc[ac][0]);
+          st32(a.q, ((unsigned)ri.y + trow) * A4 + cb, acc[ac][1]);
+          st32(a.q, ((unsigned)ri.z + trow) * A4 + cb, acc[ac][2]);
+          st32(a.q, ((unsigned)ri.w + trow) * A4 + cb, acc[ac][3]);
         }
       }
     }
@@ -329,7 +360,7 @@ struct BwdArgs {
   const float *Wih, *Whh, *W2;
   const float* dq;        // (B,T,N,A)
   const float* dhs;       // (B,T,N,64) external gradient on hs[t], or null
-  const float* saved;     // [6][B,T,N,64]
+  const float* saved;     // [T][B*N][6][64]
   const float* hs;        // (B,T,N,64) hidden after each step (for dW_2)
   float* dxp;             // (B,T,N,64): gradient at fc1 pre-activation
   float* dh0;             // (B*N,64) gradient wrt the initial hidden state, or null
@@ -369,18 +400,25 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   float* DQ1 = DQ0 + rows * QS;
   float* CAR = DQ1 + rows * QS;             // [rows][HS] carried dh (each wave touches its own columns)
   float* XM = CAR + rows * HS;              // [rows][HS] x (own columns) for the relu gate of phase C
-  long* rowbase = reinterpret_cast<long*>(XM + rows * HS);
+  int* rowidx = reinterpret_cast<int*>(XM + rows * HS);   // [rows]: output row b*T*N + n
+  int* rowrho = rowidx + rows;                            // [rows]: b*N + n
+  float* rowok = reinterpret_cast<float*>(rowrho + rows); // [rows]: 1 for real rows, 0 for rows past the batch
 
+  // rows past the batch are clamped to the last valid row for LOADS; their incoming gradients (dq, dhs) are
+  // zeroed, which makes every quantity they contribute (gate gradients, dW, bias sums) exactly zero
   const long row0 = (long)blockIdx.x * rows;
   for (int r = tid; r < rows; r += BNT) {
     long rho = row0 + r;
-    long v = -1;
-    if (rho < a.R) { long b = rho / a.N; int n = (int)(rho % a.N); v = b * a.T * a.N + n; }
-    rowbase[r] = v;
+    const float ok = rho < a.R ? 1.f : 0.f;
+    if (rho > a.R - 1) rho = a.R - 1;
+    const long b = rho / a.N;
+    const int n = (int)(rho % a.N);
+    rowidx[r] = (int)(b * a.T * a.N + n);
+    rowrho[r] = (int)rho;
+    rowok[r] = ok;
   }
   for (int e = tid; e < rows * HS; e += BNT) CAR[e] = 0.f;
   const long tstride = a.N;
-  const long plane = (long)a.B * a.T * a.N * H;
   const int j = 16 * wave + m;
 
   // B-fragments of the TRANSPOSED products: lane (q,m) holds W[k = 16c+4q+i][col 16w+m]
@@ -415,27 +453,30 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   // one row tile of saved activations, loaded in accumulator layout into NAMED registers
   // (a struct returned from a lambda ended up in scratch memory)
 #define LOAD_PRE(HP, XA, HPO_, XO_, R_, Z_, N_, HN_, DHS_, HT_, tt, rr, en)                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-    const long rb_ = rowbase[(rr) * 16 + 4 * q + i];                                                     \
-    const bool ok_ = (en) && rb_ >= 0;                                                                   \
-    const long off_ = ok_ ? (rb_ + (long)(tt) * tstride) * H : 0;                                        \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
-      HP[c][i] = ok_ ? a.saved[off_ + 16 * c + m] : 0.f;                                                 \
-      XA[c][i] = ok_ ? a.saved[plane + off_ + 16 * c + m] : 0.f;                                         \
+  {                                                                                                      \
+    const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H);     /* step base, uniform */               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+      const int r_ = (rr) * 16 + 4 * q + i;                                                              \
+      const float ok_ = (en) ? rowok[r_] : 0.f;                   /* 0 for clamped / disabled rows */    \
+      const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H);                                              \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
+        HP[c][i] = sp_[16 * c + m];                                                                      \
+        XA[c][i] = sp_[H + 16 * c + m];                                                                  \
+      }                                                                                                  \
+      HPO_[i] = sp_[j];              /* own 16 columns (a runtime pick from HP[] would go to scratch) */ \
+      XO_[i] = sp_[H + j];                                                                               \
+      R_[i] = sp_[2 * H + j];                                                                            \
+      Z_[i] = sp_[3 * H + j];                                                                            \
+      N_[i] = sp_[4 * H + j];                                                                            \
+      HN_[i] = sp_[5 * H + j];                                                                           \
+      const long off_ = ((long)rowidx[r_] + (long)(tt) * tstride) * H + j;                               \
+      HT_[i] = a.hs[off_];                                                                               \
+      DHS_[i] = a.dhs ? a.dhs[off_] * ok_ : 0.f;                                                         \
     }                                                                                                    \
-    HPO_[i] = ok_ ? a.saved[off_ + j] : 0.f;          /* own 16 columns (a runtime pick from HP[] would go to scratch) */ \
-    XO_[i] = ok_ ? a.saved[plane + off_ + j] : 0.f;                                                      \
-    R_[i] = ok_ ? a.saved[2 * plane + off_ + j] : 0.f;                                                   \
-    Z_[i] = ok_ ? a.saved[3 * plane + off_ + j] : 0.f;                                                   \
-    N_[i] = ok_ ? a.saved[4 * plane + off_ + j] : 0.f;                                                   \
-    HN_[i] = ok_ ? a.saved[5 * plane + off_ + j] : 0.f;                                                  \
-    HT_[i] = ok_ ? a.hs[off_ + j] : 0.f;                                                                 \
-    DHS_[i] = (ok_ && a.dhs) ? a.dhs[off_ + j] : 0.f;                                                    \
   }
   auto dq_elem = [&](int t, int e) -> float {
     const int r = e / QP, k = e - r * QP;
-    const long rb = rowbase[r];
-    return (rb >= 0 && k < a.A) ? a.dq[(rb + (long)t * tstride) * a.A + k] : 0.f;
+    return (k < a.A) ? a.dq[((long)rowidx[r] + (long)t * tstride) * a.A + k] * rowok[r] : 0.f;
   };
 
   for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
@@ -526,9 +567,8 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = rt * 16 + 4 * q + i;
-        const long rb = rowbase[r];
         CAR[r * HS + j] = dhp[i];
-        if (rb >= 0) a.dxp[(rb + (long)t * tstride) * H + j] = XM[r * HS + j] > 0.f ? dx[i] : 0.f;
+        if (rowok[r] != 0.f) a.dxp[((long)rowidx[r] + (long)t * tstride) * H + j] = XM[r * HS + j] > 0.f ? dx[i] : 0.f;
       }
     }
     if (t > 0) {
@@ -544,7 +584,7 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
     for (int r = 4 * q; r < rows; r += 16)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (rowbase[r + i] >= 0) a.dh0[(row0 + r + i) * H + j] = CAR[(r + i) * HS + j];
+        if (rowok[r + i] != 0.f) a.dh0[(row0 + r + i) * H + j] = CAR[(r + i) * HS + j];
   }
   // ---- this workgroup's partial weight gradients -> slab (summed in fixed order by the reduce kernel)
   float* slab = a.ws + (long)blockIdx.x * bwd_slab_floats(a.A);
@@ -644,7 +684,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.KC = (a.I + 15) / 16;
   a.R = (long)B * N;
   const int KS = a.KC * 16 + 4;
-  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;
+  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;   // + row tables: 2 long + 4 int
   const size_t fixed = (size_t)4 * a.KC * 64 * 16;
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
@@ -661,15 +701,20 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const long rows = a.RT * 16;
   dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(FNT);
   hipStream_t s = (hipStream_t)stream;
+  // per-step outputs are addressed with 32-bit byte offsets
+  if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
   hipError_t e;
+  const void* fn;
+  if (A <= 16) fn = saved ? (const void*)agent_fwd_kernel<1, true> : (const void*)agent_fwd_kernel<1, false>;
+  else fn = saved ? (const void*)agent_fwd_kernel<2, true> : (const void*)agent_fwd_kernel<2, false>;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
   if (A <= 16) {
-    e = hipFuncSetAttribute((const void*)agent_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((agent_fwd_kernel<1>), grid, block, lds, s, a);
+    if (saved) hipLaunchKernelGGL((agent_fwd_kernel<1, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((agent_fwd_kernel<1, false>), grid, block, lds, s, a);
   } else {
-    e = hipFuncSetAttribute((const void*)agent_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((agent_fwd_kernel<2>), grid, block, lds, s, a);
+    if (saved) hipLaunchKernelGGL((agent_fwd_kernel<2, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((agent_fwd_kernel<2, false>), grid, block, lds, s, a);
   }
   MARL_CHECK_LAUNCH();
   return 0;
@@ -678,7 +723,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
 static int bwd_rt(long R, int A) {
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
-  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 8;
+  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 12;
   int cap = (NQ * BNT) / (16 * AC * 16);      // dq prefetch registers cover rows*QP elements
   if (cap > 8) cap = 8;
   return pick_rt(R, per_row, 0, cap);
@@ -704,7 +749,7 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
-  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 8;
+  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 12;
   a.RT = bwd_rt(a.R, A);
   const size_t lds = per_row * a.RT * 16;
   const long rows = a.RT * 16;
