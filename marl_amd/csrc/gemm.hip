@@ -158,11 +158,12 @@ struct WgradArgs {
   int nyb;                           // column blocks of N per group
   int groups;
   long gs_g, gs_ya, gs_x0, gs_x1;
+  int gvec, xvec;                    // float4 operand loads allowed (alignment checked on the host)
 };
 
 // block = 4 waves; all waves own the same 64(n) x 64(k) tile of dW and split the slab's rows;
 // operands are D-layout loads (4 rows per lane) which ARE the A^T / B fragments - no LDS staging.
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   __shared__ float red[4][64 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -190,6 +191,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const long t_begin = (long)blockIdx.x * per;
   long t_end = t_begin + per; if (t_end > tiles) t_end = tiles;
 
+  // Column mapping of the 4 MFMA tiles inside the 64-wide block.  "perm" (block wider than 16 columns):
+  // tile c of lane m is column 4m + c, so ONE float4 per lane and row feeds all four tiles and 16 lanes
+  // read 256 contiguous bytes; otherwise (narrow blocks, e.g. N = 1) tile c is columns 16c .. 16c+15.
+  const bool gperm = (a.N - n0) > 16, xperm = (Kext - k0) > 16;
+  const int gt_used = gperm ? 4 : nt_used, xt_used = xperm ? 4 : kt_used;
+  const bool gvec = gperm && a.gvec, xvec = xperm && a.xvec;
+
   // operand tiles of row tile tt in accumulator layout; rows past M and columns past N / K+1 read zero
 #define WG_LOAD_TILE(GV, XV, tt, en)                                                                    \
   {                                                                                                      \
@@ -198,28 +206,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       const long row = r0_ + i;                                                                          \
       const bool okr = (en) && row < a.M;                                                                \
       const ConcatRow cr = concat_row(x, okr ? row : 0);                                                 \
-      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                 \
-        float v = 0.f;                                                                                   \
-        if (nt < nt_used) {                                                                              \
-          const int n = n0 + nt * 16 + m;                                                                \
-          if (okr && n < a.N) {                                                                          \
-            v = G[row * a.ldg + n];                                                                      \
-            if (Ya) v = Ya[row * a.ldya + n] > 0.f ? v : 0.f;                                            \
+      f32x4 g4 = {0.f, 0.f, 0.f, 0.f}, x4 = {0.f, 0.f, 0.f, 0.f};                                        \
+      if (okr) {                                                                                         \
+        const int nb = n0 + 4 * m;                                                                       \
+        if (gvec && nb + 3 < a.N) {                                                                      \
+          g4 = *reinterpret_cast<const f32x4*>(G + row * a.ldg + nb);                                    \
+          if (Ya) {                                                                                      \
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + nb);                    \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) g4[c] = y4[c] > 0.f ? g4[c] : 0.f;             \
+          }                                                                                              \
+        } else {                                                                                         \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                \
+            const int n = gperm ? nb + c : n0 + 16 * c + m;                                              \
+            if (c < gt_used && n < a.N) {                                                                \
+              float v = G[row * a.ldg + n];                                                              \
+              if (Ya) v = Ya[row * a.ldya + n] > 0.f ? v : 0.f;                                          \
+              g4[c] = v;                                                                                 \
+            }                                                                                            \
           }                                                                                              \
         }                                                                                                \
-        GV[nt][i] = v;                                                                                   \
-      }                                                                                                  \
-      _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) {                                                 \
-        float v = 0.f;                                                                                   \
-        if (kt < kt_used) {                                                                              \
-          const int k = k0 + kt * 16 + m;                                                                \
-          if (okr) {                                                                                     \
-            if (k < a.K) v = concat_at(x, cr, k);                                                        \
-            else if (k == a.K) v = 1.f;        /* virtual ones column => bias gradient */                \
+        const int kb = k0 + 4 * m;                                                                       \
+        if (xvec && cr.ok0 && kb + 3 < x.k0) {                                                           \
+          x4 = *reinterpret_cast<const f32x4*>(x.p0 + cr.r0 * x.ld0 + kb);                               \
+        } else {                                                                                         \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                \
+            const int k = xperm ? kb + c : k0 + 16 * c + m;                                              \
+            if (c < xt_used) {                                                                           \
+              if (k < a.K) x4[c] = concat_at(x, cr, k);                                                  \
+              else if (k == a.K) x4[c] = 1.f;    /* virtual ones column => bias gradient */              \
+            }                                                                                            \
           }                                                                                              \
         }                                                                                                \
-        XV[kt][i] = v;                                                                                   \
       }                                                                                                  \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) { GV[c][i] = g4[c]; XV[c][i] = x4[c]; }              \
     }                                                                                                    \
   }
 
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
-        if (nt < nt_used && kt < kt_used) acc[nt][kt] = mfma16x4(gA[nt], xA[kt], acc[nt][kt]);
+        if (nt < gt_used && kt < xt_used) acc[nt][kt] = mfma16x4(gA[nt], xA[kt], acc[nt][kt]);
   }
 
   // cross-wave reduction of the 64x64 tile through LDS, then one slab partial per block
@@ -241,7 +260,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) red[wave][(nt * 16 + 4 * q + i) * 64 + kt * 16 + m] = acc[nt][kt][i];
+      for (int i = 0; i < 4; ++i) {
+        const int nl = gperm ? 4 * (4 * q + i) + nt : nt * 16 + 4 * q + i;      // local n (row of dW)
+        const int kl = xperm ? 4 * m + kt : kt * 16 + m;                         // local k (column of dW)
+        red[wave][nl * 64 + kl] = acc[nt][kt][i];
+      }
   __syncthreads();
   float* ws = a.ws + ((long)blockIdx.x * a.groups + g) * (long)a.N * Kext;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -340,6 +363,9 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
   a.nyb = (N + 63) / 64; a.groups = groups;
   a.gs_g = grp ? grp->gs_y : 0; a.gs_ya = grp ? grp->gs_m0 : 0;
   a.gs_x0 = grp ? grp->gs_x0 : 0; a.gs_x1 = grp ? grp->gs_x1 : 0;
+  a.gvec = (ldg % 4 == 0) && aligned16(G) && (a.gs_g % 4 == 0) &&
+           (!Yact || ((ldya % 4 == 0) && aligned16(Yact) && (a.gs_ya % 4 == 0)));
+  a.xvec = a.x.p0 && !a.x.m0 && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.slabs, a.nyb * groups, (K + 1 + 63) / 64), block(256);
   hipLaunchKernelGGL(wgrad_kernel, grid, block, 0, s, a);
