@@ -4,24 +4,11 @@
 // is a pure function of (seed, stream, env, step, index) through a 32-bit hash, so the numpy
 // restatement in oracle/rollout.py reproduces it bit for bit.
 #include "common.h"
+#include "synth_hash.h"
 #include "../../include/marl_hip.h"
 
 namespace {
 constexpr int TPB = 256;
-enum { ST_OBS = 0, ST_STATE, ST_AVAIL, ST_REWARD, ST_LEN, ST_WON, ST_EXPLORE, ST_PICK };
-
-__host__ __device__ inline unsigned mix32(unsigned x) {
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-__host__ __device__ inline unsigned hkey(unsigned seed, unsigned stream, unsigned env, unsigned t, unsigned idx) {
-  unsigned h = mix32(seed + stream * 0x9E3779B1u);
-  h = mix32(h + env * 0x85EBCA77u + 1u);
-  h = mix32(h + t * 0xC2B2AE3Du + 2u);
-  h = mix32(h + idx * 0x27D4EB2Fu + 3u);
-  return h;
-}
-__host__ __device__ inline float u01(unsigned h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
 
 __global__ void select_kernel(const float* q, const float* avail, long avail_es, const int* alive, float eps,
                               unsigned rseed, int env0, const int* tg, int tg0, int* act_out, long act_es, int E,

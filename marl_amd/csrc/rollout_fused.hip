@@ -1,0 +1,365 @@
+// Whole-rollout persistent kernel for the synthetic SMAC-shaped environment: ONE launch plays all T
+// lock-steps of E environments (reference rollout.py:60-101 + share_params.py:37-72, vectorised).
+//
+// A workgroup owns rows = 16*RT (episode, agent) rows, a multiple of N, i.e. whole environments, for
+// the entire episode: agent weights stay in registers / LDS (they were re-staged 120x by the
+// launch-per-step path), the hidden state never leaves LDS, and because the workgroup holds every
+// agent of its environments the epsilon-greedy choice, the env step (reward / terminated / padding)
+// and the next observation are computed in place - no inter-workgroup communication at all.
+// The MFMA phases are those of agent_fwd_kernel (agent.hip); the environment is the counter-hash
+// env of synth_hash.h, so the episode record is bit-identical to the launch-per-step path and to the
+// numpy oracle.
+#include "common.h"
+#include "synth_hash.h"
+#include "../../include/marl_hip.h"
+
+namespace {
+
+constexpr int H = 64;
+constexpr int HS = H + 4;
+constexpr int RNT = 512;
+
+#define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct RollArgs {
+  const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;
+  const float* eps;       // [T] epsilon of each lock-step (device)
+  float *obs, *state, *avail;   // (E,T+1,N,O) (E,T+1,S) (E,T+1,N,A)
+  int* u;                 // (E,T,N)
+  float *r, *term, *padded;     // (E,T)
+  int *length, *won;      // (E)
+  float* h_out;           // (E*N,64) final hidden state or null
+  unsigned seed, rseed;
+  int env0, episode, fixed_len;
+  int E, T, N, O, S, A, I, KC, RT;
+  int has_act, has_id;
+  long R;
+};
+
+template <int AC>
+__global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int team = wave >> 2, ws = wave & 3;
+  const int q = lane >> 4, m = lane & 15;
+  const int rows = a.RT * 16;
+  const int KP = a.KC * 16, KS = KP + 4;
+  const int AS = a.A + 1;
+  float* W1s = smem;                                  // [4][KC][64] f32x4
+  float* In = W1s + 4 * a.KC * 64 * 4;                // [rows][KS]
+  float* Xt = In + rows * KS;                         // [rows][HS]
+  float* Ha = Xt + rows * HS;                         // [rows][HS] x2
+  float* Hb = Ha + rows * HS;
+  float* Qs = Hb + rows * HS;                         // [rows][AS]  q of the current step
+  float* Av0 = Qs + rows * AS;                        // [rows][A] x2  availability of step t / t+1
+  float* Av1 = Av0 + rows * a.A;
+  int* act = reinterpret_cast<int*>(Av1 + rows * a.A);   // [rows]
+  int* rowe = act + rows;                                // [rows]: local env index (b - b0), clamped
+  int* rown = rowe + rows;                               // [rows]: n
+  int* elen = rown + rows;                               // [rows/N]: episode length of the local env
+
+  const long row0 = (long)blockIdx.x * rows;           // multiple of N by construction
+  const int b0 = (int)(row0 / a.N);
+  const int nenv_wg = rows / a.N;
+  const int T = a.T, N = a.N, O = a.O, S = a.S, A = a.A;
+  for (int r = tid; r < rows; r += RNT) {
+    long rho = row0 + r;
+    if (rho > a.R - 1) rho = a.R - 1;                   // clamp: duplicates of the last row (same values, same addresses)
+    rowe[r] = (int)(rho / N) - b0;
+    rown[r] = (int)(rho % N);
+  }
+  const int lmin = T / 2 > 1 ? T / 2 : 1;
+  for (int e = tid; e < nenv_wg; e += RNT) {
+    int b = b0 + e; if (b > a.E - 1) b = a.E - 1;
+    const unsigned env = (unsigned)(a.env0 + b);
+    int L = lmin + (int)(hkey(a.seed, ST_LEN, env, (unsigned)a.episode, 0u) % (unsigned)(T - lmin + 1));
+    if (a.fixed_len) L = T;
+    elen[e] = L;
+    a.length[b] = L;
+    a.won[b] = (int)(hkey(a.seed, ST_WON, env, (unsigned)a.episode, 0u) & 1u);
+  }
+  for (int e = tid; e < rows * H; e += RNT) Ha[(e / H) * HS + (e % H)] = 0.f;     // init_hidden: zeros
+  __syncthreads();
+
+  // ---- environment observation of slot t -> record (+ LDS input tile / availability when wanted)
+  auto gen_slot = [&](int t, bool to_lds, float* Av) {
+    const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
+    for (int e = tid; e < rows * O; e += RNT) {           // observations: row-major, coalesced over k
+      const int r = e / O, k = e - r * O;
+      const int el = rowe[r], n = rown[r];
+      const unsigned env = (unsigned)(a.env0 + b0 + el);
+      float v = 0.f;
+      if (t <= elen[el]) v = 2.0f * u01(hfin(hprefix(a.seed, ST_OBS, env, tg), (unsigned)(n * O + k))) - 1.0f;
+      a.obs[(((long)(b0 + el) * (T + 1) + t) * N + n) * O + k] = v;
+      if (to_lds) In[r * KS + k] = (t < elen[el]) ? v : 0.f;     // padded steps feed zeros (rollout.py:122-133)
+    }
+    for (int e = tid; e < nenv_wg * S; e += RNT) {
+      const int el = e / S, k = e - el * S;
+      if (b0 + el < a.E) {
+        const unsigned env = (unsigned)(a.env0 + b0 + el);
+        float v = 0.f;
+        if (t <= elen[el]) v = 2.0f * u01(hfin(hprefix(a.seed, ST_STATE, env, tg), (unsigned)k)) - 1.0f;
+        a.state[((long)(b0 + el) * (T + 1) + t) * S + k] = v;
+      }
+    }
+    for (int e = tid; e < rows * A; e += RNT) {
+      const int r = e / A, k = e - r * A;
+      const int el = rowe[r], n = rown[r];
+      const unsigned env = (unsigned)(a.env0 + b0 + el);
+      float v = 0.f;
+      if (t <= elen[el]) v = (k == 0 || u01(hfin(hprefix(a.seed, ST_AVAIL, env, tg), (unsigned)(n * A + k))) < 0.7f) ? 1.f : 0.f;
+      a.avail[(((long)(b0 + el) * (T + 1) + t) * N + n) * A + k] = v;
+      if (Av) Av[r * A + k] = v;
+    }
+  };
+  // constant columns of the input tile: one-hot(last action) starts empty, agent id, zero pad
+  for (int e = tid; e < rows * (KP - O); e += RNT) {
+    const int r = e / (KP - O), k = O + e % (KP - O);
+    float v = 0.f;
+    if (a.has_id && k >= a.I - N && k < a.I) v = (rown[r] == k - (a.I - N)) ? 1.f : 0.f;
+    In[r * KS + k] = v;
+  }
+  gen_slot(0, true, Av0);
+
+  // ---- weights (as in agent_fwd_kernel)
+  f32x4 wih[3][4], whh[3][4], w2[AC][4];
+  float bias_r, bias_z, bias_in, bias_hn, bias1, bias2[AC];
+  const int j = 16 * ws + m;
+  {
+    if (team == 0) {
+      for (int c = 0; c < a.KC; ++c) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int k = 16 * c + 4 * q + i;
+          v[i] = k < a.I ? a.W1[(long)j * a.I + k] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(W1s + ((ws * a.KC + c) * 64 + lane) * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        wih[g][c] = *reinterpret_cast<const f32x4*>(a.Wih + (long)(g * H + j) * H + 16 * c + 4 * q);
+        whh[g][c] = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + j) * H + 16 * c + 4 * q);
+      }
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      int arow = 16 * ac + m; if (arow >= A) arow = A - 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        w2[ac][c] = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
+      bias2[ac] = a.b2[arow];
+    }
+    bias1 = a.b1[j];
+    bias_r = a.bih[j] + a.bhh[j];
+    bias_z = a.bih[H + j] + a.bhh[H + j];
+    bias_in = a.bih[2 * H + j];
+    bias_hn = a.bhh[2 * H + j];
+  }
+  WG_BARRIER();
+
+  float* Hp = Ha;
+  float* Hn = Hb;
+  float* AvC = Av0;
+  float* AvN = Av1;
+  for (int t = 0; t < T; ++t) {
+    // ---------------- phase 1: x = relu(fc1(in))
+    for (int rt = team; rt < a.RT; rt += 4) {
+      const bool two = rt + 2 < a.RT;
+      f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
+      const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
+      const float* in1 = in0 + 32 * KS;
+      const float* wf = W1s + (ws * a.KC * 64 + lane) * 4;
+      for (int c = 0; c < a.KC; ++c) {
+        f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
+        acc0 = mfma16x4(a0, bv, acc0);
+        if (two) {
+          f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
+          acc1 = mfma16x4(a1, bv, acc1);
+        }
+      }
+      const int r0 = rt * 16 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Xt[(r0 + i) * HS + j] = fmaxf(acc0[i], 0.f);
+        if (two) Xt[(r0 + 32 + i) * HS + j] = fmaxf(acc1[i], 0.f);
+      }
+    }
+    WG_BARRIER();
+    // the input tile is consumed: the env already knows the next observation (it does not depend on the
+    // actions), so slot t+1 is generated now, under the shadow of the gate MFMAs of the other waves
+    gen_slot(t + 1, t + 1 < T, AvN);
+    // ---------------- phase 2: GRU
+    for (int rt = team; rt < a.RT; rt += 2) {
+      f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
+      f32x4 az = {bias_z, bias_z, bias_z, bias_z};
+      f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
+      f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
+      const float* xr = Xt + (rt * 16 + m) * HS + 4 * q;
+      const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+        ar = mfma16x4(ax, wih[0][c], ar);
+        az = mfma16x4(ax, wih[1][c], az);
+        ain = mfma16x4(ax, wih[2][c], ain);
+        ahn = mfma16x4(ah, whh[2][c], ahn);
+        ar = mfma16x4(ah, whh[0][c], ar);
+        az = mfma16x4(ah, whh[1][c], az);
+      }
+      const int r0 = rt * 16 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float hp = Hp[(r0 + i) * HS + j];
+        const float rg = sigmoidf_(ar[i]);
+        const float zg = sigmoidf_(az[i]);
+        const float ng = tanhf_(ain[i] + rg * ahn[i]);
+        Hn[(r0 + i) * HS + j] = (1.f - zg) * ng + zg * hp;
+      }
+    }
+    WG_BARRIER();
+    // ---------------- phase 3: q = fc2(h') -> LDS
+    for (int rt = wave; rt < a.RT; rt += 8) {
+      f32x4 acc[AC];
+#pragma unroll
+      for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
+      const float* hr = Hn + (rt * 16 + m) * HS + 4 * q;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+#pragma unroll
+        for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
+      }
+#pragma unroll
+      for (int ac = 0; ac < AC; ++ac) {
+        const int col = 16 * ac + m;
+        if (col < A) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Qs[(rt * 16 + 4 * q + i) * AS + col] = acc[ac][i];
+        }
+      }
+    }
+    WG_BARRIER();
+    // ---------------- epsilon-greedy choice (share_params.py:66-70), one thread per (env, agent) row
+    const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
+    const float eps = a.eps[t];
+    if (tid < rows) {
+      const int r = tid, el = rowe[r], n = rown[r];
+      const unsigned env = (unsigned)(a.env0 + b0 + el);
+      int arg = -1;
+      if (t < elen[el]) {
+        const float* qa = Qs + r * AS;
+        const float* av = AvC + r * A;
+        float best = 0.f; int navail = 0;
+        for (int k = 0; k < A; ++k) {
+          if (av[k] == 0.f) continue;
+          ++navail;
+          if (arg < 0 || qa[k] > best) { best = qa[k]; arg = k; }
+        }
+        if (arg < 0) arg = 0;
+        const bool explore = u01(hkey(a.rseed, ST_EXPLORE, env, tg, (unsigned)n)) < eps;
+        if (explore && navail > 0) {
+          int kk = (int)floorf(u01(hkey(a.rseed, ST_PICK, env, tg, (unsigned)n)) * (float)navail);
+          if (kk > navail - 1) kk = navail - 1;
+          int c = 0;
+          for (int k = 0; k < A; ++k) {
+            if (av[k] == 0.f) continue;
+            if (c == kk) { arg = k; break; }
+            ++c;
+          }
+        }
+      }
+      act[r] = arg;
+      a.u[((long)(b0 + el) * T + t) * N + n] = arg;
+      if (a.has_act)
+        for (int k = 0; k < A; ++k) In[r * KS + O + k] = (k == arg) ? 1.f : 0.f;   // one-hot fed to step t+1
+    }
+    WG_BARRIER();
+    // ---------------- env step: reward / terminated / padded (fixed-order fp32 sum over agents)
+    if (tid < nenv_wg && b0 + tid < a.E) {
+      const int el = tid, L = elen[el];
+      const bool live = t < L;
+      const unsigned env = (unsigned)(a.env0 + b0 + el);
+      float acc = 0.f;
+      if (live) {
+        const unsigned pre = hprefix(a.seed, ST_REWARD, env, tg);
+        for (int n = 0; n < N; ++n) acc = acc + (u01(hfin(pre, (unsigned)(n * A + act[el * N + n]))) - 0.5f);
+      }
+      const long o = (long)(b0 + el) * T + t;
+      a.r[o] = live ? acc * (1.0f / (float)N) : 0.f;
+      a.term[o] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
+      a.padded[o] = live ? 0.f : 1.f;
+    }
+    float* tmp = Hp; Hp = Hn; Hn = tmp;
+    tmp = AvC; AvC = AvN; AvN = tmp;
+    // no barrier: `act` is next written after three more barriers; In/Xt/H hazards as in agent_fwd_kernel
+  }
+  if (a.h_out) {
+    WG_BARRIER();
+    for (int e = tid; e < rows * H; e += RNT) {
+      const int r = e / H, k = e % H;
+      const long rho = row0 + r;
+      if (rho < a.R) a.h_out[rho * H + k] = Hp[r * HS + k];
+    }
+  }
+}
+
+}  // namespace
+
+// rows per workgroup must hold whole environments: 16*RT % N == 0, RT <= 8
+extern "C" int marl_synth_rollout_supported(int N, int O, int A) {
+  for (int rt = 1; rt <= 8; ++rt)
+    if ((16 * rt) % N == 0) return 1;
+  return 0;
+}
+
+extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
+                                  int fixed_len, const float* eps, float* obs, float* state, float* avail, int* u,
+                                  float* r, float* term, float* padded, int* length, int* won, float* h_out,
+                                  int E, int T, int N, int O, int S, int A, int last_action, int reuse_network,
+                                  void* stream) {
+  if (E <= 0 || T <= 0) return 0;
+  if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
+  RollArgs a;
+  a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
+  a.W2 = w->fc2_w; a.b2 = w->fc2_b;
+  a.eps = eps; a.obs = obs; a.state = state; a.avail = avail; a.u = u; a.r = r; a.term = term; a.padded = padded;
+  a.length = length; a.won = won; a.h_out = h_out;
+  a.seed = seed; a.rseed = rseed; a.env0 = env0; a.episode = episode; a.fixed_len = fixed_len;
+  a.E = E; a.T = T; a.N = N; a.O = O; a.S = S; a.A = A;
+  a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
+  a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
+  a.KC = (a.I + 15) / 16;
+  a.R = (long)E * N;
+  const int KS = a.KC * 16 + 4;
+  const size_t fixed = (size_t)4 * a.KC * 64 * 16;
+  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16;
+  // smallest RT >= ceil(tiles/256) with whole environments per workgroup, within the LDS budget
+  const long tiles = (a.R + 15) / 16;
+  int want = (int)((tiles + 255) / 256); if (want < 1) want = 1;
+  int rt = 0;
+  for (int c = want; c <= 8; ++c) if ((16 * c) % N == 0 && fixed + per_row * 16 * c <= 160 * 1024) { rt = c; break; }
+  if (!rt) for (int c = want - 1; c >= 1; --c) if ((16 * c) % N == 0 && fixed + per_row * 16 * c <= 160 * 1024) { rt = c; break; }
+  if (!rt) return (int)hipErrorInvalidValue;
+  a.RT = rt;
+  const size_t lds = fixed + per_row * rt * 16;
+  const long rows = rt * 16;
+  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(RNT);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (A <= 16) {
+    e = hipFuncSetAttribute((const void*)synth_rollout_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((synth_rollout_kernel<1>), grid, block, lds, s, a);
+  } else {
+    e = hipFuncSetAttribute((const void*)synth_rollout_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((synth_rollout_kernel<2>), grid, block, lds, s, a);
+  }
+  MARL_CHECK_LAUNCH();
+  return 0;
+}

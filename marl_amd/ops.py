@@ -274,3 +274,16 @@ def synth_fused_step(seed, rseed, env0, episode, t, eps, length, q, obs, state, 
                                             _p(_i32(length)), _p(_f32(q)), _p(_f32(obs)), _p(_f32(state)), _p(_f32(avail)),
                                             _p(_i32(u)), _p(_f32(r)), _p(_f32(term)), _p(_f32(padded)), E, T, N, O, S, A,
                                             _stream()), "marl_synth_fused_step")
+
+
+def synth_rollout_supported(N, O, A):
+    return bool(_lib.load().marl_synth_rollout_supported(N, O, A))
+
+
+def synth_rollout(w, seed, rseed, env0, episode, fixed_len, eps, rec, h_out, E, T, N, O, S, A, last_action, reuse_network):
+    check(_lib.load().marl_synth_rollout(C.byref(w), int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode,
+                                         1 if fixed_len else 0, _p(_f32(eps)), _p(_f32(rec.obs)), _p(_f32(rec.state)),
+                                         _p(_f32(rec.avail)), _p(_i32(rec.u)), _p(_f32(rec.r)), _p(_f32(rec.term)),
+                                         _p(_f32(rec.padded)), _p(_i32(rec.length)), _p(_i32(rec.won)), _p(h_out),
+                                         E, T, N, O, S, A, 1 if last_action else 0, 1 if reuse_network else 0, _stream()),
+          "marl_synth_rollout")

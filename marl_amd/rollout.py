@@ -108,6 +108,9 @@ class RolloutWorker:
         if a.replay_dir != '' and evaluate:
             env.close()
         rec = env.new_record()
+        mode = getattr(self, "rollout_mode", "whole")      # "whole" | "fused_step" | "unfused" (tests)
+        if mode == "whole" and hasattr(env, "whole_rollout") and env.supports_whole_rollout():
+            return self._generate_whole(rec, evaluate)
         env.begin_episode(rec)
         mac.init_hidden(E)
         h = mac.hidden_states.view(E * N, H)
@@ -121,7 +124,7 @@ class RolloutWorker:
         if a.epsilon_anneal_scale == 'episode':
             epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
         w = mac.agent.weights()
-        fused = hasattr(env, "fused_step") and not getattr(self, "no_fused_env", False)
+        fused = hasattr(env, "fused_step") and mode != "unfused"
         env.observe(0, rec)
         for t in range(T):
             # agent step = the unroll kernel with T=1 reading slot t of the record in place
@@ -146,6 +149,34 @@ class RolloutWorker:
         wins_tag = [bool(x) for x in stats[1].tolist()]
         steps_tot = int(stats[2].sum().item())
         return EpisodeBatch(rec), episodes_reward, wins_tag, steps_tot
+
+    def _generate_whole(self, rec, evaluate):
+        """One persistent launch for the whole rollout; the epsilon schedule (one anneal per lock-step,
+        reference rollout.py:48-50,100-101) is evaluated on the host and shipped as a T-vector."""
+        env, mac, a = self.env, self.mac, self.args
+        dev = require_cuda("RolloutWorker")
+        E, T, N, H = env.n_envs, self.episode_limit, self.n_agents, a.rnn_hidden_dim
+        if a.replay_dir != '' and evaluate:
+            env.close()
+        epsilon = 0 if evaluate else self.epsilon
+        if a.epsilon_anneal_scale == 'episode':
+            epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
+        sched = np.empty(T, dtype=np.float32)
+        for t in range(T):
+            sched[t] = epsilon
+            if a.epsilon_anneal_scale == 'step':
+                epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
+        eps_dev = torch.from_numpy(sched).to(dev)
+        mac.init_hidden(E)
+        env.whole_rollout(mac.agent.weights(), eps_dev, self.rseed, rec, a.last_action, a.reuse_network,
+                          h_out=mac.hidden_states.view(E * N, H))
+        if not evaluate:
+            self.epsilon = epsilon
+        if evaluate and a.replay_dir != '':
+            env.save_replay()
+            env.close()
+        stats = torch.stack([rec.r.sum(1), rec.won.float(), rec.length.float()], 0).cpu()
+        return EpisodeBatch(rec), stats[0].tolist(), [bool(x) for x in stats[1].tolist()], int(stats[2].sum().item())
 
     # ------------------------------------------------------------------ serial path (reference loop)
     def _generate_serial(self, n_episodes, evaluate, random_select):

@@ -30,13 +30,16 @@ def test_batched_rollout_matches_oracle(eps, evaluate):
     env = SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=5, env0=2)
     w = RolloutWorker(env, mac, args)
     ep, rew, wins, steps = w.generate_episodes(E, evaluate=evaluate)
-    # the unfused select / step / observe kernels give the same record as the fused per-step kernel
-    w2 = RolloutWorker(SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=5, env0=2), mac, args)
-    w2.no_fused_env = True
-    ep_u, _, _, steps_u = w2.generate_episodes(E, evaluate=evaluate)
-    assert steps_u == steps
-    for f in ("obs", "state", "avail", "u", "r", "term", "padded"):
-        assert torch.equal(getattr(ep.record, f), getattr(ep_u.record, f)), f
+    # three device paths, one record: whole-rollout persistent kernel (default), one fused env kernel per
+    # lock-step, and the separate select / step / observe kernels
+    for mode in ("fused_step", "unfused"):
+        w2 = RolloutWorker(SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=5, env0=2), mac, args)
+        w2.rollout_mode = mode
+        ep_u, _, _, steps_u = w2.generate_episodes(E, evaluate=evaluate)
+        assert steps_u == steps, mode
+        for f in ("obs", "state", "avail", "u", "r", "term", "padded", "length", "won"):
+            assert torch.equal(getattr(ep.record, f), getattr(ep_u.record, f)), (mode, f)
+        np.testing.assert_allclose(w2.epsilon, w.epsilon, rtol=1e-12)
     sy = orl.SynthSMAC(5, 80, 120, 11, T, seed=5)
     oep, orew, owins, osteps, oeps = orl.batched_rollout(agent, args, sy, E, eps, evaluate=evaluate, rseed=77, env0=2)
     got = ep.numpy()
