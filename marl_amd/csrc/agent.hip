@@ -630,24 +630,30 @@ struct BwdRedArgs {
   float *dWih, *dWhh, *dW2, *dbih, *dbhh, *db2;
 };
 
-__global__ void agent_bwd_reduce_kernel(BwdRedArgs a) {
+__global__ __launch_bounds__(256) void agent_bwd_reduce_kernel(BwdRedArgs a) {
+  __shared__ float part[4][64];
   const long slab = bwd_slab_floats(a.A);
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int w = 0; w < a.nwg; ++w) s += a.ws[(long)w * slab + e];
-    long k = e;
-    if (k < 192 * 64) { a.dWih[k] += s; continue; }
-    k -= 192 * 64;
-    if (k < 192 * 64) { a.dWhh[k] += s; continue; }
-    k -= 192 * 64;
-    if (k < (long)a.A * 64) { a.dW2[k] += s; continue; }
-    k -= (long)a.A * 64;
-    if (k < 192) { a.dbih[k] += s; continue; }
-    k -= 192;
-    if (k < 192) { a.dbhh[k] += s; continue; }
-    k -= 192;
-    a.db2[k] += s;
-  }
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (e < slab)
+    for (int w = sg; w < a.nwg; w += 4) s += a.ws[(long)w * slab + e];
+  part[sg][el] = s;
+  __syncthreads();
+  if (sg != 0 || e >= slab) return;
+  s = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+  long k = e;
+  if (k < 192 * 64) { a.dWih[k] += s; return; }
+  k -= 192 * 64;
+  if (k < 192 * 64) { a.dWhh[k] += s; return; }
+  k -= 192 * 64;
+  if (k < (long)a.A * 64) { a.dW2[k] += s; return; }
+  k -= (long)a.A * 64;
+  if (k < 192) { a.dbih[k] += s; return; }
+  k -= 192;
+  if (k < 192) { a.dbhh[k] += s; return; }
+  k -= 192;
+  a.db2[k] += s;
 }
 
 static int marl_fwd_rt_single = 8;   // measured: 1/2/3/5 tiles per workgroup -> 12.1/9.4/8.1/6.5 ms per 120-step rollout
@@ -771,7 +777,7 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   r.ws = ws; r.nwg = (int)nwg; r.A = A;
   r.dWih = g->w_ih; r.dWhh = g->w_hh; r.dW2 = g->fc2_w; r.dbih = g->b_ih; r.dbhh = g->b_hh; r.db2 = g->fc2_b;
   const long slab = bwd_slab_floats(A);
-  hipLaunchKernelGGL(agent_bwd_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, r);
+  hipLaunchKernelGGL(agent_bwd_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, s, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }

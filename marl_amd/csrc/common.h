@@ -40,6 +40,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Virtual row-major matrix [M, K] = [dense0 | dense1 | nhot one-hot blocks | agent-id block].
 // Lets GEMMs consume concatenations ([h|onehot(u)], [s|enc], [s|joint one-hot], [obs|u|id])
 // without materialising them.
+// exact unsigned 32-bit division by an invariant divisor (Granlund-Montgomery): the row remaps and the
+// agent-id column need row / d and row % d per row; a hardware-less 64-bit '/' costs hundreds of cycles
+struct FastDiv { unsigned d, m, s; };
+__host__ inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f; f.d = d ? d : 1; f.m = 0; f.s = 0;
+  if (f.d == 1) return f;
+  unsigned s = 0; while ((1ull << s) < f.d) ++s;
+  f.s = s;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << s) - f.d)) / f.d + 1ull);
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> 1)) >> (f.s - 1);
+}
+
 struct ConcatSrc {
   const float* p0; long ld0; int k0;        // dense segment 0 (k0 columns)
   const float* p1; long ld1; int k1;        // dense segment 1
@@ -48,6 +65,7 @@ struct ConcatSrc {
   const float* m0; long ldm0;               // optional gate on segment 0: value * (m0 > 0)
   long rpe0, bs0, off0;                     // row remap of p0/m0: (row/rpe)*bs + row%rpe + off
   long rpei, bsi, offi;                     // row remap of idx; (row%rpe)+off < 0 reads "none"
+  FastDiv fd0, fdi, fdn;                    // dividers for rpe0, rpei, nid (rows < 2^31)
 };
 
 __device__ __forceinline__ long remap_row(long row, long rpe, long bs, long off, bool& valid) {
@@ -85,13 +103,23 @@ __device__ __forceinline__ float concat_elem(const ConcatSrc& s, long row, int k
 }
 
 // Two-stage form for inner loops: the row-dependent part (remaps) once per row, then cheap per-column reads.
-struct ConcatRow { long r0, ri, row; bool ok0, oki; };
+struct ConcatRow { long r0, ri, row; int nidx; bool ok0, oki; };
+
+__device__ __forceinline__ long remap_row_fast(unsigned row, long rpe, long bs, long off, const FastDiv& f, bool& valid) {
+  valid = true;
+  if (rpe == 0) return row;
+  const unsigned e = fastdiv(row, f);
+  const long w = (long)(row - e * (unsigned)rpe) + off;
+  valid = w >= 0;
+  return (long)e * bs + w;
+}
 
 __device__ __forceinline__ ConcatRow concat_row(const ConcatSrc& s, long row) {
   ConcatRow c;
   c.row = row;
-  c.r0 = remap_row(row, s.rpe0, s.bs0, s.off0, c.ok0);
-  c.ri = remap_row(row, s.rpei, s.bsi, s.offi, c.oki);
+  c.r0 = remap_row_fast((unsigned)row, s.rpe0, s.bs0, s.off0, s.fd0, c.ok0);
+  c.ri = remap_row_fast((unsigned)row, s.rpei, s.bsi, s.offi, s.fdi, c.oki);
+  c.nidx = s.nid ? (int)((unsigned)row - fastdiv((unsigned)row, s.fdn) * (unsigned)s.nid) : 0;
   return c;
 }
 
@@ -112,7 +140,7 @@ __device__ __forceinline__ float concat_at(const ConcatSrc& s, const ConcatRow& 
     return (s.idx[c.ri * s.nhot + j] == k - j * s.hot_w) ? 1.f : 0.f;
   }
   k -= hw;
-  if (k < s.nid) return ((int)(c.row % s.nid) == k) ? 1.f : 0.f;
+  if (k < s.nid) return (c.nidx == k) ? 1.f : 0.f;
   return 0.f;
 }
 

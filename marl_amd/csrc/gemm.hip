@@ -68,10 +68,11 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const int K = a.K;
   const int kfull = VEC ? (K & ~15) : 0;
   long asrc[2];   // source rows of dense segment 0 after the (T+1)-slot remap (vector path only)
+  ConcatRow crow[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    bool ok;
-    asrc[r] = remap_row(arow[r], x.rpe0, x.bs0, x.off0, ok);
+    crow[r] = concat_row(x, arow[r]);
+    asrc[r] = crow[r].r0;
   }
   for (int k0 = 0; k0 < kfull; k0 += 16) {   // vector path: 16 B per lane per operand
     const int kk = k0 + 4 * q;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[r][i] = (kk + i < K) ? concat_elem(x, arow[r], kk + i) : 0.f;
+      for (int i = 0; i < 4; ++i) av[r][i] = (kk + i < K) ? concat_at(x, crow[r], kk + i) : 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c < ct_used) {
@@ -161,11 +162,19 @@ struct WgradArgs {
   int gvec, xvec;                    // float4 operand loads allowed (alignment checked on the host)
 };
 
-// block = 4 waves; all waves own the same 64(n) x 64(k) tile of dW and split the slab's rows;
-// operands are D-layout loads (4 rows per lane) which ARE the A^T / B fragments - no LDS staging.
+// dW block (64 n x 64 k) per workgroup, rows of the slab streamed in 64-row chunks:
+//   * staging: all 256 threads copy the chunk's G [64 x 64] and X [64 x 64] sub-matrices HBM -> registers
+//     -> LDS with 16-byte accesses (coalesced; the virtual-concat / row-remap / relu-gate logic runs once
+//     per element here), one chunk ahead of the MFMAs (double-buffered LDS, one barrier per chunk);
+//   * compute: wave w owns n-tile w (16 rows of dW) x 4 k-tiles; A^T and B fragments are 4-row column
+//     reads of the LDS tiles (row stride 68 floats: the two 16-lane groups of a half-wave hit disjoint banks);
+//   * no cross-wave reduction: each wave writes its own part of the slab partial.
+constexpr int WS_ = 68;          // LDS row stride (floats)
+constexpr int WCH = 64;          // rows per chunk
+
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-  __shared__ float red[4][64 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float lds[2][2][WCH * WS_];     // [buffer][G|X][row][col]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
   const int g = blockIdx.y / a.nyb;
   const int n0 = (blockIdx.y % a.nyb) * 64;
@@ -177,99 +186,113 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   if (x.p0) x.p0 += g * a.gs_x0;
   if (x.p1) x.p1 += g * a.gs_x1;
 
-  int nt_used = (a.N - n0 + 15) / 16; if (nt_used > 4) nt_used = 4;
   int kt_used = (Kext - k0 + 15) / 16; if (kt_used > 4) kt_used = 4;
+  const bool my_n = n0 + 16 * wave < a.N;            // this wave's n-tile exists
 
-  f32x4 acc[4][4];
+  f32x4 acc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long chunks = ((long)a.M + WCH - 1) / WCH;
+  const long per = (chunks + a.slabs - 1) / a.slabs;
+  const long c_begin = (long)blockIdx.x * per;
+  long c_end = c_begin + per; if (c_end > chunks) c_end = chunks;
+
+  // staging assignment: element group e = tid + 256*i -> row e/16 of the chunk, columns 4*(e%16) .. +3
+  f32x4 gq[4], xq[4];
+  auto fetch = [&](long c) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      const int rl = e >> 4, c4 = (e & 15) * 4;
+      const long row = c * WCH + rl;
+      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      if (row < a.M) {
+        const int nb = n0 + c4;
+        if (a.gvec && nb + 3 < a.N) {
+          gv = *reinterpret_cast<const f32x4*>(G + row * a.ldg + nb);
+          if (Ya) {
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + nb);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) gv[cc] = y4[cc] > 0.f ? gv[cc] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            if (nb + cc < a.N) {
+              float v = G[row * a.ldg + nb + cc];
+              if (Ya) v = Ya[row * a.ldya + nb + cc] > 0.f ? v : 0.f;
+              gv[cc] = v;
+            }
+          }
+        }
+        const ConcatRow cr = concat_row(x, row);
+        const int kb = k0 + c4;
+        if (a.xvec && cr.ok0 && kb + 3 < x.k0) {
+          xv = *reinterpret_cast<const f32x4*>(x.p0 + cr.r0 * x.ld0 + kb);
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int k = kb + cc;
+            if (k < a.K) xv[cc] = concat_at(x, cr, k);
+            else if (k == a.K) xv[cc] = 1.f;          // virtual ones column => bias gradient
+          }
+        }
+      }
+      gq[i] = gv; xq[i] = xv;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      const int rl = e >> 4, c4 = (e & 15) * 4;
+      *reinterpret_cast<f32x4*>(&lds[buf][0][rl * WS_ + c4]) = gq[i];
+      *reinterpret_cast<f32x4*>(&lds[buf][1][rl * WS_ + c4]) = xq[i];
+    }
+  };
 
-  const long tiles = ((long)a.M + 15) / 16;
-  const long per = (tiles + a.slabs - 1) / a.slabs;
-  const long t_begin = (long)blockIdx.x * per;
-  long t_end = t_begin + per; if (t_end > tiles) t_end = tiles;
-
-  // Column mapping of the 4 MFMA tiles inside the 64-wide block.  "perm" (block wider than 16 columns):
-  // tile c of lane m is column 4m + c, so ONE float4 per lane and row feeds all four tiles and 16 lanes
-  // read 256 contiguous bytes; otherwise (narrow blocks, e.g. N = 1) tile c is columns 16c .. 16c+15.
-  const bool gperm = (a.N - n0) > 16, xperm = (Kext - k0) > 16;
-  const int gt_used = gperm ? 4 : nt_used, xt_used = xperm ? 4 : kt_used;
-  const bool gvec = gperm && a.gvec, xvec = xperm && a.xvec;
-
-  // operand tiles of row tile tt in accumulator layout; rows past M and columns past N / K+1 read zero
-#define WG_LOAD_TILE(GV, XV, tt, en)                                                                    \
-  {                                                                                                      \
-    const long r0_ = (tt) * 16 + 4 * q;                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-      const long row = r0_ + i;                                                                          \
-      const bool okr = (en) && row < a.M;                                                                \
-      const ConcatRow cr = concat_row(x, okr ? row : 0);                                                 \
-      f32x4 g4 = {0.f, 0.f, 0.f, 0.f}, x4 = {0.f, 0.f, 0.f, 0.f};                                        \
-      if (okr) {                                                                                         \
-        const int nb = n0 + 4 * m;                                                                       \
-        if (gvec && nb + 3 < a.N) {                                                                      \
-          g4 = *reinterpret_cast<const f32x4*>(G + row * a.ldg + nb);                                    \
-          if (Ya) {                                                                                      \
-            const f32x4 y4 = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + nb);                    \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) g4[c] = y4[c] > 0.f ? g4[c] : 0.f;             \
-          }                                                                                              \
-        } else {                                                                                         \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                \
-            const int n = gperm ? nb + c : n0 + 16 * c + m;                                              \
-            if (c < gt_used && n < a.N) {                                                                \
-              float v = G[row * a.ldg + n];                                                              \
-              if (Ya) v = Ya[row * a.ldya + n] > 0.f ? v : 0.f;                                          \
-              g4[c] = v;                                                                                 \
-            }                                                                                            \
-          }                                                                                              \
-        }                                                                                                \
-        const int kb = k0 + 4 * m;                                                                       \
-        if (xvec && cr.ok0 && kb + 3 < x.k0) {                                                           \
-          x4 = *reinterpret_cast<const f32x4*>(x.p0 + cr.r0 * x.ld0 + kb);                               \
-        } else {                                                                                         \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                \
-            const int k = xperm ? kb + c : k0 + 16 * c + m;                                              \
-            if (c < xt_used) {                                                                           \
-              if (k < a.K) x4[c] = concat_at(x, cr, k);                                                  \
-              else if (k == a.K) x4[c] = 1.f;    /* virtual ones column => bias gradient */              \
-            }                                                                                            \
-          }                                                                                              \
-        }                                                                                                \
-      }                                                                                                  \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) { GV[c][i] = g4[c]; XV[c][i] = x4[c]; }              \
-    }                                                                                                    \
+  if (c_begin < c_end) {
+    fetch(c_begin);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long c = c_begin; c < c_end; ++c, buf ^= 1) {
+    const bool more = c + 1 < c_end;
+    if (more) fetch(c + 1);                    // global loads of the next chunk fly during the MFMAs
+    if (my_n) {
+      const float* Gs = &lds[buf][0][0];
+      const float* Xs = &lds[buf][1][0];
+#pragma unroll
+      for (int sub = 0; sub < WCH / 16; ++sub) {
+        f32x4 af, bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = (sub * 16 + 4 * q + i) * WS_;
+          af[i] = Gs[rr + 16 * wave + m];
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) bf[kt][i] = Xs[rr + 16 * kt + m];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          if (kt < kt_used) acc[kt] = mfma16x4(af, bf[kt], acc[kt]);
+      }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
   }
 
-  // (a register double-buffer of the next tile was tried: it halves occupancy (266 regs) and was 1.5x slower;
-  //  two resident workgroups per CU hide the load latency better)
-  for (long t = t_begin + wave; t < t_end; t += 4) {
-    f32x4 gA[4], xA[4];
-    WG_LOAD_TILE(gA, xA, t, true)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (nt < gt_used && kt < xt_used) acc[nt][kt] = mfma16x4(gA[nt], xA[kt], acc[nt][kt]);
-  }
-
-  // cross-wave reduction of the 64x64 tile through LDS, then one slab partial per block
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+  // slab partial: D-layout tile (n = 16w + 4q + i, k = 16kt + m)
+  float* ws = a.ws + ((long)blockIdx.x * a.groups + g) * (long)a.N * Kext;
+  if (my_n) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int nl = gperm ? 4 * (4 * q + i) + nt : nt * 16 + 4 * q + i;      // local n (row of dW)
-        const int kl = xperm ? 4 * m + kt : kt * 16 + m;                         // local k (column of dW)
-        red[wave][nl * 64 + kl] = acc[nt][kt][i];
+        const int n = n0 + 16 * wave + 4 * q + i, k = k0 + 16 * kt + m;
+        if (n < a.N && k < Kext) ws[(long)n * Kext + k] = acc[kt][i];
       }
-  __syncthreads();
-  float* ws = a.ws + ((long)blockIdx.x * a.groups + g) * (long)a.N * Kext;
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int n = n0 + e / 64, k = k0 + e % 64;
-    if (n < a.N && k < Kext) ws[(long)n * Kext + k] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
   }
 }
 
@@ -278,18 +301,30 @@ struct WredArgs {
   int N, K, slabs, groups; long gs_dw, gs_db;
 };
 
-__global__ void wgrad_reduce_kernel(WredArgs a) {
+// 64 output elements per block, 4 slab groups per element: thread (e, sg) sums slabs sg, sg+4, ... in order,
+// then the 4 partial sums are added in a fixed order -> deterministic, and 4x shorter dependent chains
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WredArgs a) {
+  __shared__ float part[4][64];
   const int Kext = a.K + 1;
   const long per = (long)a.N * Kext;
   const long total = per * a.groups;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int g = e / per;
-    const long r = e % per;
-    const int n = r / Kext, k = r % Kext;
-    float s = 0.f;
-    for (int sl = 0; sl < a.slabs; ++sl) s += a.ws[((long)sl * a.groups + g) * per + r];
-    if (k < a.K) a.dW[g * a.gs_dw + (long)n * a.lddw + k] += s;
-    else if (a.db) a.db[g * a.gs_db + n] += s;
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (e < total) {
+    const int g = (int)(e / per);
+    const long r = e - (long)g * per;
+    for (int sl = sg; sl < a.slabs; sl += 4) s += a.ws[((long)sl * a.groups + g) * per + r];
+  }
+  part[sg][el] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    const int g = (int)(e / per);
+    const long r = e - (long)g * per;
+    const int n = (int)(r / Kext), k = (int)(r - (long)n * Kext);
+    const float v = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+    if (k < a.K) a.dW[g * a.gs_dw + (long)n * a.lddw + k] += v;
+    else if (a.db) a.db[g * a.gs_db + n] += v;
   }
 }
 
@@ -301,6 +336,9 @@ inline ConcatSrc to_src(const marl_src_t* s) {
   c.m0 = s->m0; c.ldm0 = s->ldm0;
   c.rpe0 = s->rpe0; c.bs0 = s->bs0; c.off0 = s->off0;
   c.rpei = s->rpei; c.bsi = s->bsi; c.offi = s->offi;
+  c.fd0 = make_fastdiv((unsigned)(s->rpe0 > 0 ? s->rpe0 : 1));
+  c.fdi = make_fastdiv((unsigned)(s->rpei > 0 ? s->rpei : 1));
+  c.fdn = make_fastdiv((unsigned)(s->nid > 0 ? s->nid : 1));
   return c;
 }
 
@@ -343,8 +381,8 @@ extern "C" size_t marl_linear_wgrad_workspace(int M, int N, int K, int groups) {
 }
 
 extern "C" int marl_wgrad_slabs(int M) {
-  long tiles = ((long)M + 15) / 16;
-  long s = tiles / 32;            // >= 32 row tiles (8 per wave) per block
+  long chunks = ((long)M + 63) / 64;
+  long s = chunks / 8;            // >= 8 chunks of 64 rows per block
   if (s < 1) s = 1;
   if (s > 256) s = 256;
   return (int)s;
@@ -374,8 +412,7 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
   r.ws = ws; r.dW = dW; r.lddw = lddw; r.db = db; r.N = N; r.K = K; r.slabs = a.slabs; r.groups = groups;
   r.gs_dw = grp ? grp->gs_w : 0; r.gs_db = grp ? grp->gs_b : 0;
   long total = (long)N * (K + 1) * groups;
-  int rb = (int)((total + 255) / 256); if (rb > 1024) rb = 1024;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }

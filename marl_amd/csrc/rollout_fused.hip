@@ -57,6 +57,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   int* rowe = act + rows;                                // [rows]: local env index (b - b0), clamped
   int* rown = rowe + rows;                               // [rows]: n
   int* elen = rown + rows;                               // [rows/N]: episode length of the local env
+  unsigned* pfx = reinterpret_cast<unsigned*>(elen + rows);   // [3][rows]: hash prefixes (obs, avail per row; state per env) of the slot being generated
 
   const long row0 = (long)blockIdx.x * rows;           // multiple of N by construction
   const int b0 = (int)(row0 / a.N);
@@ -82,34 +83,42 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   __syncthreads();
 
   // ---- environment observation of slot t -> record (+ LDS input tile / availability when wanted)
-  auto gen_slot = [&](int t, bool to_lds, float* Av) {
-    const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-    for (int e = tid; e < rows * O; e += RNT) {           // observations: row-major, coalesced over k
-      const int r = e / O, k = e - r * O;
-      const int el = rowe[r], n = rown[r];
-      const unsigned env = (unsigned)(a.env0 + b0 + el);
-      float v = 0.f;
-      if (t <= elen[el]) v = 2.0f * u01(hfin(hprefix(a.seed, ST_OBS, env, tg), (unsigned)(n * O + k))) - 1.0f;
-      a.obs[(((long)(b0 + el) * (T + 1) + t) * N + n) * O + k] = v;
-      if (to_lds) In[r * KS + k] = (t < elen[el]) ? v : 0.f;     // padded steps feed zeros (rollout.py:122-133)
+  // prefixes of slot t (3 of the 4 hash rounds depend only on (stream, env, t)): one thread per row
+  auto gen_prefix = [&](int t) {
+    if (tid < rows) {
+      const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
+      const unsigned env = (unsigned)(a.env0 + b0 + rowe[tid]);
+      pfx[tid] = hprefix(a.seed, ST_OBS, env, tg);
+      pfx[rows + tid] = hprefix(a.seed, ST_AVAIL, env, tg);
+      if (tid < nenv_wg) pfx[2 * rows + tid] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + tid), tg);
     }
-    for (int e = tid; e < nenv_wg * S; e += RNT) {
-      const int el = e / S, k = e - el * S;
-      if (b0 + el < a.E) {
-        const unsigned env = (unsigned)(a.env0 + b0 + el);
-        float v = 0.f;
-        if (t <= elen[el]) v = 2.0f * u01(hfin(hprefix(a.seed, ST_STATE, env, tg), (unsigned)k)) - 1.0f;
-        a.state[((long)(b0 + el) * (T + 1) + t) * S + k] = v;
+  };
+  auto gen_slot = [&](int t, bool to_lds, float* Av) {
+    // one row per wave-iteration, lanes over the columns: no integer division, coalesced stores
+    for (int r = wave; r < rows; r += RNT / 64) {
+      const int el = rowe[r], n = rown[r];
+      const bool live = t <= elen[el], feed = t < elen[el];
+      const unsigned po = pfx[r], pa = pfx[rows + r];
+      float* orow = a.obs + (((long)(b0 + el) * (T + 1) + t) * N + n) * O;
+      for (int k = lane; k < O; k += 64) {
+        const float v = live ? 2.0f * u01(hfin(po, (unsigned)(n * O + k))) - 1.0f : 0.f;
+        orow[k] = v;
+        if (to_lds) In[r * KS + k] = feed ? v : 0.f;        // padded steps feed zeros (rollout.py:122-133)
+      }
+      if (lane < A) {
+        const int k = lane;
+        const float v = live ? ((k == 0 || u01(hfin(pa, (unsigned)(n * A + k))) < 0.7f) ? 1.f : 0.f) : 0.f;
+        a.avail[(((long)(b0 + el) * (T + 1) + t) * N + n) * A + k] = v;
+        if (Av) Av[r * A + k] = v;
       }
     }
-    for (int e = tid; e < rows * A; e += RNT) {
-      const int r = e / A, k = e - r * A;
-      const int el = rowe[r], n = rown[r];
-      const unsigned env = (unsigned)(a.env0 + b0 + el);
-      float v = 0.f;
-      if (t <= elen[el]) v = (k == 0 || u01(hfin(hprefix(a.seed, ST_AVAIL, env, tg), (unsigned)(n * A + k))) < 0.7f) ? 1.f : 0.f;
-      a.avail[(((long)(b0 + el) * (T + 1) + t) * N + n) * A + k] = v;
-      if (Av) Av[r * A + k] = v;
+    for (int el = wave; el < nenv_wg; el += RNT / 64) {
+      if (b0 + el < a.E) {
+        const bool live = t <= elen[el];
+        const unsigned ps = pfx[2 * rows + el];
+        float* srow = a.state + ((long)(b0 + el) * (T + 1) + t) * S;
+        for (int k = lane; k < S; k += 64) srow[k] = live ? 2.0f * u01(hfin(ps, (unsigned)k)) - 1.0f : 0.f;
+      }
     }
   };
   // constant columns of the input tile: one-hot(last action) starts empty, agent id, zero pad
@@ -119,7 +128,11 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     if (a.has_id && k >= a.I - N && k < a.I) v = (rown[r] == k - (a.I - N)) ? 1.f : 0.f;
     In[r * KS + k] = v;
   }
+  gen_prefix(0);
+  __syncthreads();
   gen_slot(0, true, Av0);
+  __syncthreads();
+  gen_prefix(1);          // consumed by gen_slot(1) after the first barrier of step 0
 
   // ---- weights (as in agent_fwd_kernel)
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
@@ -275,6 +288,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
       }
       act[r] = arg;
       a.u[((long)(b0 + el) * T + t) * N + n] = arg;
+      // hash prefixes of slot t+2 (its observation is generated during the gates of step t+1)
+      {
+        const unsigned tg2 = tg + 2u;
+        pfx[r] = hprefix(a.seed, ST_OBS, env, tg2);
+        pfx[rows + r] = hprefix(a.seed, ST_AVAIL, env, tg2);
+        if (r < nenv_wg) pfx[2 * rows + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg2);
+      }
       if (a.has_act)
         for (int k = 0; k < A; ++k) In[r * KS + O + k] = (k == arg) ? 1.f : 0.f;   // one-hot fed to step t+1
     }
@@ -337,7 +357,7 @@ extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, 
   a.R = (long)E * N;
   const int KS = a.KC * 16 + 4;
   const size_t fixed = (size_t)4 * a.KC * 64 * 16;
-  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16;
+  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12;
   // smallest RT >= ceil(tiles/256) with whole environments per workgroup, within the LDS budget
   const long tiles = (a.R + 15) / 16;
   int want = (int)((tiles + 255) / 256); if (want < 1) want = 1;
