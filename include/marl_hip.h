@@ -128,6 +128,26 @@ int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* q
 int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
                       float* db2, float* dq, long rows, int N, int E, void* stream);
 
+/* Fused QMIX (qmix_fused.hip): hypernet GEMMs + mixing in one kernel; the backward recomputes the
+ * hypernet tile and accumulates the hypernet weight gradients in registers.  Supported when
+ * marl_qmix_fused_supported(N, S, E) (E == 32, N*E+3E <= 256, S <= 128); otherwise compose
+ * marl_linear + marl_qmix_mix_*.  `s` must be a dense-segment-0 source (row remap allowed). */
+typedef struct {
+  const float *w1, *w1_b;       /* hyper_w1   (N*E,S), (N*E) */
+  const float *b1, *b1_b;       /* hyper_b1   (E,S), (E)     */
+  const float *w2, *w2_b;       /* hyper_w2   (E,S), (E)     */
+  const float *h, *h_b;         /* hyper_b2.0 (E,S), (E)     */
+  const float *b2_w, *b2_b;     /* hyper_b2.2 (1,E), (1)     */
+} marl_qmix_weights_t;
+int marl_qmix_fused_supported(int N, int S, int E);
+size_t marl_qmix_fused_workspace(long rows, int N, int S);
+int marl_qmix_fused_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
+                        long rows, int N, int S, int E, void* stream);
+/* grads: same struct, pointing at the gradient tensors (accumulated into) */
+int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot,
+                        float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
+                        int N, int S, int E, void* stream);
+
 /* QPLEX (DMAQer.forward + calc_v/calc_adv, mixer.py:211-288; DMAQ_SI_Weight tail :158-169).
  *  wv row = [w_raw (N) | v (N)] (outputs of hyper_w_final.2 / V.2);
  *  heads = key (rows,K,1) | agents (rows,K,N) | action (rows,K,N) raw extractor outputs.

@@ -31,6 +31,10 @@ class MarlGroup(C.Structure):
                 ("gs_b", C.c_long), ("gs_y", C.c_long), ("gs_m0", C.c_long)]
 
 
+class MarlQmixWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "w1_b", "b1", "b1_b", "w2", "w2_b", "h", "h_b", "b2_w", "b2_b")]
+
+
 class MarlAgentGrads(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
                 ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
@@ -45,6 +49,7 @@ class MarlAgentWeights(C.Structure):
 P, I, L, F, U, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size_t
 SRC, GRP, AW = C.POINTER(MarlSrc), C.POINTER(MarlGroup), C.POINTER(MarlAgentWeights)
 AG = C.POINTER(MarlAgentGrads)
+QW = C.POINTER(MarlQmixWeights)
 
 # name -> (restype, argtypes); must list every symbol of include/marl_hip.h
 SIGNATURES = {
@@ -63,6 +68,10 @@ SIGNATURES = {
     "marl_agent_bcast": (I, [P, P, L, I, I, I, P]),
     "marl_qmix_mix_fwd": (I, [P, L, P, P, P, L, I, I, P]),
     "marl_qmix_mix_bwd": (I, [P, L, P, P, P, P, P, L, I, I, P]),
+    "marl_qmix_fused_supported": (I, [I, I, I]),
+    "marl_qmix_fused_workspace": (SZ, [L, I, I]),
+    "marl_qmix_fused_fwd": (I, [QW, SRC, P, P, L, I, I, I, P]),
+    "marl_qmix_fused_bwd": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, P]),
     "marl_qplex_mix_fwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_qplex_mix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_td_loss": (I, [P, P, P, P, P, F, P, P, P, L, P]),

@@ -370,39 +370,36 @@ struct BwdArgs {
 };
 
 constexpr int DGS = 256 + 4;
-constexpr int BNT = 256;
-constexpr int NQ = 16;
-
-struct Pre {            // one row tile of saved activations in accumulator layout
-  f32x4 hp_all[4], x_all[4];
-  f32x4 r, z, n, hn, dhs, ht;
-};
-
-__device__ __forceinline__ f32x4 pick4(const f32x4 (&v)[4], int w) {
-  f32x4 o = v[0];
-  if (w == 1) o = v[1];
-  if (w == 2) o = v[2];
-  if (w == 3) o = v[3];
-  return o;
-}
+constexpr int BNT = 512;      // 8 waves: two per SIMD
+constexpr int NQ = 4;         // dq prefetch registers per thread
 
 __host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + (long)A * 64 + 2 * 192 + A; }
 
+// 8 waves = 2 teams x 4 hidden-unit slices, two waves per SIMD (<= 256 registers each), so that one wave's
+// loads / pointwise math / LDS traffic overlap the other's MFMAs (the previous 4-wave, 457-register version
+// kept the matrix pipe 53 % busy).
+//   phase B (row tiles split between the teams): dh = carry + dhs + dq W2^T, gate gradients -> LDS (DG, CAR)
+//   phase C (every wave walks ALL row tiles, the teams split the PRODUCTS):
+//       team 0 ("ih"): dx = [drp|dzp|dnp] W_ih -> relu gate -> dxp ;  dW_ih += [drp|dzp|dnp]^T x
+//       team 1 ("hh"): dh_prev = carry + [drp|dzp|dhn] W_hh          ;  dW_hh += [drp|dzp|dhn]^T h_prev ; dW_2 += dq^T h
+//   Both roles run the SAME code on the same register arrays (wT, accW, cur/nxt); only base pointers and
+//   LDS column offsets differ, so the register allocation is that of one role.
 template <int AC>
-__global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
+__global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int team = wave >> 2, ws = wave & 3;
   const int q = lane >> 4, m = lane & 15;
   const int rows = a.RT * 16;
   constexpr int QP = AC * 16, QS = QP + 4;
-  float* DG = smem;                         // [rows][DGS]  drp|dzp|dnp|dhn (A operand of phase C)
+  float* DG = smem;                         // [rows][DGS]  drp|dzp|dnp|dhn
   float* DQ0 = DG + rows * DGS;             // [rows][QS] x2
   float* DQ1 = DQ0 + rows * QS;
-  float* CAR = DQ1 + rows * QS;             // [rows][HS] carried dh (each wave touches its own columns)
-  float* XM = CAR + rows * HS;              // [rows][HS] x (own columns) for the relu gate of phase C
-  int* rowidx = reinterpret_cast<int*>(XM + rows * HS);   // [rows]: output row b*T*N + n
-  int* rowrho = rowidx + rows;                            // [rows]: b*N + n
-  float* rowok = reinterpret_cast<float*>(rowrho + rows); // [rows]: 1 for real rows, 0 for rows past the batch
+  float* CAR = DQ1 + rows * QS;             // [rows][HS] carried dh
+  float* RED = CAR + rows * HS;             // [4][64] bias partial sums of team 1 (combined at the end)
+  int* rowidx = reinterpret_cast<int*>(RED + 4 * 64);   // [rows]: output row b*T*N + n
+  int* rowrho = rowidx + rows;                          // [rows]: b*N + n
+  float* rowok = reinterpret_cast<float*>(rowrho + rows);  // [rows]: 1 real row, 0 row past the batch
 
   // rows past the batch are clamped to the last valid row for LOADS; their incoming gradients (dq, dhs) are
   // zeroed, which makes every quantity they contribute (gate gradients, dW, bias sums) exactly zero
@@ -419,18 +416,15 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   }
   for (int e = tid; e < rows * HS; e += BNT) CAR[e] = 0.f;
   const long tstride = a.N;
-  const int j = 16 * wave + m;
+  const int j = 16 * ws + m;
 
-  // B-fragments of the TRANSPOSED products: lane (q,m) holds W[k = 16c+4q+i][col 16w+m]
-  f32x4 whhT[12], wihT[12], w2T[AC];
+  // role weights: B-fragments of the transposed product, lane (q,m) holds W[k = 16c+4q+i][col 16ws+m]
+  const float* Wrole = team ? a.Whh : a.Wih;
+  f32x4 wT[12], w2T[AC];
 #pragma unroll
   for (int c = 0; c < 12; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = 16 * c + 4 * q + i;
-      whhT[c][i] = a.Whh[(long)k * H + j];
-      wihT[c][i] = a.Wih[(long)k * H + j];
-    }
+    for (int i = 0; i < 4; ++i) wT[c][i] = Wrole[(long)(16 * c + 4 * q + i) * H + j];
 #pragma unroll
   for (int ac = 0; ac < AC; ++ac)
 #pragma unroll
@@ -438,11 +432,11 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
       const int k = 16 * ac + 4 * q + i;
       w2T[ac][i] = k < a.A ? a.W2[(long)k * H + j] : 0.f;
     }
-  f32x4 accIH[3][4], accHH[3][4], accW2[AC];
+  f32x4 accW[3][4], accW2[AC];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { accIH[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; accHH[g][c] = accIH[g][c]; }
+    for (int c = 0; c < 4; ++c) accW[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ac = 0; ac < AC; ++ac) accW2[ac] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_hn = 0.f, sb2[AC];
@@ -450,28 +444,33 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   for (int ac = 0; ac < AC; ++ac) sb2[ac] = 0.f;
   __syncthreads();
 
-  // one row tile of saved activations, loaded in accumulator layout into NAMED registers
-  // (a struct returned from a lambda ended up in scratch memory)
-#define LOAD_PRE(HP, XA, HPO_, XO_, R_, Z_, N_, HN_, DHS_, HT_, tt, rr, en)                                     \
+  // ---- prefetch sets (named registers; cur = tile being processed, nxt = tile in flight)
+  //   B set: [0]=h_prev(own cols) [1]=r [2]=z [3]=n [4]=hn [5]=dhs
+  //   C set: [0..3]=x (team 0) / h_prev (team 1), all 64 columns ; [4]=x own cols (team 0) / h_t own cols (team 1)
+#define LOAD_B(P, tt, rr, en)                                                                            \
   {                                                                                                      \
-    const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H);     /* step base, uniform */               \
+    const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H);                                            \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
       const int r_ = (rr) * 16 + 4 * q + i;                                                              \
-      const float ok_ = (en) ? rowok[r_] : 0.f;                   /* 0 for clamped / disabled rows */    \
+      const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H) + j;                                          \
+      P[0][i] = (en) ? sp_[0] : 0.f;                                                                     \
+      P[1][i] = (en) ? sp_[2 * H] : 0.f;                                                                 \
+      P[2][i] = (en) ? sp_[3 * H] : 0.f;                                                                 \
+      P[3][i] = (en) ? sp_[4 * H] : 0.f;                                                                 \
+      P[4][i] = (en) ? sp_[5 * H] : 0.f;                                                                 \
+      P[5][i] = ((en) && a.dhs) ? a.dhs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] * rowok[r_] : 0.f; \
+    }                                                                                                    \
+  }
+#define LOAD_C(P, tt, rr, en)                                                                            \
+  {                                                                                                      \
+    const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H) + (team ? 0 : H);                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+      const int r_ = (rr) * 16 + 4 * q + i;                                                              \
       const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H);                                              \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
-        HP[c][i] = sp_[16 * c + m];                                                                      \
-        XA[c][i] = sp_[H + 16 * c + m];                                                                  \
-      }                                                                                                  \
-      HPO_[i] = sp_[j];              /* own 16 columns (a runtime pick from HP[] would go to scratch) */ \
-      XO_[i] = sp_[H + j];                                                                               \
-      R_[i] = sp_[2 * H + j];                                                                            \
-      Z_[i] = sp_[3 * H + j];                                                                            \
-      N_[i] = sp_[4 * H + j];                                                                            \
-      HN_[i] = sp_[5 * H + j];                                                                           \
-      const long off_ = ((long)rowidx[r_] + (long)(tt) * tstride) * H + j;                               \
-      HT_[i] = a.hs[off_];                                                                               \
-      DHS_[i] = a.dhs ? a.dhs[off_] * ok_ : 0.f;                                                         \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c][i] = (en) ? sp_[16 * c + m] : 0.f;              \
+      if (team) P[4][i] = (en) ? a.hs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] : 0.f;          \
+      else P[4][i] = (en) ? sp_[j] : 0.f;                                                                \
+      P[5][i] = 0.f;                                                                                     \
     }                                                                                                    \
   }
   auto dq_elem = [&](int t, int e) -> float {
@@ -480,8 +479,10 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   };
 
   for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
-  f32x4 c_hp[4], c_x[4], c_hpo, c_xo, c_r, c_z, c_n, c_hn, c_dhs, c_ht;
-  LOAD_PRE(c_hp, c_x, c_hpo, c_xo, c_r, c_z, c_n, c_hn, c_dhs, c_ht, a.T - 1, 0, true)
+  const bool hasB = team < a.RT;                   // this team owns at least one row tile in phase B
+  f32x4 cur[6], nxt[6];
+  if (hasB) LOAD_B(cur, a.T - 1, team, true)
+  else LOAD_C(cur, a.T - 1, 0, true)
   __syncthreads();
 
   int par = 0;
@@ -494,12 +495,10 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
       const int e = tid + BNT * i;
       dqpre[i] = (t > 0 && e < rows * QP) ? dq_elem(t - 1, e) : 0.f;
     }
-    // ---------------- phase B: dh = carry + dhs + dq W2 ; gate gradients ; dW accumulation
-    for (int rt = 0; rt < a.RT; ++rt) {
-      int tn = t, rn = rt + 1;
-      if (rn >= a.RT) { rn = 0; tn = t - 1; }
-      f32x4 n_hp[4], n_x[4], n_hpo, n_xo, n_r, n_z, n_n, n_hn, n_dhs, n_ht;     // next row tile, in flight during this one
-      LOAD_PRE(n_hp, n_x, n_hpo, n_xo, n_r, n_z, n_n, n_hn, n_dhs, n_ht, (tn < 0 ? 0 : tn), rn, (tn >= 0))
+    // ---------------- phase B: dh = carry + dhs + dq W2^T ; gate gradients -> DG, carry*z -> CAR
+    for (int rt = team; rt < a.RT; rt += 2) {
+      if (rt + 2 < a.RT) LOAD_B(nxt, t, rt + 2, true)
+      else LOAD_C(nxt, t, 0, true)
       f32x4 dh;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
@@ -509,67 +508,75 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
         f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
         dh = mfma16x4(av, w2T[ac], dh);
       }
-      const f32x4 hpo = c_hpo, xo = c_xo;          // this wave's own 16 columns of h_prev / x
-      f32x4 g_r, g_z, g_n, g_hn;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = rt * 16 + 4 * q + i;
-        const float d = dh[i] + c_dhs[i];
-        const float rg = c_r[i], zg = c_z[i], ng = c_n[i];
+        const float d = dh[i] + cur[5][i];
+        const float rg = cur[1][i], zg = cur[2][i], ng = cur[3][i];
         const float dn = d * (1.f - zg);
-        const float dz = d * (hpo[i] - ng);
+        const float dz = d * (cur[0][i] - ng);
         const float dnp = dn * (1.f - ng * ng);
         const float dzp = dz * zg * (1.f - zg);
-        const float drp = dnp * c_hn[i] * rg * (1.f - rg);
+        const float drp = dnp * cur[4][i] * rg * (1.f - rg);
         const float dhn = dnp * rg;
-        g_r[i] = drp; g_z[i] = dzp; g_n[i] = dnp; g_hn[i] = dhn;
         float* l = DG + r * DGS + j;
         l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
         CAR[r * HS + j] = d * zg;
-        XM[r * HS + j] = xo[i];
         sb_r += drp; sb_z += dzp; sb_n += dnp; sb_hn += dhn;
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        accIH[0][c] = mfma16x4(g_r, c_x[c], accIH[0][c]);
-        accIH[1][c] = mfma16x4(g_z, c_x[c], accIH[1][c]);
-        accIH[2][c] = mfma16x4(g_n, c_x[c], accIH[2][c]);
-        accHH[0][c] = mfma16x4(g_r, c_hp[c], accHH[0][c]);
-        accHH[1][c] = mfma16x4(g_z, c_hp[c], accHH[1][c]);
-        accHH[2][c] = mfma16x4(g_hn, c_hp[c], accHH[2][c]);
-      }
-#pragma unroll
-      for (int ac = 0; ac < AC; ++ac) {
-        f32x4 dqf;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dqf[i] = DQ[(rt * 16 + 4 * q + i) * QS + 16 * ac + m];
-        accW2[ac] = mfma16x4(dqf, c_ht, accW2[ac]);
-        sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { c_hp[c] = n_hp[c]; c_x[c] = n_x[c]; }
-      c_hpo = n_hpo; c_xo = n_xo; c_r = n_r; c_z = n_z; c_n = n_n; c_hn = n_hn; c_dhs = n_dhs; c_ht = n_ht;
+      for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
     }
     WG_BARRIER();
-    // ---------------- phase C: dh_prev = z*dh + [drp,dzp,dhn] W_hh ; dx = [drp,dzp,dnp] W_ih
+    // ---------------- phase C: every wave, all row tiles, its role's products
     for (int rt = 0; rt < a.RT; ++rt) {
-      f32x4 dhp, dx = {0.f, 0.f, 0.f, 0.f};
+      if (rt + 1 < a.RT) LOAD_C(nxt, t, rt + 1, true)
+      else if (hasB) LOAD_B(nxt, (t > 0 ? t - 1 : 0), team, t > 0)
+      else LOAD_C(nxt, (t > 0 ? t - 1 : 0), 0, t > 0)
+      const int r0 = rt * 16 + 4 * q;
+      f32x4 main;                                   // dx (team 0)  /  dh_prev (team 1)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dhp[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+      for (int i = 0; i < 4; ++i) main[i] = team ? CAR[(r0 + i) * HS + j] : 0.f;
       const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
 #pragma unroll
       for (int c = 0; c < 12; ++c) {
-        f32x4 ai = *reinterpret_cast<const f32x4*>(gr + 16 * c);              // drp|dzp|dnp
-        dx = mfma16x4(ai, wihT[c], dx);
-        f32x4 ah = c < 8 ? ai : *reinterpret_cast<const f32x4*>(gr + 192 + 16 * (c - 8));  // drp|dzp|dhn
-        dhp = mfma16x4(ah, whhT[c], dhp);
+        const int coff = (team && c >= 8) ? 192 + 16 * (c - 8) : 16 * c;       // team 1 reads dhn instead of dnp
+        f32x4 av = *reinterpret_cast<const f32x4*>(gr + coff);
+        main = mfma16x4(av, wT[c], main);
       }
+      // gate-gradient tiles of this wave's 16 columns in accumulator layout (they ARE the A^T fragments)
+      f32x4 g0, g1, g2;
+      const int g2off = team ? 192 : 128;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = rt * 16 + 4 * q + i;
-        CAR[r * HS + j] = dhp[i];
-        if (rowok[r] != 0.f) a.dxp[((long)rowidx[r] + (long)t * tstride) * H + j] = XM[r * HS + j] > 0.f ? dx[i] : 0.f;
+        const float* l = DG + (r0 + i) * DGS + j;
+        g0[i] = l[0]; g1[i] = l[64]; g2[i] = l[g2off];
       }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        accW[0][c] = mfma16x4(g0, cur[c], accW[0][c]);
+        accW[1][c] = mfma16x4(g1, cur[c], accW[1][c]);
+        accW[2][c] = mfma16x4(g2, cur[c], accW[2][c]);
+      }
+      if (team) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = main[i];
+#pragma unroll
+        for (int ac = 0; ac < AC; ++ac) {
+          f32x4 dqf;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
+          accW2[ac] = mfma16x4(dqf, cur[4], accW2[ac]);
+          sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rowok[r0 + i] != 0.f)
+            a.dxp[((long)rowidx[r0 + i] + (long)t * tstride) * H + j] = cur[4][i] > 0.f ? main[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
     }
     if (t > 0) {
 #pragma unroll
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
     }
     WG_BARRIER();
   }
-  if (a.dh0) {
+  if (a.dh0 && team) {
     for (int r = 4 * q; r < rows; r += 16)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -588,8 +595,7 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
   }
   // ---- this workgroup's partial weight gradients -> slab (summed in fixed order by the reduce kernel)
   float* slab = a.ws + (long)blockIdx.x * bwd_slab_floats(a.A);
-  float* s_ih = slab;
-  float* s_hh = slab + 192 * 64;
+  float* s_role = slab + (team ? 192 * 64 : 0);          // dW_ih (team 0) | dW_hh (team 1)
   float* s_w2 = slab + 2 * 192 * 64;
   float* s_bih = s_w2 + (long)a.A * 64;
   float* s_bhh = s_bih + 192;
@@ -599,29 +605,30 @@ __global__ __launch_bounds__(BNT, 1) void agent_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = g * 64 + 16 * wave + 4 * q + i;     // gate row of W (output unit)
-        s_ih[row * 64 + 16 * c + m] = accIH[g][c][i];
-        s_hh[row * 64 + 16 * c + m] = accHH[g][c][i];
-      }
-#pragma unroll
-  for (int ac = 0; ac < AC; ++ac)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int arow = 16 * ac + 4 * q + i;
-      if (arow < a.A) s_w2[arow * 64 + j] = accW2[ac][i];
-    }
-  // bias sums: add the 4 lane groups (rows) together, lane group 0 writes
+      for (int i = 0; i < 4; ++i)
+        s_role[(g * 64 + 16 * ws + 4 * q + i) * 64 + 16 * c + m] = accW[g][c][i];
   auto red4 = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
   sb_r = red4(sb_r); sb_z = red4(sb_z); sb_n = red4(sb_n); sb_hn = red4(sb_hn);
-  if (q == 0) {
-    s_bih[j] = sb_r; s_bih[64 + j] = sb_z; s_bih[128 + j] = sb_n;
-    s_bhh[j] = sb_r; s_bhh[64 + j] = sb_z; s_bhh[128 + j] = sb_hn;
-  }
+  if (team) {
 #pragma unroll
-  for (int ac = 0; ac < AC; ++ac) {
-    const float v = red4(sb2[ac]);
-    if (wave == 0 && q == 0 && 16 * ac + m < a.A) s_b2[16 * ac + m] = v;
+    for (int ac = 0; ac < AC; ++ac)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int arow = 16 * ac + 4 * q + i;
+        if (arow < a.A) s_w2[arow * 64 + j] = accW2[ac][i];
+      }
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      const float v = red4(sb2[ac]);
+      if (ws == 0 && q == 0 && 16 * ac + m < a.A) s_b2[16 * ac + m] = v;
+    }
+    if (q == 0) { RED[j] = sb_r; RED[64 + j] = sb_z; RED[128 + j] = sb_n; RED[192 + j] = sb_hn; }
+  }
+  __syncthreads();
+  if (!team && q == 0) {       // both teams saw disjoint row tiles in phase B: add the two partial bias sums
+    const float br = sb_r + RED[j], bz = sb_z + RED[64 + j], bn = sb_n + RED[128 + j], bh = sb_hn + RED[192 + j];
+    s_bih[j] = br; s_bih[64 + j] = bz; s_bih[128 + j] = bn;
+    s_bhh[j] = br; s_bhh[64 + j] = bz; s_bhh[128 + j] = bh;
   }
 }
 
@@ -729,10 +736,10 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
 static int bwd_rt(long R, int A) {
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
-  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 12;
+  const size_t per_row = (size_t)(DGS + 2 * QS + HS) * 4 + 12;
   int cap = (NQ * BNT) / (16 * AC * 16);      // dq prefetch registers cover rows*QP elements
   if (cap > 8) cap = 8;
-  return pick_rt(R, per_row, 0, cap);
+  return pick_rt(R, per_row, 4 * 64 * 4, cap);
 }
 
 extern "C" size_t marl_agent_bwd_workspace(int B, int N, int A) {
@@ -755,9 +762,9 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
-  const size_t per_row = (size_t)(DGS + 2 * QS + 2 * HS) * 4 + 12;
+  const size_t per_row = (size_t)(DGS + 2 * QS + HS) * 4 + 12;
   a.RT = bwd_rt(a.R, A);
-  const size_t lds = per_row * a.RT * 16;
+  const size_t lds = per_row * a.RT * 16 + 4 * 64 * 4;
   const long rows = a.RT * 16;
   const unsigned nwg = (unsigned)((a.R + rows - 1) / rows);
   dim3 grid(nwg), block(BNT);

@@ -88,15 +88,36 @@ class QMixMixer(nn.Module):
         self.hyper_b2 = _mlp(None, [S, E, 1])
         self._s = _Scratch()
 
+    def _fused_ok(self, xs):
+        a = self.args
+        return (not a.two_hyper_layers and not getattr(self, "no_fused", False)
+                and ops.qmix_fused_supported(a.n_agents, a.state_shape, a.qmix_hidden_dim)
+                and xs.ld0 % 4 == 0 and (xs.p0 or 0) % 16 == 0 and not (xs.k1 or xs.nhot or xs.nid or xs.m0))
+
+    def _fused_tensors(self, grad=False):
+        b20, b22 = _linears(self.hyper_b2)
+        pick = (lambda p: p.grad) if grad else (lambda p: p.data)
+        return {"w1": pick(self.hyper_w1.weight), "w1_b": pick(self.hyper_w1.bias),
+                "b1": pick(self.hyper_b1.weight), "b1_b": pick(self.hyper_b1.bias),
+                "w2": pick(self.hyper_w2.weight), "w2_b": pick(self.hyper_w2.bias),
+                "h": pick(b20.weight), "h_b": pick(b20.bias), "b2_w": pick(b22.weight), "b2_b": pick(b22.bias)}
+
     def hip_forward(self, q, s, rows, ctx=None, tag="e"):
         a = self.args
         N, E, HH = a.n_agents, a.qmix_hidden_dim, a.hyper_hidden_dim
         dev = q.device
+        xs = ops.src(s)
+        if self._fused_ok(xs):
+            # one kernel: hypernet GEMMs (weights in registers) + mixing; nothing 256-wide touches HBM
+            qtot = self._s.get("qtot" + tag, (rows,), dev)
+            ops.qmix_fused_fwd(ops.qmix_weights(self._fused_tensors()), xs, q, qtot, rows, N, a.state_shape, E)
+            if ctx is not None:
+                ctx.update(q=q, s=s, fused=True)
+            return qtot
         wid = N * E + 3 * E
         hy = self._s.get("hy" + tag, (rows, wid), dev)
         b2 = self._s.get("b2" + tag, (rows, 1), dev)
         qtot = self._s.get("qtot" + tag, (rows,), dev)
-        xs = ops.src(s)
         hw1 = hw2 = None
         if a.two_hyper_layers:
             hw1 = self._s.get("hw1" + tag, (rows, HH), dev)
@@ -122,6 +143,12 @@ class QMixMixer(nn.Module):
     def hip_backward(self, ctx, dq_tot, rows):
         a = self.args
         N, E, HH = a.n_agents, a.qmix_hidden_dim, a.hyper_hidden_dim
+        if ctx.get("fused"):
+            q, s = ctx["q"], ctx["s"]
+            dq = self._s.get("dq", (rows, N), q.device)
+            ops.qmix_fused_bwd(ops.qmix_weights(self._fused_tensors()), ops.src(s), q, dq_tot, dq,
+                               ops.qmix_weights(self._fused_tensors(grad=True)), rows, N, a.state_shape, E)
+            return dq
         hy, q, s = ctx["hy"], ctx["q"], ctx["s"]
         dev = q.device
         dhy = self._s.get("dhy", hy.shape, dev)

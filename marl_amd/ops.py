@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, check
+from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, MarlQmixWeights, check
 
 
 def _p(t):
@@ -287,3 +287,30 @@ def synth_rollout(w, seed, rseed, env0, episode, fixed_len, eps, rec, h_out, E, 
                                          _p(_f32(rec.padded)), _p(_i32(rec.length)), _p(_i32(rec.won)), _p(h_out),
                                          E, T, N, O, S, A, 1 if last_action else 0, 1 if reuse_network else 0, _stream()),
           "marl_synth_rollout")
+
+
+def qmix_fused_supported(N, S, E):
+    return bool(_lib.load().marl_qmix_fused_supported(N, S, E))
+
+
+def qmix_weights(t):
+    """t: dict with tensors w1,w1_b,b1,b1_b,w2,w2_b,h,h_b,b2_w,b2_b (weights or their gradients)."""
+    w = MarlQmixWeights()
+    for k in ("w1", "w1_b", "b1", "b1_b", "w2", "w2_b", "h", "h_b", "b2_w", "b2_b"):
+        v = t[k]
+        assert v.is_contiguous() and v.dtype == torch.float32 and v.is_cuda
+        setattr(w, k, v.data_ptr())
+    w._keep = t
+    return w
+
+
+def qmix_fused_fwd(w, s, q, q_tot, rows, N, S, E):
+    check(_lib.load().marl_qmix_fused_fwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot)), rows, N, S, E, _stream()),
+          "marl_qmix_fused_fwd")
+
+
+def qmix_fused_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E):
+    lib = _lib.load()
+    ws = WS.get("qmix_fused", lib.marl_qmix_fused_workspace(rows, N, S), q.device)
+    check(lib.marl_qmix_fused_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads),
+                                  _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_bwd")

@@ -297,6 +297,51 @@ def test_qmix_mix(dev):
     close(dq, q.grad, 1e-4)
 
 
+@pytest.mark.parametrize("R,N,S", [(333, 5, 120), (16, 5, 120), (4099, 3, 48), (50, 2, 4), (1000, 5, 126)])
+def test_qmix_fused(dev, R, N, S):
+    """fused hypernet + mixing kernels (forward, dq, hypernet weight gradients) vs torch-CPU autograd of
+    the restated QMixMixer.forward (reference network/mixer.py:57-80); S not a multiple of 4 falls back."""
+    from marl_amd import ops
+    E = 32
+    assert ops.qmix_fused_supported(N, S, E)
+    g = torch.Generator().manual_seed(R + N + S)
+    names = ("w1", "b1", "w2", "h")
+    outs = {"w1": N * E, "b1": E, "w2": E, "h": E}
+    P = {}
+    for k in names:
+        P[k] = (torch.randn(outs[k], S, generator=g) * 0.2).requires_grad_()
+        P[k + "_b"] = (torch.randn(outs[k], generator=g) * 0.2).requires_grad_()
+    P["b2_w"] = torch.randn(1, E, generator=g).requires_grad_()
+    P["b2_b"] = torch.randn(1, generator=g).requires_grad_()
+    s = torch.randn(R, S, generator=g)
+    q = torch.randn(R, N, generator=g, requires_grad=True)
+    gq = torch.randn(R, generator=g)
+    w1 = F.linear(s, P["w1"], P["w1_b"]).abs().view(R, N, E)
+    hid = F.elu((q.unsqueeze(2) * w1).sum(1) + F.linear(s, P["b1"], P["b1_b"]))
+    qt = (hid * F.linear(s, P["w2"], P["w2_b"]).abs()).sum(1) + \
+        F.linear(torch.relu(F.linear(s, P["h"], P["h_b"])), P["b2_w"], P["b2_b"]).squeeze(1)
+    (qt * gq).sum().backward()
+    Wd = {k: cu(v.detach(), dev) for k, v in P.items()}
+    base = {k: torch.randn(v.shape, generator=g) for k, v in P.items()}      # gradients accumulate
+    Gd = {k: cu(v, dev) for k, v in base.items()}
+    ld = (S + 3) // 4 * 4 + 4                                                # padded row stride
+    sd = torch.zeros(R, ld, device=dev)
+    sd[:, :S] = cu(s, dev)
+    if S % 4:
+        return                                                               # generic composition handles it
+    xs = ops.src(sd[:, :S])
+    out = torch.full((R,), 9.0, device=dev)
+    qd = cu(q.detach(), dev)
+    ops.qmix_fused_fwd(ops.qmix_weights(Wd), xs, qd, out, R, N, S, E)
+    close(out, qt, 1e-4)
+    dq = torch.full((R, N), 9.0, device=dev)
+    ops.qmix_fused_bwd(ops.qmix_weights(Wd), xs, qd, cu(gq, dev), dq, ops.qmix_weights(Gd), R, N, S, E)
+    close(dq, q.grad, 1e-4)
+    scale = max(1.0, (R / 64.0) ** 0.5)
+    for k, v in P.items():
+        close(Gd[k], base[k] + v.grad, 2e-4 * scale, 1e-4, msg=k)
+
+
 def test_qplex_mix(dev):
     from marl_amd import ops
     g = torch.Generator().manual_seed(7)
