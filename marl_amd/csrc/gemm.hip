@@ -296,6 +296,143 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Direct weight gradient for N == 64 outputs (fc1 of the agent: dW1 = dxp^T [obs | one-hot(u) | id] over
+// B*T*N rows, the largest reduction of an update).  No LDS staging: the reduction index of dW = G^T X is
+// the ROW, and fp32 MFMA 16x16x4 takes one k (= row) per lane quarter, so lane (q, m) feeds the matrix
+// cores straight from two coalesced 16-byte loads of row r0+q:
+//     G[row][4m..4m+3]   -> A operands of the 4 n-tiles   (tile j holds dW rows n = 4m'+j)
+//     X[row][4m..4m+3]   -> B operands of 4 k-tiles       (tile j holds columns  k = 4m'+j)
+// i.e. the tiles are taken over a permuted column set, undone when the slab is written.  Columns past the
+// first 64 (or all of them when segment 0 is narrower than 64 / gated / unaligned) go through NTP "plain"
+// 16-column tiles read element-wise from the virtual concat.  Per 4 rows a wave issues 2-3 loads and
+// 4*(4*KP+NTP) MFMAs; rows are dealt to waves in 16-row blocks, one block prefetched in registers.
+// The bias gradient is a VALU column sum of the G operands.  8 waves (2 per SIMD) reduce through LDS into
+// one slab per workgroup; slabs are summed by wgrad_reduce_kernel (same layout as wgrad_kernel).
+constexpr int DU = 4;             // k-steps (of 4 rows) per block
+
+template <int KP, int NTP>
+__global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
+  extern __shared__ float red[];  // [64][K+1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = lane & 15;
+  const int K = a.K, Kx = K + 1;
+  constexpr int NT = 4 * KP + NTP;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const long nblk = ((long)a.M + 4 * DU - 1) / (4 * DU);
+  const long G = (long)gridDim.x * 8;
+  constexpr int NP = NTP > 0 ? NTP : 1;
+  f32x4 gA[DU], gB[DU], xA[DU], xB[DU];      // two register sets: the block in flight and the one being consumed
+  float pA[DU][NP], pB[DU][NP];
+  auto load = [&](long blk, f32x4 (&ga)[DU], f32x4 (&xb)[DU], float (&xp)[DU][NP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      long row = blk * (4 * DU) + 4 * u + q;
+      const bool live = row < a.M;
+      if (!live) row = a.M - 1;
+      f32x4 g = *reinterpret_cast<const f32x4*>(a.G + row * a.ldg + 4 * m);
+      if (!live) g = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ga[u] = g;
+      const ConcatRow cr = concat_row(a.x, row);
+      if (KP) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (cr.ok0) x = *reinterpret_cast<const f32x4*>(a.x.p0 + cr.r0 * a.x.ld0 + 4 * m);
+        xb[u] = x;
+      }
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) {
+        const int k = 64 * KP + 16 * t + m;
+        xp[u][t] = k < K ? concat_at(a.x, cr, k) : 0.f;
+      }
+    }
+  };
+  auto mac = [&](const f32x4 (&ga)[DU], const f32x4 (&xb)[DU], const float (&xp)[DU][NP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const f32x4 g = ga[u];
+      bsum += g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (KP) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[j][t] = mfma16(g[j], xb[u][t], acc[j][t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[j][4 * KP + t] = mfma16(g[j], xp[u][t], acc[j][4 * KP + t]);
+      }
+    }
+  };
+  long blk = (long)blockIdx.x * 8 + wave;
+  if (blk < nblk) load(blk, gA, xA, pA);
+  while (blk < nblk) {
+    if (blk + G < nblk) load(blk + G, gB, xB, pB);
+    mac(gA, xA, pA);
+    blk += G;
+    if (blk >= nblk) break;
+    if (blk + G < nblk) load(blk + G, gA, xA, pA);
+    mac(gB, xB, pB);
+    blk += G;
+  }
+  // ---- workgroup reduction through LDS (wave order fixed -> deterministic), then one slab
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bsum[j] += __shfl_xor(bsum[j], 16, 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bsum[j] += __shfl_xor(bsum[j], 32, 64);
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int n = 4 * (4 * q + i) + j;                               // D row -> permuted output row
+            const int k = (KP && t < 4) ? 4 * m + t : 64 * KP + 16 * (t - 4 * KP) + m;
+            if (k < K) {
+              float* d = &red[n * Kx + k];
+              *d = (w == 0 ? 0.f : *d) + acc[j][t][i];
+            }
+          }
+        if (q == 0) {
+          float* d = &red[(4 * m + j) * Kx + K];
+          *d = (w == 0 ? 0.f : *d) + bsum[j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.ws + (long)blockIdx.x * 64 * Kx;
+  for (int e = tid; e < 64 * Kx; e += 512) slab[e] = red[e];
+}
+
+template <int KP, int NTP>
+inline int launch_wgrad_direct(const WgradArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)64 * (a.K + 1) * sizeof(float);
+  hipLaunchKernelGGL((wgrad_direct_kernel<KP, NTP>), dim3(a.slabs), dim3(512), lds, s, a);
+  return 0;
+}
+
+// returns -1 when the shape is not covered (caller uses the LDS-staged kernel)
+inline int try_wgrad_direct(const WgradArgs& a, hipStream_t s) {
+  if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || a.M < 4096) return -1;
+  const bool perm = a.xvec && a.x.k0 >= 64;
+  const int KP = perm ? 1 : 0;
+  const int rest = a.K - 64 * KP;
+  const int NTP = (rest + 15) / 16;
+  if (NTP > 4 || KP + NTP == 0) return -1;
+#define WD_CASE(kp, nt) if (KP == kp && NTP == nt) return launch_wgrad_direct<kp, nt>(a, s);
+  WD_CASE(1, 0) WD_CASE(1, 1) WD_CASE(1, 2) WD_CASE(1, 3) WD_CASE(1, 4)
+  WD_CASE(0, 1) WD_CASE(0, 2) WD_CASE(0, 3) WD_CASE(0, 4)
+#undef WD_CASE
+  return -1;
+}
+
 struct WredArgs {
   const float* ws; float* dW; long lddw; float* db;
   int N, K, slabs, groups; long gs_dw, gs_db;
@@ -405,8 +542,10 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
            (!Yact || ((ldya % 4 == 0) && aligned16(Yact) && (a.gs_ya % 4 == 0)));
   a.xvec = a.x.p0 && !a.x.m0 && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(a.slabs, a.nyb * groups, (K + 1 + 63) / 64), block(256);
-  hipLaunchKernelGGL(wgrad_kernel, grid, block, 0, s, a);
+  if (try_wgrad_direct(a, s) != 0) {
+    dim3 grid(a.slabs, a.nyb * groups, (K + 1 + 63) / 64), block(256);
+    hipLaunchKernelGGL(wgrad_kernel, grid, block, 0, s, a);
+  }
   MARL_CHECK_LAUNCH();
   WredArgs r;
   r.ws = ws; r.dW = dW; r.lddw = lddw; r.db = db; r.N = N; r.K = K; r.slabs = a.slabs; r.groups = groups;

@@ -99,10 +99,12 @@ def test_linear_concat_and_groups(dev):
         close(gflat[k * per + N * Kg:(k + 1) * per], Gk.sum(0), 3e-4)
 
 
-def test_wgrad_large_rows_and_remap(dev):
+@pytest.mark.parametrize("B,O", [(6, 24), (30, 24), (20, 80), (17, 116), (21, 64), (19, 52)])
+def test_wgrad_large_rows_and_remap(dev, B, O):
+    """B >= 17 (M >= 4096 rows, 64 outputs) takes the direct no-LDS kernel, B = 6 the LDS-staged one."""
     from marl_amd import ops
-    g = torch.Generator().manual_seed(9)
-    B, T, N, O = 6, 50, 5, 24            # (T+1)-slot storage read through the row remap
+    g = torch.Generator().manual_seed(9 + B + O)
+    T, N = 50, 5                         # (T+1)-slot storage read through the row remap
     store = torch.randn(B, T + 1, N, O, generator=g)
     u = torch.randint(-1, 7, (B, T, N), generator=g)
     dY = torch.randn(B * T * N, 64, generator=g)
@@ -123,6 +125,7 @@ def test_wgrad_large_rows_and_remap(dev):
         dW, db = torch.zeros(64, K, device=dev), torch.zeros(64, device=dev)
         ops.linear_wgrad(cu(dY, dev), s, dW, db, B * T * N, 64, K)
         close(dW, dY.t() @ Xfull, 2e-3, 1e-3)
+        close(db, dY.sum(0), 2e-3, 1e-3)
         Y = torch.empty(B * T * N, 10, device=dev)
         W = torch.randn(10, K, generator=g)
         ops.linear(s, cu(W, dev), None, Y, B * T * N, 10, K)
