@@ -32,6 +32,7 @@ struct RollArgs {
   unsigned seed, rseed;
   int env0, episode, fixed_len;
   int E, T, N, O, S, A, I, KC, RT;
+  int EPW;                // whole environments per workgroup: EPW*N valid rows in 16*RT tile rows
   int has_act, has_id;
   long R;
 };
@@ -59,12 +60,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   int* elen = rown + rows;                               // [rows/N]: episode length of the local env
   unsigned* pfx = reinterpret_cast<unsigned*>(elen + rows);   // [3][rows]: hash prefixes (obs, avail per row; state per env) of the slot being generated
 
-  const long row0 = (long)blockIdx.x * rows;           // multiple of N by construction
-  const int b0 = (int)(row0 / a.N);
-  const int nenv_wg = rows / a.N;
   const int T = a.T, N = a.N, O = a.O, S = a.S, A = a.A;
+  const int nenv_wg = a.EPW;
+  const int vrows = nenv_wg * N;                       // valid rows; rows vrows..16*RT-1 are padding (zero input)
+  const int b0 = blockIdx.x * nenv_wg;
+  const long row0 = (long)b0 * N;
   for (int r = tid; r < rows; r += RNT) {
-    long rho = row0 + r;
+    long rho = row0 + (r < vrows ? r : vrows - 1);
     if (rho > a.R - 1) rho = a.R - 1;                   // clamp: duplicates of the last row (same values, same addresses)
     rowe[r] = (int)(rho / N) - b0;
     rown[r] = (int)(rho % N);
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   };
   auto gen_slot = [&](int t, bool to_lds, float* Av) {
     // one row per wave-iteration, lanes over the columns: no integer division, coalesced stores
-    for (int r = wave; r < rows; r += RNT / 64) {
+    for (int r = wave; r < vrows; r += RNT / 64) {
       const int el = rowe[r], n = rown[r];
       const bool live = t <= elen[el], feed = t < elen[el];
       const unsigned po = pfx[r], pa = pfx[rows + r];
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     if (a.has_id && k >= a.I - N && k < a.I) v = (rown[r] == k - (a.I - N)) ? 1.f : 0.f;
     In[r * KS + k] = v;
   }
+  for (int e = tid; e < (rows - vrows) * O; e += RNT) In[(vrows + e / O) * KS + e % O] = 0.f;   // padding rows
   gen_prefix(0);
   __syncthreads();
   gen_slot(0, true, Av0);
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     // ---------------- epsilon-greedy choice (share_params.py:66-70), one thread per (env, agent) row
     const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
     const float eps = a.eps[t];
-    if (tid < rows) {
+    if (tid < vrows) {
       const int r = tid, el = rowe[r], n = rown[r];
       const unsigned env = (unsigned)(a.env0 + b0 + el);
       int arg = -1;
@@ -323,18 +326,27 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     for (int e = tid; e < rows * H; e += RNT) {
       const int r = e / H, k = e % H;
       const long rho = row0 + r;
-      if (rho < a.R) a.h_out[rho * H + k] = Hp[r * HS + k];
+      if (r < vrows && rho < a.R) a.h_out[rho * H + k] = Hp[r * HS + k];
     }
   }
 }
 
 }  // namespace
 
-// rows per workgroup must hold whole environments: 16*RT % N == 0, RT <= 8
+// a workgroup holds whole environments (EPW*N rows padded to 16*RT, RT <= 8); the fc1 slice + the row state
+// must fit the 160 KB LDS (widest input assumed: last action and agent id appended)
+static int max_rt(int I, int A) {
+  const int KC = (I + 15) / 16, KS = KC * 16 + 4;
+  const size_t fixed = (size_t)4 * KC * 64 * 16;
+  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12;
+  int rt = 0;
+  for (int c = 1; c <= 8; ++c) if (fixed + per_row * 16 * c <= 160 * 1024) rt = c;
+  return rt;
+}
+
 extern "C" int marl_synth_rollout_supported(int N, int O, int A) {
-  for (int rt = 1; rt <= 8; ++rt)
-    if ((16 * rt) % N == 0) return 1;
-  return 0;
+  if (A > 32 || A < 1 || N < 1) return 0;
+  return 16 * max_rt(O + A + N, A) >= N ? 1 : 0;
 }
 
 extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
@@ -358,17 +370,16 @@ extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, 
   const int KS = a.KC * 16 + 4;
   const size_t fixed = (size_t)4 * a.KC * 64 * 16;
   const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12;
-  // smallest RT >= ceil(tiles/256) with whole environments per workgroup, within the LDS budget
-  const long tiles = (a.R + 15) / 16;
-  int want = (int)((tiles + 255) / 256); if (want < 1) want = 1;
-  int rt = 0;
-  for (int c = want; c <= 8; ++c) if ((16 * c) % N == 0 && fixed + per_row * 16 * c <= 160 * 1024) { rt = c; break; }
-  if (!rt) for (int c = want - 1; c >= 1; --c) if ((16 * c) % N == 0 && fixed + per_row * 16 * c <= 160 * 1024) { rt = c; break; }
-  if (!rt) return (int)hipErrorInvalidValue;
-  a.RT = rt;
-  const size_t lds = fixed + per_row * rt * 16;
-  const long rows = rt * 16;
-  dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(RNT);
+  // environments per workgroup: one workgroup per CU when the batch allows it (a lock-step is latency
+  // bound, so small batches spread over all CUs with partly filled tiles), capped by the LDS budget
+  const int rt_max = max_rt(a.I, A);
+  if (16 * rt_max < N) return (int)hipErrorInvalidValue;
+  int epw = (E + 255) / 256;
+  if (epw * N > 16 * rt_max) epw = (16 * rt_max) / N;
+  a.EPW = epw;
+  a.RT = (epw * N + 15) / 16;
+  const size_t lds = fixed + per_row * a.RT * 16;
+  dim3 grid((unsigned)((E + epw - 1) / epw)), block(RNT);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (A <= 16) {
