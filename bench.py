@@ -131,6 +131,7 @@ def main():
                            fixed_length=True)
     worker = RolloutWorker(env, mac, args)
     buf = ReplayBuffer(args)
+    worker.record_sink = buf          # training rollouts are played straight into the replay ring
     np.random.seed(1 + rank)
 
     # HIP-event timing of the dominant kernel (the persistent agent unroll, 3 launches per update)

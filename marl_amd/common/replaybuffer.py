@@ -41,6 +41,34 @@ class ReplayBuffer:
                         'avail_u_next': e([n, T, N, A]), 'u_onehot': e([n, T, N, A]), 'padded': e([n, T, 1]),
                         'terminated': e([n, T, 1])}
 
+    def _peek_contiguous(self, inc):
+        """first ring slot the next ``store_episode`` of ``inc`` episodes will use, or None when that
+        store wraps around (mirrors ``_get_storage_idx`` without advancing)."""
+        if self.current_idx + inc <= self.size:
+            return self.current_idx
+        if self.current_idx < self.size:
+            return None
+        return 0 if inc <= self.size else None
+
+    def next_slot_record(self, E, T, N, O, S, A, device):
+        """Zero-copy store: an EpisodeRecord VIEW over the ring slots the next store_episode(E episodes)
+        will fill, so the rollout kernel writes the episodes in place and the store is index
+        bookkeeping only.  None when the slots are not contiguous or the buffer is in host mode."""
+        if self.buffers is not None:
+            return None
+        with self.lock:
+            i0 = self._peek_contiguous(E)
+            if i0 is None:
+                return None
+            if self.record is None:
+                self.record = EpisodeRecord(self.size, T, N, O, S, A, device)
+            r = self.record
+            if (r.T, r.N, r.O, r.S, r.A) != (T, N, O, S, A):
+                return None
+            view = r.slice(i0, i0 + E)
+            view.sink_slot = i0
+            return view
+
     def store_episode(self, episode_batch):
         rec = getattr(episode_batch, "record", None)
         batch_size = rec.E if rec is not None else episode_batch['o'].shape[0]
@@ -49,6 +77,11 @@ class ReplayBuffer:
             if rec is not None and self.buffers is None:
                 if self.record is None:
                     self.record = EpisodeRecord(self.size, rec.T, rec.N, rec.O, rec.S, rec.A, rec.obs.device)
+                first = int(np.atleast_1d(idxs)[0])
+                if rec.obs.data_ptr() == self.record.obs[first].data_ptr() and getattr(rec, "sink_slot", -1) == first:
+                    return                       # written in place by the rollout (next_slot_record)
+                if getattr(rec, "sink_slot", None) is not None:
+                    rec = rec.clone()            # a view of this ring at other slots: avoid overlapping copies
                 idx_t = torch.as_tensor(np.atleast_1d(idxs), dtype=torch.long, device=rec.obs.device)
                 rec.copy_into(self.record, idx_t)
                 return

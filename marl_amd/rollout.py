@@ -107,10 +107,18 @@ class RolloutWorker:
         E, T, N, A, O, H = env.n_envs, self.episode_limit, self.n_agents, self.n_actions, self.obs_shape, a.rnn_hidden_dim
         if a.replay_dir != '' and evaluate:
             env.close()
-        rec = env.new_record()
         mode = getattr(self, "rollout_mode", "whole")      # "whole" | "fused_step" | "unfused" (tests)
         if mode == "whole" and hasattr(env, "whole_rollout") and env.supports_whole_rollout():
+            # the persistent kernel writes every field of the record, so training rollouts can be
+            # played straight into the replay ring (record_sink = the ReplayBuffer; zero-copy store)
+            sink = getattr(self, "record_sink", None)
+            rec = None
+            if sink is not None and not evaluate:
+                rec = sink.next_slot_record(E, T, N, O, self.state_shape, A, dev)
+            if rec is None:
+                rec = env.new_record()
             return self._generate_whole(rec, evaluate)
+        rec = env.new_record()
         env.begin_episode(rec)
         mac.init_hidden(E)
         h = mac.hidden_states.view(E * N, H)

@@ -24,6 +24,7 @@ class Runner:
         self.mac = SharedMAC(args)
         self.rolloutWorker = RolloutWorker(env, self.mac, args)
         self.buffer = ReplayBuffer(args)
+        self.rolloutWorker.record_sink = self.buffer   # batched rollouts write into the replay ring in place
         self.args = args
         self.eval_win_rates = []
         self.eval_episode_rewards = []

@@ -180,3 +180,36 @@ def test_replay_buffer_device_and_host(golden_dir):
     for k in ring:
         ring[k][0:2] = eps_list[2][k][2:4]     # wrap-around: last two episodes overwrite slots 0,1
         np.testing.assert_array_equal(smp[k], ring[k][idx], err_msg=k)
+
+
+def test_zero_copy_store_into_replay_ring():
+    """record_sink: the rollout kernel writes the episodes straight into the ReplayBuffer's next ring
+    slots; the result equals rollout-then-copy, including after the ring wraps (reference
+    common/replaybuffer.py:63-80 index arithmetic)."""
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd.common.replaybuffer import ReplayBuffer
+    T, E = 6, 16
+    args = seeded.make_args("2s3z", "qmix", episode_limit=T, epsilon=0.3, seed=3)
+    args.buffer_size = 40                      # 16+16 fit, the third store wraps (copy path), the 4th is in place again
+    mac, _ = _mac(args)
+    wa = RolloutWorker(SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=9), mac, args)
+    wb = RolloutWorker(SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=9), mac, args)
+    ba, bb = ReplayBuffer(args), ReplayBuffer(args)
+    wb.record_sink = bb
+    in_place = []
+    for it in range(5):
+        ea = wa.generate_episodes(E)[0]
+        eb = wb.generate_episodes(E)[0]
+        in_place.append(getattr(eb.record, "sink_slot", None))
+        ba.store_episode(ea)
+        bb.store_episode(eb)
+        assert (ba.current_idx, ba.current_size) == (bb.current_idx, bb.current_size)
+        for f in ("obs", "state", "avail", "u", "r", "term", "padded", "length", "won"):
+            n = ba.current_size
+            assert torch.equal(getattr(ba.record, f)[:n], getattr(bb.record, f)[:n]), (it, f)
+    assert in_place == [0, 16, None, 8, 24]
+    # evaluation rollouts never touch the ring
+    snap = bb.record.obs.clone()
+    ev = wb.generate_episodes(E, evaluate=True)[0]
+    assert getattr(ev.record, "sink_slot", None) is None and torch.equal(snap, bb.record.obs)
