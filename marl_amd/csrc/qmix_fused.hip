@@ -21,7 +21,8 @@ namespace {
 constexpr int E = 32;
 constexpr int KCQ = 8;            // k-chunks of 16 (S padded to 128)
 constexpr int SS = 128 + 4;       // LDS row stride of the state tile
-constexpr int QNT = 256;
+
+#define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 struct QmixArgs {
   const float *W[4], *Bv[4];      // segment weights (rows x S) and biases: w1, b1, w2, h
@@ -36,7 +37,7 @@ struct QmixArgs {
   int N, S, C;
 };
 
-__host__ __device__ inline long qmix_slab_floats(int C, int S) { return (long)C * (S + 1) + 4 * (E + 1); }
+__host__ __device__ inline long qmix_slab_floats(int C, int S) { return (long)C * (S + 1) + (E + 1); }
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 __device__ __forceinline__ float sum16(float v) {     // over the 16 lanes of a quarter-wave
@@ -45,10 +46,13 @@ __device__ __forceinline__ float sum16(float v) {     // over the 16 lanes of a 
 }
 __device__ __forceinline__ float sum32(float v) { v = sum16(v); v += __shfl_xor(v, 16, 64); return v; }
 
-template <bool BWD>
-__global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
+// TPW column tiles per wave, NW = 16/TPW waves.  Two waves share each SIMD (8 waves x 2 tiles, or two 4-wave
+// workgroups per CU): one wave's finishing math / LDS waits / barrier skew hide behind the other's MFMAs.
+template <bool BWD, int TPW>
+__global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs a) {
+  constexpr int NW = 16 / TPW, QNT = 64 * NW;
   __shared__ __attribute__((aligned(16))) float Ss[2][16 * SS];   // state tile, double buffered
-  __shared__ float PA[4][16][E];      // per-wave partial sums of the pre-activation a_e
+  __shared__ float PA[NW][16][E];      // per-wave partial sums of the pre-activation a_e
   __shared__ float W2A[16][E];        // |w2|
   __shared__ float HBA[16][E];        // relu(h)
   __shared__ float DPRE[16][E];       // dL/da_e          (backward)
@@ -60,12 +64,12 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
   const int N = a.N, S = a.S, C = a.C, NE = N * E;
 
   // ---- this wave's 4 column tiles: kind (0 w1, 1 b1, 2 w2, 3 h, -1 unused), agent n, e-half
-  int kind[4], nn[4], eh[4];
-  f32x4 wq[4][KCQ];
-  float bias[4];
+  int kind[TPW], nn[TPW], eh[TPW];
+  f32x4 wq[TPW][KCQ];
+  float bias[TPW];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int gt = 4 * wave + c, col0 = 16 * gt;
+  for (int c = 0; c < TPW; ++c) {
+    const int gt = TPW * wave + c, col0 = 16 * gt;
     int k = -1, seg_col = 0;
     if (col0 < NE) { k = 0; seg_col = col0; }
     else if (col0 < NE + E) { k = 1; seg_col = col0 - NE; }
@@ -82,12 +86,14 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
         wq[c][kc][i] = (k >= 0 && kk < S) ? Wp[kk] : 0.f;
       }
   }
-  f32x4 accW[BWD ? 4 : 1][BWD ? KCQ : 1];
-  float sbW[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 accW[BWD ? TPW : 1][BWD ? KCQ : 1];
+  float sbW[TPW];
+#pragma unroll
+  for (int c = 0; c < TPW; ++c) sbW[c] = 0.f;
   float acc_wb2 = 0.f, acc_bb2 = 0.f;      // hyper_b2.2 gradients (finishing lanes)
   if (BWD) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < TPW; ++c)
 #pragma unroll
       for (int kc = 0; kc < KCQ; ++kc) accW[c][kc] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -96,10 +102,11 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
 
   // ---- state tile staging: thread -> (row tid/16 .. , float4 column); 16 rows x 32 float4 = 512 = 2 per thread
   const long tiles = (a.rows + 15) / 16;
-  f32x4 pf[2];
+  constexpr int NPF = 512 / QNT;
+  f32x4 pf[NPF];
   auto fetch = [&](long tile) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NPF; ++i) {
       const int e = tid + QNT * i;
       const int r = e >> 5, c4 = (e & 31) * 4;
       long row = tile * 16 + r;
@@ -119,46 +126,57 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NPF; ++i) {
       const int e = tid + QNT * i;
       *reinterpret_cast<f32x4*>(&Ss[buf][(e >> 5) * SS + (e & 31) * 4]) = pf[i];
     }
   };
+  // q / g elements of this thread, also one tile ahead (threads 0..16N-1: q, threads 192..207: g)
+  float pq = 0.f, pg = 0.f;
+  const int qr = tid / N, qn = tid - qr * N;
+  auto fetch_qg = [&](long tile) {
+    pq = 0.f; pg = 0.f;
+    if (tid < 16 * N) {
+      const long row = tile * 16 + qr;
+      if (row < a.rows) pq = a.q[row * N + qn];
+    }
+    if (BWD && tid >= 192 && tid < 208) {
+      const long row = tile * 16 + (tid - 192);
+      if (row < a.rows) pg = a.g[row];
+    }
+  };
+  float wb2c[TPW];                                   // hyper_b2.2 weight of this lane's column in each tile
+#pragma unroll
+  for (int c = 0; c < TPW; ++c) wb2c[c] = a.wb2[16 * eh[c] + m];
   long tile = blockIdx.x;
-  if (tile < tiles) { fetch(tile); stash(0); }
+  if (tile < tiles) { fetch(tile); fetch_qg(tile); stash(0); }
   int buf = 0;
+  // barriers below only order LDS traffic (s_waitcnt lgkmcnt): the prefetch loads of the next tile stay in
+  // flight across them - a __syncthreads() would drain vmcnt and expose the HBM latency on every tile
   for (; tile < tiles; tile += gridDim.x, buf ^= 1) {
     const long row0 = tile * 16;
     float (*Qs)[16] = Qs2[buf];
     float* Gs = Gs2[buf];
-    // q / g tiles (small) and the next state tile
-    if (tid < 16 * N) {
-      const int r = tid / N, n = tid - r * N;
-      const long row = row0 + r;
-      Qs[r][n] = row < a.rows ? a.q[row * N + n] : 0.f;
-    }
-    if (BWD && tid >= 192 && tid < 208) {
-      const long row = row0 + (tid - 192);
-      Gs[tid - 192] = row < a.rows ? a.g[row] : 0.f;
-    }
+    if (tid < 16 * N) Qs[qr][qn] = pq;
+    if (BWD && tid >= 192 && tid < 208) Gs[tid - 192] = pg;
     const long nt = tile + gridDim.x;
-    if (nt < tiles) fetch(nt);
-    __syncthreads();                               // Ss[buf], Qs, Gs ready
+    if (nt < tiles) { fetch(nt); fetch_qg(nt); }
+    WG_BARRIER();                                  // Ss[buf], Qs, Gs ready
     // ---- hypernet tile: out[row 4q+i][col 16gt+m], 4 column tiles x 8 k-chunks
-    f32x4 acc[4];
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){bias[c], bias[c], bias[c], bias[c]};
+    for (int c = 0; c < TPW; ++c) acc[c] = (f32x4){bias[c], bias[c], bias[c], bias[c]};
     const float* sr = &Ss[buf][m * SS + 4 * q4];
 #pragma unroll
     for (int kc = 0; kc < KCQ; ++kc) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(sr + 16 * kc);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = mfma16x4(a4, wq[c][kc], acc[c]);
+      for (int c = 0; c < TPW; ++c) acc[c] = mfma16x4(a4, wq[c][kc], acc[c]);
     }
     // ---- partial pre-activations: a_e = b1_e + sum_n q_n |w1[n,e]|  (this wave's agents / b1 tiles)
     float pa[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < TPW; ++c) {
       if (kind[c] == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pa[eh[c]][i] += Qs[4 * q4 + i][nn[c]] * fabsf(acc[c][i]);
@@ -177,12 +195,14 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) PA[wave][4 * q4 + i][16 * h + m] = pa[h][i];
-    __syncthreads();
-    // ---- finish: wave w takes rows 4w..4w+3, two rows per pass (lane = e of row `half`)
+    WG_BARRIER();
+    // ---- finish: wave w takes rows (16/NW)w .., two rows per pass (lane = e of row `half`)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int r = 4 * wave + 2 * p + (lane >> 5), e = lane & 31;
-      const float ae = PA[0][r][e] + PA[1][r][e] + PA[2][r][e] + PA[3][r][e];
+    for (int p = 0; p < 8 / NW; ++p) {
+      const int r = (16 / NW) * wave + 2 * p + (lane >> 5), e = lane & 31;
+      float ae = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) ae += PA[w][r][e];
       const float ex = __expf(ae);
       const float hid = ae > 0.f ? ae : ex - 1.f;                 // elu, alpha = 1
       const float w2 = W2A[r][e], hb = HBA[r][e];
@@ -198,11 +218,11 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
       }
     }
     if (BWD) {
-      __syncthreads();
+      WG_BARRIER();
       // ---- d(hypernet output) in accumulator layout, dq, then dW += dhy^T [s | 1]
-      f32x4 dhy[4];
+      f32x4 dhy[TPW];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < TPW; ++c) {
         const int ecol = 16 * eh[c] + m;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -211,14 +231,14 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
           if (kind[c] == 0) v = Qs[r][nn[c]] * DPRE[r][ecol] * sgn(acc[c][i]);
           else if (kind[c] == 1) v = DPRE[r][ecol];
           else if (kind[c] == 2) v = Gs[r] * HID[r][ecol] * sgn(acc[c][i]);
-          else if (kind[c] == 3) v = acc[c][i] > 0.f ? Gs[r] * a.wb2[ecol] : 0.f;
+          else if (kind[c] == 3) v = acc[c][i] > 0.f ? Gs[r] * wb2c[c] : 0.f;
           dhy[c][i] = v;
         }
         sbW[c] += dhy[c][0] + dhy[c][1] + dhy[c][2] + dhy[c][3];
       }
       // dq_n = sum_e |w1[n,e]| dpre_e : tiles (2n, 2n+1) sit in the same wave as (c, c+1), c even
 #pragma unroll
-      for (int c = 0; c < 4; c += 2) {
+      for (int c = 0; c < TPW; c += 2) {
         if (kind[c] == 0) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sD[i] = sd[i * SS + 16 * kc];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) accW[c][kc] = mfma16x4(dhy[c], sD, accW[c][kc]);
+        for (int c = 0; c < TPW; ++c) accW[c][kc] = mfma16x4(dhy[c], sD, accW[c][kc]);
       }
     }
     if (nt < tiles) stash(buf ^ 1);
@@ -247,9 +267,9 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
     float* slab = a.ws + (long)blockIdx.x * qmix_slab_floats(C, S);
     const int Sx = S + 1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < TPW; ++c) {
       if (kind[c] < 0) continue;
-      const int col0 = 16 * (4 * wave + c);
+      const int col0 = 16 * (TPW * wave + c);
 #pragma unroll
       for (int kc = 0; kc < KCQ; ++kc)
 #pragma unroll
@@ -261,12 +281,20 @@ __global__ __launch_bounds__(QNT, 1) void qmix_fused_kernel(QmixArgs a) {
       sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);                    // over the 4 row groups
       if (q4 == 0) slab[(long)(col0 + m) * Sx + S] = sb;
     }
-    // hyper_b2.2 partials: lanes e of both halves, 4 waves -> [wave][E+1]
+    // hyper_b2.2 partials: lanes e of both halves, then the 4 waves in fixed order through LDS
     float v = acc_wb2 + __shfl_xor(acc_wb2, 32, 64);
     float b = acc_bb2 + __shfl_xor(acc_bb2, 32, 64);
-    float* tail = slab + (long)C * Sx + wave * (E + 1);
-    if (lane < 32) tail[lane] = v;
-    if (lane == 0) tail[E] = b;
+    __syncthreads();
+    float* wred = &PA[0][0][0];                 // reuse: [4][E+1]
+    if (lane < 32) wred[wave * (E + 1) + lane] = v;
+    if (lane == 0) wred[wave * (E + 1) + E] = b;
+    __syncthreads();
+    if (tid < E + 1) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += wred[w * (E + 1) + tid];
+      slab[(long)C * Sx + tid] = tot;
+    }
   }
 }
 
@@ -275,18 +303,22 @@ struct QmixRedArgs {
   float *dW[4], *dB[4], *dwb2, *dbb2;
 };
 
-__global__ __launch_bounds__(256) void qmix_fused_reduce_kernel(QmixRedArgs a) {
-  __shared__ float part[4][64];
+constexpr int RSG = 16;            // slab groups per output element (fixed summation order -> deterministic)
+
+__global__ __launch_bounds__(64 * RSG) void qmix_fused_reduce_kernel(QmixRedArgs a) {
+  __shared__ float part[RSG][64];
   const long slab = qmix_slab_floats(a.C, a.S);
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + el;
   float s = 0.f;
   if (e < slab)
-    for (int w = sg; w < a.nwg; w += 4) s += a.ws[(long)w * slab + e];
+    for (int w = sg; w < a.nwg; w += RSG) s += a.ws[(long)w * slab + e];
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0 || e >= slab) return;
-  s = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+  s = 0.f;
+#pragma unroll
+  for (int g = 0; g < RSG; ++g) s += part[g][el];
   const int Sx = a.S + 1, NE = a.N * E;
   if (e < (long)a.C * Sx) {
     const int col = (int)(e / Sx), k = (int)(e - (long)col * Sx);
@@ -298,16 +330,9 @@ __global__ __launch_bounds__(256) void qmix_fused_reduce_kernel(QmixRedArgs a) {
     if (k < a.S) a.dW[seg][(long)sc * a.S + k] += s;
     else a.dB[seg][sc] += s;
   } else {
-    // tail: 4 wave partials of [dwb2 (E) | dbb2]; thread of partial 0 gathers the other three (fixed order)
+    // tail: [dwb2 (E) | dbb2]
     const long tpos = e - (long)a.C * Sx;
-    if (tpos < E + 1) {
-      float tot = 0.f;
-      for (int w = 0; w < a.nwg; ++w) {
-        const float* t = a.ws + (long)w * slab + (long)a.C * Sx;
-        tot += ((t[tpos] + t[(E + 1) + tpos]) + t[2 * (E + 1) + tpos]) + t[3 * (E + 1) + tpos];
-      }
-      if (tpos < E) a.dwb2[tpos] += tot; else a.dbb2[0] += tot;
-    }
+    if (tpos < E) a.dwb2[tpos] += s; else a.dbb2[0] += s;
   }
 }
 
@@ -332,9 +357,13 @@ inline int fill(QmixArgs& a, const marl_qmix_weights_t* w, const marl_src_t* s, 
   return 0;
 }
 
-inline unsigned grid_for(long rows) {
+#ifndef FWD_TPW
+#define FWD_TPW 4
+#endif
+
+inline unsigned grid_for(long rows, int per_cu = 1) {
   long tiles = (rows + 15) / 16;
-  return (unsigned)(tiles < 256 ? tiles : 256);
+  return (unsigned)(tiles < 256 * per_cu ? tiles : 256 * per_cu);
 }
 
 }  // namespace
@@ -352,7 +381,8 @@ extern "C" int marl_qmix_fused_fwd(const marl_qmix_weights_t* w, const marl_src_
   QmixArgs a;
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
   a.g = nullptr; a.q_tot = q_tot; a.dq = nullptr; a.ws = nullptr;
-  hipLaunchKernelGGL((qmix_fused_kernel<false>), dim3(grid_for(rows)), dim3(QNT), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((qmix_fused_kernel<false, FWD_TPW>), dim3(grid_for(rows, 2)), dim3(64 * (16 / FWD_TPW)), 0,
+                     (hipStream_t)stream, a);
   MARL_CHECK_LAUNCH();
   return 0;
 }
@@ -368,7 +398,7 @@ extern "C" int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_
   a.g = dq_tot; a.q_tot = nullptr; a.dq = dq; a.ws = ws;
   const unsigned nwg = grid_for(rows);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((qmix_fused_kernel<true>), dim3(nwg), dim3(QNT), 0, st, a);
+  hipLaunchKernelGGL((qmix_fused_kernel<true, 2>), dim3(nwg), dim3(512), 0, st, a);
   MARL_CHECK_LAUNCH();
   QmixRedArgs r;
   r.ws = ws; r.nwg = (int)nwg; r.N = N; r.S = S; r.C = a.C;
@@ -378,7 +408,7 @@ extern "C" int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_
   r.dW[3] = const_cast<float*>(grads->h); r.dB[3] = const_cast<float*>(grads->h_b);
   r.dwb2 = const_cast<float*>(grads->b2_w); r.dbb2 = const_cast<float*>(grads->b2_b);
   const long slab = qmix_slab_floats(a.C, S);
-  hipLaunchKernelGGL(qmix_fused_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(qmix_fused_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(64 * RSG), 0, st, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }
