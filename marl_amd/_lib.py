@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarl_hip.so")
+LIB_PATH = os.environ.get("MARL_HIP_LIB") or os.path.join(_HERE, "libmarl_hip.so")   # override: diagnostic builds
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_int_p = C.c_void_p

@@ -146,4 +146,20 @@ __device__ __forceinline__ float concat_at(const ConcatSrc& s, const ConcatRow& 
 
 __host__ __device__ inline int concat_width(const ConcatSrc& s) { return s.k0 + s.k1 + s.nhot * s.hot_w + s.nid; }
 
+// ---- diagnostic build only (make stamps -> libmarl_hip_stamps.so): per-segment s_memtime sums of every wave of
+// workgroup 0, written to a buffer of their own (tools/stamps.py).  No stamp executes in the product library.
+#ifdef MARL_STAMPS
+static __device__ unsigned long long* marl_stamp_buf;   // one per translation unit
+#define ST_DEFINE_SETTER(name) extern "C" int name(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(marl_stamp_buf), &p, sizeof(p)); }
+#define ST_NOW(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ST_DECL(n) unsigned long long st_sum_[n]; for (int i_ = 0; i_ < (n); ++i_) st_sum_[i_] = 0ull; unsigned long long st_prev_; ST_NOW(st_prev_)
+#define ST_MARK(i) do { unsigned long long n_; ST_NOW(n_); st_sum_[i] += n_ - st_prev_; st_prev_ = n_; } while (0)
+#define ST_DUMP(n) do { if (marl_stamp_buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < (n); ++i_) marl_stamp_buf[(threadIdx.x >> 6) * 16 + i_] = st_sum_[i_]; } while (0)
+#else
+#define ST_DEFINE_SETTER(name)
+#define ST_DECL(n)
+#define ST_MARK(i)
+#define ST_DUMP(n)
+#endif
+
 #define MARL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

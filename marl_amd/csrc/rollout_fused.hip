@@ -21,6 +21,19 @@ constexpr int RNT = 512;
 
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// max over each aligned group of 16 lanes with DPP moves (no LDS crossbar round trips)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float group_max16(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov<0x141>(v));    // row_half_mirror: the other quad of each 8 lanes
+  v = fmaxf(v, dpp_mov<0x140>(v));    // row_mirror: the other half of the row
+  return v;
+}
+
 struct RollArgs {
   const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;
   const float* eps;       // [T] epsilon of each lock-step (device)
@@ -59,6 +72,10 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   int* rown = rowe + rows;                               // [rows]: n
   int* elen = rown + rows;                               // [rows/N]: episode length of the local env
   unsigned* pfx = reinterpret_cast<unsigned*>(elen + rows);   // [3][rows]: hash prefixes (obs, avail per row; state per env) of the slot being generated
+  int4* rmeta = reinterpret_cast<int4*>(pfx + 3 * rows);      // [rows]: {obs offset of (b,0,n,0), avail offset, episode length, n}
+  int4* emeta = rmeta + rows;                                 // [rows/N..]: {state offset of (b,0,0), episode length, env in range, -}
+  float* uex = reinterpret_cast<float*>(emeta + rows);        // [2][rows]: explore / pick uniforms of the coming choice
+  int* tilecnt = reinterpret_cast<int*>(uex + 2 * rows);      // [4]: next GRU row tile of each hidden-unit slice
 
   const int T = a.T, N = a.N, O = a.O, S = a.S, A = a.A;
   const int nenv_wg = a.EPW;
@@ -83,6 +100,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   }
   for (int e = tid; e < rows * H; e += RNT) Ha[(e / H) * HS + (e % H)] = 0.f;     // init_hidden: zeros
   __syncthreads();
+  for (int r = tid; r < vrows; r += RNT) {
+    const int el = rowe[r], n = rown[r];
+    const int bn = (b0 + el) * (T + 1) * N + n;
+    rmeta[r] = make_int4(bn * O, bn * A, elen[el], n);
+  }
+  for (int el = tid; el < nenv_wg; el += RNT)
+    emeta[el] = make_int4((b0 + el) * (T + 1) * S, elen[el], b0 + el < a.E ? 1 : 0, 0);
 
   // ---- environment observation of slot t -> record (+ LDS input tile / availability when wanted)
   // prefixes of slot t (3 of the 4 hash rounds depend only on (stream, env, t)): one thread per row
@@ -95,31 +119,71 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
       if (tid < nenv_wg) pfx[2 * rows + tid] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + tid), tg);
     }
   };
-  auto gen_slot = [&](int t, bool to_lds, float* Av) {
-    // one row per wave-iteration, lanes over the columns: no integer division, coalesced stores
-    for (int r = wave; r < vrows; r += RNT / 64) {
-      const int el = rowe[r], n = rown[r];
-      const bool live = t <= elen[el], feed = t < elen[el];
-      const unsigned po = pfx[r], pa = pfx[rows + r];
-      float* orow = a.obs + (((long)(b0 + el) * (T + 1) + t) * N + n) * O;
-      for (int k = lane; k < O; k += 64) {
-        const float v = live ? 2.0f * u01(hfin(po, (unsigned)(n * O + k))) - 1.0f : 0.f;
-        orow[k] = v;
-        if (to_lds) In[r * KS + k] = feed ? v : 0.f;        // padded steps feed zeros (rollout.py:122-133)
+  // Flattened over the slot's elements: every thread handles independent (row, column group) items - the row
+  // lookup is one 16-byte LDS read of the metadata table, so nothing serialises on per-row dependent chains and
+  // the stores are 16 bytes per lane (the row-per-wave form of this took 30-55 % of a lock-step).
+  const int O4 = O >> 2, S4 = S >> 2;
+  const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1), invO = 1.0f / (float)O, invA = 1.0f / (float)A;
+  const float invS4 = 1.0f / (float)(S4 > 0 ? S4 : 1), invS = 1.0f / (float)S;
+  const bool ovec = (O & 3) == 0, svec = (S & 3) == 0;
+  auto gen_slot = [&](int t, bool to_lds, float* Av, int first, int nthr) {
+    if (tid < first || tid >= first + nthr) return;
+    const int tl = tid - first;
+    const int tNO = t * N * O, tNA = t * N * A, tS = t * S;
+    if (ovec) {
+      for (int e = tl; e < vrows * O4; e += nthr) {
+        const int r = (int)(((float)e + 0.5f) * invO4);
+        const int k = 4 * (e - r * O4);
+        const int4 mt = rmeta[r];
+        const unsigned po = pfx[r];
+        const bool live = t <= mt.z, feed = t < mt.z;
+        const unsigned idx = (unsigned)(mt.w * O + k);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = live ? 2.0f * u01(hfin(po, idx + (unsigned)i)) - 1.0f : 0.f;
+        *reinterpret_cast<f32x4*>(a.obs + (long)mt.x + tNO + k) = v;
+        if (to_lds) *reinterpret_cast<f32x4*>(In + r * KS + k) = feed ? v : (f32x4){0.f, 0.f, 0.f, 0.f};   // padded steps feed zeros (rollout.py:122-133)
       }
-      if (lane < A) {
-        const int k = lane;
-        const float v = live ? ((k == 0 || u01(hfin(pa, (unsigned)(n * A + k))) < 0.7f) ? 1.f : 0.f) : 0.f;
-        a.avail[(((long)(b0 + el) * (T + 1) + t) * N + n) * A + k] = v;
-        if (Av) Av[r * A + k] = v;
+    } else {
+      for (int e = tl; e < vrows * O; e += nthr) {
+        const int r = (int)(((float)e + 0.5f) * invO);
+        const int k = e - r * O;
+        const int4 mt = rmeta[r];
+        const bool live = t <= mt.z, feed = t < mt.z;
+        const float v = live ? 2.0f * u01(hfin(pfx[r], (unsigned)(mt.w * O + k))) - 1.0f : 0.f;
+        a.obs[(long)mt.x + tNO + k] = v;
+        if (to_lds) In[r * KS + k] = feed ? v : 0.f;
       }
     }
-    for (int el = wave; el < nenv_wg; el += RNT / 64) {
-      if (b0 + el < a.E) {
-        const bool live = t <= elen[el];
-        const unsigned ps = pfx[2 * rows + el];
-        float* srow = a.state + ((long)(b0 + el) * (T + 1) + t) * S;
-        for (int k = lane; k < S; k += 64) srow[k] = live ? 2.0f * u01(hfin(ps, (unsigned)k)) - 1.0f : 0.f;
+    for (int e = tl; e < vrows * A; e += nthr) {
+      const int r = (int)(((float)e + 0.5f) * invA);
+      const int k = e - r * A;
+      const int4 mt = rmeta[r];
+      const bool live = t <= mt.z;
+      const float v = live ? ((k == 0 || u01(hfin(pfx[rows + r], (unsigned)(mt.w * A + k))) < 0.7f) ? 1.f : 0.f) : 0.f;
+      a.avail[(long)mt.y + tNA + k] = v;
+      if (Av) Av[r * A + k] = v;
+    }
+    if (svec) {
+      for (int e = tl; e < nenv_wg * S4; e += nthr) {
+        const int el = (int)(((float)e + 0.5f) * invS4);
+        const int k = 4 * (e - el * S4);
+        const int4 mt = emeta[el];
+        if (mt.z) {
+          const unsigned ps = pfx[2 * rows + el];
+          const bool live = t <= mt.y;
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = live ? 2.0f * u01(hfin(ps, (unsigned)(k + i))) - 1.0f : 0.f;
+          *reinterpret_cast<f32x4*>(a.state + (long)mt.x + tS + k) = v;
+        }
+      }
+    } else {
+      for (int e = tl; e < nenv_wg * S; e += nthr) {
+        const int el = (int)(((float)e + 0.5f) * invS);
+        const int k = e - el * S;
+        const int4 mt = emeta[el];
+        if (mt.z) a.state[(long)mt.x + tS + k] = (t <= mt.y) ? 2.0f * u01(hfin(pfx[2 * rows + el], (unsigned)k)) - 1.0f : 0.f;
       }
     }
   };
@@ -133,9 +197,15 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   for (int e = tid; e < (rows - vrows) * O; e += RNT) In[(vrows + e / O) * KS + e % O] = 0.f;   // padding rows
   gen_prefix(0);
   __syncthreads();
-  gen_slot(0, true, Av0);
+  gen_slot(0, true, Av0, 0, RNT);
   __syncthreads();
   gen_prefix(1);          // consumed by gen_slot(1) after the first barrier of step 0
+  if (tid < rows) {       // uniforms of the first choice; tile counters
+    const unsigned env = (unsigned)(a.env0 + b0 + rowe[tid]), tg0 = (unsigned)(a.episode * (T + 1));
+    uex[tid] = u01(hkey(a.rseed, ST_EXPLORE, env, tg0, (unsigned)rown[tid]));
+    uex[rows + tid] = u01(hkey(a.rseed, ST_PICK, env, tg0, (unsigned)rown[tid]));
+    if (tid < 4) tilecnt[tid] = 0;
+  }
 
   // ---- weights (as in agent_fwd_kernel)
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
@@ -180,7 +250,11 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   float* Hn = Hb;
   float* AvC = Av0;
   float* AvN = Av1;
+  ST_DECL(10);
+  float eps_next = a.eps[0];
   for (int t = 0; t < T; ++t) {
+    const float eps = eps_next;                    // scalar load issued a step ahead
+    if (t + 1 < T) eps_next = a.eps[t + 1];
     // ---------------- phase 1: x = relu(fc1(in))
     for (int rt = team; rt < a.RT; rt += 4) {
       const bool two = rt + 2 < a.RT;
@@ -204,12 +278,31 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
         if (two) Xt[(r0 + 32 + i) * HS + j] = fmaxf(acc1[i], 0.f);
       }
     }
+    ST_MARK(0);
     WG_BARRIER();
+    ST_MARK(1);
     // the input tile is consumed: the env already knows the next observation (it does not depend on the
     // actions), so slot t+1 is generated now, under the shadow of the gate MFMAs of the other waves
-    gen_slot(t + 1, t + 1 < T, AvN);
+    // The two waves of a SIMD (same hidden-unit slice, one per team) share that slice's row tiles through a
+    // counter: team 1 first generates the whole slot (VALU + stores, overlapping team 0's MFMAs), then joins.
+    // (waves 4-7 are the younger half and lose the VALU arbitration against their partners' MFMA streams: raise
+    // their priority while they generate)
+    if (team == 1) {
+      __builtin_amdgcn_s_setprio(2);
+      gen_slot(t + 1, t + 1 < T, AvN, RNT / 2, RNT / 2);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    ST_MARK(2);
     // ---------------- phase 2: GRU
-    for (int rt = team; rt < a.RT; rt += 2) {
+    auto grab = [&]() {
+      int v = 0;
+      if (lane == 0) v = atomicAdd(&tilecnt[ws], 1);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    int rt_next = grab();
+    while (rt_next < a.RT) {
+      const int rt = rt_next;
+      rt_next = grab();
       f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
       f32x4 az = {bias_z, bias_z, bias_z, bias_z};
       f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
@@ -237,8 +330,20 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
         Hn[(r0 + i) * HS + j] = (1.f - zg) * ng + zg * hp;
       }
     }
+    ST_MARK(3);
     WG_BARRIER();
-    // ---------------- phase 3: q = fc2(h') -> LDS
+    ST_MARK(4);
+    // ---------------- phase 3: q = fc2(h') -> LDS; the two last waves (no fc2 tile unless RT > 6) hash the prefixes
+    // of slot t+2, whose observation is generated during the gates of step t+1
+    if (tid >= RNT - 128 && tid - (RNT - 128) < rows) {
+      const int r = tid - (RNT - 128);
+      const unsigned tg2 = (unsigned)(a.episode * (T + 1) + t) + 2u;
+      const unsigned env = (unsigned)(a.env0 + b0 + rowe[r]);
+      pfx[r] = hprefix(a.seed, ST_OBS, env, tg2);
+      pfx[rows + r] = hprefix(a.seed, ST_AVAIL, env, tg2);
+      if (r < nenv_wg) pfx[2 * rows + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg2);
+      if (r < 4) tilecnt[r] = 0;                  // all tiles of this step were grabbed before the barrier above
+    }
     for (int rt = wave; rt < a.RT; rt += 8) {
       f32x4 acc[AC];
 #pragma unroll
@@ -259,50 +364,58 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
         }
       }
     }
+    ST_MARK(5);
     WG_BARRIER();
-    // ---------------- epsilon-greedy choice (share_params.py:66-70), one thread per (env, agent) row
+    ST_MARK(6);
+    // ---------------- epsilon-greedy choice (share_params.py:66-70): 16*AC lanes per (env, agent) row, lane = action;
+    // first-index argmax over the available actions by a lane-group max + ballot, the explored action is the
+    // kk-th set bit of the availability mask (the serial per-thread form of this took 13-35 % of a lock-step)
     const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-    const float eps = a.eps[t];
-    if (tid < vrows) {
-      const int r = tid, el = rowe[r], n = rown[r];
-      const unsigned env = (unsigned)(a.env0 + b0 + el);
-      int arg = -1;
-      if (t < elen[el]) {
-        const float* qa = Qs + r * AS;
-        const float* av = AvC + r * A;
-        float best = 0.f; int navail = 0;
-        for (int k = 0; k < A; ++k) {
-          if (av[k] == 0.f) continue;
-          ++navail;
-          if (arg < 0 || qa[k] > best) { best = qa[k]; arg = k; }
-        }
-        if (arg < 0) arg = 0;
-        const bool explore = u01(hkey(a.rseed, ST_EXPLORE, env, tg, (unsigned)n)) < eps;
-        if (explore && navail > 0) {
-          int kk = (int)floorf(u01(hkey(a.rseed, ST_PICK, env, tg, (unsigned)n)) * (float)navail);
-          if (kk > navail - 1) kk = navail - 1;
-          int c = 0;
-          for (int k = 0; k < A; ++k) {
-            if (av[k] == 0.f) continue;
-            if (c == kk) { arg = k; break; }
-            ++c;
+    {
+      constexpr int LG = 16 * AC;
+      constexpr unsigned GM = LG == 32 ? 0xffffffffu : ((1u << LG) - 1u);
+      const int gl = lane & (LG - 1), sh = lane & ~(LG - 1);
+      for (int base = wave * (64 / LG); base < vrows; base += (RNT / 64) * (64 / LG)) {
+        const int r = base + lane / LG;
+        const bool valid = r < vrows;
+        const int rr = valid ? r : vrows - 1;
+        const int4 mt = rmeta[rr];
+        const int n = mt.w;
+        const bool on = gl < A && AvC[rr * A + (gl < A ? gl : 0)] != 0.f;
+        const float v = on ? Qs[rr * AS + gl] : -3.0e38f;
+        float mx = group_max16(v);
+        if (LG == 32) mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        const unsigned am = (unsigned)(__ballot(on) >> sh) & GM;
+        const unsigned em = (unsigned)(__ballot(on && v == mx) >> sh) & GM;
+        const int navail = __popc(am);
+        int arg = em ? __ffs(em) - 1 : (am ? __ffs(am) - 1 : 0);
+        const bool explore = uex[rr] < eps;
+        int kk = (int)floorf(uex[rows + rr] * (float)navail);
+        if (kk > navail - 1) kk = navail - 1;
+        const bool sel = explore && on && __popc(am & ((1u << gl) - 1u)) == kk;
+        const unsigned sm = (unsigned)(__ballot(sel) >> sh) & GM;
+        if (sm) arg = __ffs(sm) - 1;
+        if (!(t < mt.z)) arg = -1;
+        if (valid) {
+          if (gl == 0) {
+            act[r] = arg;
+            a.u[((long)(b0 + rowe[rr]) * T + t) * N + n] = arg;
           }
+          if (a.has_act && gl < A) In[r * KS + O + gl] = (gl == arg) ? 1.f : 0.f;      // one-hot fed to step t+1
         }
       }
-      act[r] = arg;
-      a.u[((long)(b0 + el) * T + t) * N + n] = arg;
-      // hash prefixes of slot t+2 (its observation is generated during the gates of step t+1)
-      {
-        const unsigned tg2 = tg + 2u;
-        pfx[r] = hprefix(a.seed, ST_OBS, env, tg2);
-        pfx[rows + r] = hprefix(a.seed, ST_AVAIL, env, tg2);
-        if (r < nenv_wg) pfx[2 * rows + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg2);
-      }
-      if (a.has_act)
-        for (int k = 0; k < A; ++k) In[r * KS + O + k] = (k == arg) ? 1.f : 0.f;   // one-hot fed to step t+1
     }
+    ST_MARK(7);
     WG_BARRIER();
-    // ---------------- env step: reward / terminated / padded (fixed-order fp32 sum over agents)
+    ST_MARK(8);
+    // ---------------- env step: reward / terminated / padded (fixed-order fp32 sum over agents); the two last
+    // waves hash the uniforms of the NEXT step's epsilon-greedy choice (they do not depend on q)
+    if (tid >= RNT - 128 && tid - (RNT - 128) < rows) {
+      const int r = tid - (RNT - 128);
+      const unsigned env = (unsigned)(a.env0 + b0 + rowe[r]), nn_ = (unsigned)rown[r];
+      uex[r] = u01(hkey(a.rseed, ST_EXPLORE, env, tg + 1u, nn_));
+      uex[rows + r] = u01(hkey(a.rseed, ST_PICK, env, tg + 1u, nn_));
+    }
     if (tid < nenv_wg && b0 + tid < a.E) {
       const int el = tid, L = elen[el];
       const bool live = t < L;
@@ -319,8 +432,10 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     }
     float* tmp = Hp; Hp = Hn; Hn = tmp;
     tmp = AvC; AvC = AvN; AvN = tmp;
+    ST_MARK(9);
     // no barrier: `act` is next written after three more barriers; In/Xt/H hazards as in agent_fwd_kernel
   }
+  ST_DUMP(10);
   if (a.h_out) {
     WG_BARRIER();
     for (int e = tid; e < rows * H; e += RNT) {
@@ -333,12 +448,14 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
 
 }  // namespace
 
+ST_DEFINE_SETTER(marl_debug_stamps_rollout)
+
 // a workgroup holds whole environments (EPW*N rows padded to 16*RT, RT <= 8); the fc1 slice + the row state
 // must fit the 160 KB LDS (widest input assumed: last action and agent id appended)
 static int max_rt(int I, int A) {
   const int KC = (I + 15) / 16, KS = KC * 16 + 4;
-  const size_t fixed = (size_t)4 * KC * 64 * 16;
-  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12;
+  const size_t fixed = (size_t)4 * KC * 64 * 16 + 16;
+  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12 + 32 + 8;
   int rt = 0;
   for (int c = 1; c <= 8; ++c) if (fixed + per_row * 16 * c <= 160 * 1024) rt = c;
   return rt;
@@ -368,10 +485,13 @@ extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, 
   a.KC = (a.I + 15) / 16;
   a.R = (long)E * N;
   const int KS = a.KC * 16 + 4;
-  const size_t fixed = (size_t)4 * a.KC * 64 * 16;
-  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12;
+  const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16;
+  const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12 + 32 + 8;
   // environments per workgroup: one workgroup per CU when the batch allows it (a lock-step is latency
   // bound, so small batches spread over all CUs with partly filled tiles), capped by the LDS budget
+  // record offsets are 32-bit element offsets inside the kernel
+  if ((double)E * (T + 1) * N * (O > A ? O : A) >= 2147483648.0 || (double)E * (T + 1) * S >= 2147483648.0)
+    return (int)hipErrorInvalidValue;
   const int rt_max = max_rt(a.I, A);
   if (16 * rt_max < N) return (int)hipErrorInvalidValue;
   int epw = (E + 255) / 256;
