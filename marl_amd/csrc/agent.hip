@@ -59,7 +59,7 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-template <int AC, bool SAVE>
+template <int AC, bool SAVE, bool VL>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,47 +107,58 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const int O4 = O >> 2, n4 = rows * O4;
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
   f32x4 pf[NLDW];
-  int pu = -1;
+  int pt = 0;                         // step the prefetch registers belong to
+  int pu = -1, pu_lds = -1;           // action fed at the step being prefetched / one-hot column currently set in LDS
+  // the element -> (row, column group) map of the prefetch is the same every step: resolve it once
+  long goff[NLDW]; int loff[NLDW], plen[NLDW];
+#pragma unroll
+  for (int i = 0; i < NLDW; ++i) {
+    // elements past the tile are clamped to its last one (same value, same address): branch-free step loop
+    int e = tid + FNT * i;
+    if (e > n4 - 1) e = n4 - 1;
+    if (e < 0) e = 0;
+    const int r = (int)(((float)e + 0.5f) * invO4);
+    const int k4 = e - r * O4;
+    loff[i] = r * KS + 4 * k4;
+    goff[i] = rowobs[r] + 4 * k4;
+    plen[i] = rowlen[r];
+  }
+  const long urow = tid < rows ? rowu[tid] : 0;
   auto issue = [&](int t) {           // start the loads of step t's observations (vector path)
     const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
     for (int i = 0; i < NLDW; ++i) {
-      int e = tid + FNT * i;
-      asm volatile("" : "+v"(e));     // keep the address math inside the step (no hoisting -> no spills)
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < n4) {
-        const int r = (int)(((float)e + 0.5f) * invO4);
-        const int k4 = e - r * O4;
-        if (t < rowlen[r]) v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + toff + 4 * k4);
-      }
-      pf[i] = v;
+      // always loaded (the record has every slot); steps past the episode end are zeroed at commit
+      pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
     }
+    pt = t;
     int u = -1;
-    if (tid < rows && a.ufed && t + a.u_t0 >= 0) u = a.ufed[rowu[tid] + (long)(t + a.u_t0) * a.N];
+    if (tid < rows && a.ufed && t + a.u_t0 >= 0) u = a.ufed[urow + (long)(t + a.u_t0) * a.N];
     pu = u;
   };
-  auto commit = [&]() {               // registers -> LDS tile, plus the synthesised one-hot / id columns
+  auto commit = [&]() {               // registers -> LDS tile; the one-hot(last action) column is flipped in place
 #pragma unroll
-    for (int i = 0; i < NLDW; ++i) {
-      int e = tid + FNT * i;
-      asm volatile("" : "+v"(e));
-      if (e < n4) {
-        const int r = (int)(((float)e + 0.5f) * invO4);
-        const int k4 = e - r * O4;
-        *reinterpret_cast<f32x4*>(In + r * KS + 4 * k4) = pf[i];
-      }
-    }
-    if (tid < rows) {
-      const int r = tid;
-      const int n = rown[r];
-      for (int k = O; k < KP; ++k) {
-        float v = 0.f;
-        if (a.has_act && k < O + a.A) v = (pu == k - O) ? 1.f : 0.f;
-        else if (a.has_id && k >= a.I - a.N && k < a.I) v = (n == k - (a.I - a.N)) ? 1.f : 0.f;
-        In[r * KS + k] = v;
+    for (int i = 0; i < NLDW; ++i)
+      *reinterpret_cast<f32x4*>(In + loff[i]) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.has_act && tid < rows) {
+      const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
+      if (pn != pu_lds) {
+        if (pu_lds >= 0) In[tid * KS + O + pu_lds] = 0.f;
+        if (pn >= 0) In[tid * KS + O + pn] = 1.f;
+        pu_lds = pn;
       }
     }
   };
+  // constant columns of the input tile: empty one-hot, agent id, zero pad (vector path; written once)
+  if (VL) {
+    for (int e = tid; e < rows * (KP - O); e += FNT) {
+      const int r = e / (KP - O), k = O + e % (KP - O);
+      float v = 0.f;
+      if (a.has_id && k >= a.I - a.N && k < a.I) v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
+      In[r * KS + k] = v;
+    }
+    __syncthreads();
+  }
   auto load_generic = [&](int t) {    // element loads, no run-ahead (obs width not a multiple of 4 / unaligned)
     for (int e = tid; e < rows * KP; e += FNT) {
       const int r = e / KP, k = e - r * KP;
@@ -164,7 +175,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       In[r * KS + k] = v;
     }
   };
-  if (a.vload) { issue(0); commit(); if (a.T > 1) issue(1); }
+  // NOTE the prefetch is issued UNCONDITIONALLY every step (the step index is clamped): a conditional issue makes
+  // the prefetch registers a phi of (loaded, old) and the compiler then drains vmcnt right after the loads to copy
+  if (VL) { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
   else load_generic(0);
 
   // ---- stage weights: fc1 slice -> LDS fragments (team 0 writes, both teams read); GRU / fc2 -> registers
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const unsigned jb = (unsigned)j * 4u;
   float* Hp = Ha;
   float* Hn = Hb;
+  ST_DECL(6);
   for (int t = 0; t < a.T; ++t) {
     const unsigned trow = (unsigned)t * (unsigned)a.N;
     float* const svt = SAVE ? a.saved + (long)t * a.R * (6 * H) : nullptr;
@@ -259,12 +273,17 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         }
       }
     }
+    ST_MARK(0);
     WG_BARRIER();
+    ST_MARK(1);
     // the input tile has been consumed: refill it for step t+1, start the loads of step t+2
-    if (t + 1 < a.T) {
-      if (a.vload) { commit(); if (t + 2 < a.T) issue(t + 2); }
-      else load_generic(t + 1);
+    if (VL) {
+      commit();                                   // (after the last step this writes a tile nobody reads)
+      issue(t + 2 < a.T ? t + 2 : a.T - 1);
+    } else if (t + 1 < a.T) {
+      load_generic(t + 1);
     }
+    ST_MARK(2);
     // ---------------- phase 2: GRU gates + pointwise update
     const bool last = (t == a.T - 1) && a.h_last;
     for (int rt = team; rt < a.RT; rt += 2) {
@@ -316,7 +335,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         st32(a.h_last, (unsigned)rr.z * 256u + jb, vh[2]); st32(a.h_last, (unsigned)rr.w * 256u + jb, vh[3]);
       }
     }
+    ST_MARK(3);
     WG_BARRIER();
+    ST_MARK(4);
     // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the 8 waves)
     for (int rt = wave; rt < a.RT; rt += 8) {
       f32x4 acc[AC];
@@ -344,9 +365,11 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       }
     }
     float* tmp = Hp; Hp = Hn; Hn = tmp;
+    ST_MARK(5);
     // no barrier here: phase 1 of t+1 reads In (refilled before the 2nd barrier above) and writes Xt
     // (last read before it); Hn of step t is only re-written in phase 2 of t+2, two barriers later.
   }
+  ST_DUMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -666,6 +689,8 @@ __global__ __launch_bounds__(256) void agent_bwd_reduce_kernel(BwdRedArgs a) {
 static int marl_fwd_rt_single = 8;   // measured: 1/2/3/5 tiles per workgroup -> 12.1/9.4/8.1/6.5 ms per 120-step rollout
 extern "C" void marl_debug_set_rt_single(int v) { marl_fwd_rt_single = v < 1 ? 1 : v; }
 
+ST_DEFINE_SETTER(marl_debug_stamps_fwd)
+
 // choose row tiles per workgroup: fill 256 CUs, keep LDS within budget
 inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap) {
   const long tiles = (R + 15) / 16;
@@ -718,17 +743,16 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
   hipError_t e;
   const void* fn;
-  if (A <= 16) fn = saved ? (const void*)agent_fwd_kernel<1, true> : (const void*)agent_fwd_kernel<1, false>;
-  else fn = saved ? (const void*)agent_fwd_kernel<2, true> : (const void*)agent_fwd_kernel<2, false>;
+#define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
+  const bool sv = saved != nullptr, vl = a.vload != 0;
+  if (A <= 16) fn = sv ? (vl ? FWD_PICK(1, true, true) : FWD_PICK(1, true, false)) : (vl ? FWD_PICK(1, false, true) : FWD_PICK(1, false, false));
+  else fn = sv ? (vl ? FWD_PICK(2, true, true) : FWD_PICK(2, true, false)) : (vl ? FWD_PICK(2, false, true) : FWD_PICK(2, false, false));
+#undef FWD_PICK
   e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  if (A <= 16) {
-    if (saved) hipLaunchKernelGGL((agent_fwd_kernel<1, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((agent_fwd_kernel<1, false>), grid, block, lds, s, a);
-  } else {
-    if (saved) hipLaunchKernelGGL((agent_fwd_kernel<2, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((agent_fwd_kernel<2, false>), grid, block, lds, s, a);
-  }
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, grid, block, kargs, lds, s);
+  if (e != hipSuccess) return (int)e;
   MARL_CHECK_LAUNCH();
   return 0;
 }
