@@ -407,7 +407,7 @@ __host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + 
 //       team 1 ("hh"): dh_prev = carry + [drp|dzp|dhn] W_hh          ;  dW_hh += [drp|dzp|dhn]^T h_prev ; dW_2 += dq^T h
 //   Both roles run the SAME code on the same register arrays (wT, accW, cur/nxt); only base pointers and
 //   LDS column offsets differ, so the register allocation is that of one role.
-template <int AC>
+template <int AC, bool DHS>
 __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       P[2][i] = (en) ? sp_[3 * H] : 0.f;                                                                 \
       P[3][i] = (en) ? sp_[4 * H] : 0.f;                                                                 \
       P[4][i] = (en) ? sp_[5 * H] : 0.f;                                                                 \
-      P[5][i] = ((en) && a.dhs) ? a.dhs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] * rowok[r_] : 0.f; \
+      if (DHS) P[5][i] = (en) ? a.dhs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] * rowok[r_] : 0.f; \
     }                                                                                                    \
   }
 #define LOAD_C(P, tt, rr, en)                                                                            \
@@ -493,7 +493,6 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c][i] = (en) ? sp_[16 * c + m] : 0.f;              \
       if (team) P[4][i] = (en) ? a.hs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] : 0.f;          \
       else P[4][i] = (en) ? sp_[j] : 0.f;                                                                \
-      P[5][i] = 0.f;                                                                                     \
     }                                                                                                    \
   }
   auto dq_elem = [&](int t, int e) -> float {
@@ -503,12 +502,109 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 
   for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
   const bool hasB = team < a.RT;                   // this team owns at least one row tile in phase B
-  f32x4 cur[6], nxt[6];
-  if (hasB) LOAD_B(cur, a.T - 1, team, true)
-  else LOAD_C(cur, a.T - 1, 0, true)
+  const bool full_wg = row0 + rows <= a.R;         // no rows past the batch in this workgroup
+  // Register sets of the software pipeline.  NO set is ever copied into another inside the step loop: a copy
+  // needs the loaded values and makes the compiler drain vmcnt right where the prefetch was issued.
+  //   both phases alternate their row tiles between sA and sB
+  f32x4 sA[6], sB[6];
+  if (hasB) LOAD_B(sA, a.T - 1, team, true)
+  else LOAD_C(sA, a.T - 1, 0, true)
   __syncthreads();
 
+  // ---- phase B body for one row tile: dh = carry + dhs + dq W2^T ; gate gradients -> DG, carry*z -> CAR
+  auto procB = [&](const f32x4 (&P)[6], int rt, const float* DQ) __attribute__((always_inline)) {
+    f32x4 dh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+    const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
+      dh = mfma16x4(av, w2T[ac], dh);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rt * 16 + 4 * q + i;
+      const float d = DHS ? dh[i] + P[5][i] : dh[i];
+      const float rg = P[1][i], zg = P[2][i], ng = P[3][i];
+      const float dn = d * (1.f - zg);
+      const float dz = d * (P[0][i] - ng);
+      const float dnp = dn * (1.f - ng * ng);
+      const float dzp = dz * zg * (1.f - zg);
+      const float drp = dnp * P[4][i] * rg * (1.f - rg);
+      const float dhn = dnp * rg;
+      float* l = DG + r * DGS + j;
+      l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
+      CAR[r * HS + j] = d * zg;
+      sb_r += drp; sb_z += dzp; sb_n += dnp; sb_hn += dhn;
+    }
+  };
+  // ---- phase C body for one row tile: this role's products
+  auto procC = [&](const f32x4 (&P)[6], int rt, int t, const float* DQ) __attribute__((always_inline)) {
+    const int r0 = rt * 16 + 4 * q;
+    f32x4 main;                                   // dx (team 0)  /  dh_prev (team 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) main[i] = team ? CAR[(r0 + i) * HS + j] : 0.f;
+    const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const int coff = (team && c >= 8) ? 192 + 16 * (c - 8) : 16 * c;       // team 1 reads dhn instead of dnp
+      f32x4 av = *reinterpret_cast<const f32x4*>(gr + coff);
+      main = mfma16x4(av, wT[c], main);
+    }
+    // gate-gradient tiles of this wave's 16 columns in accumulator layout (they ARE the A^T fragments)
+    f32x4 g0, g1, g2;
+    const int g2off = team ? 192 : 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* l = DG + (r0 + i) * DGS + j;
+      g0[i] = l[0]; g1[i] = l[64]; g2[i] = l[g2off];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      accW[0][c] = mfma16x4(g0, P[c], accW[0][c]);
+      accW[1][c] = mfma16x4(g1, P[c], accW[1][c]);
+      accW[2][c] = mfma16x4(g2, P[c], accW[2][c]);
+    }
+    if (team) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = main[i];
+#pragma unroll
+      for (int ac = 0; ac < AC; ++ac) {
+        f32x4 dqf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
+        accW2[ac] = mfma16x4(dqf, P[4], accW2[ac]);
+        sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
+      }
+    } else {
+      // uniform base + 32-bit byte offsets (B*T*N*64*4 < 4 GB is checked on the host); only the last workgroup
+      // can hold rows past the batch and needs the per-row predicate
+      const int4 ri = *reinterpret_cast<const int4*>(rowidx + r0);
+      const unsigned trow = (unsigned)t * (unsigned)a.N, jb = (unsigned)j * 4u;
+      const unsigned o0 = ((unsigned)ri.x + trow) * 256u + jb, o1 = ((unsigned)ri.y + trow) * 256u + jb;
+      const unsigned o2 = ((unsigned)ri.z + trow) * 256u + jb, o3 = ((unsigned)ri.w + trow) * 256u + jb;
+      const float v0 = P[4][0] > 0.f ? main[0] : 0.f, v1 = P[4][1] > 0.f ? main[1] : 0.f;
+      const float v2 = P[4][2] > 0.f ? main[2] : 0.f, v3 = P[4][3] > 0.f ? main[3] : 0.f;
+      if (full_wg) {
+        st32(a.dxp, o0, v0); st32(a.dxp, o1, v1); st32(a.dxp, o2, v2); st32(a.dxp, o3, v3);
+      } else {
+        if (rowok[r0] != 0.f) st32(a.dxp, o0, v0);
+        if (rowok[r0 + 1] != 0.f) st32(a.dxp, o1, v1);
+        if (rowok[r0 + 2] != 0.f) st32(a.dxp, o2, v2);
+        if (rowok[r0 + 3] != 0.f) st32(a.dxp, o3, v3);
+      }
+    }
+  };
+  // loads of the first item of the NEXT step (its phase-B tile, or phase-C tile 0 for a team without one)
+#define LOAD_NEXT_STEP(P, t)                                  \
+  {                                                           \
+    if (hasB) LOAD_B(P, ((t) > 0 ? (t) - 1 : 0), team, (t) > 0) \
+    else LOAD_C(P, ((t) > 0 ? (t) - 1 : 0), 0, (t) > 0)       \
+  }
+
   int par = 0;
+  ST_DECL(5);
   for (int t = a.T - 1; t >= 0; --t, par ^= 1) {
     float* DQ = par ? DQ1 : DQ0;
     float* DQn = par ? DQ0 : DQ1;
@@ -518,89 +614,48 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       const int e = tid + BNT * i;
       dqpre[i] = (t > 0 && e < rows * QP) ? dq_elem(t - 1, e) : 0.f;
     }
-    // ---------------- phase B: dh = carry + dhs + dq W2^T ; gate gradients -> DG, carry*z -> CAR
-    for (int rt = team; rt < a.RT; rt += 2) {
-      if (rt + 2 < a.RT) LOAD_B(nxt, t, rt + 2, true)
-      else LOAD_C(nxt, t, 0, true)
-      f32x4 dh;
+    // ---------------- phase B.  Entering: sA = the team's first tile (or, without one, phase-C tile 0).
+    // Tiles alternate between sA and sB; the item after the last tile is phase-C tile 0, which must end up in sA.
+    if (hasB) {
+      int rt = team;
+      while (true) {
+        bool more = rt + 2 < a.RT;
+        if (more) LOAD_B(sB, t, rt + 2, true)
+        else LOAD_C(sB, t, 0, true)
+        procB(sA, rt, DQ);
+        if (!more) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
-      const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
-#pragma unroll
-      for (int ac = 0; ac < AC; ++ac) {
-        f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
-        dh = mfma16x4(av, w2T[ac], dh);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = rt * 16 + 4 * q + i;
-        const float d = dh[i] + cur[5][i];
-        const float rg = cur[1][i], zg = cur[2][i], ng = cur[3][i];
-        const float dn = d * (1.f - zg);
-        const float dz = d * (cur[0][i] - ng);
-        const float dnp = dn * (1.f - ng * ng);
-        const float dzp = dz * zg * (1.f - zg);
-        const float drp = dnp * cur[4][i] * rg * (1.f - rg);
-        const float dhn = dnp * rg;
-        float* l = DG + r * DGS + j;
-        l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
-        CAR[r * HS + j] = d * zg;
-        sb_r += drp; sb_z += dzp; sb_n += dnp; sb_hn += dhn;
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
-    }
-    WG_BARRIER();
-    // ---------------- phase C: every wave, all row tiles, its role's products
-    for (int rt = 0; rt < a.RT; ++rt) {
-      if (rt + 1 < a.RT) LOAD_C(nxt, t, rt + 1, true)
-      else if (hasB) LOAD_B(nxt, (t > 0 ? t - 1 : 0), team, t > 0)
-      else LOAD_C(nxt, (t > 0 ? t - 1 : 0), 0, t > 0)
-      const int r0 = rt * 16 + 4 * q;
-      f32x4 main;                                   // dx (team 0)  /  dh_prev (team 1)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) main[i] = team ? CAR[(r0 + i) * HS + j] : 0.f;
-      const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
-#pragma unroll
-      for (int c = 0; c < 12; ++c) {
-        const int coff = (team && c >= 8) ? 192 + 16 * (c - 8) : 16 * c;       // team 1 reads dhn instead of dnp
-        f32x4 av = *reinterpret_cast<const f32x4*>(gr + coff);
-        main = mfma16x4(av, wT[c], main);
-      }
-      // gate-gradient tiles of this wave's 16 columns in accumulator layout (they ARE the A^T fragments)
-      f32x4 g0, g1, g2;
-      const int g2off = team ? 192 : 128;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* l = DG + (r0 + i) * DGS + j;
-        g0[i] = l[0]; g1[i] = l[64]; g2[i] = l[g2off];
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        accW[0][c] = mfma16x4(g0, cur[c], accW[0][c]);
-        accW[1][c] = mfma16x4(g1, cur[c], accW[1][c]);
-        accW[2][c] = mfma16x4(g2, cur[c], accW[2][c]);
-      }
-      if (team) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = main[i];
-#pragma unroll
-        for (int ac = 0; ac < AC; ++ac) {
-          f32x4 dqf;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
-          accW2[ac] = mfma16x4(dqf, cur[4], accW2[ac]);
-          sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
+          for (int k = 0; k < 5; ++k) sA[k] = sB[k];               // (one copy per step, a tile of work after the issue)
+          break;
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (rowok[r0 + i] != 0.f)
-            a.dxp[((long)rowidx[r0 + i] + (long)t * tstride) * H + j] = cur[4][i] > 0.f ? main[i] : 0.f;
+        rt += 2;
+        more = rt + 2 < a.RT;
+        if (more) LOAD_B(sA, t, rt + 2, true)
+        else LOAD_C(sA, t, 0, true)
+        procB(sB, rt, DQ);
+        if (!more) break;
+        rt += 2;
       }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
     }
+    ST_MARK(0);
+    WG_BARRIER();
+    ST_MARK(1);
+    // ---------------- phase C: every wave, all row tiles, alternating sA / sB
+    for (int rt = 0; rt < a.RT; rt += 2) {
+      if (rt + 1 < a.RT) LOAD_C(sB, t, rt + 1, true)
+      else LOAD_NEXT_STEP(sB, t)
+      procC(sA, rt, t, DQ);
+      if (rt + 1 < a.RT) {
+        if (rt + 2 < a.RT) LOAD_C(sA, t, rt + 2, true)
+        else LOAD_NEXT_STEP(sA, t)
+        procC(sB, rt + 1, t, DQ);
+      }
+    }
+    if (a.RT & 1) {                 // odd tile count: the next step's first item landed in sB (one copy per step,
+#pragma unroll                      // a whole tile after its loads were issued)
+      for (int k = 0; k < (DHS ? 6 : 5); ++k) sA[k] = sB[k];
+    }
+    ST_MARK(2);
     if (t > 0) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
@@ -608,8 +663,11 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
         if (e < rows * QP) DQn[(e / QP) * QS + (e % QP)] = dqpre[i];
       }
     }
+    ST_MARK(3);
     WG_BARRIER();
+    ST_MARK(4);
   }
+  ST_DUMP(5);
   if (a.dh0 && team) {
     for (int r = 4 * q; r < rows; r += 16)
 #pragma unroll
@@ -690,6 +748,9 @@ static int marl_fwd_rt_single = 8;   // measured: 1/2/3/5 tiles per workgroup ->
 extern "C" void marl_debug_set_rt_single(int v) { marl_fwd_rt_single = v < 1 ? 1 : v; }
 
 ST_DEFINE_SETTER(marl_debug_stamps_fwd)
+#ifdef MARL_STAMPS
+extern "C" int marl_debug_stamps_bwd(void* p) { return marl_debug_stamps_fwd(p); }
+#endif
 
 // choose row tiles per workgroup: fill 256 CUs, keep LDS within budget
 inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap) {
@@ -780,6 +841,7 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   if (B <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
   if (ws_bytes < marl_agent_bwd_workspace(B, N, A)) return (int)hipErrorInvalidValue;
+  if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;   // 32-bit byte offsets into dxp
   BwdArgs a;
   a.Wih = w->w_ih; a.Whh = w->w_hh; a.W2 = w->fc2_w;
   a.dq = dq; a.dhs = dhs; a.saved = saved; a.hs = hs; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
@@ -794,15 +856,14 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   dim3 grid(nwg), block(BNT);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
-  if (AC == 1) {
-    e = hipFuncSetAttribute((const void*)agent_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((agent_bwd_kernel<1>), grid, block, lds, s, a);
-  } else {
-    e = hipFuncSetAttribute((const void*)agent_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((agent_bwd_kernel<2>), grid, block, lds, s, a);
-  }
+  const void* fn;
+  if (AC == 1) fn = dhs ? (const void*)agent_bwd_kernel<1, true> : (const void*)agent_bwd_kernel<1, false>;
+  else fn = dhs ? (const void*)agent_bwd_kernel<2, true> : (const void*)agent_bwd_kernel<2, false>;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, grid, block, kargs, lds, s);
+  if (e != hipSuccess) return (int)e;
   MARL_CHECK_LAUNCH();
   BwdRedArgs r;
   r.ws = ws; r.nwg = (int)nwg; r.A = A;

@@ -12,7 +12,7 @@ from marl_amd import _lib  # noqa: E402
 SEGS = {
     "rollout": ["fc1", "bar1", "gen_slot", "gru", "bar2", "fc2", "bar3", "choice", "bar4", "envstep"],
     "fwd": ["fc1", "bar1", "commit", "gru", "bar2", "fc2"],
-    "bwd": ["s%d" % i for i in range(12)],
+    "bwd": ["phaseB", "bar1", "phaseC", "dqwrite", "bar2"],
 }
 
 
