@@ -410,8 +410,8 @@ __host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + 
 template <int AC, bool DHS>
 __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int team = wave >> 2, ws = wave & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, ws = wave & 3;      // wave-uniform (scalar registers)
   const int q = lane >> 4, m = lane & 15;
   const int rows = a.RT * 16;
   constexpr int QP = AC * 16, QS = QP + 4;
@@ -507,8 +507,16 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   // needs the loaded values and makes the compiler drain vmcnt right where the prefetch was issued.
   //   both phases alternate their row tiles between sA and sB
   f32x4 sA[6], sB[6];
+  // item 1 of a step (the team's 2nd phase-B tile, or phase-C tile 0 when it has only one) is issued into sB as
+  // soon as the previous step's last phase-C tile has released that set - before the end-of-step barrier
+#define LOAD_ITEM1(tt, en)                                         \
+  {                                                                \
+    if (team + 2 < a.RT) LOAD_B(sB, tt, team + 2, en)              \
+    else LOAD_C(sB, tt, 0, en)                                     \
+  }
   if (hasB) LOAD_B(sA, a.T - 1, team, true)
   else LOAD_C(sA, a.T - 1, 0, true)
+  if (hasB) LOAD_ITEM1(a.T - 1, true)
   __syncthreads();
 
   // ---- phase B body for one row tile: dh = carry + dhs + dq W2^T ; gate gradients -> DG, carry*z -> CAR
@@ -616,18 +624,19 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     }
     // ---------------- phase B.  Entering: sA = the team's first tile (or, without one, phase-C tile 0).
     // Tiles alternate between sA and sB; the item after the last tile is phase-C tile 0, which must end up in sA.
+    bool c0A = true;                 // phase-C tile 0 ends up in sA (else sB)
     if (hasB) {
       int rt = team;
+      bool pre = true;               // sB already holds (in flight) the item after the first tile
       while (true) {
         bool more = rt + 2 < a.RT;
-        if (more) LOAD_B(sB, t, rt + 2, true)
-        else LOAD_C(sB, t, 0, true)
-        procB(sA, rt, DQ);
-        if (!more) {
-#pragma unroll
-          for (int k = 0; k < 5; ++k) sA[k] = sB[k];               // (one copy per step, a tile of work after the issue)
-          break;
+        if (!pre) {
+          if (more) LOAD_B(sB, t, rt + 2, true)
+          else LOAD_C(sB, t, 0, true)
         }
+        pre = false;
+        procB(sA, rt, DQ);
+        if (!more) { c0A = false; break; }
         rt += 2;
         more = rt + 2 < a.RT;
         if (more) LOAD_B(sA, t, rt + 2, true)
@@ -641,9 +650,20 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     WG_BARRIER();
     ST_MARK(1);
     // ---------------- phase C: every wave, all row tiles, alternating sA / sB
-    for (int rt = 0; rt < a.RT; rt += 2) {
+    // tiles alternate between the sets; when tile 0 sits in sB (odd number of phase-B tiles) a prologue processes
+    // it from there and the main loop starts at tile 1.  Item 0 of the next step is loaded while the last tile is
+    // processed and must end up in sA.
+    int rt0 = 0;
+    bool in_a = true;                 // next-step item 0 landed in sA
+    if (!c0A) {
+      if (1 < a.RT) LOAD_C(sA, t, 1, true)
+      else LOAD_NEXT_STEP(sA, t)
+      procC(sB, 0, t, DQ);
+      rt0 = 1;
+    }
+    for (int rt = rt0; rt < a.RT; rt += 2) {
       if (rt + 1 < a.RT) LOAD_C(sB, t, rt + 1, true)
-      else LOAD_NEXT_STEP(sB, t)
+      else { LOAD_NEXT_STEP(sB, t) in_a = false; }
       procC(sA, rt, t, DQ);
       if (rt + 1 < a.RT) {
         if (rt + 2 < a.RT) LOAD_C(sA, t, rt + 2, true)
@@ -651,10 +671,11 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
         procC(sB, rt + 1, t, DQ);
       }
     }
-    if (a.RT & 1) {                 // odd tile count: the next step's first item landed in sB (one copy per step,
-#pragma unroll                      // a whole tile after its loads were issued)
+    if (!in_a) {                      // one copy per step, a whole tile after the loads were issued
+#pragma unroll
       for (int k = 0; k < (DHS ? 6 : 5); ++k) sA[k] = sB[k];
     }
+    if (hasB && t > 0) LOAD_ITEM1(t - 1, true)
     ST_MARK(2);
     if (t > 0) {
 #pragma unroll
