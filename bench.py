@@ -83,8 +83,8 @@ def cpu_baseline(alg, shape, T, envs, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=4096, help="GLOBAL number of parallel envs / episodes per update")
     ap.add_argument("--alg", default="qmix")
     ap.add_argument("--shape", default="2s3z")
@@ -167,13 +167,25 @@ def main():
 
     for _ in range(o.warmup):
         one_step()
+    # a full (generation-2) Python garbage collection costs ~35 ms here - three pipeline steps; collect now and
+    # keep the collector off inside the timed regions (what timeit does)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     timing["on"] = True
     t0 = time.perf_counter()
     env_steps = 0
     for _ in range(o.steps):
+        ts = time.perf_counter()
         s, loss = one_step()
         env_steps += s
+        if os.environ.get("MARL_BENCH_DEBUG"):
+            torch.cuda.synchronize()
+            import gc
+            ms = torch.cuda.memory_stats()
+            print("step %.2f ms gc=%s segs=%d reserved=%.2fGB allocs=%d" % ((time.perf_counter() - ts) * 1e3, gc.get_count(),
+                  ms["segment.all.current"], ms["reserved_bytes.all.current"] / 2**30, ms["allocation.all.allocated"]), file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
     timing["on"] = False
@@ -197,6 +209,7 @@ def main():
     for i in range(o.leg_iters):
         rs += worker.generate_episodes(E)[3]
     barrier(); t_roll = (time.perf_counter() - t1) / o.leg_iters
+    gc.enable()
 
     if rank == 0:
         fl = agent_flops(args) * E * N * T                 # algorithmic FLOP of one unroll launch

@@ -32,6 +32,9 @@ typedef struct {
   const float* m0; long ldm0;               /* optional relu gate on segment 0: v * (m0 > 0) */
   long rpe0, bs0, off0;                     /* row remap for p0 (and m0) */
   long rpei, bsi, offi;                     /* row remap for idx */
+  const int* emap0;                         /* optional episode map of the p0 remap (needs rpe0 > 0): episode
+                                               e = row / rpe0 reads storage episode emap0[e] - replay samples are
+                                               read in place from the ring (common/replaybuffer.py:54-60) */
 } marl_src_t;
 
 /* Batched ("grouped") launches over equally shaped problems whose operands sit at a constant
@@ -74,13 +77,16 @@ int marl_wgrad_slabs(int M);
  *           value < 0 or ufed == NULL (one-hot of zeros, share_params.py:96-100)
  *   ep_len: per-episode int32 length or NULL; observations of steps t >= ep_len[b] read as zeros
  *           (the zero padding rollout.py:122-133 writes, needed when obs is (T+1)-slot storage)
+ *   ep_map: per-episode int32 storage index or NULL: batch episode b reads obs of storage episode
+ *           ep_map[b] (replay samples read in place, common/replaybuffer.py:54-60); ufed / ep_len / outputs
+ *           stay indexed by b
  *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
  *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = [T][B*N][6][64] floats
  *   (time-major; per row-step the 6 vectors hprev,x,r,z,n,hn) for the backward pass or NULL */
 int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
-                          const int* ufed, long u_bs, int u_t0, const int* ep_len, const float* h0,
-                          float* q, float* hs, float* h_last, float* saved, int B, int T, int N, int O,
-                          int A, int last_action, int reuse_network, void* stream);
+                          const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
+                          const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T,
+                          int N, int O, int A, int last_action, int reuse_network, void* stream);
 /* Gradient destinations of the recurrent / output layers (accumulated into, torch layouts). */
 typedef struct {
   float *w_ih, *w_hh;           /* (3H,H) */

@@ -23,7 +23,8 @@ class MarlSrc(C.Structure):
                 ("nid", C.c_int),
                 ("m0", C.c_void_p), ("ldm0", C.c_long),
                 ("rpe0", C.c_long), ("bs0", C.c_long), ("off0", C.c_long),
-                ("rpei", C.c_long), ("bsi", C.c_long), ("offi", C.c_long)]
+                ("rpei", C.c_long), ("bsi", C.c_long), ("offi", C.c_long),
+                ("emap0", C.c_void_p)]
 
 
 class MarlGroup(C.Structure):
@@ -57,7 +58,7 @@ SIGNATURES = {
     "marl_linear_wgrad": (I, [P, L, P, L, SRC, P, L, P, I, I, I, GRP, P, SZ, P]),
     "marl_linear_wgrad_workspace": (SZ, [I, I, I, I]),
     "marl_wgrad_slabs": (I, [I]),
-    "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "marl_agent_bwd_workspace": (SZ, [I, I, I]),
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),

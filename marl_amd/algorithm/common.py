@@ -116,7 +116,10 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf):
     kw = {}
     if args.last_action:
         kw.update(idx=db.u_fed.reshape(-1, 1), nhot=1, hot_w=A, remapi=(T * N, db.u_bs, (-1 if which == "cur" else 0) * N))
-    xin = ops.src(obs.reshape(-1, O), nid=N if args.reuse_network else 0, remap0=remap0, **kw)
+    emap = getattr(db, 'o_map', None)
+    if emap is not None and remap0 is None:
+        remap0 = (T * N, obs_bs, obs_t0 * N)
+    xin = ops.src(obs.reshape(-1, O), nid=N if args.reuse_network else 0, remap0=remap0, emap0=emap, **kw)
     I = O + (A if args.last_action else 0) + (N if args.reuse_network else 0)
     ops.linear_wgrad(dxp.view(M, H), xin, ag.fc1.weight.grad, ag.fc1.bias.grad, M, H, I)
 

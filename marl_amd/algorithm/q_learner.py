@@ -95,13 +95,13 @@ class QLearner:
         u_act = db.u_act.reshape(-1)
 
         # eval current-Q unroll (keeps activations), target next-Q unroll
-        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved, h0=None, ep_len=db.ep_len)
-        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None, h0=None, ep_len=db.ep_len)
+        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
+        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
         ops.q_gather(q_evals, u_act, q_chosen, R, A)
         cur_max = None
         if a.double_q:
             # quirk Q1: no init_hidden between the two eval passes (reference :96-110)
-            self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last, ep_len=db.ep_len)
+            self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
             cur_max = g("cur_max", (R,), torch.int32)
             ops.q_masked_max(q_en, db.avail_next, MASK_BIG, None, cur_max, R, A)
             ops.q_gather(q_tgt, cur_max, q_tgt_chosen, R, A, avail=db.avail_next, mask_val=MASK_BIG)
@@ -143,6 +143,12 @@ class QLearner:
     def train(self, batch, train_step):
         if isinstance(batch, DeviceBatch):
             db = batch
+        elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
+            # replay sample: big arrays are read in place from the ring through the episode index
+            small = batch.ring.select_small(batch.index)
+            T = DeviceBatch.first_terminated_len(small.term, self.args.episode_limit)
+            db = DeviceBatch.from_record(batch.ring, self.args, T=self.reducer.max_int(T, self.device), index=batch.index,
+                                         small=small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
             T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit)
             db = DeviceBatch.from_record(batch.record, self.args, T=self.reducer.max_int(T, self.device))

@@ -88,8 +88,8 @@ class QTRANLearner:
         u_act = db.u_act.reshape(-1)
         u_taken = db.u_taken.reshape(-1)          # one-hot(u) with zeros on padding (batch['u_onehot'])
 
-        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved, h0=None, ep_len=db.ep_len)
-        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None, h0=None, ep_len=db.ep_len)
+        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
+        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
 
         # local greedy actions (reference :103-114): eval clone masked with -999999, targets with -9999999
         opt_eval, opt_tgt = g("opt_eval", (R,), torch.int32), g("opt_tgt", (R,), torch.int32)
@@ -127,6 +127,12 @@ class QTRANLearner:
     def train(self, batch, train_step):
         if isinstance(batch, DeviceBatch):
             db = batch
+        elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
+            # replay sample: big arrays are read in place from the ring through the episode index
+            small = batch.ring.select_small(batch.index)
+            T = DeviceBatch.first_terminated_len(small.term, self.args.episode_limit)
+            db = DeviceBatch.from_record(batch.ring, self.args, T=self.reducer.max_int(T, self.device), index=batch.index,
+                                         small=small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
             T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit)
             db = DeviceBatch.from_record(batch.record, self.args, T=self.reducer.max_int(T, self.device))

@@ -98,7 +98,7 @@ class ReplayBuffer:
         idx = np.random.randint(0, self.current_size, batch_size)
         if self.record is not None:
             idx_t = torch.as_tensor(idx, dtype=torch.long, device=self.record.obs.device)
-            return EpisodeBatch(self.record.index_select(idx_t))
+            return EpisodeBatch(ring=self.record, index=idx_t)     # read in place by the learners (no gather copy)
         return {k: self.buffers[k][idx] for k in self.buffers}
 
     def _get_storage_idx(self, inc=None):

@@ -29,6 +29,7 @@ struct FwdArgs {
   const int* ufed;        // action fed back at step t: ufed[b*u_bs + (t+u_t0)*N + n]; <0 / t+u_t0<0 = none
   long u_bs; int u_t0;
   const int* ep_len;      // per-episode length or null: observations of steps t >= ep_len[b] read as zero
+  const int* ep_map;      // per-episode storage index of obs or null (replay samples read in place)
   const float* h0;        // (B*N,64) or null (zeros)
   float* q;               // (B,T,N,A)
   float* hs;              // (B,T,N,64) or null
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     const long b = rho / a.N;
     const int n = (int)(rho % a.N);
     rowidx[r] = (int)(b * a.T * a.N + n);
-    rowobs[r] = (b * a.obs_bs + n) * a.O;
+    rowobs[r] = ((a.ep_map ? (long)a.ep_map[b] : b) * a.obs_bs + n) * a.O;
     rowu[r] = b * a.u_bs + n;
     rown[r] = n;
     rowlen[r] = a.ep_len ? a.ep_len[b] : 0x7fffffff;
@@ -789,15 +790,15 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap)
 }  // namespace
 
 extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
-                                     const int* ufed, long u_bs, int u_t0, const int* ep_len, const float* h0,
-                                     float* q, float* hs, float* h_last, float* saved, int B, int T, int N,
-                                     int O, int A, int last_action, int reuse_network, void* stream) {
+                                     const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
+                                     const float* h0, float* q, float* hs, float* h_last, float* saved, int B,
+                                     int T, int N, int O, int A, int last_action, int reuse_network, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
   FwdArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
-  a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.ep_len = ep_len; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
+  a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.ep_len = ep_len; a.ep_map = ep_map; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
   a.B = B; a.T = T; a.N = N; a.O = O; a.A = A;
   a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);

@@ -66,6 +66,7 @@ struct ConcatSrc {
   long rpe0, bs0, off0;                     // row remap of p0/m0: (row/rpe)*bs + row%rpe + off
   long rpei, bsi, offi;                     // row remap of idx; (row%rpe)+off < 0 reads "none"
   FastDiv fd0, fdi, fdn;                    // dividers for rpe0, rpei, nid (rows < 2^31)
+  const int* emap0;                         // optional episode map of the p0 remap
 };
 
 __device__ __forceinline__ long remap_row(long row, long rpe, long bs, long off, bool& valid) {
@@ -79,7 +80,14 @@ __device__ __forceinline__ long remap_row(long row, long rpe, long bs, long off,
 __device__ __forceinline__ float concat_elem(const ConcatSrc& s, long row, int k) {
   if (k < s.k0) {
     bool ok;
-    const long r0 = remap_row(row, s.rpe0, s.bs0, s.off0, ok);
+    long r0;
+    if (s.emap0 && s.rpe0) {
+      const long e = row / s.rpe0, w = row - e * s.rpe0 + s.off0;
+      ok = w >= 0;
+      r0 = (long)s.emap0[e] * s.bs0 + w;
+    } else {
+      r0 = remap_row(row, s.rpe0, s.bs0, s.off0, ok);
+    }
     if (!ok) return 0.f;
     float v = s.p0[r0 * s.ld0 + k];
     if (s.m0) v = s.m0[r0 * s.ldm0 + k] > 0.f ? v : 0.f;
@@ -117,7 +125,14 @@ __device__ __forceinline__ long remap_row_fast(unsigned row, long rpe, long bs, 
 __device__ __forceinline__ ConcatRow concat_row(const ConcatSrc& s, long row) {
   ConcatRow c;
   c.row = row;
-  c.r0 = remap_row_fast((unsigned)row, s.rpe0, s.bs0, s.off0, s.fd0, c.ok0);
+  if (s.emap0 && s.rpe0) {
+    const unsigned e = fastdiv((unsigned)row, s.fd0);
+    const long w = (long)((unsigned)row - e * (unsigned)s.rpe0) + s.off0;
+    c.ok0 = w >= 0;
+    c.r0 = (long)s.emap0[e] * s.bs0 + w;
+  } else {
+    c.r0 = remap_row_fast((unsigned)row, s.rpe0, s.bs0, s.off0, s.fd0, c.ok0);
+  }
   c.ri = remap_row_fast((unsigned)row, s.rpei, s.bsi, s.offi, s.fdi, c.oki);
   c.nidx = s.nid ? (int)((unsigned)row - fastdiv((unsigned)row, s.fdn) * (unsigned)s.nid) : 0;
   return c;

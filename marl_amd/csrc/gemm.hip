@@ -473,6 +473,7 @@ inline ConcatSrc to_src(const marl_src_t* s) {
   c.m0 = s->m0; c.ldm0 = s->ldm0;
   c.rpe0 = s->rpe0; c.bs0 = s->bs0; c.off0 = s->off0;
   c.rpei = s->rpei; c.bsi = s->bsi; c.offi = s->offi;
+  c.emap0 = s->emap0;
   c.fd0 = make_fastdiv((unsigned)(s->rpe0 > 0 ? s->rpe0 : 1));
   c.fdi = make_fastdiv((unsigned)(s->rpei > 0 ? s->rpei : 1));
   c.fdn = make_fastdiv((unsigned)(s->nid > 0 ? s->nid : 1));

@@ -345,6 +345,7 @@ inline ConcatSrc state_src(const marl_src_t* s) {
   c.rpe0 = s->rpe0; c.bs0 = s->bs0; c.off0 = s->off0; c.rpei = 0; c.bsi = 0; c.offi = 0;
   c.fd0 = make_fastdiv((unsigned)(s->rpe0 > 0 ? s->rpe0 : 1));
   c.fdi = make_fastdiv(1); c.fdn = make_fastdiv(1);
+  c.emap0 = s->emap0;
   return c;
 }
 

@@ -140,28 +140,37 @@ class DeviceBatch:
         return self
 
     @classmethod
-    def from_record(cls, rec, args, T=None):
+    def from_record(cls, rec, args, T=None, index=None, small=None):
         """Zero-copy view of a device EpisodeRecord ((T+1)-slot storage): observations are read in
-        place for both passes; only the small per-step arrays are re-packed when T < episode_limit."""
+        place for both passes; only the small per-step arrays are re-packed when T < episode_limit.
+        ``index`` (int64/int32 episode indices into ``rec``, e.g. a replay sample): the big arrays (obs, state)
+        are read in place through an episode map, only the small arrays are gathered."""
         self = cls()
-        E, Ta, N, O, S, A = rec.E, rec.T, rec.N, rec.O, rec.S, rec.A
+        Ta, N, O, S, A = rec.T, rec.N, rec.O, rec.S, rec.A
+        big = rec
+        self.o_map = None
+        if index is not None:
+            idx = index.to(device=rec.obs.device, dtype=torch.long)
+            self.o_map = idx.to(torch.int32).contiguous()
+            rec = small if small is not None else rec.select_small(idx)
+        E = rec.E
         if T is None:
             T = cls.first_terminated_len(rec.term, args.episode_limit)
         self.B, self.T, self.N, self.O, self.S, self.A = E, T, N, O, S, A
-        self.o_cur = (rec.obs, (Ta + 1) * N, 0)
-        self.o_next = (rec.obs, (Ta + 1) * N, 1)
+        self.o_cur = (big.obs, (Ta + 1) * N, 0)
+        self.o_next = (big.obs, (Ta + 1) * N, 1)
         self.ep_len = rec.length
-        st2 = rec.state.view(E * (Ta + 1), S)
-        self.s = ops.Rows(st2, (T, Ta + 1, 0))
-        self.s_next = ops.Rows(st2, (T, Ta + 1, 1))
+        st2 = big.state.view(big.E * (Ta + 1), S)
+        self.s = ops.Rows(st2, (T, Ta + 1, 0), self.o_map)
+        self.s_next = ops.Rows(st2, (T, Ta + 1, 1), self.o_map)
         self.u_fed = rec.u
         self.u_bs = Ta * N
         cutc = lambda x: x[:, :T].contiguous()
         self.u_taken = cutc(rec.u)
         self.u_act = self.u_taken.clamp(min=0)
         self.r, self.term, self.padded = cutc(rec.r).view(-1), cutc(rec.term).view(-1), cutc(rec.padded).view(-1)
-        t_idx = torch.arange(T, device=rec.obs.device)[None, :, None, None]
+        t_idx = torch.arange(T, device=big.obs.device)[None, :, None, None]
         live = t_idx < rec.length[:, None, None, None]
-        self.avail = torch.where(live, rec.avail[:, :T], torch.zeros((), device=rec.obs.device)).reshape(E * T * N, A)
+        self.avail = torch.where(live, rec.avail[:, :T], torch.zeros((), device=big.obs.device)).reshape(E * T * N, A)
         self.avail_next = rec.avail[:, 1:T + 1].reshape(E * T * N, A)
         return self

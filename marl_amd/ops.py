@@ -50,19 +50,20 @@ WS = Workspace()
 
 
 class Rows:
-    """A 2-D row source read through a row remap (rpe, bs, off) - e.g. the (T+1)-slot state storage."""
+    """A 2-D row source read through a row remap (rpe, bs, off) - e.g. the (T+1)-slot state storage - and
+    optionally an int32 episode map (replay samples read in place from the ring)."""
 
-    def __init__(self, t, remap):
-        self.t, self.remap = t, remap
+    def __init__(self, t, remap, emap=None):
+        self.t, self.remap, self.emap = t, remap, emap
         self.device = t.device
 
 
-def src(x0=None, x1=None, idx=None, nhot=0, hot_w=0, nid=0, gate=None, remap0=None, remapi=None, k0=None):
+def src(x0=None, x1=None, idx=None, nhot=0, hot_w=0, nid=0, gate=None, remap0=None, remapi=None, k0=None, emap0=None):
     """Build a marl_src_t.  x0/x1: 2-D (rows, k) float32 views with unit inner stride (x0 may be Rows)."""
     s = MarlSrc()
     keep = []
     if isinstance(x0, Rows):
-        x0, remap0 = x0.t, x0.remap
+        x0, remap0, emap0 = x0.t, x0.remap, x0.emap
     if x0 is not None:
         _f32(x0); assert x0.dim() == 2 and x0.stride(1) == 1
         s.p0, s.ld0, s.k0 = x0.data_ptr(), x0.stride(0), (x0.shape[1] if k0 is None else k0)
@@ -82,6 +83,10 @@ def src(x0=None, x1=None, idx=None, nhot=0, hot_w=0, nid=0, gate=None, remap0=No
         keep.append(gate)
     if remap0 is not None:
         s.rpe0, s.bs0, s.off0 = remap0
+    if emap0 is not None:
+        assert remap0 is not None and emap0.dtype == torch.int32 and emap0.is_contiguous()
+        s.emap0 = emap0.data_ptr()
+        keep.append(emap0)
     if remapi is not None:
         s.rpei, s.bsi, s.offi = remapi
     s._keep = keep
@@ -139,9 +144,10 @@ def agent_weights(params):
 
 
 def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
-                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None):
+                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None):
     lib = _lib.load()
-    check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len), _p(h0),
+    check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
+                                    _p(_i32(ep_map)) if ep_map is not None else None, _p(h0),
                                     _p(_f32(q)), _p(hs), _p(h_last), _p(saved), B, T, N, O, A,
                                     1 if last_action else 0, 1 if reuse_network else 0, _stream()),
           "marl_agent_unroll_fwd")

@@ -22,9 +22,18 @@ class EpisodeBatch(dict):
 
     KEYS = ("o", "s", "u", "r", "avail_u", "o_next", "s_next", "avail_u_next", "u_onehot", "padded", "terminated")
 
-    def __init__(self, record):
+    def __init__(self, record=None, ring=None, index=None):
+        """``record``: the episodes themselves; or ``ring`` + ``index``: a replay sample that learners read in
+        place (the gathered copy is only made if somebody asks for ``.record`` / a dict key)."""
         super().__init__()
-        self.record = record
+        self._record = record
+        self.ring, self.index = ring, index
+
+    @property
+    def record(self):
+        if self._record is None and self.ring is not None:
+            self._record = self.ring.index_select(self.index)
+        return self._record
 
     def _build(self, k):
         r = self.record

@@ -213,3 +213,41 @@ def test_zero_copy_store_into_replay_ring():
     snap = bb.record.obs.clone()
     ev = wb.generate_episodes(E, evaluate=True)[0]
     assert getattr(ev.record, "sink_slot", None) is None and torch.equal(snap, bb.record.obs)
+
+
+@pytest.mark.parametrize("alg,shape", [("qmix", "2s3z"), ("qplex", "2s3z"), ("qtran_base", "3s5z")])
+def test_replay_sample_is_read_in_place(alg, shape):
+    """ReplayBuffer.sample returns a (ring, index) view: the learner reads observations / states in place
+    through the episode map (sampling WITH replacement -> duplicates, reference replaybuffer.py:54-60) and the
+    result equals training on the gathered copy."""
+    from marl_amd.rollout import RolloutWorker, EpisodeBatch
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd.common.replaybuffer import ReplayBuffer
+    from test_gpu_learners import build_product
+    T, E = 25, 24
+    case = ("x", shape, alg, E, T, None, {})
+    args, mac, learner_a = build_product(case)
+    _, _, learner_b = build_product(case)
+    args.epsilon, args.seed, args.buffer_size = 0.3, 5, 64
+    sh = seeded.SHAPES[shape]
+    env = SyntheticSMACEnv(E, sh["n_agents"], sh["obs_shape"], sh["state_shape"], sh["n_actions"], T, seed=9)
+    w = RolloutWorker(env, mac, args)
+    buf = ReplayBuffer(args)
+    w.record_sink = buf
+    for _ in range(2):
+        buf.store_episode(w.generate_episodes(E)[0])
+    np.random.seed(3)
+    batch = buf.sample(40)                                   # 40 draws from 48 stored episodes
+    assert batch.ring is buf.record and batch._record is None
+    idx = batch.index.cpu().numpy()
+    assert len(set(idx.tolist())) < len(idx), "want duplicates"
+    la = learner_a.train(batch, 0)
+    assert batch._record is None                             # nothing was gathered
+    gathered = EpisodeBatch(buf.record.index_select(batch.index))
+    lb = learner_b.train(gathered, 0)
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    ga, gb = learner_a._flat.grad.cpu().numpy(), learner_b._flat.grad.cpu().numpy()
+    np.testing.assert_allclose(ga, gb, atol=1e-6 * max(1.0, np.abs(gb).max()), rtol=1e-4)
+    # generic consumers still get the reference's 11-key dict
+    d = batch.numpy()
+    assert d["o"].shape == (40, T, sh["n_agents"], sh["obs_shape"])
