@@ -214,9 +214,12 @@ def main():
     if rank == 0:
         fl = agent_flops(args) * E * N * T                 # algorithmic FLOP of one unroll launch
         traffic = None                                     # HBM bytes/launch from the committed PMC passes (same workload only)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_agent.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc) and (o.alg, o.shape, o.envs, world, T) == ("qmix", "2s3z", 4096, 1, 120):
-            traffic = json.load(open(pmc))["agent_fwd_kernel"]["avg_hbm_bytes_per_launch"]
+            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if k.startswith("agent_fwd_kernel")]
+            n = sum(v["launches"] for v in ks)
+            if n and all("hbm_bytes_per_launch" in v for v in ks):
+                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / n
         avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         ach = fl / (avg_ms * 1e-3) / 1e12
         out = {
@@ -235,7 +238,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
                          "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                         "separate passes; profiles/r01_pmc_agent.json)", "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "separate passes; profiles/r01_pmc.json)", "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
                          "flop_per_launch": fl},
         }
         if not o.no_cpu_baseline:

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     WG_BARRIER();
     ST_MARK(4);
   }
-  ST_DUMP(5);
+  ST_DUMP_AT(5, 8);     // columns 8.. of the stamp rows (the forward kernel uses 0..5)
   if (a.dh0 && team) {
     for (int r = 4 * q; r < rows; r += 16)
 #pragma unroll

@@ -169,12 +169,14 @@ static __device__ unsigned long long* marl_stamp_buf;   // one per translation u
 #define ST_NOW(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define ST_DECL(n) unsigned long long st_sum_[n]; for (int i_ = 0; i_ < (n); ++i_) st_sum_[i_] = 0ull; unsigned long long st_prev_; ST_NOW(st_prev_)
 #define ST_MARK(i) do { unsigned long long n_; ST_NOW(n_); st_sum_[i] += n_ - st_prev_; st_prev_ = n_; } while (0)
-#define ST_DUMP(n) do { if (marl_stamp_buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < (n); ++i_) marl_stamp_buf[(threadIdx.x >> 6) * 16 + i_] = st_sum_[i_]; } while (0)
+#define ST_DUMP_AT(n, col) do { if (marl_stamp_buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < (n); ++i_) marl_stamp_buf[(threadIdx.x >> 6) * 16 + (col) + i_] = st_sum_[i_]; } while (0)
+#define ST_DUMP(n) ST_DUMP_AT(n, 0)
 #else
 #define ST_DEFINE_SETTER(name)
 #define ST_DECL(n)
 #define ST_MARK(i)
 #define ST_DUMP(n)
+#define ST_DUMP_AT(n, col)
 #endif
 
 #define MARL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -40,6 +40,8 @@ def main():
     torch.cuda.synchronize()
     v = buf.cpu().view(16, 16).numpy()
     names = SEGS[which]
+    if which == "bwd":
+        v = v[:, 8:]
     print("segment shares per wave of workgroup 0 (%s, %d envs); cycles/step in the last column" % (which, E))
     print("wave " + " ".join("%9s" % n for n in names) + "   total/step")
     for wv in range(16):

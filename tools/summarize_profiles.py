@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/<tag>_* (written by tools/refresh_profiles.sh on the GPU box) into the committed
+evidence under profiles/:  <tag>_bench_kernel_stats.csv, <tag>_bench_line.json, <tag>_pmc.json, <tag>_stamps.txt."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+
+shutil.copy(os.path.join(G, tag + "_bench", "p_kernel_stats.csv"), os.path.join(P, tag + "_bench_kernel_stats.csv"))
+for name in ("_bench_line.json", "_bench_full_line.json"):
+    src = os.path.join(G, tag + name)
+    if os.path.exists(src):
+        line = open(src).read().strip()
+        json.loads(line)
+        open(os.path.join(P, tag + name), "w").write(line + "\n")
+shutil.copy(os.path.join(G, tag + "_stamps.txt"), os.path.join(P, tag + "_stamps.txt"))
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0]
+
+
+per = defaultdict(lambda: defaultdict(list))        # kernel -> counter -> per-dispatch values
+dur = defaultdict(list)
+for f in sorted(glob.glob(os.path.join(G, tag + "_pmc", "pass*", "p_counter_collection.csv"))):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if not any(x in k for x in ("agent_", "qmix_fused_kernel", "wgrad_direct", "synth_rollout")):
+            continue
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        d = (r["Dispatch_Id"], f)
+        if d not in seen:
+            seen.add(d)
+            dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+out = {"source": "rocprofv3 --pmc <group> --kernel-trace, four separate passes of tools/prof_learner.py --updates 3 --rollouts 2 "
+                 "(QMIX 2s3z, 4096 envs, T=120, 1x MI355X); values are means per launch",
+       "hbm_correction": "gfx950: FETCH_SIZE counts half of wide (16 B/lane) coalesced reads -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB "
+                         "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+       "kernels": {}}
+for k, cs in sorted(per.items()):
+    e = {c: sum(v) / len(v) for c, v in cs.items()}
+    e["launches"] = max(len(v) for v in cs.values())
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs (256 CUs x 4)
+        e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0)
+    if dur[k]:
+        e["avg_ns_under_pmc"] = sum(dur[k]) / len(dur[k])
+        if "GRBM_GUI_ACTIVE" in e:
+            e["clock_ghz_est"] = e["GRBM_GUI_ACTIVE"] / 8.0 / e["avg_ns_under_pmc"]
+    out["kernels"][k] = e
+json.dump(out, open(os.path.join(P, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+fw = [v for k, v in out["kernels"].items() if k.startswith("agent_fwd_kernel")]
+if fw:
+    tot = sum(v.get("hbm_bytes_per_launch", 0) * v["launches"] for v in fw)
+    n = sum(v["launches"] for v in fw)
+    print("agent_fwd avg HBM bytes per launch: %.4g over %d launches" % (tot / max(n, 1), n))
+for k, v in out["kernels"].items():
+    print("%-40s launches %3d  mfma_busy %.3f  clock %.2f GHz  hbm %.3g B" % (k[:40], v["launches"], v.get("mfma_busy_frac", float("nan")),
+          v.get("clock_ghz_est", float("nan")), v.get("hbm_bytes_per_launch", float("nan"))))
