@@ -97,11 +97,14 @@ typedef struct {
 /* BPTT (autograd of the unroll above; q_learner.py:171 loss.backward()), fused: per step the delta
  * pass AND the weight-gradient reductions of W_ih, W_hh, W_2 and their biases (in-register
  * accumulators, one partial slab per workgroup in `ws`, fixed-order reduce => reproducible).
- *   dq (B,T,N,A) gradient on q; dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
+ *   dq (B,T,N,A) gradient on q, OR (dq_idx != NULL) its sparse form: row (b,t,n) has the single non-zero
+ *   dq_val[b,t,n] in column dq_idx[b,t,n] (the TD loss reaches q only through th.gather, q_learner.py:100;
+ *   the dense tile is then never materialised); dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
  *   saved, hs: outputs of the forward pass;  dxp (B,T,N,64) = gradient at the fc1 pre-activation
  * The fc1 gradient follows as ONE marl_linear_wgrad over dxp and the virtual input [obs|u|id]. */
 size_t marl_agent_bwd_workspace(int B, int N, int A);
-int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const float* dhs,
+int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const int* dq_idx,
+                          const float* dq_val, const float* dhs,
                           const float* saved, const float* hs, float* dxp, float* dh0,
                           const marl_agent_grads_t* g, float* ws, size_t ws_bytes,
                           int B, int T, int N, int A, void* stream);

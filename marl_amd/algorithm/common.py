@@ -95,7 +95,7 @@ class Scratch:
         return t
 
 
-def agent_backward(mac, db, which, saved, hs, dq, dhs, buf):
+def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=None):
     """BPTT of the eval unroll: the fused kernel (delta pass + W_ih/W_hh/W_2 gradients), then the
     fc1 weight gradient as one reduction over the virtual input [obs | one-hot(u_{t-1}) | agent id]
     (autograd of controller/share_params.py:125-146 + network/q_network.py:16-21)."""
@@ -103,14 +103,14 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf):
     B, T, N, A, O = db.B, db.T, db.N, db.A, db.O
     H = args.rnn_hidden_dim
     M = B * T * N
-    dev = dq.device
+    dev = saved.device
     dxp = buf.get("dxp", (B, T, N, H), dev)
     w = mac.agent.weights()
     ag = mac.agent
     grads = {"rnn.weight_ih": ag.rnn.weight_ih.grad, "rnn.weight_hh": ag.rnn.weight_hh.grad,
              "rnn.bias_ih": ag.rnn.bias_ih.grad, "rnn.bias_hh": ag.rnn.bias_hh.grad,
              "fc2.weight": ag.fc2.weight.grad, "fc2.bias": ag.fc2.bias.grad}
-    ops.agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, None, grads, B, T, N, A)
+    ops.agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, None, grads, B, T, N, A, dq_idx=dq_idx, dq_val=dq_val)
     obs, obs_bs, obs_t0 = db.o_cur if which == "cur" else db.o_next
     remap0 = None if (obs_bs == T * N and obs_t0 == 0) else (T * N, obs_bs, obs_t0 * N)
     kw = {}

@@ -135,9 +135,10 @@ class QLearner:
 
         # backward: mixer, gather, BPTT
         dq_chosen = self.mixer.hip_backward(ctx, dq_tot, BT)
-        dq = g("dq", (B, T, N, A))
-        ops.q_scatter(dq, u_act, dq_chosen.reshape(-1), None, None, R, A, 1)
-        agent_backward(self.eval_net, db, "cur", saved, hs, dq, None, self._buf)
+        # the loss reaches q_evals only through the gather above: hand BPTT the sparse (action, gradient) pairs
+        # instead of scattering them into a dense (B,T,N,A) tensor
+        agent_backward(self.eval_net, db, "cur", saved, hs, None, None, self._buf,
+                       dq_idx=u_act, dq_val=dq_chosen.reshape(-1).contiguous())
         self._dbg = dict(q_evals=q_evals, hs=hs, q_targets=q_tgt, q_tot=q_tot, q_tot_target=q_tot_tgt)
 
     def train(self, batch, train_step):

@@ -382,7 +382,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 // saved activations are software-pipelined one row tile ahead straight into registers.
 struct BwdArgs {
   const float *Wih, *Whh, *W2;
-  const float* dq;        // (B,T,N,A)
+  const float* dq;        // (B,T,N,A) dense gradient on q, or (when dq_idx != null) unused
+  const int* dq_idx;      // (B,T,N) sparse form: the only non-zero of row (b,t,n) is column dq_idx with value dq_val
+  const float* dq_val;    // (B,T,N)   (the Q-learning losses touch one action per row, q_learner.py:93)
   const float* dhs;       // (B,T,N,64) external gradient on hs[t], or null
   const float* saved;     // [T][B*N][6][64]
   const float* hs;        // (B,T,N,64) hidden after each step (for dW_2)
@@ -408,7 +410,7 @@ __host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + 
 //       team 1 ("hh"): dh_prev = carry + [drp|dzp|dhn] W_hh          ;  dW_hh += [drp|dzp|dhn]^T h_prev ; dW_2 += dq^T h
 //   Both roles run the SAME code on the same register arrays (wT, accW, cur/nxt); only base pointers and
 //   LDS column offsets differ, so the register allocation is that of one role.
-template <int AC, bool DHS>
+template <int AC, bool DHS, bool SPQ>
 __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -501,7 +503,23 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     return (k < a.A) ? a.dq[((long)rowidx[r] + (long)t * tstride) * a.A + k] * rowok[r] : 0.f;
   };
 
-  for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
+  // sparse form: the dq tile is never materialised - per row one (column, value) pair, the MFMA operand
+  // fragments are synthesised from it in registers
+  auto sp_load = [&](int t, int r, int& u, float& g) {
+    const long o = (long)rowidx[r] + (long)t * tstride;
+    u = a.dq_idx[o];
+    g = a.dq_val[o] * rowok[r];
+  };
+  if (SPQ) {
+    for (int r = tid; r < rows; r += BNT) {
+      int u; float g;
+      sp_load(a.T - 1, r, u, g);
+      reinterpret_cast<int*>(DQ0)[r] = u;
+      DQ0[rows + r] = g;
+    }
+  } else {
+    for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
+  }
   const bool hasB = team < a.RT;                   // this team owns at least one row tile in phase B
   const bool full_wg = row0 + rows <= a.R;         // no rows past the batch in this workgroup
   // Register sets of the software pipeline.  NO set is ever copied into another inside the step loop: a copy
@@ -526,9 +544,17 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
     const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
+    const int su = SPQ ? reinterpret_cast<const int*>(DQ)[rt * 16 + m] : 0;
+    const float sg = SPQ ? DQ[rows + rt * 16 + m] : 0.f;
 #pragma unroll
     for (int ac = 0; ac < AC; ++ac) {
-      f32x4 av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
+      f32x4 av;
+      if (SPQ) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = (su == 16 * ac + 4 * q + i) ? sg : 0.f;
+      } else {
+        av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
+      }
       dh = mfma16x4(av, w2T[ac], dh);
     }
 #pragma unroll
@@ -582,7 +608,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       for (int ac = 0; ac < AC; ++ac) {
         f32x4 dqf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
+        for (int i = 0; i < 4; ++i) {
+          if (SPQ) dqf[i] = (reinterpret_cast<const int*>(DQ)[r0 + i] == 16 * ac + m) ? DQ[rows + r0 + i] : 0.f;
+          else dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
+        }
         accW2[ac] = mfma16x4(dqf, P[4], accW2[ac]);
         sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
       }
@@ -618,10 +647,15 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     float* DQ = par ? DQ1 : DQ0;
     float* DQn = par ? DQ0 : DQ1;
     float dqpre[NQ];
+    int spu = -1; float spg = 0.f;
+    if (SPQ) {
+      if (t > 0 && tid < rows) sp_load(t - 1, tid, spu, spg);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int e = tid + BNT * i;
-      dqpre[i] = (t > 0 && e < rows * QP) ? dq_elem(t - 1, e) : 0.f;
+      for (int i = 0; i < NQ; ++i) {
+        const int e = tid + BNT * i;
+        dqpre[i] = (t > 0 && e < rows * QP) ? dq_elem(t - 1, e) : 0.f;
+      }
     }
     // ---------------- phase B.  Entering: sA = the team's first tile (or, without one, phase-C tile 0).
     // Tiles alternate between sA and sB; the item after the last tile is phase-C tile 0, which must end up in sA.
@@ -679,10 +713,14 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     if (hasB && t > 0) LOAD_ITEM1(t - 1, true)
     ST_MARK(2);
     if (t > 0) {
+      if (SPQ) {
+        if (tid < rows) { reinterpret_cast<int*>(DQn)[tid] = spu; DQn[rows + tid] = spg; }
+      } else {
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        const int e = tid + BNT * i;
-        if (e < rows * QP) DQn[(e / QP) * QS + (e % QP)] = dqpre[i];
+        for (int i = 0; i < NQ; ++i) {
+          const int e = tid + BNT * i;
+          if (e < rows * QP) DQn[(e / QP) * QS + (e % QP)] = dqpre[i];
+        }
       }
     }
     ST_MARK(3);
@@ -856,7 +894,8 @@ extern "C" size_t marl_agent_bwd_workspace(int B, int N, int A) {
   return (size_t)nwg * bwd_slab_floats(A) * sizeof(float);
 }
 
-extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const float* dhs,
+extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const int* dq_idx,
+                                     const float* dq_val, const float* dhs,
                                      const float* saved, const float* hs, float* dxp, float* dh0,
                                      const marl_agent_grads_t* g, float* ws, size_t ws_bytes,
                                      int B, int T, int N, int A, void* stream) {
@@ -866,7 +905,7 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;   // 32-bit byte offsets into dxp
   BwdArgs a;
   a.Wih = w->w_ih; a.Whh = w->w_hh; a.W2 = w->fc2_w;
-  a.dq = dq; a.dhs = dhs; a.saved = saved; a.hs = hs; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
+  a.dq = dq; a.dq_idx = dq_idx; a.dq_val = dq_val; a.dhs = dhs; a.saved = saved; a.hs = hs; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
@@ -879,8 +918,14 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   const void* fn;
-  if (AC == 1) fn = dhs ? (const void*)agent_bwd_kernel<1, true> : (const void*)agent_bwd_kernel<1, false>;
-  else fn = dhs ? (const void*)agent_bwd_kernel<2, true> : (const void*)agent_bwd_kernel<2, false>;
+  const bool sp = dq_idx != nullptr;
+  if (sp && !dq_val) return (int)hipErrorInvalidValue;
+  if (!sp && !dq) return (int)hipErrorInvalidValue;
+#define BWD_PICK(AC_) (dhs ? (sp ? (const void*)agent_bwd_kernel<AC_, true, true> : (const void*)agent_bwd_kernel<AC_, true, false>) \
+                           : (sp ? (const void*)agent_bwd_kernel<AC_, false, true> : (const void*)agent_bwd_kernel<AC_, false, false>))
+  if (AC == 1) fn = BWD_PICK(1);
+  else fn = BWD_PICK(2);
+#undef BWD_PICK
   e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   void* kargs[] = {(void*)&a};

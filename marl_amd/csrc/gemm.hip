@@ -310,10 +310,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // 4*(4*KP+NTP) MFMAs; rows are dealt to waves in 16-row blocks, one block prefetched in registers.
 // The bias gradient is a VALU column sum of the G operands.  8 waves (2 per SIMD) reduce through LDS into
 // one slab per workgroup; slabs are summed by wgrad_reduce_kernel (same layout as wgrad_kernel).
-constexpr int DU = 4;             // k-steps (of 4 rows) per block
+#ifndef WD_DU
+#define WD_DU 4
+#define WD_WAVES 8
+#endif
+constexpr int DU = WD_DU;         // k-steps (of 4 rows) per block
+constexpr int WDW = WD_WAVES;     // waves per workgroup (8 = two per SIMD; 4 waves with a 32-row block in flight measured 1.6x slower)
 
 template <int KP, int NTP>
-__global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
+__global__ __launch_bounds__(64 * WDW, 1) void wgrad_direct_kernel(WgradArgs a) {
   extern __shared__ float red[];  // [64][K+1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -326,8 +331,23 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
     for (int t = 0; t < NT; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   const long nblk = ((long)a.M + 4 * DU - 1) / (4 * DU);
-  const long G = (long)gridDim.x * 8;
+  const long G = (long)gridDim.x * WDW;
   constexpr int NP = NTP > 0 ? NTP : 1;
+  // per-lane description of its column in each plain tile: segment kind (0 dense, 2 one-hot, 3 agent id, -1 pad),
+  // clamped dense column, one-hot block and the value that makes the element 1
+  int pkind[NP], pcol[NP], pj[NP], pc[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    int k = 64 * KP + 16 * t + m;
+    pkind[t] = -1; pcol[t] = 0; pj[t] = 0; pc[t] = -1;
+    if (k < a.x.k0) { pkind[t] = 0; pcol[t] = k; }
+    else {
+      k -= a.x.k0;
+      const int hw = a.x.nhot * a.x.hot_w;
+      if (k < hw) { pkind[t] = 2; pj[t] = k / a.x.hot_w; pc[t] = k - pj[t] * a.x.hot_w; }
+      else if (k - hw < a.x.nid) { pkind[t] = 3; pc[t] = k - hw; }
+    }
+  }
   f32x4 gA[DU], gB[DU], xA[DU], xB[DU];      // two register sets: the block in flight and the one being consumed
   float pA[DU][NP], pB[DU][NP];
   auto load = [&](long blk, f32x4 (&ga)[DU], f32x4 (&xb)[DU], float (&xp)[DU][NP]) __attribute__((always_inline)) {
@@ -345,10 +365,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
         if (cr.ok0) x = *reinterpret_cast<const f32x4*>(a.x.p0 + cr.r0 * a.x.ld0 + 4 * m);
         xb[u] = x;
       }
+      // plain tiles, branch-free: the lane's column (hence its segment) is fixed, so every lane issues the dense
+      // load and the index load at clamped addresses and selects (lanes of one wave sit in different segments)
 #pragma unroll
       for (int t = 0; t < NTP; ++t) {
-        const int k = 64 * KP + 16 * t + m;
-        xp[u][t] = k < K ? concat_at(a.x, cr, k) : 0.f;
+        const float vd = cr.ok0 ? a.x.p0[cr.r0 * a.x.ld0 + pcol[t]] : 0.f;
+        float vo = 0.f;
+        if (a.x.nhot) vo = (cr.oki && a.x.idx[cr.ri * a.x.nhot + pj[t]] == pc[t]) ? 1.f : 0.f;
+        const float vi = cr.nidx == pc[t] ? 1.f : 0.f;
+        xp[u][t] = pkind[t] == 0 ? vd : (pkind[t] == 2 ? vo : (pkind[t] == 3 ? vi : 0.f));
       }
     }
   };
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
       }
     }
   };
-  long blk = (long)blockIdx.x * 8 + wave;
+  long blk = (long)blockIdx.x * WDW + wave;
   if (blk < nblk) load(blk, gA, xA, pA);
   while (blk < nblk) {
     if (blk + G < nblk) load(blk + G, gB, xB, pB);
@@ -384,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
   for (int j = 0; j < 4; ++j) bsum[j] += __shfl_xor(bsum[j], 16, 64);
 #pragma unroll
   for (int j = 0; j < 4; ++j) bsum[j] += __shfl_xor(bsum[j], 32, 64);
-  for (int w = 0; w < 8; ++w) {
+  for (int w = 0; w < WDW; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -408,19 +433,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WgradArgs a) {
     __syncthreads();
   }
   float* slab = a.ws + (long)blockIdx.x * 64 * Kx;
-  for (int e = tid; e < 64 * Kx; e += 512) slab[e] = red[e];
+  for (int e = tid; e < 64 * Kx; e += 64 * WDW) slab[e] = red[e];
 }
 
 template <int KP, int NTP>
 inline int launch_wgrad_direct(const WgradArgs& a, hipStream_t s) {
   const size_t lds = (size_t)64 * (a.K + 1) * sizeof(float);
-  hipLaunchKernelGGL((wgrad_direct_kernel<KP, NTP>), dim3(a.slabs), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((wgrad_direct_kernel<KP, NTP>), dim3(a.slabs), dim3(64 * WDW), lds, s, a);
   return 0;
 }
 
 // returns -1 when the shape is not covered (caller uses the LDS-staged kernel)
 inline int try_wgrad_direct(const WgradArgs& a, hipStream_t s) {
-  if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || a.M < 4096) return -1;
+  if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || a.M < 4096 || a.x.k1 || a.x.m0 || a.x.k0 < 1) return -1;
   const bool perm = a.xvec && a.x.k0 >= 64;
   const int KP = perm ? 1 : 0;
   const int rest = a.K - 64 * KP;

@@ -153,7 +153,7 @@ def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last
           "marl_agent_unroll_fwd")
 
 
-def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A):
+def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None):
     """grads: dict name -> gradient tensor for rnn.weight_ih/hh, rnn.bias_ih/hh, fc2.weight/bias (accumulated)."""
     lib = _lib.load()
     g = MarlAgentGrads()
@@ -162,8 +162,12 @@ def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A):
     g.fc2_w, g.fc2_b = grads["fc2.weight"].data_ptr(), grads["fc2.bias"].data_ptr()
     for v in grads.values():
         assert v.is_contiguous() and v.dtype == torch.float32 and v.is_cuda
-    ws = WS.get("agent_bwd", lib.marl_agent_bwd_workspace(B, N, A), dq.device)
-    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)), _p(dhs), _p(_f32(saved)), _p(_f32(hs)), _p(_f32(dxp)),
+    ws = WS.get("agent_bwd", lib.marl_agent_bwd_workspace(B, N, A), saved.device)
+    if dq_idx is not None:
+        assert dq is None and dq_val is not None and dq_idx.is_contiguous() and dq_val.is_contiguous()
+        _i32(dq_idx); _f32(dq_val)
+    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)) if dq is not None else None, _p(dq_idx), _p(dq_val), _p(dhs),
+                                    _p(_f32(saved)), _p(_f32(hs)), _p(_f32(dxp)),
                                     _p(dh0), C.byref(g), _p(ws), ws.numel() * 4, B, T, N, A, _stream()),
           "marl_agent_unroll_bwd")
 

@@ -238,6 +238,20 @@ def test_agent_unroll_bwd(dev, shape, B, T):
         ref = p[k].grad
         scale = max(1.0, float(ref.abs().max()))
         close(grads[k] / scale, ref / scale, 2e-4, 1e-3, msg=k)
+    # sparse form of dq (one (action, gradient) pair per row, no dhs) == the dense tensor it stands for
+    idx = torch.randint(0, A, (B, T, N), generator=g)
+    val = torch.randn(B, T, N, generator=g)
+    dense = torch.zeros(B, T, N, A).scatter_(3, idx[..., None], val[..., None])
+    names = ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh", "fc2.weight", "fc2.bias")
+    ga = {k: torch.zeros_like(pd[k]) for k in names}
+    gb = {k: torch.zeros_like(pd[k]) for k in names}
+    dxa, dxb = torch.empty(B, T, N, 64, device=dev), torch.empty(B, T, N, 64, device=dev)
+    ops.agent_unroll_bwd(w, cu(dense, dev), None, saved, hs, dxa, None, ga, B, T, N, A)
+    ops.agent_unroll_bwd(w, None, None, saved, hs, dxb, None, gb, B, T, N, A,
+                         dq_idx=cu(idx, dev, torch.int32), dq_val=cu(val, dev))
+    close(dxb, dxa, 1e-6, 1e-5)
+    for k in names:
+        close(gb[k], ga[k], 1e-5, 1e-5, msg="sparse " + k)
 
 
 # ------------------------------------------------------------------------------------- per-row
