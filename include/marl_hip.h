@@ -118,6 +118,10 @@ int marl_q_gather(const float* q, const int* idx, const float* avail, float mask
  * qtran_learner.py:104-113). avail may be NULL. out_max / out_arg may be NULL. */
 int marl_q_masked_max(const float* q, const float* avail, float mask_val, float* out_max, int* out_arg,
                       long rows, int A, void* stream);
+/* Double-Q selection in one pass (q_learner.py:104-117): arg[row] = first-index argmax of q_sel masked with
+ * avail (mask_val where avail == 0), out_val[row] = q_val[row, arg] masked the same way; out_arg may be NULL. */
+int marl_q_double_select(const float* q_sel, const float* q_val, const float* avail, float mask_val,
+                         float* out_val, int* out_arg, long rows, int A, void* stream);
 /* dq = 0; dq[row,idx1[row]] += g1[row/gdiv]; dq[row,idx2[row]] += g2[row/gdiv] (idx2/g2 may be
  * NULL): autograd of gather / max (+ of the sum over agents when gdiv = N). */
 int marl_q_scatter(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),
     "marl_q_masked_max": (I, [P, P, F, P, P, L, I, P]),
+    "marl_q_double_select": (I, [P, P, P, F, P, P, L, I, P]),
     "marl_q_scatter": (I, [P, P, P, P, P, L, I, I, P]),
     "marl_vec_add": (I, [P, P, P, L, P]),
     "marl_agent_sum": (I, [P, P, L, I, I, P]),

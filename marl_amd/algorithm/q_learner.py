@@ -103,8 +103,7 @@ class QLearner:
             # quirk Q1: no init_hidden between the two eval passes (reference :96-110)
             self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
             cur_max = g("cur_max", (R,), torch.int32)
-            ops.q_masked_max(q_en, db.avail_next, MASK_BIG, None, cur_max, R, A)
-            ops.q_gather(q_tgt, cur_max, q_tgt_chosen, R, A, avail=db.avail_next, mask_val=MASK_BIG)
+            ops.q_double_select(q_en, q_tgt, db.avail_next, MASK_BIG, q_tgt_chosen, cur_max, R, A)
         else:
             ops.q_masked_max(q_tgt, db.avail_next, MASK_BIG, q_tgt_chosen, None, R, A)
 

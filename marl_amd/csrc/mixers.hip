@@ -39,6 +39,45 @@ __global__ void q_masked_max_kernel(const float* q, const float* avail, float ma
   }
 }
 
+// Double-Q selection in one pass (reference q_learner.py:104-117): arg = first-index argmax over the available
+// actions of q_sel (the eval net on the next observations), out = q_val (target net) at arg, masked the same way.
+// A wave stages 64 rows of each operand through LDS with fully coalesced loads (rows are A floats = 44 B for
+// 2s3z, a thread-per-row global read pattern wastes most of every 64-byte request); stride A is odd or the
+// tile is padded to an odd stride, so the per-row LDS reads are conflict-free.
+constexpr int DS_ROWS = 64;      // rows per wave-tile
+__global__ __launch_bounds__(256) void q_double_select_kernel(const float* q_sel, const float* q_val, const float* avail,
+                                                              float mask_val, float* out_val, int* out_arg, long rows, int A) {
+  extern __shared__ float ds_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int AS = A | 1;                                   // odd LDS row stride
+  float* Sq = ds_smem + (size_t)wave * 3 * DS_ROWS * AS;
+  float* Sv = Sq + DS_ROWS * AS;
+  float* Sa = Sv + DS_ROWS * AS;
+  const long tiles = (rows + DS_ROWS - 1) / DS_ROWS;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    const long r0 = tile * DS_ROWS;
+    const long n = (rows - r0 < DS_ROWS ? rows - r0 : DS_ROWS) * A;
+    for (long e = lane; e < n; e += 64) {
+      const int r = (int)(e / A), k = (int)(e - (long)r * A);
+      Sq[r * AS + k] = q_sel[r0 * A + e];
+      Sv[r * AS + k] = q_val[r0 * A + e];
+      Sa[r * AS + k] = avail ? avail[r0 * A + e] : 1.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                   // this wave's LDS writes (lgkmcnt(0)); no cross-wave sharing
+    const long r = r0 + lane;
+    if (r < rows) {
+      float best = 0.f; int arg = 0;
+      for (int a = 0; a < A; ++a) {
+        float v = Sq[lane * AS + a];
+        if (Sa[lane * AS + a] == 0.f) v = mask_val;
+        if (a == 0 || v > best) { best = v; arg = a; }   // strict >: first index wins ties (torch)
+      }
+      out_val[r] = Sa[lane * AS + arg] == 0.f ? mask_val : Sv[lane * AS + arg];
+      if (out_arg) out_arg[r] = arg;
+    }
+  }
+}
+
 __global__ void q_scatter_kernel(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,
                                  long rows, int A, int gdiv) {
   for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
@@ -303,6 +342,20 @@ extern "C" int marl_q_masked_max(const float* q, const float* avail, float mask_
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(q_masked_max_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, q, avail, mask_val,
                      out_max, out_arg, rows, A);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int marl_q_double_select(const float* q_sel, const float* q_val, const float* avail, float mask_val,
+                                    float* out_val, int* out_arg, long rows, int A, void* stream) {
+  if (rows <= 0) return 0;
+  const long tiles = (rows + DS_ROWS - 1) / DS_ROWS;
+  long nb = (tiles + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  const size_t lds = (size_t)4 * 3 * DS_ROWS * (A | 1) * sizeof(float);
+  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(q_double_select_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, q_sel, q_val, avail,
+                     mask_val, out_val, out_arg, rows, A);
   MARL_CHECK_LAUNCH();
   return 0;
 }

@@ -169,8 +169,19 @@ class DeviceBatch:
         self.u_taken = cutc(rec.u)
         self.u_act = self.u_taken.clamp(min=0)
         self.r, self.term, self.padded = cutc(rec.r).view(-1), cutc(rec.term).view(-1), cutc(rec.padded).view(-1)
-        t_idx = torch.arange(T, device=big.obs.device)[None, :, None, None]
-        live = t_idx < rec.length[:, None, None, None]
-        self.avail = torch.where(live, rec.avail[:, :T], torch.zeros((), device=big.obs.device)).reshape(E * T * N, A)
+        self._avail_src = (rec, T)            # `avail` (current-step availability, QPLEX / QTRAN only) is built lazily
         self.avail_next = rec.avail[:, 1:T + 1].reshape(E * T * N, A)
         return self
+
+    @property
+    def avail(self):
+        if "_avail" not in self.__dict__:
+            rec, T = self._avail_src
+            t_idx = torch.arange(T, device=rec.avail.device)[None, :, None, None]
+            live = t_idx < rec.length[:, None, None, None]
+            self._avail = torch.where(live, rec.avail[:, :T], torch.zeros((), device=rec.avail.device)).reshape(-1, rec.A)
+        return self._avail
+
+    @avail.setter
+    def avail(self, v):
+        self._avail = v

@@ -182,6 +182,11 @@ def q_masked_max(q, avail, mask_val, out_max, out_arg, rows, A):
                                         _stream()), "marl_q_masked_max")
 
 
+def q_double_select(q_sel, q_val, avail, mask_val, out_val, out_arg, rows, A):
+    check(_lib.load().marl_q_double_select(_p(_f32(q_sel)), _p(_f32(q_val)), _p(avail), float(mask_val), _p(_f32(out_val)),
+                                           _p(out_arg), rows, A, _stream()), "marl_q_double_select")
+
+
 def q_scatter(dq, idx1, g1, idx2, g2, rows, A, gdiv=1):
     check(_lib.load().marl_q_scatter(_p(_f32(dq)), _p(idx1), _p(g1), _p(idx2), _p(g2), rows, A, gdiv, _stream()),
           "marl_q_scatter")

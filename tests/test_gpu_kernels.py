@@ -273,6 +273,19 @@ def test_select_kernels(dev):
     ops.q_masked_max(qd, ad, -9999999.0, mx, am, R, A)
     close(mx, qm.max(1)[0], 0, 0)
     assert (am.cpu().long() == qm.argmax(1)).all()
+    # fused double-Q selection: argmax of the masked eval-next Q, target Q gathered there (q_learner.py:104-117)
+    for RR, AA in ((R, A), (4099, 18), (63, 3)):
+        qs, qv = torch.randn(RR, AA, generator=g), torch.randn(RR, AA, generator=g)
+        av = (torch.rand(RR, AA, generator=g) < 0.6).float()
+        av[::7] = 0                                    # rows with nothing available
+        qs[3, 1] = qs[3, AA - 1] = 5.0; av[3] = 1      # tie -> first index
+        qsm, qvm = qs.clone(), qv.clone()
+        qsm[av == 0] = -9999999.0; qvm[av == 0] = -9999999.0
+        ref_arg = qsm.argmax(1)
+        ov, oa = torch.empty(RR, device=dev), torch.empty(RR, dtype=torch.int32, device=dev)
+        ops.q_double_select(cu(qs, dev), cu(qv, dev), cu(av, dev), -9999999.0, ov, oa, RR, AA)
+        assert (oa.cpu().long() == ref_arg).all()
+        close(ov, qvm.gather(1, ref_arg[:, None]).squeeze(1), 0, 0)
     g1, g2 = torch.randn(R // 5, generator=g), torch.randn(R // 5, generator=g)
     dq = torch.empty(R, A, device=dev)
     ops.q_scatter(dq, idd, cu(g1, dev), am, cu(g2, dev), R, A, gdiv=5)
