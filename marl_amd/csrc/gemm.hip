@@ -26,8 +26,13 @@ struct LinArgs {
   long gs_x0, gs_x1, gs_w, gs_b, gs_y, gs_m0;
 };
 
-// block = 256 threads = 4 waves; wave tile = 32 rows x 64 cols (2 x 4 MFMA tiles)
-template <bool VEC, bool W_KMAJOR>
+// block = 256 threads = 4 waves; wave tile = 32 rows x 64 cols (2 x 4 MFMA tiles).
+// K is walked in chunks of 16.  Chunks that lie entirely inside dense segment 0 (no relu gate) take the FAST path:
+// operands go straight to VGPRs (AMODE 1: one 16-byte load per lane and row tile; AMODE 2: four dword loads, for
+// row strides / bases that are not 16-byte aligned, e.g. S = 322) and are software-pipelined one chunk ahead in a
+// second register set (static ping-pong, no copies).  The remaining chunks (other segments of the virtual concat,
+// segment boundaries, gated inputs) take the guarded element path.
+template <int AMODE, bool W_KMAJOR>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     int cc = col0 + c * 16 + m;
-    bcol[c] = cc < a.N ? cc : a.N - 1;
+    bcol[c] = cc < a.N ? cc : a.N - 1;      // clamped: tiles past N compute garbage that is never stored
   }
 
   f32x4 acc[2][4];
@@ -66,39 +71,65 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
     for (int c = 0; c < 4; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int K = a.K;
-  const int kfull = VEC ? (K & ~15) : 0;
-  long asrc[2];   // source rows of dense segment 0 after the (T+1)-slot remap (vector path only)
+  const int kfast = AMODE ? (x.k0 & ~15) : 0;     // chunks [0, kfast) are whole chunks of dense segment 0
   ConcatRow crow[2];
+  const float* ap[2];                             // row base pointers of segment 0 (fast path)
+  bool aok[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     crow[r] = concat_row(x, arow[r]);
-    asrc[r] = crow[r].r0;
+    ap[r] = x.p0 + crow[r].r0 * x.ld0 + 4 * q;
+    aok[r] = crow[r].ok0;
   }
-  for (int k0 = 0; k0 < kfull; k0 += 16) {   // vector path: 16 B per lane per operand
+  const bool wvec = !W_KMAJOR && (a.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  auto load = [&](f32x4 (&av)[2], f32x4 (&bv)[4], int k0) __attribute__((always_inline)) {
     const int kk = k0 + 4 * q;
-    f32x4 av[2], bv[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) av[r] = *reinterpret_cast<const f32x4*>(x.p0 + asrc[r] * x.ld0 + kk);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c < ct_used) {
-        if (!W_KMAJOR) {
-          bv[c] = *reinterpret_cast<const f32x4*>(W + (long)bcol[c] * a.ldw + kk);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bv[c][i] = W[(long)(kk + i) * a.ldw + bcol[c]];
-        }
+    for (int r = 0; r < 2; ++r) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (aok[r]) {
+        if (AMODE == 1) v = *reinterpret_cast<const f32x4*>(ap[r] + k0);
+        else { v[0] = ap[r][k0]; v[1] = ap[r][k0 + 1]; v[2] = ap[r][k0 + 2]; v[3] = ap[r][k0 + 3]; }
       }
+      av[r] = v;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (c < ct_used) {
+      if (c >= ct_used) continue;
+      if (!W_KMAJOR) {
+        const float* wp = W + (long)bcol[c] * a.ldw + kk;
+        if (wvec) bv[c] = *reinterpret_cast<const f32x4*>(wp);
+        else { bv[c][0] = wp[0]; bv[c][1] = wp[1]; bv[c][2] = wp[2]; bv[c][3] = wp[3]; }
+      } else {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) acc[r][c] = mfma16x4(av[r], bv[c], acc[r][c]);
+        for (int i = 0; i < 4; ++i) bv[c][i] = W[(long)(kk + i) * a.ldw + bcol[c]];
       }
+    }
+  };
+  auto mma = [&](const f32x4 (&av)[2], const f32x4 (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= ct_used) continue;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) acc[r][c] = mfma16x4(av[r], bv[c], acc[r][c]);
+    }
+  };
+  if (AMODE && kfast > 0) {
+    f32x4 aA[2], bA[4], aB[2], bB[4];
+    load(aA, bA, 0);
+    int k0 = 0;
+    while (true) {
+      if (k0 + 16 < kfast) load(aB, bB, k0 + 16);
+      mma(aA, bA);
+      k0 += 16;
+      if (k0 >= kfast) break;
+      if (k0 + 16 < kfast) load(aA, bA, k0 + 16);
+      mma(aB, bB);
+      k0 += 16;
+      if (k0 >= kfast) break;
     }
   }
-  for (int k0 = kfull; k0 < K; k0 += 16) {   // generic path: guarded element loads
+  for (int k0 = kfast; k0 < K; k0 += 16) {   // generic path: guarded element loads
     const int kk = k0 + 4 * q;
     f32x4 av[2], bv[4];
 #pragma unroll
@@ -521,18 +552,23 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
   a.groups = grp ? grp->groups : 1;
   a.gs_x0 = grp ? grp->gs_x0 : 0; a.gs_x1 = grp ? grp->gs_x1 : 0; a.gs_w = grp ? grp->gs_w : 0;
   a.gs_b = grp ? grp->gs_b : 0; a.gs_y = grp ? grp->gs_y : 0; a.gs_m0 = grp ? grp->gs_m0 : 0;
-  bool vec = a.x.k0 >= 16 && !a.x.m0 && (a.x.rpe0 == 0 || a.x.off0 >= 0) && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
-  if (!w_kmajor) vec = vec && (ldw % 4 == 0) && aligned16(W) && (a.gs_w % 4 == 0);
-  // the vector loop only covers whole 16-chunks that lie inside dense segment 0
-  LinArgs av = a;
+  // fast-path mode of the chunks inside dense segment 0: 1 = 16-byte loads, 2 = dword loads, 0 = none
+  int amode = 0;
+  if (a.x.p0 && a.x.k0 >= 16 && !a.x.m0) {
+    const bool al = (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
+    amode = al ? 1 : 2;
+  }
   dim3 grid((M + 127) / 128, (N + 63) / 64, a.groups), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (vec && a.x.k0 == K) {
-    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<true, true>), grid, block, 0, s, av);
-    else hipLaunchKernelGGL((linear_kernel<true, false>), grid, block, 0, s, av);
+  if (amode == 1) {
+    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<1, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((linear_kernel<1, false>), grid, block, 0, s, a);
+  } else if (amode == 2) {
+    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((linear_kernel<2, false>), grid, block, 0, s, a);
   } else {
-    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<false, true>), grid, block, 0, s, av);
-    else hipLaunchKernelGGL((linear_kernel<false, false>), grid, block, 0, s, av);
+    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<0, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((linear_kernel<0, false>), grid, block, 0, s, a);
   }
   MARL_CHECK_LAUNCH();
   return 0;
