@@ -16,6 +16,8 @@ import sys
 import time
 import types
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL / tensor sharing across ranks)
+
 import numpy as np
 import torch
 
