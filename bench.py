@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--alg", default="qmix")
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
+    ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: mixer GEMMs on the bf16 matrix cores (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--leg-iters", type=int, default=3, help="iterations of the separately timed learner / rollout legs")
@@ -122,6 +123,7 @@ def main():
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
 
     args = make_args(o.alg, o.shape, o.T)
+    args.mixer_dtype = o.mixer_dtype
     T, N = args.episode_limit, args.n_agents
     E = o.envs // world                      # envs / episodes per rank
     args.buffer_size = 2 * E
@@ -231,6 +233,7 @@ def main():
             "config": {"workload": "%s_%s_T%d_envs%d" % (o.alg, o.shape, T, o.envs), "alg": o.alg, "shape": o.shape,
                        "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
                        "n_actions": args.n_actions, "episode_limit": T, "global_envs": o.envs, "envs_per_gpu": E,
+                       "mixer_dtype": o.mixer_dtype,
                        "parallelism": "dp%d" % world,
                        "step": "batched rollout (T lock-steps) + replay store/sample + 1 learner.train()"},
             "learner_updates_per_sec": 1.0 / t_learn,

@@ -56,14 +56,17 @@ typedef struct {
 /* ---- dense layers on the fp32 matrix cores (gemm.hip) ---------------------------------------
  * Y = act(X W^T + b) [+ beta*Y].  Replaces every nn.Linear(+ReLU) on the path
  * (network/mixer.py:37-55,117-145,200-206,365-375,399-409).  w_kmajor=1 reads W as [K][N]
- * so the same kernel computes dX = dY W (autograd of nn.Linear wrt input). act: 0 none, 1 relu. */
+ * so the same kernel computes dX = dY W (autograd of nn.Linear wrt input). act: 0 none, 1 relu;
+ * | 0x100 = round both operands to bf16 and use the bf16 matrix cores (fp32 accumulate) - opt-in for the
+ * MIXER layers only (BASELINE config 5 "bf16 mixer with MFMA"; tolerance ~1e-2 instead of 1e-4). */
 int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_kmajor, const float* bias,
                 float* Y, long ldy, int M, int N, int K, int act, float beta,
                 const marl_group_t* grp, void* stream);
 /* dW += G^T X, db += colsum(G) with G = dY * (Yact > 0 if Yact). Fixed-order slab reduction.
- * In grp: gs_y = dY stride, gs_m0 = Yact stride, gs_w / gs_b = dW / db strides. */
+ * In grp: gs_y = dY stride, gs_m0 = Yact stride, gs_w / gs_b = dW / db strides.  flags: 1 = bf16 operands
+ * (as act | 0x100 above). */
 int marl_linear_wgrad(const float* dY, long lddy, const float* Yact, long ldya, const marl_src_t* x,
-                      float* dW, long lddw, float* db, int M, int N, int K,
+                      float* dW, long lddw, float* db, int M, int N, int K, int flags,
                       const marl_group_t* grp, float* ws, size_t ws_bytes, void* stream);
 size_t marl_linear_wgrad_workspace(int M, int N, int K, int groups);
 int marl_wgrad_slabs(int M);

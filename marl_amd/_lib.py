@@ -55,7 +55,7 @@ QW = C.POINTER(MarlQmixWeights)
 # name -> (restype, argtypes); must list every symbol of include/marl_hip.h
 SIGNATURES = {
     "marl_linear": (I, [SRC, P, L, I, P, P, L, I, I, I, I, F, GRP, P]),
-    "marl_linear_wgrad": (I, [P, L, P, L, SRC, P, L, P, I, I, I, GRP, P, SZ, P]),
+    "marl_linear_wgrad": (I, [P, L, P, L, SRC, P, L, P, I, I, I, I, GRP, P, SZ, P]),
     "marl_linear_wgrad_workspace": (SZ, [I, I, I, I]),
     "marl_wgrad_slabs": (I, [I]),
     "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),

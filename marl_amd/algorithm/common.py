@@ -121,7 +121,7 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=
         remap0 = (T * N, obs_bs, obs_t0 * N)
     xin = ops.src(obs.reshape(-1, O), nid=N if args.reuse_network else 0, remap0=remap0, emap0=emap, **kw)
     I = O + (A if args.last_action else 0) + (N if args.reuse_network else 0)
-    ops.linear_wgrad(dxp.view(M, H), xin, ag.fc1.weight.grad, ag.fc1.bias.grad, M, H, I)
+    ops.linear_wgrad(dxp.view(M, H), xin, ag.fc1.weight.grad, ag.fc1.bias.grad, M, H, I, bf16=False)   # agent layers stay fp32
 
 
 class GradReducer:

@@ -78,6 +78,7 @@ class QTRANLearner:
 
     def _forward_backward(self, db):
         a = self.args
+        ops.set_mixer_dtype(getattr(a, "mixer_dtype", "fp32"))     # "bf16": mixer GEMMs on the bf16 matrix cores (opt-in)
         dev = self.device
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T

@@ -42,6 +42,8 @@ def get_mixer_args(args):
     args.rnn_hidden_dim = 64
     args.qmix_hidden_dim = 32
     args.two_hyper_layers = False
+    if not hasattr(args, "mixer_dtype"):
+        args.mixer_dtype = "fp32"     # build extension (BASELINE config 5): "bf16" = mixer GEMMs on the bf16 matrix cores
     args.hyper_hidden_dim = 64
     args.qtran_hidden_dim = 64
     args.lr = 5e-4

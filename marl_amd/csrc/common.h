@@ -23,6 +23,21 @@ __device__ __forceinline__ f32x4 mfma16x4(const f32x4& a, const f32x4& b, f32x4 
   return c;
 }
 
+// bf16 operands, fp32 accumulate (v_mfma_f32_16x16x16_bf16): with the K-permutation above one instruction replaces
+// the four fp32 MFMAs of a 16-chunk.  Opt-in for the MIXER GEMMs only (BASELINE config 5, "bf16 mixer with MFMA").
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16x4_bf16(const f32x4& a, const f32x4& b, f32x4 c) {
+  const s16x4 ab = __builtin_bit_cast(s16x4, __builtin_convertvector(a, bf16x4_t));      // round to nearest even
+  const s16x4 bb = __builtin_bit_cast(s16x4, __builtin_convertvector(b, bf16x4_t));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, bb, c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 mm16x4(const f32x4& a, const f32x4& b, f32x4 c) {
+  if (BF) return mfma16x4_bf16(a, b, c);
+  return mfma16x4(a, b, c);
+}
+
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: abs error ~1e-7 on (0,1)
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {

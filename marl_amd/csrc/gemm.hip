@@ -32,7 +32,7 @@ struct LinArgs {
 // row strides / bases that are not 16-byte aligned, e.g. S = 322) and are software-pipelined one chunk ahead in a
 // second register set (static ping-pong, no copies).  The remaining chunks (other segments of the virtual concat,
 // segment boundaries, gated inputs) take the guarded element path.
-template <int AMODE, bool W_KMAJOR>
+template <int AMODE, bool W_KMAJOR, bool BF>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
     for (int c = 0; c < 4; ++c) {
       if (c >= ct_used) continue;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) acc[r][c] = mfma16x4(av[r], bv[c], acc[r][c]);
+      for (int r = 0; r < 2; ++r) acc[r][c] = mm16x4<BF>(av[r], bv[c], acc[r][c]);
     }
   };
   if (AMODE && kfast > 0) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
     for (int c = 0; c < 4; ++c) {
       if (c < ct_used) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) acc[r][c] = mfma16x4(av[r], bv[c], acc[r][c]);
+        for (int r = 0; r < 2; ++r) acc[r][c] = mm16x4<BF>(av[r], bv[c], acc[r][c]);
       }
     }
   }
@@ -203,6 +203,7 @@ struct WgradArgs {
 constexpr int WS_ = 68;          // LDS row stride (floats)
 constexpr int WCH = 64;          // rows per chunk
 
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][WCH * WS_];     // [buffer][G|X][row][col]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
-          if (kt < kt_used) acc[kt] = mfma16x4(af, bf[kt], acc[kt]);
+          if (kt < kt_used) acc[kt] = mm16x4<BF>(af, bf[kt], acc[kt]);
       }
     }
     if (more) stash(buf ^ 1);
@@ -560,16 +561,16 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
   }
   dim3 grid((M + 127) / 128, (N + 63) / 64, a.groups), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (amode == 1) {
-    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<1, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((linear_kernel<1, false>), grid, block, 0, s, a);
-  } else if (amode == 2) {
-    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<2, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((linear_kernel<2, false>), grid, block, 0, s, a);
-  } else {
-    if (w_kmajor) hipLaunchKernelGGL((linear_kernel<0, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((linear_kernel<0, false>), grid, block, 0, s, a);
-  }
+  const bool bf = (act & 0x100) != 0;        // bf16 operands, fp32 accumulate (mixer GEMMs, opt-in)
+  a.act = act & 0xff;
+#define LIN_GO(AM, KM, BFV) hipLaunchKernelGGL((linear_kernel<AM, KM, BFV>), grid, block, 0, s, a)
+#define LIN_KM(AM, BFV) do { if (w_kmajor) LIN_GO(AM, true, BFV); else LIN_GO(AM, false, BFV); } while (0)
+#define LIN_AM(BFV) do { if (amode == 1) LIN_KM(1, BFV); else if (amode == 2) LIN_KM(2, BFV); else LIN_KM(0, BFV); } while (0)
+  if (bf) LIN_AM(true);
+  else LIN_AM(false);
+#undef LIN_AM
+#undef LIN_KM
+#undef LIN_GO
   MARL_CHECK_LAUNCH();
   return 0;
 }
@@ -588,7 +589,7 @@ extern "C" int marl_wgrad_slabs(int M) {
 }
 
 extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, long ldya, const marl_src_t* x,
-                                 float* dW, long lddw, float* db, int M, int N, int K,
+                                 float* dW, long lddw, float* db, int M, int N, int K, int flags,
                                  const marl_group_t* grp, float* ws, size_t ws_bytes, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int groups = grp ? grp->groups : 1;
@@ -604,9 +605,11 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
            (!Yact || ((ldya % 4 == 0) && aligned16(Yact) && (a.gs_ya % 4 == 0)));
   a.xvec = a.x.p0 && !a.x.m0 && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
-  if (try_wgrad_direct(a, s) != 0) {
+  const bool bf = (flags & 1) != 0;           // bf16 operands, fp32 accumulate (mixer GEMMs, opt-in)
+  if (bf || try_wgrad_direct(a, s) != 0) {
     dim3 grid(a.slabs, a.nyb * groups, (K + 1 + 63) / 64), block(256);
-    hipLaunchKernelGGL(wgrad_kernel, grid, block, 0, s, a);
+    if (bf) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, s, a);
   }
   MARL_CHECK_LAUNCH();
   WredArgs r;

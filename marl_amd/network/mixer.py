@@ -90,7 +90,7 @@ class QMixMixer(nn.Module):
 
     def _fused_ok(self, xs):
         a = self.args
-        return (not a.two_hyper_layers and not getattr(self, "no_fused", False)
+        return (not a.two_hyper_layers and not getattr(self, "no_fused", False) and not ops.MIXER_BF16
                 and ops.qmix_fused_supported(a.n_agents, a.state_shape, a.qmix_hidden_dim)
                 and xs.ld0 % 4 == 0 and (xs.p0 or 0) % 16 == 0 and not (xs.k1 or xs.nhot or xs.nid or xs.m0))
 

@@ -101,9 +101,24 @@ def group(groups, x0=0, x1=0, w=0, b=0, y=0, m0=0):
     return MarlGroup(groups, x0, x1, w, b, y, m0)
 
 
-def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, grp=None):
+# Precision of the MIXER GEMMs (marl_linear / marl_linear_wgrad called by network/mixer.py): "fp32" (exact, default)
+# or "bf16" operands with fp32 accumulation on the bf16 matrix cores (BASELINE config 5).  The agent's layers never
+# use it (their call sites pass bf16=False).
+MIXER_BF16 = False
+
+
+def set_mixer_dtype(name):
+    global MIXER_BF16
+    if name not in ("fp32", "bf16"):
+        raise ValueError("mixer_dtype must be 'fp32' or 'bf16'")
+    MIXER_BF16 = name == "bf16"
+
+
+def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, grp=None, bf16=None):
     """Y[M,N] = act(X W^T + b) (+beta*Y).  W: (N,K) view, or (K,N) when w_kmajor."""
     lib = _lib.load()
+    if MIXER_BF16 if bf16 is None else bf16:
+        act |= 0x100
     if ldw is None:
         ldw = W.stride(0) if W.dim() == 2 else (N if w_kmajor else K)
     ldy = Y.stride(0) if Y.dim() == 2 else N
@@ -113,9 +128,10 @@ def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, gr
           "marl_linear")
 
 
-def linear_wgrad(dY, x, dW, db, M, N, K, Yact=None, grp=None, lddw=None):
+def linear_wgrad(dY, x, dW, db, M, N, K, Yact=None, grp=None, lddw=None, bf16=None):
     """dW[N,K] += (dY * (Yact>0))^T X ; db[N] += column sums."""
     lib = _lib.load()
+    flags = 1 if (MIXER_BF16 if bf16 is None else bf16) else 0
     g = grp.groups if grp is not None else 1
     nbytes = lib.marl_linear_wgrad_workspace(M, N, K, g)
     ws = WS.get("wgrad", nbytes, dY.device)
@@ -124,7 +140,7 @@ def linear_wgrad(dY, x, dW, db, M, N, K, Yact=None, grp=None, lddw=None):
     assert src_width(x) == K, (src_width(x), K)
     check(lib.marl_linear_wgrad(_p(_f32(dY)), dY.stride(0) if dY.dim() == 2 else N,
                                 _p(Yact), (Yact.stride(0) if Yact.dim() == 2 else N) if Yact is not None else 0,
-                                C.byref(x), _p(_f32(dW)), lddw, _p(db), M, N, K,
+                                C.byref(x), _p(_f32(dW)), lddw, _p(db), M, N, K, flags,
                                 C.byref(grp) if grp is not None else None, _p(ws), ws.numel() * 4, _stream()),
           "marl_linear_wgrad")
 

@@ -51,6 +51,29 @@ def test_linear_fwd(dev, M, N, K, act):
     close(dX, refdx, 3e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 416, 322), (1000, 64, 120)])
+def test_linear_bf16_operands(dev, M, N, K):
+    """opt-in bf16 mixer GEMMs (BASELINE config 5): operands rounded to bf16 (RNE), fp32 accumulation - compared
+    with the same rounding in torch (tight) and with exact fp32 (tolerance 2e-2 of the output scale)."""
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    X, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    Y = torch.empty(M, N, device=dev)
+    ops.linear(ops.src(cu(X, dev)), cu(W, dev), cu(b, dev), Y, M, N, K, bf16=True)
+    close(Y, F.linear(rb(X), rb(W), b), 1e-3, 1e-3)
+    exact = F.linear(X, W, b)
+    assert float((Y.cpu() - exact).abs().max()) < 2e-2 * float(exact.abs().max())
+    dY = torch.randn(M, N, generator=g)
+    dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.linear_wgrad(cu(dY, dev), ops.src(cu(X, dev)), dW, db, M, N, K, bf16=True)
+    ref = rb(dY).t() @ rb(X)
+    close(dW / M ** 0.5, ref / M ** 0.5, 2e-3, 2e-3)
+    dX = torch.empty(M, K, device=dev)
+    ops.linear(ops.src(cu(dY, dev)), cu(W, dev), None, dX, M, K, N, w_kmajor=True, bf16=True)
+    close(dX, rb(dY) @ rb(W), 2e-3, 2e-3)
+
+
 def test_linear_concat_and_groups(dev):
     from marl_amd import ops
     g = torch.Generator().manual_seed(5)

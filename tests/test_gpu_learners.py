@@ -146,3 +146,24 @@ def test_checkpoint_roundtrip(tmp_path):
     sd = torch.load(learner.model_dir + "/rnn_net_params.pkl")
     assert set(sd) == {"fc1.weight", "fc1.bias", "rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh",
                        "fc2.weight", "fc2.bias"}
+
+
+def test_bf16_mixer_config5_tolerance():
+    """BASELINE config 5 (QMIX, MMM2 shape) with the opt-in bf16 mixer GEMMs: forward within 2e-2 of the fp32
+    path's scale, gradients almost parallel to the fp32 ones (the agent stays fp32 in both).  Stated tolerance -
+    bf16 has an 8-bit mantissa, so the 1e-4 fp32 bar does not apply to this option."""
+    from marl_amd.hostutil import DeviceBatch
+    case = ("c5", "MMM2", "qmix", 6, 8, None, {})
+    out = {}
+    for dt in ("fp32", "bf16"):
+        args, mac, learner = build_product(case)
+        args.mixer_dtype = dt
+        batch = seeded.make_batch(args, 6, seed=5, lengths=None)
+        loss = learner.train({k: v.copy() for k, v in batch.items()}, 0)
+        out[dt] = (loss, learner._flat.grad.detach().cpu().double().numpy().copy(),
+                   learner._dbg["q_tot"].detach().cpu().numpy().copy())
+    (l32, g32, q32), (l16, g16, q16) = out["fp32"], out["bf16"]
+    assert abs(l16 - l32) <= 3e-2 * abs(l32) and l16 != l32
+    assert np.abs(q16 - q32).max() <= 2e-2 * max(1.0, np.abs(q32).max())
+    cos = float((g16 * g32).sum() / np.sqrt((g16 * g16).sum() * (g32 * g32).sum()))
+    assert cos > 0.999, cos
