@@ -581,12 +581,20 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) main[i] = team ? CAR[(r0 + i) * HS + j] : 0.f;
     const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
+    // three independent accumulation chains (one per gate block) instead of 48 dependent MFMAs: with few row
+    // tiles per workgroup (small shards) nothing else hides the dependent-issue latency
+    f32x4 m1 = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const int coff = (team && c >= 8) ? 192 + 16 * (c - 8) : 16 * c;       // team 1 reads dhn instead of dnp
-      f32x4 av = *reinterpret_cast<const f32x4*>(gr + coff);
-      main = mfma16x4(av, wT[c], main);
+    for (int c = 0; c < 4; ++c) {
+      const int c2off = team ? 192 + 16 * c : 128 + 16 * c;                  // team 1 reads dhn instead of dnp
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(gr + 16 * c);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(gr + 64 + 16 * c);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(gr + c2off);
+      main = mfma16x4(a0, wT[c], main);
+      m1 = mfma16x4(a1, wT[4 + c], m1);
+      m2 = mfma16x4(a2, wT[8 + c], m2);
     }
+    main += m1 + m2;
     // gate-gradient tiles of this wave's 16 columns in accumulator layout (they ARE the A^T fragments)
     f32x4 g0, g1, g2;
     const int g2off = team ? 192 : 128;
@@ -642,6 +650,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   }
 
   int par = 0;
+  bool c0A_carry = true;             // where a team WITHOUT phase-B tiles finds phase-C tile 0 of the coming step
   ST_DECL(5);
   for (int t = a.T - 1; t >= 0; --t, par ^= 1) {
     float* DQ = par ? DQ1 : DQ0;
@@ -659,8 +668,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     }
     // ---------------- phase B.  Entering: sA = the team's first tile (or, without one, phase-C tile 0).
     // Tiles alternate between sA and sB; the item after the last tile is phase-C tile 0, which must end up in sA.
-    bool c0A = true;                 // phase-C tile 0 ends up in sA (else sB)
+    bool c0A = c0A_carry;            // phase-C tile 0 ends up in sA (else sB)
     if (hasB) {
+      c0A = true;
       int rt = team;
       bool pre = true;               // sB already holds (in flight) the item after the first tile
       while (true) {
@@ -706,9 +716,14 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
         procC(sB, rt + 1, t, DQ);
       }
     }
-    if (!in_a) {                      // one copy per step, a whole tile after the loads were issued
+    c0A_carry = true;
+    if (!in_a) {
+      if (hasB) {                     // phase B wants its first tile in sA: one copy per step, a whole tile after the issue
 #pragma unroll
-      for (int k = 0; k < (DHS ? 6 : 5); ++k) sA[k] = sB[k];
+        for (int k = 0; k < (DHS ? 6 : 5); ++k) sA[k] = sB[k];
+      } else {
+        c0A_carry = false;            // a team without phase-B tiles (one row tile per workgroup) just starts from sB
+      }
     }
     if (hasB && t > 0) LOAD_ITEM1(t - 1, true)
     ST_MARK(2);
