@@ -374,6 +374,316 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Software-pipelined variant for ONE row tile per workgroup (the 512-env shards of the 8-GPU strong-scaling run):
+// the step is a chain  h(t-1) -> GRU(t) -> h(t)  and with one or two tiles per workgroup nothing hides the LDS
+// round trips and barrier skew around its three phases.  Only the GRU is on that chain: fc1(t+1) needs just the
+// observation and fc2(t-1) just h(t-1), so here ONE barrier separates the steps and inside a step
+//     team 0 : GRU(t) row tiles
+//     team 1 : fc1(t+1) -> Xt[(t+1)&1],  q(t-1) = fc2(h(t-1)),  then joins the GRU tiles (per-slice counter)
+// with the input tile and the fc1 output double-buffered in LDS (which is why it needs RT <= 3-4).
+// Results are bit-identical to agent_fwd_kernel (same MFMA sequences per output element).
+template <int AC, bool SAVE>
+__global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, ws = wave & 3;
+  const int q = lane >> 4, m = lane & 15;
+  const int rows = a.RT * 16;
+  const int KP = a.KC * 16, KS = KP + 4;
+  float* W1s = smem;                                  // [4][KC][64] f32x4
+  float* In0 = W1s + 4 * a.KC * 64 * 4;               // [2][rows][KS]
+  float* Xt0 = In0 + 2 * rows * KS;                   // [2][rows][HS]
+  float* Ha = Xt0 + 2 * rows * HS;                    // [rows][HS] x2
+  float* Hb = Ha + rows * HS;
+  long* rowobs = reinterpret_cast<long*>(Hb + rows * HS);
+  long* rowu = rowobs + rows;
+  int* rowidx = reinterpret_cast<int*>(rowu + rows);
+  int* rown = rowidx + rows;
+  int* rowlen = rown + rows;
+  int* rowrho = rowlen + rows;
+  int* tilecnt = rowrho + rows;                       // [2][4]: next GRU tile of each hidden-unit slice, by step parity
+
+  const long row0 = (long)blockIdx.x * rows;
+  for (int r = tid; r < rows; r += FNT) {
+    long rho = row0 + r;
+    if (rho > a.R - 1) rho = a.R - 1;                 // clamped duplicates (see agent_fwd_kernel)
+    const long b = rho / a.N;
+    const int n = (int)(rho % a.N);
+    rowidx[r] = (int)(b * a.T * a.N + n);
+    rowobs[r] = ((a.ep_map ? (long)a.ep_map[b] : b) * a.obs_bs + n) * a.O;
+    rowu[r] = b * a.u_bs + n;
+    rown[r] = n;
+    rowlen[r] = a.ep_len ? a.ep_len[b] : 0x7fffffff;
+    rowrho[r] = (int)rho;
+  }
+  if (tid < 8) tilecnt[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < rows * H; e += FNT) {
+    int r = e / H, k = e % H;
+    Ha[r * HS + k] = a.h0 ? a.h0[(long)rowrho[r] * H + k] : 0.f;
+  }
+  const int O = a.O;
+  const int O4 = O >> 2, n4 = rows * O4;
+  const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
+  f32x4 pf[NLDW];
+  int pt = 0, pu = -1;
+  int pu_lds0 = -1, pu_lds1 = -1;     // one-hot column currently set in each input buffer
+  long goff[NLDW]; int loff[NLDW], plen[NLDW];
+#pragma unroll
+  for (int i = 0; i < NLDW; ++i) {
+    int e = tid + FNT * i;
+    if (e > n4 - 1) e = n4 - 1;
+    if (e < 0) e = 0;
+    const int r = (int)(((float)e + 0.5f) * invO4);
+    const int k4 = e - r * O4;
+    loff[i] = r * KS + 4 * k4;
+    goff[i] = rowobs[r] + 4 * k4;
+    plen[i] = rowlen[r];
+  }
+  const long urow = tid < rows ? rowu[tid] : 0;
+  auto issue = [&](int t) {
+    const long toff = (long)(t + a.obs_t0) * a.N * O;
+#pragma unroll
+    for (int i = 0; i < NLDW; ++i) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
+    pt = t;
+    int u = -1;
+    if (tid < rows && a.ufed && t + a.u_t0 >= 0) u = a.ufed[urow + (long)(t + a.u_t0) * a.N];
+    pu = u;
+  };
+  auto commit = [&](float* In, int& pu_lds) {
+#pragma unroll
+    for (int i = 0; i < NLDW; ++i)
+      *reinterpret_cast<f32x4*>(In + loff[i]) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.has_act && tid < rows) {
+      const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
+      if (pn != pu_lds) {
+        if (pu_lds >= 0) In[tid * KS + O + pu_lds] = 0.f;
+        if (pn >= 0) In[tid * KS + O + pn] = 1.f;
+        pu_lds = pn;
+      }
+    }
+  };
+  for (int e = tid; e < 2 * rows * (KP - O); e += FNT) {        // constant columns of both input buffers
+    const int bsel = e / (rows * (KP - O)), e2 = e - bsel * rows * (KP - O);
+    const int r = e2 / (KP - O), k = O + e2 % (KP - O);
+    float v = 0.f;
+    if (a.has_id && k >= a.I - a.N && k < a.I) v = (rown[r] == k - (a.I - a.N)) ? 1.f : 0.f;
+    In0[bsel * rows * KS + r * KS + k] = v;
+  }
+  __syncthreads();
+  const int Tm1 = a.T - 1;
+  issue(0); commit(In0, pu_lds0);
+  issue(Tm1 < 1 ? Tm1 : 1); commit(In0 + rows * KS, pu_lds1);
+  issue(Tm1 < 2 ? Tm1 : 2);
+
+  f32x4 wih[3][4], whh[3][4], w2[AC][4];
+  float bias_r, bias_z, bias_in, bias_hn, bias1, bias2[AC];
+  const int j = 16 * ws + m;
+  {
+    if (team == 0) {
+      for (int c = 0; c < a.KC; ++c) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int k = 16 * c + 4 * q + i;
+          v[i] = k < a.I ? a.W1[(long)j * a.I + k] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(W1s + ((ws * a.KC + c) * 64 + lane) * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        wih[g][c] = *reinterpret_cast<const f32x4*>(a.Wih + (long)(g * H + j) * H + 16 * c + 4 * q);
+        whh[g][c] = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + j) * H + 16 * c + 4 * q);
+      }
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      int arow = 16 * ac + m; if (arow >= a.A) arow = a.A - 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        w2[ac][c] = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
+      bias2[ac] = a.b2[arow];
+    }
+    bias1 = a.b1[j];
+    bias_r = a.bih[j] + a.bhh[j];
+    bias_z = a.bih[H + j] + a.bhh[H + j];
+    bias_in = a.bih[2 * H + j];
+    bias_hn = a.bhh[2 * H + j];
+  }
+  WG_BARRIER();
+  const unsigned jb = (unsigned)j * 4u;
+
+  // x(ts) = relu(fc1(in)) for row tiles rt, rt+stride.. of this wave's slice (pairs share the B fragments)
+  auto fc1 = [&](const float* In, float* Xt, int ts, int rt_first, int rt_stride) __attribute__((always_inline)) {
+    float* const svt = SAVE ? a.saved + (long)ts * a.R * (6 * H) : nullptr;
+    for (int rt = rt_first; rt < a.RT; rt += 2 * rt_stride) {
+      const bool two = rt + rt_stride < a.RT;
+      f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
+      const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
+      const float* in1 = in0 + rt_stride * 16 * KS;
+      const float* wf = W1s + (ws * a.KC * 64 + lane) * 4;
+      for (int c = 0; c < a.KC; ++c) {
+        f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
+        acc0 = mfma16x4(a0, bv, acc0);
+        if (two) {
+          f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
+          acc1 = mfma16x4(a1, bv, acc1);
+        }
+      }
+      const int r0 = rt * 16 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc0[i] = fmaxf(acc0[i], 0.f);
+        Xt[(r0 + i) * HS + j] = acc0[i];
+      }
+      if (SAVE) {
+        const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
+        st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc0[0]);
+        st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc0[1]);
+        st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc0[2]);
+        st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc0[3]);
+      }
+      if (two) {
+        const int r1 = r0 + rt_stride * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc1[i] = fmaxf(acc1[i], 0.f);
+          Xt[(r1 + i) * HS + j] = acc1[i];
+        }
+        if (SAVE) {
+          const int4 rr = *reinterpret_cast<const int4*>(rowrho + r1);
+          st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc1[0]);
+          st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc1[1]);
+          st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc1[2]);
+          st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc1[3]);
+        }
+      }
+    }
+  };
+  // q(ts) = fc2(h) for row tile rt (whole K = 64 in one wave)
+  auto fc2 = [&](const float* Hs, int ts, int rt) __attribute__((always_inline)) {
+    f32x4 acc[AC];
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
+    const float* hr = Hs + (rt * 16 + m) * HS + 4 * q;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+#pragma unroll
+      for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
+    }
+    const int4 ri = *reinterpret_cast<const int4*>(rowidx + rt * 16 + 4 * q);
+    const unsigned A4 = (unsigned)a.A * 4u, trow = (unsigned)ts * (unsigned)a.N;
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      const int col = 16 * ac + m;
+      if (col < a.A) {
+        const unsigned cb = (unsigned)col * 4u;
+        st32(a.q, ((unsigned)ri.x + trow) * A4 + cb, acc[ac][0]);
+        st32(a.q, ((unsigned)ri.y + trow) * A4 + cb, acc[ac][1]);
+        st32(a.q, ((unsigned)ri.z + trow) * A4 + cb, acc[ac][2]);
+        st32(a.q, ((unsigned)ri.w + trow) * A4 + cb, acc[ac][3]);
+      }
+    }
+  };
+
+  // prologue: x(0) by both teams (tiles alternate between them)
+  fc1(In0, Xt0, 0, team, 2);
+  WG_BARRIER();
+
+  float* Hp = Ha;
+  float* Hn = Hb;
+  ST_DECL(6);
+  for (int t = 0; t < a.T; ++t) {
+    const int par = t & 1;
+    const unsigned trow = (unsigned)t * (unsigned)a.N;
+    float* const svt = SAVE ? a.saved + (long)t * a.R * (6 * H) : nullptr;
+    float* Xc = Xt0 + par * rows * HS;                 // x(t), written in the previous step
+    float* Inn = In0 + (par ^ 1) * rows * KS;           // input of step t+1 (committed during step t-1)
+    if (team == 1) {
+      if (t + 1 < a.T) fc1(Inn, Xt0 + (par ^ 1) * rows * HS, t + 1, 0, 1);
+      if (t > 0)
+        for (int rt = ws; rt < a.RT; rt += 4) fc2(Hp, t - 1, rt);
+    }
+    ST_MARK(0);
+    if (tid < 4) tilecnt[(par ^ 1) * 4 + tid] = 0;      // counters of the NEXT step (nobody grabs them before the barrier)
+    // ---------------- GRU row tiles of this slice, shared by the two waves of the SIMD through a counter
+    const bool last = (t == a.T - 1) && a.h_last;
+    auto grab = [&]() {
+      int v = 0;
+      if (lane == 0) v = atomicAdd(&tilecnt[par * 4 + ws], 1);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    int rt_next = grab();
+    while (rt_next < a.RT) {
+      const int rt = rt_next;
+      rt_next = grab();
+      f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
+      f32x4 az = {bias_z, bias_z, bias_z, bias_z};
+      f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
+      f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
+      const float* xr = Xc + (rt * 16 + m) * HS + 4 * q;
+      const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+        ar = mfma16x4(ax, wih[0][c], ar);
+        az = mfma16x4(ax, wih[1][c], az);
+        ain = mfma16x4(ax, wih[2][c], ain);
+        ahn = mfma16x4(ah, whh[2][c], ahn);
+        ar = mfma16x4(ah, whh[0][c], ar);
+        az = mfma16x4(ah, whh[1][c], az);
+      }
+      const int r0 = rt * 16 + 4 * q;
+      f32x4 vhp, vr, vz, vn, vh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vhp[i] = Hp[(r0 + i) * HS + j];
+        vr[i] = sigmoidf_(ar[i]);
+        vz[i] = sigmoidf_(az[i]);
+        vn[i] = tanhf_(ain[i] + vr[i] * ahn[i]);
+        vh[i] = (1.f - vz[i]) * vn[i] + vz[i] * vhp[i];
+        Hn[(r0 + i) * HS + j] = vh[i];
+      }
+      if (a.hs) {
+        const int4 ri = *reinterpret_cast<const int4*>(rowidx + r0);
+        st32(a.hs, ((unsigned)ri.x + trow) * 256u + jb, vh[0]); st32(a.hs, ((unsigned)ri.y + trow) * 256u + jb, vh[1]);
+        st32(a.hs, ((unsigned)ri.z + trow) * 256u + jb, vh[2]); st32(a.hs, ((unsigned)ri.w + trow) * 256u + jb, vh[3]);
+      }
+      const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
+      if (SAVE) {
+        const unsigned e0 = (unsigned)rr.x * 1536u + jb, e1 = (unsigned)rr.y * 1536u + jb;
+        const unsigned e2 = (unsigned)rr.z * 1536u + jb, e3 = (unsigned)rr.w * 1536u + jb;
+        st32(svt, e0, vhp[0]); st32(svt, e1, vhp[1]); st32(svt, e2, vhp[2]); st32(svt, e3, vhp[3]);
+        st32(svt, e0 + 512u, vr[0]); st32(svt, e1 + 512u, vr[1]); st32(svt, e2 + 512u, vr[2]); st32(svt, e3 + 512u, vr[3]);
+        st32(svt, e0 + 768u, vz[0]); st32(svt, e1 + 768u, vz[1]); st32(svt, e2 + 768u, vz[2]); st32(svt, e3 + 768u, vz[3]);
+        st32(svt, e0 + 1024u, vn[0]); st32(svt, e1 + 1024u, vn[1]); st32(svt, e2 + 1024u, vn[2]); st32(svt, e3 + 1024u, vn[3]);
+        st32(svt, e0 + 1280u, ahn[0]); st32(svt, e1 + 1280u, ahn[1]); st32(svt, e2 + 1280u, ahn[2]); st32(svt, e3 + 1280u, ahn[3]);
+      }
+      if (last) {
+        st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
+        st32(a.h_last, (unsigned)rr.z * 256u + jb, vh[2]); st32(a.h_last, (unsigned)rr.w * 256u + jb, vh[3]);
+      }
+    }
+    ST_MARK(1);
+    // input tile of step t+2 -> the buffer fc1 finished with in the previous step; start the loads of step t+3
+    if (par) commit(In0 + rows * KS, pu_lds1);
+    else commit(In0, pu_lds0);
+    issue(t + 3 < a.T ? t + 3 : Tm1);
+    ST_MARK(2);
+    WG_BARRIER();
+    ST_MARK(3);
+    float* tmp = Hp; Hp = Hn; Hn = tmp;
+  }
+  ST_DUMP(6);
+  for (int rt = wave; rt < a.RT; rt += 8) fc2(Hp, a.T - 1, rt);      // q of the last step
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward through time, fully fused: per step the delta pass (dh carry, gate gradients, dx) AND
 // the weight-gradient reductions of W_ih, W_hh, W_2 and their biases.  4 waves, one per SIMD
 // (up to 512 VGPRs): wave w keeps its B-fragments of W_ih^T / W_hh^T / W_2^T and 100 accumulator
@@ -819,6 +1129,8 @@ __global__ __launch_bounds__(256) void agent_bwd_reduce_kernel(BwdRedArgs a) {
   a.db2[k] += s;
 }
 
+static int marl_fwd_pipe_max_rt = 1;   // row tiles per workgroup up to which the pipelined unroll is used (measured: -6 % per update at 1 tile, neutral at 2-3; 0 = never)
+extern "C" void marl_debug_set_pipe_max_rt(int v) { marl_fwd_pipe_max_rt = v; }
 static int marl_fwd_rt_single = 8;   // measured: 1/2/3/5 tiles per workgroup -> 12.1/9.4/8.1/6.5 ms per 120-step rollout
 extern "C" void marl_debug_set_rt_single(int v) { marl_fwd_rt_single = v < 1 ? 1 : v; }
 
@@ -878,6 +1190,23 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   // per-step outputs are addressed with 32-bit byte offsets
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
   hipError_t e;
+  // few row tiles per workgroup and a long unroll: the software-pipelined variant (one barrier per step)
+  if (a.vload && a.RT <= marl_fwd_pipe_max_rt && T >= 4) {
+    const size_t per_row_p = (size_t)(2 * KS + 4 * HS) * 4 + 32;
+    const size_t lds_p = fixed + per_row_p * a.RT * 16 + 64;
+    if (lds_p <= 160 * 1024) {
+      const void* fp;
+      if (A <= 16) fp = saved ? (const void*)agent_fwd_pipe_kernel<1, true> : (const void*)agent_fwd_pipe_kernel<1, false>;
+      else fp = saved ? (const void*)agent_fwd_pipe_kernel<2, true> : (const void*)agent_fwd_pipe_kernel<2, false>;
+      e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+      if (e != hipSuccess) return (int)e;
+      void* kp[] = {(void*)&a};
+      e = hipLaunchKernel(fp, grid, block, kp, lds_p, s);
+      if (e != hipSuccess) return (int)e;
+      MARL_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const void* fn;
 #define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
   const bool sv = saved != nullptr, vl = a.vload != 0;

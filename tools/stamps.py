@@ -12,6 +12,7 @@ from marl_amd import _lib  # noqa: E402
 SEGS = {
     "rollout": ["fc1", "bar1", "gen_slot", "gru", "bar2", "fc2", "bar3", "choice", "bar4", "envstep"],
     "fwd": ["fc1", "bar1", "commit", "gru", "bar2", "fc2"],
+    "fwd_pipe": ["side", "gru", "commit", "bar"],
     "bwd": ["phaseB", "bar1", "phaseC", "dqwrite", "bar2"],
 }
 
@@ -22,7 +23,7 @@ def main():
     lib = _lib.load()
     buf = torch.zeros(16 * 16, dtype=torch.int64, device="cuda")
     import ctypes
-    fn = getattr(lib, "marl_debug_stamps_" + which)
+    fn = getattr(lib, "marl_debug_stamps_" + which.replace("_pipe", ""))
     fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
     assert fn(buf.data_ptr()) == 0
     from marl_amd.controller.share_params import SharedMAC
