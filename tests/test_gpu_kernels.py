@@ -74,6 +74,64 @@ def test_linear_bf16_operands(dev, M, N, K):
     close(dX, rb(dY) @ rb(W), 2e-3, 2e-3)
 
 
+def test_linear_and_wgrad_random_shapes(dev):
+    """Seeded sweep over odd sizes and virtual-concat compositions (aligned / unaligned dense segment 0, second
+    dense segment, one-hot blocks, agent id, relu gate, k-major weights): every dispatch branch of the GEMM kernels
+    (16-byte / dword / element operand paths, partial tiles) against torch."""
+    from marl_amd import ops
+    rng = np.random.RandomState(1234)
+    g = torch.Generator().manual_seed(99)
+    for case in range(40):
+        M = int(rng.choice([1, 15, 16, 17, 100, 129, 300, 700]))
+        N = int(rng.choice([1, 5, 16, 33, 64, 70, 130]))
+        K0 = int(rng.choice([1, 3, 16, 20, 47, 64, 120, 130]))
+        pad = int(rng.choice([0, 0, 1, 3]))                       # row stride K0 + pad: unaligned rows when odd
+        off = int(rng.choice([0, 0, 1]))                          # base pointer offset in floats
+        K1 = int(rng.choice([0, 0, 9]))
+        NH, HW = (int(rng.choice([1, 3])), int(rng.choice([4, 11]))) if rng.rand() < 0.4 else (0, 0)
+        NID = int(rng.choice([0, 0, 5]))
+        base = torch.randn(M * (K0 + pad) + 4, generator=g)
+        x0 = base[off:off + M * (K0 + pad)].view(M, K0 + pad)[:, :K0]
+        parts = [x0]
+        x1 = torch.randn(M, K1, generator=g) if K1 else None
+        if K1:
+            parts.append(x1)
+        idx = None
+        if NH:
+            idx = torch.randint(-1, HW, (M, NH), generator=g)
+            oh = torch.zeros(M, NH, HW)
+            for jj in range(NH):
+                v = idx[:, jj] >= 0
+                oh[v, jj, idx[v, jj]] = 1
+            parts.append(oh.reshape(M, -1))
+        if NID:
+            parts.append(torch.eye(NID)[torch.arange(M) % NID])
+        X = torch.cat(parts, 1)
+        K = X.shape[1]
+        W, b = torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)
+        act = int(rng.rand() < 0.5)
+        bd = cu(base, dev)
+        x0d = bd[off:off + M * (K0 + pad)].view(M, K0 + pad)[:, :K0]
+        src = ops.src(x0d, cu(x1, dev) if K1 else None, cu(idx, dev, torch.int32) if NH else None, NH, HW, NID)
+        Y = torch.full((M, N), 3.0, device=dev)
+        ops.linear(src, cu(W, dev), cu(b, dev), Y, M, N, K, act=act)
+        ref = F.linear(X, W, b)
+        ref = torch.relu(ref) if act else ref
+        close(Y, ref, 3e-4, 3e-4, msg="linear case %d M%d N%d K%d" % (case, M, N, K))
+        dY = torch.randn(M, N, generator=g)
+        gate = torch.randn(M, N, generator=g) if rng.rand() < 0.5 else None
+        Gm = dY * (gate > 0) if gate is not None else dY
+        dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        ops.linear_wgrad(cu(dY, dev), src, dW, db, M, N, K, Yact=cu(gate, dev) if gate is not None else None)
+        sc = max(1.0, M ** 0.5)
+        close(dW / sc, (Gm.t() @ X) / sc, 3e-4, 3e-4, msg="wgrad case %d" % case)
+        close(db / sc, Gm.sum(0) / sc, 3e-4, 3e-4, msg="bgrad case %d" % case)
+        dX = torch.empty(M, K, device=dev)                        # dX = (dY * gate) W through the k-major path
+        ops.linear(ops.src(cu(dY, dev), gate=cu(gate, dev) if gate is not None else None), cu(W, dev), None, dX, M, K, N,
+                   w_kmajor=True)
+        close(dX, Gm @ W, 3e-4, 3e-4, msg="dX case %d" % case)
+
+
 def test_linear_concat_and_groups(dev):
     from marl_amd import ops
     g = torch.Generator().manual_seed(5)
