@@ -380,60 +380,81 @@ __global__ __launch_bounds__(64 * WDW, 1) void wgrad_direct_kernel(WgradArgs a) 
       else if (k - hw < a.x.nid) { pkind[t] = 3; pc[t] = k - hw; }
     }
   }
+  // every load below is issued UNCONDITIONALLY (blocks past the end read clamped rows and contribute zeros): with a
+  // conditional prefetch the compiler cannot count the outstanding loads and waits vmcnt(0) - i.e. for the
+  // prefetch it has just issued - in front of every MFMA block, which serialises streaming and math
+  const int* idxp = a.x.idx ? a.x.idx : reinterpret_cast<const int*>(a.x.p0);
+  const int nhot_e = a.x.nhot ? a.x.nhot : 1;
+  // NOTHING in load() may consume a loaded value (no masking, no select): the first use of a value makes the
+  // compiler wait for that load before it issues the next one, and a block's loads then pay their latencies one
+  // after the other.  load() stores raw bits plus a small predicate word; mac() masks right before the MFMAs.
   f32x4 gA[DU], gB[DU], xA[DU], xB[DU];      // two register sets: the block in flight and the one being consumed
-  float pA[DU][NP], pB[DU][NP];
-  auto load = [&](long blk, f32x4 (&ga)[DU], f32x4 (&xb)[DU], float (&xp)[DU][NP]) __attribute__((always_inline)) {
+  int pA[DU][NP], pB[DU][NP];                // plain tiles: raw 32-bit words (dense float / action index / ready value)
+  int fA, fB;                                // per k-step predicate bits: 1 row inside M, 2 dense row valid, 4 index row valid
+  auto load = [&](long blk, f32x4 (&ga)[DU], f32x4 (&xb)[DU], int (&xp)[DU][NP], int& flags) __attribute__((always_inline)) {
+    int fl = 0;
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
       long row = blk * (4 * DU) + 4 * u + q;
       const bool live = row < a.M;
       if (!live) row = a.M - 1;
-      f32x4 g = *reinterpret_cast<const f32x4*>(a.G + row * a.ldg + 4 * m);
-      if (!live) g = (f32x4){0.f, 0.f, 0.f, 0.f};
-      ga[u] = g;
+      ga[u] = *reinterpret_cast<const f32x4*>(a.G + row * a.ldg + 4 * m);
       const ConcatRow cr = concat_row(a.x, row);
-      if (KP) {
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (cr.ok0) x = *reinterpret_cast<const f32x4*>(a.x.p0 + cr.r0 * a.x.ld0 + 4 * m);
-        xb[u] = x;
-      }
-      // plain tiles, branch-free: the lane's column (hence its segment) is fixed, so every lane issues the dense
-      // load and the index load at clamped addresses and selects (lanes of one wave sit in different segments)
+      const long r0c = cr.ok0 ? cr.r0 : 0, ric = cr.oki ? cr.ri : 0;      // clamped: loads are never predicated
+      fl |= ((live ? 1 : 0) | (cr.ok0 ? 2 : 0) | (cr.oki ? 4 : 0)) << (4 * u);
+      if (KP) xb[u] = *reinterpret_cast<const f32x4*>(a.x.p0 + r0c * a.x.ld0 + 4 * m);
+      // plain tiles: the lane's column (hence its segment) is fixed -> ONE raw 32-bit load per element from a
+      // per-lane selected address (dense float, or the action index of its one-hot block); agent-id lanes need no
+      // memory at all and store their finished value
 #pragma unroll
       for (int t = 0; t < NTP; ++t) {
-        const float vd = cr.ok0 ? a.x.p0[cr.r0 * a.x.ld0 + pcol[t]] : 0.f;
-        float vo = 0.f;
-        if (a.x.nhot) vo = (cr.oki && a.x.idx[cr.ri * a.x.nhot + pj[t]] == pc[t]) ? 1.f : 0.f;
-        const float vi = cr.nidx == pc[t] ? 1.f : 0.f;
-        xp[u][t] = pkind[t] == 0 ? vd : (pkind[t] == 2 ? vo : (pkind[t] == 3 ? vi : 0.f));
+        const uintptr_t pd = reinterpret_cast<uintptr_t>(a.x.p0 + r0c * a.x.ld0 + pcol[t]);
+        const uintptr_t po = reinterpret_cast<uintptr_t>(idxp + ric * nhot_e + pj[t]);
+        const int raw = *reinterpret_cast<const int*>(pkind[t] == 2 ? po : pd);      // one load, address selected per lane
+        xp[u][t] = pkind[t] == 3 ? __float_as_int(cr.nidx == pc[t] ? 1.f : 0.f) : raw;
       }
     }
+    flags = fl;
   };
-  auto mac = [&](const f32x4 (&ga)[DU], const f32x4 (&xb)[DU], const float (&xp)[DU][NP]) __attribute__((always_inline)) {
+  auto mac = [&](const f32x4 (&ga)[DU], const f32x4 (&xb)[DU], const int (&xp)[DU][NP], int flags) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-      const f32x4 g = ga[u];
+      const int f = flags >> (4 * u);
+      f32x4 g = ga[u];
+      if (!(f & 1)) g = (f32x4){0.f, 0.f, 0.f, 0.f};                       // row past M: contributes nothing
       bsum += g;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (KP) x = (f & 2) ? xb[u] : x;
+      float xs[NP];
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) {
+        const int raw = xp[u][t];
+        float v = 0.f;
+        if (pkind[t] == 0) v = (f & 2) ? __int_as_float(raw) : 0.f;
+        else if (pkind[t] == 2) v = ((f & 4) && raw == pc[t]) ? 1.f : 0.f;
+        else if (pkind[t] == 3) v = __int_as_float(raw);
+        xs[t] = v;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (KP) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[j][t] = mfma16(g[j], xb[u][t], acc[j][t]);
+          for (int t = 0; t < 4; ++t) acc[j][t] = mfma16(g[j], x[t], acc[j][t]);
         }
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) acc[j][4 * KP + t] = mfma16(g[j], xp[u][t], acc[j][4 * KP + t]);
+        for (int t = 0; t < NTP; ++t) acc[j][4 * KP + t] = mfma16(g[j], xs[t], acc[j][4 * KP + t]);
       }
     }
   };
   long blk = (long)blockIdx.x * WDW + wave;
-  if (blk < nblk) load(blk, gA, xA, pA);
+  load(blk, gA, xA, pA, fA);
   while (blk < nblk) {
-    if (blk + G < nblk) load(blk + G, gB, xB, pB);
-    mac(gA, xA, pA);
+    load(blk + G, gB, xB, pB, fB);
+    mac(gA, xA, pA, fA);
     blk += G;
     if (blk >= nblk) break;
-    if (blk + G < nblk) load(blk + G, gA, xA, pA);
-    mac(gB, xB, pB);
+    load(blk + G, gA, xA, pA, fA);
+    mac(gB, xB, pB, fB);
     blk += G;
   }
   // ---- workgroup reduction through LDS (wave order fixed -> deterministic), then one slab
