@@ -783,18 +783,20 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   // ---- prefetch sets (named registers; cur = tile being processed, nxt = tile in flight)
   //   B set: [0]=h_prev(own cols) [1]=r [2]=z [3]=n [4]=hn [5]=dhs
   //   C set: [0..3]=x (team 0) / h_prev (team 1), all 64 columns ; [4]=x own cols (team 0) / h_t own cols (team 1)
+  // (every load is unconditional: at t = 0 the "next step" loads re-read step 0 and are never consumed - a
+  // predicated load makes the compiler zero the register first and that write waits for older loads)
 #define LOAD_B(P, tt, rr, en)                                                                            \
   {                                                                                                      \
     const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H);                                            \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
       const int r_ = (rr) * 16 + 4 * q + i;                                                              \
       const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H) + j;                                          \
-      P[0][i] = (en) ? sp_[0] : 0.f;                                                                     \
-      P[1][i] = (en) ? sp_[2 * H] : 0.f;                                                                 \
-      P[2][i] = (en) ? sp_[3 * H] : 0.f;                                                                 \
-      P[3][i] = (en) ? sp_[4 * H] : 0.f;                                                                 \
-      P[4][i] = (en) ? sp_[5 * H] : 0.f;                                                                 \
-      if (DHS) P[5][i] = (en) ? a.dhs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] * rowok[r_] : 0.f; \
+      P[0][i] = sp_[0];                                                                                  \
+      P[1][i] = sp_[2 * H];                                                                              \
+      P[2][i] = sp_[3 * H];                                                                              \
+      P[3][i] = sp_[4 * H];                                                                              \
+      P[4][i] = sp_[5 * H];                                                                              \
+      if (DHS) P[5][i] = a.dhs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j];                       \
     }                                                                                                    \
   }
 #define LOAD_C(P, tt, rr, en)                                                                            \
@@ -803,9 +805,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
       const int r_ = (rr) * 16 + 4 * q + i;                                                              \
       const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H);                                              \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c][i] = (en) ? sp_[16 * c + m] : 0.f;              \
-      if (team) P[4][i] = (en) ? a.hs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j] : 0.f;          \
-      else P[4][i] = (en) ? sp_[j] : 0.f;                                                                \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c][i] = sp_[16 * c + m];                           \
+      if (team) P[4][i] = a.hs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j];                       \
+      else P[4][i] = sp_[j];                                                                             \
     }                                                                                                    \
   }
   auto dq_elem = [&](int t, int e) -> float {
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rt * 16 + 4 * q + i;
-      const float d = DHS ? dh[i] + P[5][i] : dh[i];
+      const float d = DHS ? dh[i] + P[5][i] * rowok[r] : dh[i];
       const float rg = P[1][i], zg = P[2][i], ng = P[3][i];
       const float dn = d * (1.f - zg);
       const float dz = d * (P[0][i] - ng);
@@ -922,13 +924,22 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     if (team) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = main[i];
+      int4 su4 = {0, 0, 0, 0};
+      f32x4 sg4 = {0.f, 0.f, 0.f, 0.f};
+      if (SPQ) {                                   // the 4 rows' (action, gradient) pairs: two 16-byte LDS reads
+        su4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(DQ) + r0);
+        sg4 = *reinterpret_cast<const f32x4*>(DQ + rows + r0);
+      }
 #pragma unroll
       for (int ac = 0; ac < AC; ++ac) {
         f32x4 dqf;
+        if (SPQ) {
+          const int col = 16 * ac + m;
+          dqf[0] = su4.x == col ? sg4[0] : 0.f; dqf[1] = su4.y == col ? sg4[1] : 0.f;
+          dqf[2] = su4.z == col ? sg4[2] : 0.f; dqf[3] = su4.w == col ? sg4[3] : 0.f;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (SPQ) dqf[i] = (reinterpret_cast<const int*>(DQ)[r0 + i] == 16 * ac + m) ? DQ[rows + r0 + i] : 0.f;
-          else dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
+          for (int i = 0; i < 4; ++i) dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
         }
         accW2[ac] = mfma16x4(dqf, P[4], accW2[ac]);
         sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
