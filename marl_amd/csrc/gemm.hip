@@ -230,48 +230,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const long c_begin = (long)blockIdx.x * per;
   long c_end = c_begin + per; if (c_end > chunks) c_end = chunks;
 
-  // staging assignment: element group e = tid + 256*i -> row e/16 of the chunk, columns 4*(e%16) .. +3
-  f32x4 gq[4], xq[4];
+  // staging assignment: element group e = tid + 256*i -> row e/16 of the chunk, columns 4*(e%16) .. +3.
+  // fetch() only ISSUES loads (raw values, clamped addresses, no masking / gating / selecting on a loaded value -
+  // the first use of a value makes the compiler wait for its load before issuing the next one, which serialised
+  // every load of a chunk); stash() masks, gates and writes the LDS tile one chunk later.
+  const bool nvb = a.gvec && n0 + 64 <= a.N;                       // uniform: the whole 64-column block is inside N
+  const bool kvb = a.xvec && k0 + 64 <= x.k0;                      // uniform: the whole k block is inside dense segment 0
+  const bool kdb = !kvb && !x.m0 && x.p0 && k0 + 64 <= x.k0;       // same, but rows not 16-byte aligned: dword loads
+  f32x4 gq[4], yq[4], xq[4];
+  int fq[4];                                                       // 1 row inside M, 2 dense row valid
   auto fetch = [&](long c) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + 256 * i;
       const int rl = e >> 4, c4 = (e & 15) * 4;
-      const long row = c * WCH + rl;
-      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
-      if (row < a.M) {
-        const int nb = n0 + c4;
-        if (a.gvec && nb + 3 < a.N) {
-          gv = *reinterpret_cast<const f32x4*>(G + row * a.ldg + nb);
-          if (Ya) {
-            const f32x4 y4 = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + nb);
+      long row = c * WCH + rl;
+      const bool live = row < a.M;
+      if (!live) row = a.M - 1;
+      const int nb = n0 + c4;
+      if (nvb) {
+        gq[i] = *reinterpret_cast<const f32x4*>(G + row * a.ldg + nb);
+        if (Ya) yq[i] = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + nb);
+      } else {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) gv[cc] = y4[cc] > 0.f ? gv[cc] : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            if (nb + cc < a.N) {
-              float v = G[row * a.ldg + nb + cc];
-              if (Ya) v = Ya[row * a.ldya + nb + cc] > 0.f ? v : 0.f;
-              gv[cc] = v;
-            }
-          }
-        }
-        const ConcatRow cr = concat_row(x, row);
-        const int kb = k0 + c4;
-        if (a.xvec && cr.ok0 && kb + 3 < x.k0) {
-          xv = *reinterpret_cast<const f32x4*>(x.p0 + cr.r0 * x.ld0 + kb);
-        } else {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int k = kb + cc;
-            if (k < a.K) xv[cc] = concat_at(x, cr, k);
-            else if (k == a.K) xv[cc] = 1.f;          // virtual ones column => bias gradient
-          }
+        for (int cc = 0; cc < 4; ++cc) {
+          const int n = nb + cc < a.N ? nb + cc : a.N - 1;         // clamped; masked in stash()
+          gq[i][cc] = G[row * a.ldg + n];
+          if (Ya) yq[i][cc] = Ya[row * a.ldya + n];
         }
       }
-      gq[i] = gv; xq[i] = xv;
+      const ConcatRow cr = concat_row(x, row);
+      fq[i] = (live ? 1 : 0) | (cr.ok0 ? 2 : 0);
+      const int kb = k0 + c4;
+      if (kvb) {
+        xq[i] = *reinterpret_cast<const f32x4*>(x.p0 + (cr.ok0 ? cr.r0 : 0) * x.ld0 + kb);
+      } else if (kdb) {
+        const float* xp_ = x.p0 + (cr.ok0 ? cr.r0 : 0) * x.ld0 + kb;
+        xq[i][0] = xp_[0]; xq[i][1] = xp_[1]; xq[i][2] = xp_[2]; xq[i][3] = xp_[3];
+      } else {
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int k = kb + cc;
+          if (k < a.K) xv[cc] = concat_at(x, cr, k);
+          else if (k == a.K) xv[cc] = 1.f;            // virtual ones column => bias gradient
+        }
+        xq[i] = xv;
+      }
     }
   };
   auto stash = [&](int buf) {
@@ -279,8 +284,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int e = tid + 256 * i;
       const int rl = e >> 4, c4 = (e & 15) * 4;
-      *reinterpret_cast<f32x4*>(&lds[buf][0][rl * WS_ + c4]) = gq[i];
-      *reinterpret_cast<f32x4*>(&lds[buf][1][rl * WS_ + c4]) = xq[i];
+      f32x4 gv = gq[i], xv = xq[i];
+      if (Ya) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) gv[cc] = yq[i][cc] > 0.f ? gv[cc] : 0.f;
+      }
+      if (!nvb) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) gv[cc] = n0 + c4 + cc < a.N ? gv[cc] : 0.f;
+      }
+      if (!(fq[i] & 1)) gv = (f32x4){0.f, 0.f, 0.f, 0.f};          // row past M contributes nothing
+      if ((kvb || kdb) && !(fq[i] & 2)) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&lds[buf][0][rl * WS_ + c4]) = gv;
+      *reinterpret_cast<f32x4*>(&lds[buf][1][rl * WS_ + c4]) = xv;
     }
   };
 
