@@ -78,24 +78,21 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     crow[r] = concat_row(x, arow[r]);
-    ap[r] = x.p0 + crow[r].r0 * x.ld0 + 4 * q;
     aok[r] = crow[r].ok0;
+    ap[r] = x.p0 + (aok[r] ? crow[r].r0 : 0) * x.ld0 + 4 * q;
   }
   const bool wvec = !W_KMAJOR && (a.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  // load() issues a FIXED number of unpredicated loads (invalid rows read row 0 and are zeroed in mma(), column
+  // tiles past N read a clamped column): predicated or conditional loads keep the compiler from counting them
   auto load = [&](f32x4 (&av)[2], f32x4 (&bv)[4], int k0) __attribute__((always_inline)) {
     const int kk = k0 + 4 * q;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (aok[r]) {
-        if (AMODE == 1) v = *reinterpret_cast<const f32x4*>(ap[r] + k0);
-        else { v[0] = ap[r][k0]; v[1] = ap[r][k0 + 1]; v[2] = ap[r][k0 + 2]; v[3] = ap[r][k0 + 3]; }
-      }
-      av[r] = v;
+      if (AMODE == 1) av[r] = *reinterpret_cast<const f32x4*>(ap[r] + k0);
+      else { av[r][0] = ap[r][k0]; av[r][1] = ap[r][k0 + 1]; av[r][2] = ap[r][k0 + 2]; av[r][3] = ap[r][k0 + 3]; }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (c >= ct_used) continue;
       if (!W_KMAJOR) {
         const float* wp = W + (long)bcol[c] * a.ldw + kk;
         if (wvec) bv[c] = *reinterpret_cast<const f32x4*>(wp);
@@ -107,23 +104,29 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
     }
   };
   auto mma = [&](const f32x4 (&av)[2], const f32x4 (&bv)[4]) __attribute__((always_inline)) {
+    f32x4 am[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) am[r] = aok[r] ? av[r] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c >= ct_used) continue;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) acc[r][c] = mm16x4<BF>(av[r], bv[c], acc[r][c]);
+      for (int r = 0; r < 2; ++r) acc[r][c] = mm16x4<BF>(am[r], bv[c], acc[r][c]);
     }
   };
   if (AMODE && kfast > 0) {
+    // the prefetch is issued unconditionally (the last chunk is simply loaded again): a conditional issue makes the
+    // compiler wait vmcnt(0) - for the prefetch it has just issued - in front of every MFMA block
     f32x4 aA[2], bA[4], aB[2], bB[4];
+    const int klast = kfast - 16;
     load(aA, bA, 0);
     int k0 = 0;
     while (true) {
-      if (k0 + 16 < kfast) load(aB, bB, k0 + 16);
+      load(aB, bB, k0 + 16 < klast ? k0 + 16 : klast);
       mma(aA, bA);
       k0 += 16;
       if (k0 >= kfast) break;
-      if (k0 + 16 < kfast) load(aA, bA, k0 + 16);
+      load(aA, bA, k0 + 16 < klast ? k0 + 16 : klast);
       mma(aB, bB);
       k0 += 16;
       if (k0 >= kfast) break;
