@@ -151,6 +151,7 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
   long tile = blockIdx.x;
   if (tile < tiles) { fetch(tile); fetch_qg(tile); stash(0); }
   int buf = 0;
+  ST_DECL(8);
   // barriers below only order LDS traffic (s_waitcnt lgkmcnt): the prefetch loads of the next tile stay in
   // flight across them - a __syncthreads() would drain vmcnt and expose the HBM latency on every tile
   for (; tile < tiles; tile += gridDim.x, buf ^= 1) {
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
     if (BWD && tid >= 192 && tid < 208) Gs[tid - 192] = pg;
     const long nt = tile + gridDim.x;
     if (nt < tiles) { fetch(nt); fetch_qg(nt); }
+    ST_MARK(0);
     WG_BARRIER();                                  // Ss[buf], Qs, Gs ready
+    ST_MARK(1);
     // ---- hypernet tile: out[row 4q+i][col 16gt+m], 4 column tiles x 8 k-chunks
     f32x4 acc[TPW];
 #pragma unroll
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
 #pragma unroll
       for (int c = 0; c < TPW; ++c) acc[c] = mfma16x4(a4, wq[c][kc], acc[c]);
     }
+    ST_MARK(2);
     // ---- partial pre-activations: a_e = b1_e + sum_n q_n |w1[n,e]|  (this wave's agents / b1 tiles)
     float pa[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -195,7 +199,9 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) PA[wave][4 * q4 + i][16 * h + m] = pa[h][i];
+    ST_MARK(3);
     WG_BARRIER();
+    ST_MARK(4);
     // ---- finish: wave w takes rows (16/NW)w .., two rows per pass (lane = e of row `half`)
 #pragma unroll
     for (int p = 0; p < 8 / NW; ++p) {
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
         if (e == 0) acc_bb2 += gr;
       }
     }
+    ST_MARK(5);
     if (BWD) {
       WG_BARRIER();
       // ---- d(hypernet output) in accumulator layout, dq, then dW += dhy^T [s | 1]
@@ -259,10 +266,13 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
         for (int c = 0; c < TPW; ++c) accW[c][kc] = mfma16x4(dhy[c], sD, accW[c][kc]);
       }
     }
+    ST_MARK(6);
     if (nt < tiles) stash(buf ^ 1);
+    ST_MARK(7);
     // the next iteration's first barrier orders these LDS writes before their readers; the small tiles
     // (PA, W2A, ...) are rewritten only after that barrier too
   }
+  ST_DUMP(8);
   if (BWD) {
     float* slab = a.ws + (long)blockIdx.x * qmix_slab_floats(C, S);
     const int Sx = S + 1;
@@ -335,6 +345,10 @@ __global__ __launch_bounds__(64 * RSG) void qmix_fused_reduce_kernel(QmixRedArgs
     if (tpos < E) a.dwb2[tpos] += s; else a.dbb2[0] += s;
   }
 }
+
+}  // namespace
+ST_DEFINE_SETTER(marl_debug_stamps_qmix)
+namespace {
 
 inline bool supported(int N, int S, int Eq) { return Eq == E && N * E + 3 * E <= 256 && S <= 128 && N <= 16 && S >= 1; }
 

@@ -13,6 +13,7 @@ SEGS = {
     "rollout": ["fc1", "bar1", "gen_slot", "gru", "bar2", "fc2", "bar3", "choice", "bar4", "envstep"],
     "fwd": ["fc1", "bar1", "commit", "gru", "bar2", "fc2"],
     "fwd_pipe": ["side", "gru", "commit", "bar"],
+    "qmix": ["top+fetch", "bar1", "mfma", "pa", "bar2", "finish", "bwd", "stash"],
     "bwd": ["phaseB", "bar1", "phaseC", "dqwrite", "bar2"],
 }
 
