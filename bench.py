@@ -246,7 +246,7 @@ def main():
                          "separate passes; profiles/r01_pmc.json)", "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
                          "flop_per_launch": fl},
         }
-        if not o.no_cpu_baseline:
+        if not o.no_cpu_baseline and world == 1:      # a reported baseline of the N=1 line only
             out["cpu_baseline"] = cpu_baseline(o.alg, o.shape, T, o.cpu_envs, budget_s=20)
         print(json.dumps(out))
     if world > 1:
