@@ -46,33 +46,41 @@ __global__ void q_masked_max_kernel(const float* q, const float* avail, float ma
 // tile is padded to an odd stride, so the per-row LDS reads are conflict-free.
 constexpr int DS_ROWS = 64;      // rows per wave-tile
 __global__ __launch_bounds__(256) void q_double_select_kernel(const float* q_sel, const float* q_val, const float* avail,
-                                                              float mask_val, float* out_val, int* out_arg, long rows, int A) {
-  extern __shared__ float ds_smem[];
+                                                              float mask_val, float* out_val, int* out_arg, long rows, int A, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float ds_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int AS = A | 1;                                   // odd LDS row stride
-  float* Sq = ds_smem + (size_t)wave * 3 * DS_ROWS * AS;
-  float* Sv = Sq + DS_ROWS * AS;
-  float* Sa = Sv + DS_ROWS * AS;
+  const int TS = (DS_ROWS * A + 3) & ~3;                  // floats per operand tile (16-byte multiple)
+  float* Sq = ds_smem + (size_t)wave * 3 * TS;
+  float* Sv = Sq + TS;
+  float* Sa = Sv + TS;
   const long tiles = (rows + DS_ROWS - 1) / DS_ROWS;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
     const long r0 = tile * DS_ROWS;
-    const long n = (rows - r0 < DS_ROWS ? rows - r0 : DS_ROWS) * A;
-    for (long e = lane; e < n; e += 64) {
-      const int r = (int)(e / A), k = (int)(e - (long)r * A);
-      Sq[r * AS + k] = q_sel[r0 * A + e];
-      Sv[r * AS + k] = q_val[r0 * A + e];
-      Sa[r * AS + k] = avail ? avail[r0 * A + e] : 1.f;
+    const int n = (int)((rows - r0 < DS_ROWS ? rows - r0 : DS_ROWS) * A);
+    // the tile is one contiguous run of n floats (64 rows x A): copied as it lies, 16 bytes per lane, no index math
+    // (r0 * A * 4 is a multiple of 16, the operands themselves are 16-byte aligned - checked on the host)
+    const float* gq = q_sel + r0 * A;
+    const float* gv = q_val + r0 * A;
+    const float* ga = avail ? avail + r0 * A : nullptr;
+    const int n4 = vec ? n >> 2 : 0;                   // (operands not 16-byte aligned: plain element copy)
+    for (int e = lane; e < n4; e += 64) {
+      reinterpret_cast<f32x4*>(Sq)[e] = reinterpret_cast<const f32x4*>(gq)[e];
+      reinterpret_cast<f32x4*>(Sv)[e] = reinterpret_cast<const f32x4*>(gv)[e];
+      reinterpret_cast<f32x4*>(Sa)[e] = ga ? reinterpret_cast<const f32x4*>(ga)[e] : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+    for (int e = 4 * n4 + lane; e < n; e += 64) {
+      Sq[e] = gq[e]; Sv[e] = gv[e]; Sa[e] = ga ? ga[e] : 1.f;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                   // this wave's LDS writes (lgkmcnt(0)); no cross-wave sharing
     const long r = r0 + lane;
     if (r < rows) {
       float best = 0.f; int arg = 0;
       for (int a = 0; a < A; ++a) {
-        float v = Sq[lane * AS + a];
-        if (Sa[lane * AS + a] == 0.f) v = mask_val;
+        float v = Sq[lane * A + a];
+        if (Sa[lane * A + a] == 0.f) v = mask_val;
         if (a == 0 || v > best) { best = v; arg = a; }   // strict >: first index wins ties (torch)
       }
-      out_val[r] = Sa[lane * AS + arg] == 0.f ? mask_val : Sv[lane * AS + arg];
+      out_val[r] = Sa[lane * A + arg] == 0.f ? mask_val : Sv[lane * A + arg];
       if (out_arg) out_arg[r] = arg;
     }
   }
@@ -352,10 +360,11 @@ extern "C" int marl_q_double_select(const float* q_sel, const float* q_val, cons
   const long tiles = (rows + DS_ROWS - 1) / DS_ROWS;
   long nb = (tiles + 3) / 4;
   if (nb > 2048) nb = 2048;
-  const size_t lds = (size_t)4 * 3 * DS_ROWS * (A | 1) * sizeof(float);
+  const size_t lds = (size_t)4 * 3 * ((DS_ROWS * A + 3) & ~3) * sizeof(float);
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  const int vec = ((reinterpret_cast<uintptr_t>(q_sel) | reinterpret_cast<uintptr_t>(q_val) | reinterpret_cast<uintptr_t>(avail)) & 15) == 0;
   hipLaunchKernelGGL(q_double_select_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, q_sel, q_val, avail,
-                     mask_val, out_val, out_arg, rows, A);
+                     mask_val, out_val, out_arg, rows, A, vec);
   MARL_CHECK_LAUNCH();
   return 0;
 }

@@ -366,6 +366,11 @@ def test_select_kernels(dev):
         ov, oa = torch.empty(RR, device=dev), torch.empty(RR, dtype=torch.int32, device=dev)
         ops.q_double_select(cu(qs, dev), cu(qv, dev), cu(av, dev), -9999999.0, ov, oa, RR, AA)
         assert (oa.cpu().long() == ref_arg).all()
+        un = torch.empty(RR * AA + 1, device=dev)           # operand at an address that is not 16-byte aligned
+        un[1:] = cu(qs, dev).reshape(-1)
+        ov2, oa2 = torch.empty(RR, device=dev), torch.empty(RR, dtype=torch.int32, device=dev)
+        ops.q_double_select(un[1:].view(RR, AA), cu(qv, dev), cu(av, dev), -9999999.0, ov2, oa2, RR, AA)
+        assert torch.equal(oa2, oa) and torch.equal(ov2, ov)
         close(ov, qvm.gather(1, ref_arg[:, None]).squeeze(1), 0, 0)
     g1, g2 = torch.randn(R // 5, generator=g), torch.randn(R // 5, generator=g)
     dq = torch.empty(R, A, device=dev)
