@@ -32,7 +32,7 @@ struct LinArgs {
 // row strides / bases that are not 16-byte aligned, e.g. S = 322) and are software-pipelined one chunk ahead in a
 // second register set (static ping-pong, no copies).  The remaining chunks (other segments of the virtual concat,
 // segment boundaries, gated inputs) take the guarded element path.
-template <int AMODE, bool W_KMAJOR, bool BF>
+template <int AMODE, bool W_KMAJOR, bool BF, bool GATE>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -74,22 +74,28 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const int kfast = AMODE ? (x.k0 & ~15) : 0;     // chunks [0, kfast) are whole chunks of dense segment 0
   ConcatRow crow[2];
   const float* ap[2];                             // row base pointers of segment 0 (fast path)
+  const float* mp[2];                             // ... and of its relu gate (GATE: value * (gate > 0), the dX = (dY*relu') W calls)
   bool aok[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     crow[r] = concat_row(x, arow[r]);
     aok[r] = crow[r].ok0;
     ap[r] = x.p0 + (aok[r] ? crow[r].r0 : 0) * x.ld0 + 4 * q;
+    mp[r] = GATE ? x.m0 + (aok[r] ? crow[r].r0 : 0) * x.ldm0 + 4 * q : nullptr;
   }
   const bool wvec = !W_KMAJOR && (a.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   // load() issues a FIXED number of unpredicated loads (invalid rows read row 0 and are zeroed in mma(), column
   // tiles past N read a clamped column): predicated or conditional loads keep the compiler from counting them
-  auto load = [&](f32x4 (&av)[2], f32x4 (&bv)[4], int k0) __attribute__((always_inline)) {
+  auto load = [&](f32x4 (&av)[2], f32x4 (&mv)[2], f32x4 (&bv)[4], int k0) __attribute__((always_inline)) {
     const int kk = k0 + 4 * q;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (AMODE == 1) av[r] = *reinterpret_cast<const f32x4*>(ap[r] + k0);
       else { av[r][0] = ap[r][k0]; av[r][1] = ap[r][k0 + 1]; av[r][2] = ap[r][k0 + 2]; av[r][3] = ap[r][k0 + 3]; }
+      if (GATE) {
+        if (AMODE == 1) mv[r] = *reinterpret_cast<const f32x4*>(mp[r] + k0);
+        else { mv[r][0] = mp[r][k0]; mv[r][1] = mp[r][k0 + 1]; mv[r][2] = mp[r][k0 + 2]; mv[r][3] = mp[r][k0 + 3]; }
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -103,10 +109,16 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
       }
     }
   };
-  auto mma = [&](const f32x4 (&av)[2], const f32x4 (&bv)[4]) __attribute__((always_inline)) {
+  auto mma = [&](const f32x4 (&av)[2], const f32x4 (&mv)[2], const f32x4 (&bv)[4]) __attribute__((always_inline)) {
     f32x4 am[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) am[r] = aok[r] ? av[r] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 2; ++r) {
+      am[r] = aok[r] ? av[r] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (GATE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) am[r][i] = mv[r][i] > 0.f ? am[r][i] : 0.f;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c >= ct_used) continue;
@@ -117,17 +129,17 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   if (AMODE && kfast > 0) {
     // the prefetch is issued unconditionally (the last chunk is simply loaded again): a conditional issue makes the
     // compiler wait vmcnt(0) - for the prefetch it has just issued - in front of every MFMA block
-    f32x4 aA[2], bA[4], aB[2], bB[4];
+    f32x4 aA[2], bA[4], aB[2], bB[4], mA[2], mB[2];
     const int klast = kfast - 16;
-    load(aA, bA, 0);
+    load(aA, mA, bA, 0);
     int k0 = 0;
     while (true) {
-      load(aB, bB, k0 + 16 < klast ? k0 + 16 : klast);
-      mma(aA, bA);
+      load(aB, mB, bB, k0 + 16 < klast ? k0 + 16 : klast);
+      mma(aA, mA, bA);
       k0 += 16;
       if (k0 >= kfast) break;
-      load(aA, bA, k0 + 16 < klast ? k0 + 16 : klast);
-      mma(aB, bB);
+      load(aA, mA, bA, k0 + 16 < klast ? k0 + 16 : klast);
+      mma(aB, mB, bB);
       k0 += 16;
       if (k0 >= kfast) break;
     }
@@ -595,15 +607,19 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
   a.gs_b = grp ? grp->gs_b : 0; a.gs_y = grp ? grp->gs_y : 0; a.gs_m0 = grp ? grp->gs_m0 : 0;
   // fast-path mode of the chunks inside dense segment 0: 1 = 16-byte loads, 2 = dword loads, 0 = none
   int amode = 0;
-  if (a.x.p0 && a.x.k0 >= 16 && !a.x.m0) {
-    const bool al = (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
+  const bool gate = a.x.m0 != nullptr;
+  if (a.x.p0 && a.x.k0 >= 16) {
+    bool al = (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
+    if (gate) al = al && (a.x.ldm0 % 4 == 0) && aligned16(a.x.m0) && (a.gs_m0 % 4 == 0);
     amode = al ? 1 : 2;
   }
   dim3 grid((M + 127) / 128, (N + 63) / 64, a.groups), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool bf = (act & 0x100) != 0;        // bf16 operands, fp32 accumulate (mixer GEMMs, opt-in)
   a.act = act & 0xff;
-#define LIN_GO(AM, KM, BFV) hipLaunchKernelGGL((linear_kernel<AM, KM, BFV>), grid, block, 0, s, a)
+#define LIN_GT(AM, KM, BFV) do { if (gate) hipLaunchKernelGGL((linear_kernel<AM, KM, BFV, true>), grid, block, 0, s, a); \
+                                else hipLaunchKernelGGL((linear_kernel<AM, KM, BFV, false>), grid, block, 0, s, a); } while (0)
+#define LIN_GO(AM, KM, BFV) LIN_GT(AM, KM, BFV)
 #define LIN_KM(AM, BFV) do { if (w_kmajor) LIN_GO(AM, true, BFV); else LIN_GO(AM, false, BFV); } while (0)
 #define LIN_AM(BFV) do { if (amode == 1) LIN_KM(1, BFV); else if (amode == 2) LIN_KM(2, BFV); else LIN_KM(0, BFV); } while (0)
   if (bf) LIN_AM(true);
@@ -611,6 +627,7 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
 #undef LIN_AM
 #undef LIN_KM
 #undef LIN_GO
+#undef LIN_GT
   MARL_CHECK_LAUNCH();
   return 0;
 }
