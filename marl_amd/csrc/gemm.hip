@@ -250,8 +250,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   // the first use of a value makes the compiler wait for its load before issuing the next one, which serialised
   // every load of a chunk); stash() masks, gates and writes the LDS tile one chunk later.
   const bool nvb = a.gvec && n0 + 64 <= a.N;                       // uniform: the whole 64-column block is inside N
-  const bool kvb = a.xvec && k0 + 64 <= x.k0;                      // uniform: the whole k block is inside dense segment 0
-  const bool kdb = !kvb && !x.m0 && x.p0 && k0 + 64 <= x.k0;       // same, but rows not 16-byte aligned: dword loads
   f32x4 gq[4], yq[4], xq[4];
   int fq[4];                                                       // 1 row inside M, 2 dense row valid
   auto fetch = [&](long c) {
@@ -275,11 +273,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
       }
       const ConcatRow cr = concat_row(x, row);
-      fq[i] = (live ? 1 : 0) | (cr.ok0 ? 2 : 0);
       const int kb = k0 + c4;
-      if (kvb) {
+      // per ITEM (4 columns): inside dense segment 0 and ungated -> raw 16-byte / dword loads, masked in stash();
+      // only items that straddle a segment boundary or lie in the one-hot / id / ones columns take the element path
+      // (a per-BLOCK test sent every partial last block - e.g. columns 64..120 of a 120-wide state - down that path)
+      const bool ins = x.p0 && !x.m0 && kb + 3 < x.k0;
+      fq[i] = (live ? 1 : 0) | (cr.ok0 ? 2 : 0) | (ins ? 4 : 0);
+      if (ins && a.xvec) {
         xq[i] = *reinterpret_cast<const f32x4*>(x.p0 + (cr.ok0 ? cr.r0 : 0) * x.ld0 + kb);
-      } else if (kdb) {
+      } else if (ins) {
         const float* xp_ = x.p0 + (cr.ok0 ? cr.r0 : 0) * x.ld0 + kb;
         xq[i][0] = xp_[0]; xq[i][1] = xp_[1]; xq[i][2] = xp_[2]; xq[i][3] = xp_[3];
       } else {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         for (int cc = 0; cc < 4; ++cc) gv[cc] = n0 + c4 + cc < a.N ? gv[cc] : 0.f;
       }
       if (!(fq[i] & 1)) gv = (f32x4){0.f, 0.f, 0.f, 0.f};          // row past M contributes nothing
-      if ((kvb || kdb) && !(fq[i] & 2)) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if ((fq[i] & 4) && !(fq[i] & 2)) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&lds[buf][0][rl * WS_ + c4]) = gv;
       *reinterpret_cast<f32x4*>(&lds[buf][1][rl * WS_ + c4]) = xv;
     }
