@@ -164,6 +164,29 @@ int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const
                         float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
                         int N, int S, int E, void* stream);
 
+/* ---- fused three-layer heads (mlp3_fused.hip) -----------------------------------------------
+ * Y[:, g*gs_y + 0..N3) = W3_g relu(W2_g relu(W1_g x + b1_g) + b2_g) + b3_g for `groups` equally shaped heads
+ * with hidden width 64 whose parameters sit at constant element strides: the key / agents / action extractors
+ * of DMAQ_SI_Weight (network/mixer.py:117-145, evaluated at :155-169 - 10 heads x 3 families per mixer call).
+ * One kernel per family: the 64-wide hidden activations never leave the CU (composed from marl_linear they
+ * cross HBM four times per update).  x: [dense0 | dense1 | one-hot blocks], shared by all heads; no gate / id
+ * block.  The backward recomputes the hidden activations, keeps the weight gradients of a stripe of rows in
+ * registers and accumulates them (fixed-order slab reduction) into `grads` (same struct, gradient tensors);
+ * inputs get no gradient (states / actions).  Use when marl_mlp3_supported(); otherwise compose marl_linear. */
+typedef struct {
+  const float *w1, *b1;         /* (64,K1), (64) of head 0 */
+  const float *w2, *b2;         /* (64,64), (64)           */
+  const float *w3, *b3;         /* (N3,64), (N3)           */
+  long gs_w1, gs_b1, gs_w2, gs_b2, gs_w3, gs_b3;   /* element strides between consecutive heads */
+} marl_mlp3_weights_t;
+int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups);
+int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
+                  long M, int K1, int N3, int groups, void* stream);
+size_t marl_mlp3_bwd_workspace(long M, int K1, int N3, int groups);
+int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
+                  const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, long M, int K1, int N3,
+                  int groups, void* stream);
+
 /* QPLEX (DMAQer.forward + calc_v/calc_adv, mixer.py:211-288; DMAQ_SI_Weight tail :158-169).
  *  wv row = [w_raw (N) | v (N)] (outputs of hyper_w_final.2 / V.2);
  *  heads = key (rows,K,1) | agents (rows,K,N) | action (rows,K,N) raw extractor outputs.

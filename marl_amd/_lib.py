@@ -36,6 +36,11 @@ class MarlQmixWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "w1_b", "b1", "b1_b", "w2", "w2_b", "h", "h_b", "b2_w", "b2_b")]
 
 
+class MarlMlp3Weights(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")] +
+                [(n, C.c_long) for n in ("gs_w1", "gs_b1", "gs_w2", "gs_b2", "gs_w3", "gs_b3")])
+
+
 class MarlAgentGrads(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
                 ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
@@ -51,6 +56,7 @@ P, I, L, F, U, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size
 SRC, GRP, AW = C.POINTER(MarlSrc), C.POINTER(MarlGroup), C.POINTER(MarlAgentWeights)
 AG = C.POINTER(MarlAgentGrads)
 QW = C.POINTER(MarlQmixWeights)
+M3 = C.POINTER(MarlMlp3Weights)
 
 # name -> (restype, argtypes); must list every symbol of include/marl_hip.h
 SIGNATURES = {
@@ -74,6 +80,10 @@ SIGNATURES = {
     "marl_qmix_fused_workspace": (SZ, [L, I, I]),
     "marl_qmix_fused_fwd": (I, [QW, SRC, P, P, L, I, I, I, P]),
     "marl_qmix_fused_bwd": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, P]),
+    "marl_mlp3_supported": (I, [SRC, I, I, I, I, I]),
+    "marl_mlp3_fwd": (I, [M3, SRC, P, L, L, L, I, I, I, P]),
+    "marl_mlp3_bwd_workspace": (SZ, [L, I, I, I]),
+    "marl_mlp3_bwd": (I, [M3, SRC, P, L, L, M3, P, SZ, L, I, I, I, P]),
     "marl_qplex_mix_fwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_qplex_mix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_td_loss": (I, [P, P, P, P, P, F, P, P, P, L, P]),

@@ -265,6 +265,18 @@ class DMAQer(nn.Module):
         t = x._keep[0]
         return t[:, k * gs:k * gs + width]
 
+    def _fused_family(self, mods, x_in, nout, grad=False):
+        """marl_mlp3_weights_t of an extractor family when the fused three-layer kernel covers it, else None."""
+        if ops.MIXER_BF16 or getattr(self, "no_fused", False):
+            return None
+        heads = [_linears(m) for m in mods]
+        if len(heads[0]) != 3:
+            return None
+        l0, l1, l2 = heads[0]
+        if not ops.mlp3_supported(x_in, l0.in_features, l0.out_features, l1.out_features, nout, len(heads)):
+            return None
+        return ops.mlp3_weights(heads, grad=grad)
+
     def _lambda_fwd(self, s, u_idx, rows, tag, keep):
         """raw head outputs key (rows,K), ag (rows,K,N), ac (rows,K,N) + hidden activations."""
         a = self.args
@@ -275,6 +287,15 @@ class DMAQer(nn.Module):
         xsa = ops.src(s, idx=u_idx.view(rows, N), nhot=N, hot_w=A)
         for name, mods, nout in self.si_weight.families():
             x_in = xsa if name == "ac" else xs
+            out = self._s.get("%s_out%s" % (name, tag), (rows, K * nout), dev)
+            outs[name] = out
+            fw = self._fused_family(mods, x_in, nout)
+            if fw is not None:
+                # one kernel per family: the 10 heads' hidden activations never leave the CU
+                ops.mlp3_fwd(fw, x_in, out, rows, ops.src_width(x_in), nout, K)
+                if keep is not None:
+                    keep[name + "_h"] = None
+                continue
             nl = len(_linears(mods[0]))
             hs = []
             cur, cur_gs = x_in, 0
@@ -283,9 +304,7 @@ class DMAQer(nn.Module):
                 self._layer(mods, li, cur, cur_gs, hbuf, AE, rows, act=1)
                 hs.append(hbuf)
                 cur, cur_gs = ops.src(hbuf, k0=AE), AE
-            out = self._s.get("%s_out%s" % (name, tag), (rows, K * nout), dev)
             self._layer(mods, nl - 1, cur, cur_gs, out, nout, rows, act=0)
-            outs[name] = out
             if keep is not None:
                 keep[name + "_h"] = hs
         return outs
@@ -347,6 +366,10 @@ class DMAQer(nn.Module):
         for name, mods, nout in self.si_weight.families():
             x_in = xsa if name == "ac" else xs
             hs = ctx[name + "_h"]
+            if hs is None:      # fused forward: the backward recomputes the hidden activations on chip
+                ops.mlp3_bwd(self._fused_family(mods, x_in, nout), x_in, douts[name],
+                             self._fused_family(mods, x_in, nout, grad=True), rows, ops.src_width(x_in), nout, K)
+                continue
             nl = len(_linears(mods[0]))
             dcur, dcur_gs, gate = douts[name], nout, None
             for li in range(nl - 1, -1, -1):

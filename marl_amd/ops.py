@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, MarlQmixWeights, check
+from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, MarlQmixWeights, MarlMlp3Weights, check
 
 
 def _p(t):
@@ -345,3 +345,54 @@ def qmix_fused_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E):
     ws = WS.get("qmix_fused", lib.marl_qmix_fused_workspace(rows, N, S), q.device)
     check(lib.marl_qmix_fused_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads),
                                   _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_bwd")
+
+
+def _uniform_stride(ts):
+    """element stride between consecutive heads' tensors (one flat parameter buffer), None if not uniform."""
+    if len(ts) == 1:
+        return 0
+    d = [ts[i + 1].data_ptr() - ts[i].data_ptr() for i in range(len(ts) - 1)]
+    if any(x != d[0] for x in d) or d[0] <= 0 or d[0] % 16 != 0:
+        return None
+    return d[0] // 4
+
+
+def mlp3_weights(heads, grad=False):
+    """heads: per head the three nn.Linear of a Linear-ReLU-Linear-ReLU-Linear stack.  Returns the
+    marl_mlp3_weights_t of head 0 + per-tensor head strides, or None when the heads are not laid out at
+    constant strides / not 16-byte aligned (the caller then composes marl_linear)."""
+    pick = (lambda p: p.grad) if grad else (lambda p: p.data)
+    w = MarlMlp3Weights()
+    keep = []
+    for li, (wn, bn) in enumerate((("w1", "b1"), ("w2", "b2"), ("w3", "b3"))):
+        for name, attr in ((wn, "weight"), (bn, "bias")):
+            ts = [pick(getattr(h[li], attr)) for h in heads]
+            if any(t is None or not t.is_contiguous() or t.dtype != torch.float32 or not t.is_cuda for t in ts):
+                return None
+            st = _uniform_stride(ts)
+            if st is None or ts[0].data_ptr() % 16 != 0:
+                return None
+            setattr(w, name, ts[0].data_ptr())
+            setattr(w, "gs_" + name, st)
+            keep.append(ts)
+    w._keep = keep
+    return w
+
+
+def mlp3_supported(x, K1, H1, H2, N3, groups):
+    return bool(_lib.load().marl_mlp3_supported(C.byref(x), K1, H1, H2, N3, groups))
+
+
+def mlp3_fwd(w, x, Y, M, K1, N3, groups):
+    """Y (M, groups*N3): head g writes columns [g*N3, (g+1)*N3)."""
+    assert Y.dim() == 2 and Y.stride(1) == 1 and Y.shape[1] == groups * N3 and src_width(x) == K1
+    check(_lib.load().marl_mlp3_fwd(C.byref(w), C.byref(x), _p(_f32(Y)), Y.stride(0), N3, M, K1, N3, groups, _stream()),
+          "marl_mlp3_fwd")
+
+
+def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups):
+    lib = _lib.load()
+    assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[1] == groups * N3 and src_width(x) == K1
+    ws = WS.get("mlp3", lib.marl_mlp3_bwd_workspace(M, K1, N3, groups), dY.device)
+    check(lib.marl_mlp3_bwd(C.byref(w), C.byref(x), _p(_f32(dY)), dY.stride(0), N3, C.byref(grads), _p(ws), ws.numel() * 4,
+                            M, K1, N3, groups, _stream()), "marl_mlp3_bwd")

@@ -180,6 +180,78 @@ def test_linear_concat_and_groups(dev):
         close(gflat[k * per + N * Kg:(k + 1) * per], Gk.sum(0), 3e-4)
 
 
+@pytest.mark.parametrize("rows,S,NH,HW,N3,G,remap", [(333, 120, 0, 0, 1, 10, False), (1000, 120, 5, 11, 5, 10, False),
+                                                     (70, 24, 2, 3, 2, 3, False), (4100, 120, 5, 11, 5, 4, True),
+                                                     (129, 70, 0, 0, 16, 2, False), (50, 33, 4, 9, 3, 1, False)])
+def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap):
+    """Fused three-layer heads (QPLEX lambda-net families, mixer.py:117-145) vs torch-CPU autograd: outputs and all six
+    parameter gradients of every head; x = [state | one-hot actions] with ragged sizes, 'no action' indices and
+    (remap) (T+1)-slot state storage read through an episode map."""
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(rows + S + NH + N3)
+    K1 = S + NH * HW
+    if remap:
+        T, E = 41, 100
+        B = rows // T
+        rows = B * T
+        store = torch.randn(E, T + 1, S, generator=g)
+        emap = torch.randperm(E, generator=g)[:B]
+        x0 = store[emap][:, 1:T + 1].reshape(rows, S)
+        x0_src = ops.Rows(cu(store.reshape(-1, S), dev), (T, T + 1, 1), cu(emap, dev, torch.int32))
+    else:
+        x0 = torch.randn(rows, S, generator=g)
+        x0_src = cu(x0, dev) if S % 4 == 0 else cu(torch.cat([x0, x0[:, :1]], 1), dev)[:, :S]   # unaligned rows: element path
+    parts = [x0]
+    idx = None
+    if NH:
+        idx = torch.randint(-1, HW, (rows, NH), generator=g)
+        oh = torch.zeros(rows, NH, HW)
+        for j in range(NH):
+            v = idx[:, j] >= 0
+            oh[v, j, idx[v, j]] = 1
+        parts.append(oh.reshape(rows, -1))
+    X = torch.cat(parts, 1)
+    sizes = [(64, K1), (64,), (64, 64), (64,), (N3, 64), (N3,)]
+    pad = lambda n: (n + 3) // 4 * 4
+    per = sum(pad(int(np.prod(z))) for z in sizes)
+    flat = torch.randn(G * per, generator=g) * 0.2
+    fd, gd = cu(flat, dev), torch.zeros(G * per, device=dev)
+
+    def views(buf, k):
+        out, off = [], k * per
+        for z in sizes:
+            n = int(np.prod(z))
+            out.append(buf[off:off + n].view(z))
+            off += pad(n)
+        return out
+
+    class L:      # stands in for nn.Linear: .weight / .bias with .data and .grad
+        def __init__(self, w, b, gw, gb):
+            self.weight, self.bias = torch.nn.Parameter(w, requires_grad=False), torch.nn.Parameter(b, requires_grad=False)
+            self.weight.grad, self.bias.grad = gw, gb
+    heads = []
+    for k in range(G):
+        w, gr = views(fd, k), views(gd, k)
+        heads.append([L(w[0], w[1], gr[0], gr[1]), L(w[2], w[3], gr[2], gr[3]), L(w[4], w[5], gr[4], gr[5])])
+    xs = ops.src(x0_src, idx=cu(idx, dev, torch.int32) if NH else None, nhot=NH, hot_w=HW)
+    assert ops.mlp3_supported(xs, K1, 64, 64, N3, G)
+    Y = torch.full((rows, G * N3), 7.0, device=dev)
+    ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G)
+    dY = torch.randn(rows, G * N3, generator=g)
+    for rep in range(2):      # gradients ACCUMULATE: the second call doubles them
+        ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G)
+    for k in range(G):
+        ps = [v.clone().requires_grad_(True) for v in views(flat, k)]
+        h1 = torch.relu(F.linear(X, ps[0], ps[1]))
+        h2 = torch.relu(F.linear(h1, ps[2], ps[3]))
+        y = F.linear(h2, ps[4], ps[5])
+        close(Y[:, k * N3:(k + 1) * N3], y, 2e-4, msg="head %d out" % k)
+        y.backward(dY[:, k * N3:(k + 1) * N3])
+        for name, pr, gv in zip(("W1", "b1", "W2", "b2", "W3", "b3"), ps, views(gd, k)):
+            scale = max(1.0, float(pr.grad.abs().max()))
+            close(gv / scale, 2.0 * pr.grad / scale, 3e-4, 1e-4, msg="head %d d%s" % (k, name))
+
+
 @pytest.mark.parametrize("B,O", [(6, 24), (30, 24), (20, 80), (17, 116), (21, 64), (19, 52)])
 def test_wgrad_large_rows_and_remap(dev, B, O):
     """B >= 17 (M >= 4096 rows, 64 outputs) takes the direct no-LDS kernel, B = 6 the LDS-staged one."""
