@@ -172,7 +172,9 @@ int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const
  * cross HBM four times per update).  x: [dense0 | dense1 | one-hot blocks], shared by all heads; no gate / id
  * block.  The backward recomputes the hidden activations, keeps the weight gradients of a stripe of rows in
  * registers and accumulates them (fixed-order slab reduction) into `grads` (same struct, gradient tensors);
- * inputs get no gradient (states / actions).  Use when marl_mlp3_supported(); otherwise compose marl_linear. */
+ * inputs get no gradient (states / actions).  Use when marl_mlp3_supported(); otherwise compose marl_linear.
+ * w2 == NULL (H2 = 0 in marl_mlp3_supported): two-layer heads y = W3 relu(W1 x + b1) + b3 - the transformation nets
+ * hyper_w_final / V of DMAQer (network/mixer.py:200-206), evaluated as one launch with groups = 2. */
 typedef struct {
   const float *w1, *b1;         /* (64,K1), (64) of head 0 */
   const float *w2, *b2;         /* (64,64), (64)           */

@@ -214,7 +214,8 @@ __device__ __forceinline__ void fwd2(const f32x4 (&h1)[4], const float* W2s, con
 }
 
 // ------------------------------------------------------------------------------------------------- forward
-template <int KC>
+// THREE = false: two-layer heads  y = W3 relu(W1 x + b1) + b3  (W2 == NULL; QPLEX transformation nets)
+template <int KC, bool THREE>
 __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
@@ -229,14 +230,14 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
   stage_w(W1s, W1, a.K1, HD, a.K1, KC, 4, 64 * FNW);
-  stage_w(W2s, W2, HD, HD, HD, 4, 4, 64 * FNW);
+  if (THREE) stage_w(W2s, W2, HD, HD, HD, 4, 4, 64 * FNW);
   stage_w(W3s, W3, HD, a.N3, HD, 4, 1, 64 * FNW);
   build_tab(tab, a.x, a.K1, a.CF, KC, 64 * FNW);
   f32x4 b1v[4], b2v[4], b3v;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     b1v[t] = *reinterpret_cast<const f32x4*>(a.b1 + g * a.gs_b1 + 16 * t + 4 * q);
-    b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
+    if (THREE) b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) b3v[i] = 4 * q + i < a.N3 ? a.b3[g * a.gs_b3 + 4 * q + i] : 0.f;
@@ -267,7 +268,11 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
       xr = x_row(a.x, nt * 16 + m, a.M);
       x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
     }
-    fwd2(h1, W2s, b2v, h2, lane);
+    if (THREE) fwd2(h1, W2s, b2v, h2, lane);
+    else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h2[t] = h1[t];
+    }
     f32x4 acc = b3v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -291,7 +296,7 @@ __device__ __forceinline__ void stash4(float* st, const f32x4 (&v)[4], int wave,
     for (int i = 0; i < 4; ++i) st[(16 * t + 4 * q + i) * RS + 16 * wave + m] = v[t][i];
 }
 
-template <int KC>
+template <int KC, bool THREE>
 __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
@@ -309,8 +314,10 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
   stage_w(W1s, W1, a.K1, HD, a.K1, KC, 4, 64 * BNW);
-  stage_w(W2s, W2, HD, HD, HD, 4, 4, 64 * BNW);
-  stage_wT(W2Ts, W2, HD, 64 * BNW);
+  if (THREE) {
+    stage_w(W2s, W2, HD, HD, HD, 4, 4, 64 * BNW);
+    stage_wT(W2Ts, W2, HD, 64 * BNW);
+  }
   for (int e = tid; e < 16 * 64; e += 64 * BNW) {
     const int l = e & 63, tj = e >> 6, t = tj >> 2, j = tj & 3;
     const int n3 = 4 * j + (l >> 4);
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     b1v[t] = *reinterpret_cast<const f32x4*>(a.b1 + g * a.gs_b1 + 16 * t + 4 * q);
-    b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
+    if (THREE) b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
   }
   __syncthreads();
 
@@ -374,25 +381,35 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
       xr = x_row(a.x, (ni * BNW + wave) * 16 + m, a.M);
       x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
     }
-    fwd2(h1, W2s, b2v, h2, lane);
+    if (THREE) fwd2(h1, W2s, b2v, h2, lane);
+    else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = mfma16(W3Ts[(t * 4 + j) * 64 + lane], dy[j], acc);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dh2[t][i] = h2[t][i] > 0.f ? acc[i] : 0.f;
+      for (int t = 0; t < 4; ++t) h2[t] = h1[t];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(W2Ts + ((t * 4 + c) * 64 + lane) * 4);
-        acc = mfma16x4(w, dh2[c], acc);
-      }
+      for (int j = 0; j < 4; ++j)
+        if (4 * j < a.N3) acc = mfma16(W3Ts[(t * 4 + j) * 64 + lane], dy[j], acc);      // heads n3 = 4j + q
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dh1[t][i] = h1[t][i] > 0.f ? acc[i] : 0.f;
+      for (int i = 0; i < 4; ++i) dh2[t][i] = h2[t][i] > 0.f ? acc[i] : 0.f;
+    }
+    if (THREE) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(W2Ts + ((t * 4 + c) * 64 + lane) * 4);
+          acc = mfma16x4(w, dh2[c], acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh1[t][i] = h1[t][i] > 0.f ? acc[i] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dh1[t] = dh2[t];
     }
     stash4(dh1T, dh1, wave, q, m);
     WG_BARRIER();
@@ -409,8 +426,10 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     }
     WG_BARRIER();
     // ---------------- stage 2 operands
-    stash4(h1T, h1, wave, q, m);
-    stash4(dh2T, dh2, wave, q, m);
+    if (THREE) {
+      stash4(h1T, h1, wave, q, m);
+      stash4(dh2T, dh2, wave, q, m);
+    }
     stash4(h2T, h2, wave, q, m);
 #pragma unroll
     for (int j = 0; j < 4; ++j) dYT[(4 * j + q) * RS + 16 * wave + m] = dy[j];
@@ -418,12 +437,14 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     // ---------------- phase B2: dW2 rows [16w, 16w+16), dW3 columns [16w, 16w+16)
 #pragma unroll
     for (int rt = 0; rt < BNW; ++rt) {
-      const f32x4 af = *reinterpret_cast<const f32x4*>(dh2T + (16 * wave + m) * RS + 16 * rt + 4 * q);
-      bs2 += (af[0] + af[1]) + (af[2] + af[3]);
+      if (THREE) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(dh2T + (16 * wave + m) * RS + 16 * rt + 4 * q);
+        bs2 += (af[0] + af[1]) + (af[2] + af[3]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(h1T + (16 * c + m) * RS + 16 * rt + 4 * q);
-        dW2[c] = mfma16x4(af, bf, dW2[c]);
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 bf = *reinterpret_cast<const f32x4*>(h1T + (16 * c + m) * RS + 16 * rt + 4 * q);
+          dW2[c] = mfma16x4(af, bf, dW2[c]);
+        }
       }
       const f32x4 ay = *reinterpret_cast<const f32x4*>(dYT + m * RS + 16 * rt + 4 * q);
       const f32x4 bh = *reinterpret_cast<const f32x4*>(h2T + (16 * wave + m) * RS + 16 * rt + 4 * q);
@@ -487,6 +508,7 @@ __global__ __launch_bounds__(256) void mlp3_reduce_kernel(Mlp3RedArgs a) {
   r -= (long)HD * K1x;
   if (r < HD * (HD + 1)) {
     const int n = (int)(r / (HD + 1)), k = (int)(r - n * (HD + 1));
+    if (!a.dW2) return;                       // two-layer head
     if (k < HD) a.dW2[g * a.gs_w2 + n * HD + k] += s;
     else a.db2[g * a.gs_b2 + n] += s;
     return;
@@ -548,7 +570,7 @@ bool fill_args(Mlp3Args& a, const marl_mlp3_weights_t* w, const marl_src_t* x, l
 }  // namespace
 
 extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups) {
-  if (H1 != HD || H2 != HD || N3 < 1 || N3 > 16 || groups < 1 || K1 < 1) return 0;
+  if (H1 != HD || (H2 != HD && H2 != 0) || N3 < 1 || N3 > 16 || groups < 1 || K1 < 1) return 0;
   if (!x->p0 || x->k0 < 1 || x->m0 || x->nid) return 0;
   if (x->nhot && (x->hot_w < 1 || x->hot_w >= 16384 || x->nhot >= 16384)) return 0;
   if (x->k0 >= 16384 || x->k1 >= 16384) return 0;
@@ -561,9 +583,10 @@ extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, 
 extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
                              long M, int K1, int N3, int groups, void* stream) {
   if (M <= 0) return 0;
-  if (!marl_mlp3_supported(x, K1, HD, HD, N3, groups)) return (int)hipErrorInvalidValue;
+  const bool three = w->w2 != nullptr;
+  if (!marl_mlp3_supported(x, K1, HD, three ? HD : 0, N3, groups)) return (int)hipErrorInvalidValue;
   // bias rows are read with 16-byte loads
-  if (!aligned16(w->b1) || !aligned16(w->b2) || w->gs_b1 % 4 || w->gs_b2 % 4) return (int)hipErrorInvalidValue;
+  if (!aligned16(w->b1) || w->gs_b1 % 4 || (three && (!aligned16(w->b2) || w->gs_b2 % 4))) return (int)hipErrorInvalidValue;
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   a.Y = Y; a.ldy = ldy; a.gs_y = gs_y; a.ws = nullptr;
@@ -571,7 +594,8 @@ extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = fwd_lds(KC, a.CF);
-  const void* fn = KC == 4 ? (const void*)mlp3_fwd_kernel<4> : KC == 8 ? (const void*)mlp3_fwd_kernel<8> : (const void*)mlp3_fwd_kernel<12>;
+  const void* fn = three ? (KC == 4 ? (const void*)mlp3_fwd_kernel<4, true> : KC == 8 ? (const void*)mlp3_fwd_kernel<8, true> : (const void*)mlp3_fwd_kernel<12, true>)
+                         : (KC == 4 ? (const void*)mlp3_fwd_kernel<4, false> : KC == 8 ? (const void*)mlp3_fwd_kernel<8, false> : (const void*)mlp3_fwd_kernel<12, false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * FNW);
@@ -592,8 +616,10 @@ extern "C" int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
                              const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, long M, int K1, int N3,
                              int groups, void* stream) {
   if (M <= 0) return 0;
-  if (!marl_mlp3_supported(x, K1, HD, HD, N3, groups)) return (int)hipErrorInvalidValue;
-  if (!aligned16(w->b1) || !aligned16(w->b2) || w->gs_b1 % 4 || w->gs_b2 % 4) return (int)hipErrorInvalidValue;
+  const bool three = w->w2 != nullptr;
+  if (!marl_mlp3_supported(x, K1, HD, three ? HD : 0, N3, groups)) return (int)hipErrorInvalidValue;
+  if (!aligned16(w->b1) || w->gs_b1 % 4 || (three && (!aligned16(w->b2) || w->gs_b2 % 4))) return (int)hipErrorInvalidValue;
+  if (three != (grads->w2 != nullptr)) return (int)hipErrorInvalidValue;
   if (ws_bytes < marl_mlp3_bwd_workspace(M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
@@ -601,7 +627,8 @@ extern "C" int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   a.nst = stripes((M + 63) / 64, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = bwd_lds(KC, a.CF);
-  const void* fn = KC == 4 ? (const void*)mlp3_bwd_kernel<4> : KC == 8 ? (const void*)mlp3_bwd_kernel<8> : (const void*)mlp3_bwd_kernel<12>;
+  const void* fn = three ? (KC == 4 ? (const void*)mlp3_bwd_kernel<4, true> : KC == 8 ? (const void*)mlp3_bwd_kernel<8, true> : (const void*)mlp3_bwd_kernel<12, true>)
+                         : (KC == 4 ? (const void*)mlp3_bwd_kernel<4, false> : KC == 8 ? (const void*)mlp3_bwd_kernel<8, false> : (const void*)mlp3_bwd_kernel<12, false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * BNW);

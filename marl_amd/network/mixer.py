@@ -277,6 +277,15 @@ class DMAQer(nn.Module):
             return None
         return ops.mlp3_weights(heads, grad=grad)
 
+    def _fused_transform(self, xs, grad=False):
+        """hyper_w_final and V (Linear-ReLU-Linear, same shapes) as two heads of the fused kernel, or None."""
+        if ops.MIXER_BF16 or getattr(self, "no_fused", False):
+            return None
+        heads = [_linears(self.hyper_w_final), _linears(self.V)]
+        if len(heads[0]) != 2 or not ops.mlp3_supported(xs, self.state_dim, heads[0][0].out_features, 0, self.n_agents, 2):
+            return None
+        return ops.mlp3_weights(heads, grad=grad)
+
     def _lambda_fwd(self, s, u_idx, rows, tag, keep):
         """raw head outputs key (rows,K), ag (rows,K,N), ac (rows,K,N) + hidden activations."""
         a = self.args
@@ -318,14 +327,22 @@ class DMAQer(nn.Module):
         xs = ops.src(s)
         w0, w2 = _linears(self.hyper_w_final)
         v0, v2 = _linears(self.V)
-        hw = self._s.get("hw" + tag, (rows, HE), dev)
-        hv = self._s.get("hv" + tag, (rows, HE), dev)
-        w_raw = self._s.get("wraw" + tag, (rows, N), dev)
-        v = self._s.get("v" + tag, (rows, N), dev)
-        lin_of(w0).fwd(xs, hw, rows, act=1)
-        lin_of(w2).fwd(ops.src(hw), w_raw, rows)
-        lin_of(v0).fwd(xs, hv, rows, act=1)
-        lin_of(v2).fwd(ops.src(hv), v, rows)
+        hw = hv = None
+        tw = self._fused_transform(xs)
+        if tw is not None:
+            # hyper_w_final and V as ONE two-head launch of the fused kernel; wv[0] = w_raw, wv[1] = v
+            wv = self._s.get("wv" + tag, (2, rows, N), dev)
+            ops.mlp3_fwd(tw, xs, wv, rows, self.state_dim, N, 2)
+            w_raw, v = wv[0], wv[1]
+        else:
+            hw = self._s.get("hw" + tag, (rows, HE), dev)
+            hv = self._s.get("hv" + tag, (rows, HE), dev)
+            w_raw = self._s.get("wraw" + tag, (rows, N), dev)
+            v = self._s.get("v" + tag, (rows, N), dev)
+            lin_of(w0).fwd(xs, hw, rows, act=1)
+            lin_of(w2).fwd(ops.src(hw), w_raw, rows)
+            lin_of(v0).fwd(xs, hv, rows, act=1)
+            lin_of(v2).fwd(ops.src(hv), v, rows)
         v_tot = self._s.get("vtot" + tag, (rows,), dev)
         a_tot = lam = None
         heads = {}
@@ -347,20 +364,23 @@ class DMAQer(nn.Module):
         dev = q.device
         heads = ctx["heads"]
         dq = self._s.get("dq", (rows, N), dev)
-        dw_raw = self._s.get("dwraw", (rows, N), dev)
-        dv = self._s.get("dv", (rows, N), dev)
+        dwv = self._s.get("dwv", (2, rows, N), dev)
+        dw_raw, dv = dwv[0], dwv[1]
         douts = {"key": self._s.get("dkey", (rows, K), dev), "ag": self._s.get("dag", (rows, K * N), dev),
                  "ac": self._s.get("dac", (rows, K * N), dev)}
         ops.qplex_mix_bwd(ctx["w_raw"], q, ctx["max_q"], heads["key"], heads["ag"], heads["ac"], g, dq, dw_raw, dv,
                           douts["key"], douts["ag"], douts["ac"], rows, N, K, a.weighted_head, a.is_minus_one)
         xs = ops.src(s)
         # transformation nets
-        for seq, hbuf, dout in ((self.hyper_w_final, ctx["hw"], dw_raw), (self.V, ctx["hv"], dv)):
-            l0, l2 = _linears(seq)
-            lin_of(l2).wgrad(dout, ops.src(hbuf), rows)
-            dh = self._s.get("dh_t", (rows, HE), dev)
-            lin_of(l2).bwd_x(dout, dh, rows)
-            lin_of(l0).wgrad(dh, xs, rows, Yact=hbuf)
+        if ctx["hw"] is None:
+            ops.mlp3_bwd(self._fused_transform(xs), xs, dwv, self._fused_transform(xs, grad=True), rows, self.state_dim, N, 2)
+        else:
+            for seq, hbuf, dout in ((self.hyper_w_final, ctx["hw"], dw_raw), (self.V, ctx["hv"], dv)):
+                l0, l2 = _linears(seq)
+                lin_of(l2).wgrad(dout, ops.src(hbuf), rows)
+                dh = self._s.get("dh_t", (rows, HE), dev)
+                lin_of(l2).bwd_x(dout, dh, rows)
+                lin_of(l0).wgrad(dh, xs, rows, Yact=hbuf)
         # lambda-net, family by family, heads batched
         xsa = ops.src(s, idx=ctx["u_idx"].view(rows, N), nhot=N, hot_w=A)
         for name, mods, nout in self.si_weight.families():

@@ -358,13 +358,15 @@ def _uniform_stride(ts):
 
 
 def mlp3_weights(heads, grad=False):
-    """heads: per head the three nn.Linear of a Linear-ReLU-Linear-ReLU-Linear stack.  Returns the
-    marl_mlp3_weights_t of head 0 + per-tensor head strides, or None when the heads are not laid out at
-    constant strides / not 16-byte aligned (the caller then composes marl_linear)."""
+    """heads: per head the nn.Linear layers of a Linear-ReLU-Linear-ReLU-Linear stack (or the two of a
+    Linear-ReLU-Linear stack: w2 = NULL).  Returns the marl_mlp3_weights_t of head 0 + per-tensor head strides, or
+    None when the heads are not laid out at constant strides / not 16-byte aligned (the caller then composes
+    marl_linear)."""
     pick = (lambda p: p.grad) if grad else (lambda p: p.data)
     w = MarlMlp3Weights()
     keep = []
-    for li, (wn, bn) in enumerate((("w1", "b1"), ("w2", "b2"), ("w3", "b3"))):
+    names = (("w1", "b1"), ("w2", "b2"), ("w3", "b3")) if len(heads[0]) == 3 else (("w1", "b1"), ("w3", "b3"))
+    for li, (wn, bn) in enumerate(names):
         for name, attr in ((wn, "weight"), (bn, "bias")):
             ts = [pick(getattr(h[li], attr)) for h in heads]
             if any(t is None or not t.is_contiguous() or t.dtype != torch.float32 or not t.is_cuda for t in ts):
@@ -383,16 +385,27 @@ def mlp3_supported(x, K1, H1, H2, N3, groups):
     return bool(_lib.load().marl_mlp3_supported(C.byref(x), K1, H1, H2, N3, groups))
 
 
+def _head_layout(Y, M, N3, groups):
+    """(ld, group stride) of the head outputs: (M, groups*N3) with head g in columns [g*N3, (g+1)*N3), or
+    (groups, M, N3) with one contiguous (M, N3) block per head."""
+    if Y.dim() == 3:
+        assert Y.shape == (groups, M, N3) and Y.is_contiguous()
+        return N3, M * N3
+    assert Y.dim() == 2 and Y.stride(1) == 1 and Y.shape[1] == groups * N3
+    return Y.stride(0), N3
+
+
 def mlp3_fwd(w, x, Y, M, K1, N3, groups):
-    """Y (M, groups*N3): head g writes columns [g*N3, (g+1)*N3)."""
-    assert Y.dim() == 2 and Y.stride(1) == 1 and Y.shape[1] == groups * N3 and src_width(x) == K1
-    check(_lib.load().marl_mlp3_fwd(C.byref(w), C.byref(x), _p(_f32(Y)), Y.stride(0), N3, M, K1, N3, groups, _stream()),
+    ld, gs = _head_layout(Y, M, N3, groups)
+    assert src_width(x) == K1
+    check(_lib.load().marl_mlp3_fwd(C.byref(w), C.byref(x), _p(_f32(Y)), ld, gs, M, K1, N3, groups, _stream()),
           "marl_mlp3_fwd")
 
 
 def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups):
     lib = _lib.load()
-    assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[1] == groups * N3 and src_width(x) == K1
+    ld, gs = _head_layout(dY, M, N3, groups)
+    assert src_width(x) == K1
     ws = WS.get("mlp3", lib.marl_mlp3_bwd_workspace(M, K1, N3, groups), dY.device)
-    check(lib.marl_mlp3_bwd(C.byref(w), C.byref(x), _p(_f32(dY)), dY.stride(0), N3, C.byref(grads), _p(ws), ws.numel() * 4,
+    check(lib.marl_mlp3_bwd(C.byref(w), C.byref(x), _p(_f32(dY)), ld, gs, C.byref(grads), _p(ws), ws.numel() * 4,
                             M, K1, N3, groups, _stream()), "marl_mlp3_bwd")

@@ -180,10 +180,12 @@ def test_linear_concat_and_groups(dev):
         close(gflat[k * per + N * Kg:(k + 1) * per], Gk.sum(0), 3e-4)
 
 
-@pytest.mark.parametrize("rows,S,NH,HW,N3,G,remap", [(333, 120, 0, 0, 1, 10, False), (1000, 120, 5, 11, 5, 10, False),
-                                                     (70, 24, 2, 3, 2, 3, False), (4100, 120, 5, 11, 5, 4, True),
-                                                     (129, 70, 0, 0, 16, 2, False), (50, 33, 4, 9, 3, 1, False)])
-def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap):
+@pytest.mark.parametrize("rows,S,NH,HW,N3,G,remap,nl", [(333, 120, 0, 0, 1, 10, False, 3), (1000, 120, 5, 11, 5, 10, False, 3),
+                                                        (70, 24, 2, 3, 2, 3, False, 3), (4100, 120, 5, 11, 5, 4, True, 3),
+                                                        (129, 70, 0, 0, 16, 2, False, 3), (50, 33, 4, 9, 3, 1, False, 3),
+                                                        (777, 120, 0, 0, 5, 2, False, 2), (4100, 120, 0, 0, 5, 2, True, 2),
+                                                        (65, 30, 1, 4, 7, 3, False, 2)])
+def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     """Fused three-layer heads (QPLEX lambda-net families, mixer.py:117-145) vs torch-CPU autograd: outputs and all six
     parameter gradients of every head; x = [state | one-hot actions] with ragged sizes, 'no action' indices and
     (remap) (T+1)-slot state storage read through an episode map."""
@@ -211,7 +213,7 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap):
             oh[v, j, idx[v, j]] = 1
         parts.append(oh.reshape(rows, -1))
     X = torch.cat(parts, 1)
-    sizes = [(64, K1), (64,), (64, 64), (64,), (N3, 64), (N3,)]
+    sizes = [(64, K1), (64,), (64, 64), (64,), (N3, 64), (N3,)] if nl == 3 else [(64, K1), (64,), (N3, 64), (N3,)]
     pad = lambda n: (n + 3) // 4 * 4
     per = sum(pad(int(np.prod(z))) for z in sizes)
     flat = torch.randn(G * per, generator=g) * 0.2
@@ -232,9 +234,9 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap):
     heads = []
     for k in range(G):
         w, gr = views(fd, k), views(gd, k)
-        heads.append([L(w[0], w[1], gr[0], gr[1]), L(w[2], w[3], gr[2], gr[3]), L(w[4], w[5], gr[4], gr[5])])
+        heads.append([L(w[2 * i], w[2 * i + 1], gr[2 * i], gr[2 * i + 1]) for i in range(nl)])
     xs = ops.src(x0_src, idx=cu(idx, dev, torch.int32) if NH else None, nhot=NH, hot_w=HW)
-    assert ops.mlp3_supported(xs, K1, 64, 64, N3, G)
+    assert ops.mlp3_supported(xs, K1, 64, 64 if nl == 3 else 0, N3, G)
     Y = torch.full((rows, G * N3), 7.0, device=dev)
     ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G)
     dY = torch.randn(rows, G * N3, generator=g)
@@ -242,12 +244,13 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap):
         ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G)
     for k in range(G):
         ps = [v.clone().requires_grad_(True) for v in views(flat, k)]
-        h1 = torch.relu(F.linear(X, ps[0], ps[1]))
-        h2 = torch.relu(F.linear(h1, ps[2], ps[3]))
-        y = F.linear(h2, ps[4], ps[5])
+        h = torch.relu(F.linear(X, ps[0], ps[1]))
+        if nl == 3:
+            h = torch.relu(F.linear(h, ps[2], ps[3]))
+        y = F.linear(h, ps[-2], ps[-1])
         close(Y[:, k * N3:(k + 1) * N3], y, 2e-4, msg="head %d out" % k)
         y.backward(dY[:, k * N3:(k + 1) * N3])
-        for name, pr, gv in zip(("W1", "b1", "W2", "b2", "W3", "b3"), ps, views(gd, k)):
+        for name, pr, gv in zip(("W1", "b1", "W2", "b2", "W3", "b3") if nl == 3 else ("W1", "b1", "W3", "b3"), ps, views(gd, k)):
             scale = max(1.0, float(pr.grad.abs().max()))
             close(gv / scale, 2.0 * pr.grad / scale, 3e-4, 1e-4, msg="head %d d%s" % (k, name))
 
