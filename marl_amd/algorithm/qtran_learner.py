@@ -144,7 +144,10 @@ class QTRANLearner:
                     torch.as_tensor(np.asarray(batch['terminated'])), self.args.episode_limit), self.device)
             db = DeviceBatch.from_dict(batch, self.args, self.device, T=T)
         self.max_episode_len = db.T
-        self._forward_backward(db)
+        try:
+            self._forward_backward(db)
+        finally:
+            ops.set_mixer_dtype("fp32")        # the opt-in bf16 mode never outlives the call that asked for it
         self.reducer.allreduce_(self._flat.gradx)
         st = self._flat.stats
         self.optimizer.step(den=st[3:4])

@@ -537,7 +537,8 @@ inline ConcatSrc to_src3(const marl_src_t* s) {
   return c;
 }
 
-inline int kc_bucket(int K1) { const int kc = (K1 + 15) / 16; return (kc + 3) / 4 * 4; }
+// instantiated chunk counts: 4, 8, 11 (QPLEX [state 120 | one-hot 55] exactly), 12
+inline int kc_bucket(int K1) { const int kc = (K1 + 15) / 16; return kc == 11 ? 11 : (kc + 3) / 4 * 4; }
 inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 256 * 4; }
 inline size_t bwd_lds(int KC, int CF) {
   const int SF = (16 * KC + HD) > 208 ? (16 * KC + HD) : 208;
@@ -594,8 +595,8 @@ extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = fwd_lds(KC, a.CF);
-  const void* fn = three ? (KC == 4 ? (const void*)mlp3_fwd_kernel<4, true> : KC == 8 ? (const void*)mlp3_fwd_kernel<8, true> : (const void*)mlp3_fwd_kernel<12, true>)
-                         : (KC == 4 ? (const void*)mlp3_fwd_kernel<4, false> : KC == 8 ? (const void*)mlp3_fwd_kernel<8, false> : (const void*)mlp3_fwd_kernel<12, false>);
+#define MLP3_PICK(K, T3) (KC == 4 ? (const void*)K<4, T3> : KC == 8 ? (const void*)K<8, T3> : KC == 11 ? (const void*)K<11, T3> : (const void*)K<12, T3>)
+  const void* fn = three ? MLP3_PICK(mlp3_fwd_kernel, true) : MLP3_PICK(mlp3_fwd_kernel, false);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * FNW);
@@ -627,8 +628,7 @@ extern "C" int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   a.nst = stripes((M + 63) / 64, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = bwd_lds(KC, a.CF);
-  const void* fn = three ? (KC == 4 ? (const void*)mlp3_bwd_kernel<4, true> : KC == 8 ? (const void*)mlp3_bwd_kernel<8, true> : (const void*)mlp3_bwd_kernel<12, true>)
-                         : (KC == 4 ? (const void*)mlp3_bwd_kernel<4, false> : KC == 8 ? (const void*)mlp3_bwd_kernel<8, false> : (const void*)mlp3_bwd_kernel<12, false>);
+  const void* fn = three ? MLP3_PICK(mlp3_bwd_kernel, true) : MLP3_PICK(mlp3_bwd_kernel, false);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * BNW);

@@ -22,4 +22,7 @@ make -C marl_amd/csrc stamps > /dev/null 2>&1
 ( for k in rollout fwd bwd; do python3 tools/stamps.py $k 4096 2>/dev/null | grep -v amdgpu.ids; echo; done ) > $OUT/${TAG}_stamps.txt
 python3 bench.py > $OUT/${TAG}_bench_full.log 2>&1
 grep '^{"metric"' $OUT/${TAG}_bench_full.log | tail -1 > $OUT/${TAG}_bench_full_line.json
+# 4. QPLEX learner (config 3 shape, 4096 envs): kernel stats + standalone timings of the fused head kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qplex -o p -- python3 tools/prof_learner.py --alg qplex --shape 2s3z --envs 4096 --updates 6 > $OUT/${TAG}_qplex.log 2>&1
+python3 tools/time_mlp3.py 4096 > $OUT/${TAG}_mlp3_times.txt 2>&1
 ls $OUT/${TAG}_bench $OUT/${TAG}_pmc/* | head -40

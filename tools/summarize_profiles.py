@@ -21,6 +21,12 @@ for name in ("_bench_line.json", "_bench_full_line.json"):
         json.loads(line)
         open(os.path.join(P, tag + name), "w").write(line + "\n")
 shutil.copy(os.path.join(G, tag + "_stamps.txt"), os.path.join(P, tag + "_stamps.txt"))
+# QPLEX (BASELINE config 3 shape at 4096 envs): kernel stats of tools/prof_learner.py --alg qplex + the standalone
+# timings of the fused head kernels (tools/time_mlp3.py)
+if os.path.exists(os.path.join(G, tag + "_qplex", "p_kernel_stats.csv")):
+    shutil.copy(os.path.join(G, tag + "_qplex", "p_kernel_stats.csv"), os.path.join(P, tag + "_qplex_kernel_stats.csv"))
+if os.path.exists(os.path.join(G, tag + "_mlp3_times.txt")):
+    shutil.copy(os.path.join(G, tag + "_mlp3_times.txt"), os.path.join(P, tag + "_mlp3_times.txt"))
 
 
 def short(n):
