@@ -531,15 +531,15 @@ inline int launch_wgrad_direct(const WgradArgs& a, hipStream_t s) {
 
 // returns -1 when the shape is not covered (caller uses the LDS-staged kernel)
 inline int try_wgrad_direct(const WgradArgs& a, hipStream_t s) {
-  if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || a.M < 4096 || a.x.k1 || a.x.m0 || a.x.k0 < 1) return -1;
+  if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || a.M < 4096 || a.x.k1 || a.x.m0 || a.x.k0 < 0 || !a.x.p0) return -1;
   const bool perm = a.xvec && a.x.k0 >= 64;
   const int KP = perm ? 1 : 0;
   const int rest = a.K - 64 * KP;
   const int NTP = (rest + 15) / 16;
-  if (NTP > 4 || KP + NTP == 0) return -1;
+  if (NTP > (KP ? 4 : 5) || KP + NTP == 0) return -1;
 #define WD_CASE(kp, nt) if (KP == kp && NTP == nt) return launch_wgrad_direct<kp, nt>(a, s);
   WD_CASE(1, 0) WD_CASE(1, 1) WD_CASE(1, 2) WD_CASE(1, 3) WD_CASE(1, 4)
-  WD_CASE(0, 1) WD_CASE(0, 2) WD_CASE(0, 3) WD_CASE(0, 4)
+  WD_CASE(0, 1) WD_CASE(0, 2) WD_CASE(0, 3) WD_CASE(0, 4) WD_CASE(0, 5)
 #undef WD_CASE
   return -1;
 }
@@ -636,7 +636,7 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
 
 extern "C" size_t marl_linear_wgrad_workspace(int M, int N, int K, int groups) {
   int slabs = marl_wgrad_slabs(M);
-  return (size_t)slabs * groups * N * (K + 1) * sizeof(float);
+  return (size_t)slabs * groups * N * (K + 4) * sizeof(float);      // + 3: column passes of the direct kernel each carry a bias column
 }
 
 extern "C" int marl_wgrad_slabs(int M) {
@@ -665,6 +665,39 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
   a.xvec = a.x.p0 && !a.x.m0 && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const bool bf = (flags & 1) != 0;           // bf16 operands, fp32 accumulate (mixer GEMMs, opt-in)
+  // Wide inputs of a 64-output layer (fc1 of the agent on 3s5z / MMM2: 150 / 204 columns - more accumulator tiles than
+  // one pass of the direct kernel holds): column passes [0,64), [64,128) as permuted blocks and the rest as plain
+  // tiles, each a direct launch over its own sub-source with its own slabs; G is re-read per pass (3 x 315 MB at
+  // MMM2 / 1024 envs) but nothing is staged through LDS (the LDS-staged kernel took 1.35 ms there).
+  if (!bf && a.N == 64 && groups == 1 && !Yact && a.gvec && a.xvec && a.M >= 4096 && !a.x.k1 && !a.x.m0 && a.x.k0 >= 64 &&
+      K - 64 > 64) {
+    const int c_rest = a.x.k0 >= 128 ? 128 : 64;
+    if ((K - c_rest + 15) / 16 <= 5) {
+      size_t ws_off = 0;
+      int c0 = 0;
+      for (int pass = 0; c0 < K; ++pass) {
+        WgradArgs b = a;
+        const bool perm = c0 < c_rest;
+        const int kw = perm ? 64 : K - c0;
+        b.x.p0 = a.x.p0 + c0;
+        b.x.k0 = perm ? 64 : a.x.k0 - c0;
+        if (perm) { b.x.idx = nullptr; b.x.nhot = 0; b.x.hot_w = 0; b.x.nid = 0; }
+        b.K = kw;
+        b.ws = ws + ws_off;
+        if (try_wgrad_direct(b, s) != 0) return (int)hipErrorInvalidValue;
+        MARL_CHECK_LAUNCH();
+        WredArgs r;
+        r.ws = b.ws; r.dW = dW + c0; r.lddw = lddw; r.db = pass == 0 ? db : nullptr; r.N = N; r.K = kw; r.slabs = a.slabs;
+        r.groups = 1; r.gs_dw = 0; r.gs_db = 0;
+        const long total = (long)N * (kw + 1);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, r);
+        MARL_CHECK_LAUNCH();
+        ws_off += (size_t)a.slabs * N * (kw + 1);
+        c0 += kw;
+      }
+      return 0;
+    }
+  }
   if (bf || try_wgrad_direct(a, s) != 0) {
     dim3 grid(a.slabs, a.nyb * groups, (K + 1 + 63) / 64), block(256);
     if (bf) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, s, a);

@@ -255,9 +255,10 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
             close(gv / scale, 2.0 * pr.grad / scale, 3e-4, 1e-4, msg="head %d d%s" % (k, name))
 
 
-@pytest.mark.parametrize("B,O", [(6, 24), (30, 24), (20, 80), (17, 116), (21, 64), (19, 52)])
+@pytest.mark.parametrize("B,O", [(6, 24), (30, 24), (20, 80), (17, 116), (21, 64), (19, 52), (18, 128), (17, 176), (17, 148)])
 def test_wgrad_large_rows_and_remap(dev, B, O):
-    """B >= 17 (M >= 4096 rows, 64 outputs) takes the direct no-LDS kernel, B = 6 the LDS-staged one."""
+    """B >= 17 (M >= 4096 rows, 64 outputs) takes the direct no-LDS kernel (O >= 128: in column passes), B = 6 the
+    LDS-staged one."""
     from marl_amd import ops
     g = torch.Generator().manual_seed(9 + B + O)
     T, N = 50, 5                         # (T+1)-slot storage read through the row remap
