@@ -52,22 +52,32 @@ __device__ __forceinline__ bool wg_map(int groups, int nst, int& stripe, int& g)
   return stripe < nst;
 }
 
-// element table of the generic chunks: sel (0 dense0, 1 dense1, 2 one-hot index, 3 zero) << 28 | cmp << 14 | off
+// Table of the generic chunks (those not wholly inside the 16-byte aligned part of dense0), two int4 per (chunk, lane):
+//   [0] byte offsets of the lane's four elements from the base of its group's source row
+//   [1] {cmp0 | cmp1 << 16, cmp2 | cmp3 << 16, kind, -}   kind: 0 zero, 1 dense0, 2 one-hot index, 3 dense1
+// Segment widths are multiples of 4 (checked on the host), so the four elements k = 16c+4q+0..3 of a lane come from
+// ONE source: a lane selects one row base per chunk and the element loads are base + offset - no per-element branching.
 __device__ __forceinline__ void build_tab(int* tab, const ConcatSrc& x, int K1, int CF, int KC, int nthreads) {
-  for (int e = threadIdx.x; e < (KC - CF) * 256; e += nthreads) {
-    const int gc = e >> 8, l = (e >> 2) & 63, i = e & 3;
-    int k = 16 * (CF + gc) + 4 * (l >> 4) + i;
-    int code = 3 << 28;
-    if (k < K1) {
-      if (k < x.k0) code = k;
-      else if (k - x.k0 < x.k1) code = (1 << 28) | (k - x.k0);
+  for (int e = threadIdx.x; e < (KC - CF) * 64; e += nthreads) {
+    const int gc = e >> 6, l = e & 63;
+    const int kb = 16 * (CF + gc) + 4 * (l >> 4);
+    int off[4], cmp[4], kind = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int k = kb + i;
+      off[i] = 0; cmp[i] = 0xffff;
+      if (k >= K1) continue;
+      if (k < x.k0) { kind = 1; off[i] = 4 * k; }
+      else if (k - x.k0 < x.k1) { kind = 3; off[i] = 4 * (k - x.k0); }
       else {
         k -= x.k0 + x.k1;
         const int j = k / x.hot_w;
-        code = (2 << 28) | ((k - j * x.hot_w) << 14) | j;
+        kind = 2; off[i] = 4 * j; cmp[i] = k - j * x.hot_w;
       }
     }
-    tab[e] = code;
+    int* t = tab + e * 8;
+    t[0] = off[0]; t[1] = off[1]; t[2] = off[2]; t[3] = off[3];
+    t[4] = cmp[0] | (cmp[1] << 16); t[5] = cmp[2] | (cmp[3] << 16); t[6] = kind; t[7] = 0;
   }
 }
 
@@ -110,48 +120,46 @@ __device__ __forceinline__ XRow x_row(const ConcatSrc& x, long row, long M) {
 template <int KC>
 __device__ __forceinline__ void x_issue(f32x4 (&xv)[KC], const ConcatSrc& x, const XRow& r, const int* tab, int CF, int lane) {
   const int q = lane >> 4;
-  const float* d0 = x.p0 + r.r0c * x.ld0;
-  const float* d1 = x.p1 + r.rowc * x.ld1;
-  const int* di = x.idx + r.ric * x.nhot;
+  const char* d0 = reinterpret_cast<const char*>(x.p0 + r.r0c * x.ld0);
+  const char* d1 = x.p1 ? reinterpret_cast<const char*>(x.p1 + r.rowc * x.ld1) : d0;
+  const char* di = x.idx ? reinterpret_cast<const char*>(x.idx + r.ric * x.nhot) : d0;
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     if (c < CF) {
-      xv[c] = *reinterpret_cast<const f32x4*>(d0 + 16 * c + 4 * q);
+      xv[c] = *reinterpret_cast<const f32x4*>(d0 + 64 * c + 16 * q);
     } else {
-      const int4 code = *reinterpret_cast<const int4*>(tab + ((c - CF) * 64 + lane) * 4);
-      const int cs[4] = {code.x, code.y, code.z, code.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int sel = (unsigned)cs[i] >> 28, off = cs[i] & 0x3fff;
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(d0 + (sel == 0 ? off : 0));
-        const uintptr_t a1 = reinterpret_cast<uintptr_t>(d1 + off);
-        const uintptr_t a2 = reinterpret_cast<uintptr_t>(di + off);
-        const uintptr_t ad = sel == 2 ? a2 : (sel == 1 ? a1 : a0);
-        xv[c][i] = __int_as_float(*reinterpret_cast<const int*>(ad));
-      }
+      const int* t = tab + ((c - CF) * 64 + lane) * 8;
+      const uint4 off = *reinterpret_cast<const uint4*>(t);            // unsigned: no sign extension per address
+      const int kind = t[6];
+      const char* base = kind == 2 ? di : (kind == 3 ? d1 : d0);      // one row base per lane and chunk
+      xv[c][0] = __int_as_float(*reinterpret_cast<const int*>(base + off.x));
+      xv[c][1] = __int_as_float(*reinterpret_cast<const int*>(base + off.y));
+      xv[c][2] = __int_as_float(*reinterpret_cast<const int*>(base + off.z));
+      xv[c][3] = __int_as_float(*reinterpret_cast<const int*>(base + off.w));
     }
   }
 }
-// raw -> values of the virtual concat
+// raw -> values of the virtual concat (selects only)
 template <int KC>
 __device__ __forceinline__ void x_finish(f32x4 (&xv)[KC], const XRow& r, const int* tab, int CF, int lane) {
   const bool ok0 = (r.flags & 2) != 0, oki = (r.flags & 4) != 0;
+  // rows that read as zero (remap before the first slot) are rare: one wave-uniform test instead of 4 selects per chunk
+  const bool any_bad0 = __builtin_amdgcn_ballot_w64(!ok0) != 0;
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     if (c < CF) {
-      if (!ok0) xv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (any_bad0 && !ok0) xv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
-      const int4 code = *reinterpret_cast<const int4*>(tab + ((c - CF) * 64 + lane) * 4);
-      const int cs[4] = {code.x, code.y, code.z, code.w};
+      const int4 t1 = *reinterpret_cast<const int4*>(tab + ((c - CF) * 64 + lane) * 8 + 4);
+      const int kind = t1.z;
+      const bool dense = (kind == 1 && ok0) || kind == 3;
+      const bool hot = kind == 2 && oki;
+      const int cmp[4] = {t1.x & 0xffff, (int)((unsigned)t1.x >> 16), t1.y & 0xffff, (int)((unsigned)t1.y >> 16)};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int sel = (unsigned)cs[i] >> 28, cmp = (cs[i] >> 14) & 0x3fff;
         const float raw = xv[c][i];
-        float v = 0.f;
-        if (sel == 0) v = ok0 ? raw : 0.f;
-        else if (sel == 1) v = raw;
-        else if (sel == 2) v = (oki && __float_as_int(raw) == cmp) ? 1.f : 0.f;
-        xv[c][i] = v;
+        const float vd = dense ? raw : 0.f;
+        xv[c][i] = (hot && __float_as_int(raw) == cmp[i]) ? 1.f : vd;
       }
     }
   }
@@ -539,10 +547,10 @@ inline ConcatSrc to_src3(const marl_src_t* s) {
 
 // instantiated chunk counts: 4, 8, 11 (QPLEX [state 120 | one-hot 55] exactly), 12
 inline int kc_bucket(int K1) { const int kc = (K1 + 15) / 16; return kc == 11 ? 11 : (kc + 3) / 4 * 4; }
-inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 256 * 4; }
+inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 512 * 4; }
 inline size_t bwd_lds(int KC, int CF) {
   const int SF = (16 * KC + HD) > 208 ? (16 * KC + HD) : 208;
-  return (size_t)(4 * KC * 256 + 2 * 16 * 256 + 16 * 64 + SF * RS) * 4 + (size_t)(KC - CF) * 256 * 4;
+  return (size_t)(4 * KC * 256 + 2 * 16 * 256 + 16 * 64 + SF * RS) * 4 + (size_t)(KC - CF) * 512 * 4;
 }
 inline int lead_chunks(const marl_src_t* x) {
   const bool al = x->p0 && (x->ld0 % 4 == 0) && aligned16(x->p0);
@@ -572,9 +580,10 @@ bool fill_args(Mlp3Args& a, const marl_mlp3_weights_t* w, const marl_src_t* x, l
 
 extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups) {
   if (H1 != HD || (H2 != HD && H2 != 0) || N3 < 1 || N3 > 16 || groups < 1 || K1 < 1) return 0;
-  if (!x->p0 || x->k0 < 1 || x->m0 || x->nid) return 0;
-  if (x->nhot && (x->hot_w < 1 || x->hot_w >= 16384 || x->nhot >= 16384)) return 0;
+  if (!x->p0 || x->k0 < 4 || x->m0 || x->nid) return 0;
+  if (x->nhot && (x->hot_w < 1 || x->hot_w >= 16384 || x->nhot >= 8192)) return 0;
   if (x->k0 >= 16384 || x->k1 >= 16384) return 0;
+  if (x->k0 % 4 || x->k1 % 4) return 0;               // a lane's four consecutive columns come from one segment
   const int KC = kc_bucket(K1);
   if (KC > 12) return 0;
   const int CF = lead_chunks(x);
