@@ -203,6 +203,11 @@ int marl_qplex_mix_bwd(const float* w_raw, const float* q, const float* max_q, c
                        float* dv, float* dkey, float* dag, float* dac, long rows, int N, int K,
                        int weighted_head, int minus_one, void* stream);
 
+/* QLearner.get_max_episode_len (q_learner.py:49-66; qtran_learner.py:52-69): out[0] = max over episodes of
+ * (first step t with terminated[e,t] == 1) + 1, 0 when no episode terminates (the caller then uses
+ * episode_limit); episodes that never terminate are ignored (quirk Q2).  term: (E, >=T) fp32, row stride ld. */
+int marl_first_terminated_len(const float* term, long ld, int E, int T, int* out, void* stream);
+
 /* TD target + masked squared error (q_learner.py:165-168).  Writes the UN-normalised gradient
  * dq_tot = -2 mask^2 td and out2 = {sum (mask td)^2, sum mask}; the 1/sum(mask) factor is applied
  * in the optimizer so that data-parallel ranks can all-reduce numerators. */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "marl_mlp3_bwd": (I, [M3, SRC, P, L, L, M3, P, SZ, L, I, I, I, P]),
     "marl_qplex_mix_fwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_qplex_mix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
+    "marl_first_terminated_len": (I, [P, L, I, I, P, P]),
     "marl_td_loss": (I, [P, P, P, P, P, F, P, P, P, L, P]),
     "marl_qtran_loss": (I, [P, P, P, P, P, P, P, P, P, F, F, F, P, P, P, P, P, P, L, P]),
     "marl_loss_workspace": (SZ, [L]),

@@ -170,7 +170,8 @@ class QLearner:
         if train_step > 0 and train_step % self.args.target_update_cycle == 0:
             self._update_targets()
         self.last_stats = stats
-        return float((stats[0] / stats[1]).item())
+        s = stats[:2].cpu()                  # one copy + sync; the division runs on the host in fp32 as before
+        return float(s[0] / s[1])
 
     # ------------------------------------------------------------------ checkpoints (reference :193-209)
     def save_models(self, train_step):

@@ -588,6 +588,36 @@ extern "C" int marl_qplex_mix_bwd(const float* w_raw, const float* q, const floa
   return 0;
 }
 
+// get_max_episode_len (algorithm/q_learner.py:49-66) in one launch: per episode the first step with terminated == 1,
+// max over episodes of (that step + 1); episodes that never terminate contribute nothing (quirk Q2).  One wave per
+// episode scans its row 64 steps at a time (ballot + first set bit), one atomicMax per episode.
+__global__ __launch_bounds__(TPB) void first_term_kernel(const float* term, long ld, int E, int T, int* out) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = ((long)blockIdx.x * TPB + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * TPB) >> 6;
+  for (long e = wave_id; e < E; e += nwaves) {
+    int first = 0;
+    for (int t0 = 0; t0 < T && first == 0; t0 += 64) {
+      const int t = t0 + lane;
+      const bool hit = t < T && term[e * ld + t] == 1.f;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+      if (m) first = t0 + __builtin_ctzll(m) + 1;
+    }
+    if (lane == 0 && first > 0) atomicMax(out, first);
+  }
+}
+
+extern "C" int marl_first_terminated_len(const float* term, long ld, int E, int T, int* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  if (E <= 0 || T <= 0) return 0;
+  long nb = ((long)E * 64 + TPB - 1) / TPB; if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(first_term_kernel, dim3((unsigned)nb), dim3(TPB), 0, s, term, ld, E, T, out);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" size_t marl_loss_workspace(long rows) { return (size_t)1024 * 4 * sizeof(float); }
 
 extern "C" int marl_td_loss(const float* q_tot, const float* q_tot_tgt, const float* r, const float* term,

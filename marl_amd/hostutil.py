@@ -104,6 +104,9 @@ class DeviceBatch:
     def first_terminated_len(term, episode_limit):
         """get_max_episode_len (algorithm/q_learner.py:49-66) on device: max over episodes of the first
         terminated index + 1; episodes that never terminate are ignored; 0 -> episode_limit."""
+        if term.is_cuda and term.dtype == torch.float32 and term.shape[0] > 0:
+            m = int(ops.first_terminated_len(term, episode_limit).item())      # one kernel + one sync
+            return m if m > 0 else episode_limit
         t = (term.reshape(term.shape[0], -1)[:, :episode_limit] == 1)
         anyt = t.any(dim=1)
         first = t.to(torch.int32).argmax(dim=1) + 1

@@ -244,6 +244,22 @@ def qplex_mix_bwd(w_raw, q, max_q, key, ag, ac, g, dq, dw_raw, dv, dkey, dag, da
                                          int(minus_one), _stream()), "marl_qplex_mix_bwd")
 
 
+_FT_OUT = {}
+
+
+def first_terminated_len(term, T):
+    """max over episodes of (first terminated step + 1) within the first T steps as a 1-element int32 device tensor
+    (0 = no episode terminates).  term: (E, >=T[, 1]) CUDA float32 with unit inner stride."""
+    t2 = term.reshape(term.shape[0], -1)
+    assert t2.dtype == torch.float32 and t2.is_cuda and t2.stride(1) == 1
+    out = _FT_OUT.get(t2.device)
+    if out is None:
+        out = _FT_OUT[t2.device] = torch.zeros(1, dtype=torch.int32, device=t2.device)
+    check(_lib.load().marl_first_terminated_len(_p(t2), t2.stride(0), t2.shape[0], min(T, t2.shape[1]), _p(out), _stream()),
+          "marl_first_terminated_len")
+    return out
+
+
 def td_loss(q_tot, q_tgt, r, term, padded, gamma, dq_tot, out2, rows):
     lib = _lib.load()
     ws = WS.get("loss", lib.marl_loss_workspace(rows), q_tot.device)

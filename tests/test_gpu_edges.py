@@ -67,3 +67,29 @@ def test_zero_rows_are_noops():
     ops.vec_add(out, out, out, 0)
     torch.cuda.synchronize()
     assert float(Y.min()) == 3.0 and float(dW.min()) == 2.0 and float(db.min()) == 2.0 and float(out.min()) == 5.0
+
+
+def test_first_terminated_len_kernel_matches_reference_rule():
+    """marl_first_terminated_len vs the reference's get_max_episode_len rule (q_learner.py:49-66, quirk Q2)."""
+    from marl_amd import ops
+    from marl_amd.hostutil import DeviceBatch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    for E, T in ((1, 1), (7, 5), (300, 120), (4096, 150), (5, 64), (3, 65)):
+        term = np.zeros((E, T, 1), np.float32)
+        lens = rng.integers(0, T + 1, size=E)              # 0 = never terminates
+        for e, L in enumerate(lens):
+            if L > 0:
+                term[e, L - 1:, 0] = 1.0
+        ref = 0
+        for e in range(E):                                 # the reference's loop
+            for t in range(T):
+                if term[e, t, 0] == 1:
+                    ref = max(ref, t + 1)
+                    break
+        got = int(ops.first_terminated_len(torch.as_tensor(term).to(dev), T).item())
+        assert got == ref, (E, T, got, ref)
+        assert DeviceBatch.first_terminated_len(torch.as_tensor(term).to(dev), T) == (ref if ref > 0 else T)
+        assert DeviceBatch.first_terminated_len(torch.as_tensor(term), T) == (ref if ref > 0 else T)      # host path
+    none = torch.zeros(4, 9, device=dev)
+    assert DeviceBatch.first_terminated_len(none, 9) == 9
