@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--updates", type=int, default=3)
     ap.add_argument("--rollouts", type=int, default=0)
+    ap.add_argument("--warmup", type=int, default=0, help="untimed updates before the timed ones (first-call allocations)")
     o = ap.parse_args()
     from marl_amd.controller.share_params import SharedMAC
     from marl_amd.algorithm.q_learner import QLearner
@@ -37,6 +38,8 @@ def main():
     ep, _, _, _ = w.generate_episodes(o.envs)
     for _ in range(o.rollouts):
         w.generate_episodes(o.envs)
+    for i in range(o.warmup):
+        learner.train(ep, i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(o.updates):
