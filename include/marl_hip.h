@@ -90,6 +90,12 @@ int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long 
                           const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                           const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T,
                           int N, int O, int A, int last_action, int reuse_network, void* stream);
+/* CUs (= workgroups) a T > 1 unroll launch spreads its rows over, 1..256 (default 256 = the whole chip).  With 128
+ * the two independent unrolls of an update - eval current-Q and target next-Q (q_learner.py:97,104) - fit on the chip
+ * together and can be launched on two HIP streams; results do not depend on it (rows are independent).
+ * Process-wide setting. */
+int marl_agent_set_cu_budget(int cus);
+
 /* Gradient destinations of the recurrent / output layers (accumulated into, torch layouts). */
 typedef struct {
   float *w_ih, *w_hh;           /* (3H,H) */

@@ -147,3 +147,40 @@ class GradReducer:
         t = torch.tensor([value], dtype=torch.int64, device=device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
+
+
+class PairedUnroll:
+    """Launches two independent agent unrolls (eval current-Q and target next-Q: reference q_learner.py:97,104) side by
+    side: each is limited to half of the CUs (marl_agent_set_cu_budget) and the second runs on a side HIP stream.  A
+    T-step unroll is a chain of T dependent steps whose latency barely depends on how many row tiles a workgroup
+    carries (0.39 / 0.62 / 0.95 ms at 1 / 2 / 3 tiles), so below ~3000 episodes per GPU - the shards of the multi-GPU
+    runs - two half-chip launches finish sooner than two whole-chip launches back to back.  Results do not depend on
+    the split (rows are independent)."""
+
+    MAX_TILES = 1024          # 128 workgroups x 8 row tiles of 16 rows (the LDS cap of the unroll kernel)
+
+    def __init__(self):
+        self.side = None
+        self.enabled = True
+
+    def applies(self, rows, T):
+        return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES
+
+    def run(self, rows, T, first, second):
+        """first(), second(): closures that launch one unroll each on the current stream."""
+        if not self.applies(rows, T):
+            first()
+            second()
+            return
+        cur = torch.cuda.current_stream()
+        if self.side is None or self.side.device != cur.device:
+            self.side = torch.cuda.Stream(device=cur.device)
+        ops.agent_set_cu_budget(128)
+        try:
+            self.side.wait_stream(cur)              # inputs written on the main stream are visible to the side launch
+            with torch.cuda.stream(self.side):
+                second()
+            first()
+            cur.wait_stream(self.side)
+        finally:
+            ops.agent_set_cu_budget(256)

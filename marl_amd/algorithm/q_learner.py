@@ -19,7 +19,7 @@ from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import VDNMixer, QMixMixer, DMAQer
-from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer)
+from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll)
 
 
 class QLearner:
@@ -49,6 +49,7 @@ class QLearner:
         self.optimizer = FusedOptimizer(self._flat, args.optimizer, self.lr, args.grad_norm_clip)
         self._buf = Scratch()
         self.reducer = GradReducer()
+        self.pair = PairedUnroll()
         self.last_stats = None
 
     # ------------------------------------------------------------------ storage
@@ -96,8 +97,13 @@ class QLearner:
         u_act = db.u_act.reshape(-1)
 
         # eval current-Q unroll (keeps activations), target next-Q unroll
-        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
-        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
+        # (independent of each other: on small shards they run side by side on two streams, half of the CUs each)
+        emap = getattr(db, 'o_map', None)
+        self.pair.run(B * N, T,
+                      lambda: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
+                                                   h0=None, ep_len=db.ep_len, ep_map=emap),
+                      lambda: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None,
+                                                     h0=None, ep_len=db.ep_len, ep_map=emap))
         ops.q_gather(q_evals, u_act, q_chosen, R, A)
         cur_max = None
         if a.double_q:

@@ -19,7 +19,7 @@ from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import QtranQBase, QtranQAlt, QtranV, QMixMixer
 from .common import (MASK_BIG, MASK_QTRAN_EVAL, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward,
-                     GradReducer)
+                     GradReducer, PairedUnroll)
 
 
 class QTRANLearner:
@@ -50,6 +50,7 @@ class QTRANLearner:
         self.optimizer = FusedOptimizer(self._flat, args.optimizer, self.lr, args.grad_norm_clip)
         self._buf = Scratch()
         self.reducer = GradReducer()
+        self.pair = PairedUnroll()
         self.last_stats = None
 
     def cuda(self):
@@ -89,8 +90,12 @@ class QTRANLearner:
         u_act = db.u_act.reshape(-1)
         u_taken = db.u_taken.reshape(-1)          # one-hot(u) with zeros on padding (batch['u_onehot'])
 
-        self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
-        self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None, h0=None, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
+        emap = getattr(db, 'o_map', None)
+        self.pair.run(B * N, T,
+                      lambda: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved,
+                                                   h0=None, ep_len=db.ep_len, ep_map=emap),
+                      lambda: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None,
+                                                     h0=None, ep_len=db.ep_len, ep_map=emap))
 
         # local greedy actions (reference :103-114): eval clone masked with -999999, targets with -9999999
         opt_eval, opt_tgt = g("opt_eval", (R,), torch.int32), g("opt_tgt", (R,), torch.int32)

@@ -1150,20 +1150,30 @@ ST_DEFINE_SETTER(marl_debug_stamps_fwd)
 extern "C" int marl_debug_stamps_bwd(void* p) { return marl_debug_stamps_fwd(p); }
 #endif
 
-// choose row tiles per workgroup: fill 256 CUs, keep LDS within budget
-inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap) {
+// CUs one unroll launch may occupy (marl_agent_set_cu_budget): 256 = the whole chip; 128 lets two independent
+// unrolls - eval current-Q and target next-Q, q_learner.py:97,104 - run side by side on two streams
+static int marl_cu_budget = 256;
+
+// choose row tiles per workgroup: fill the CU budget, keep LDS within budget
+inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap, int cus = 256) {
   const long tiles = (R + 15) / 16;
   const size_t budget = 160 * 1024;
   int rt_max = (int)((budget - fixed_bytes) / (bytes_per_row * 16));
   if (rt_max > rt_cap) rt_max = rt_cap;
   if (rt_max < 1) rt_max = 1;
-  int rt = (int)((tiles + 255) / 256);
+  int rt = (int)((tiles + cus - 1) / cus);
   if (rt < 1) rt = 1;
   if (rt > rt_max) rt = rt_max;
   return rt;
 }
 
 }  // namespace
+
+extern "C" int marl_agent_set_cu_budget(int cus) {
+  if (cus < 1 || cus > 256) return (int)hipErrorInvalidValue;
+  marl_cu_budget = cus;
+  return 0;
+}
 
 extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                                      const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
@@ -1192,7 +1202,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   // a single step (rollout) is latency-bound: many small workgroups overlap their prologues better than
   // 256 big ones; a long unroll amortises the prologue and wants one workgroup per CU
   if (T == 1 && rt_cap > marl_fwd_rt_single) rt_cap = marl_fwd_rt_single;
-  a.RT = pick_rt(a.R, per_row, fixed, rt_cap);
+  a.RT = pick_rt(a.R, per_row, fixed, rt_cap, T > 1 ? marl_cu_budget : 256);
   const size_t lds = fixed + per_row * a.RT * 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const long rows = a.RT * 16;

@@ -169,6 +169,10 @@ def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last
           "marl_agent_unroll_fwd")
 
 
+def agent_set_cu_budget(cus):
+    check(_lib.load().marl_agent_set_cu_budget(int(cus)), "marl_agent_set_cu_budget")
+
+
 def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None):
     """grads: dict name -> gradient tensor for rnn.weight_ih/hh, rnn.bias_ih/hh, fc2.weight/bias (accumulated)."""
     lib = _lib.load()

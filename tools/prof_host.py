@@ -7,6 +7,9 @@ from marl_amd.rollout import RolloutWorker
 from marl_amd.env.synthetic_smac import SyntheticSMACEnv
 from marl_amd.common.replaybuffer import ReplayBuffer
 E = int(sys.argv[1])
+if os.environ.get("MARL_PIPE_MAX_RT"):
+    from marl_amd import _lib
+    _lib.load().marl_debug_set_pipe_max_rt(int(os.environ["MARL_PIPE_MAX_RT"]))
 args = bench.make_args("qmix", "2s3z", 0); args.buffer_size = 2 * E; args.batch_size = E
 mac = SharedMAC(args); learner = QLearner(mac, args)
 env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, args.episode_limit, seed=1, fixed_length=True)
