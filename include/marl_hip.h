@@ -137,10 +137,12 @@ int marl_q_scatter(float* dq, const int* idx1, const float* g1, const int* idx2,
                    long rows, int A, int gdiv, void* stream);
 /* out = a + b (q_tot = v_tot + a_tot, q_learner.py:135,154) */
 int marl_vec_add(const float* a, const float* b, float* out, long n, void* stream);
-/* out[r,d] = sum_n in[r,n,d]   (VDNMixer, mixer.py:15-16 with D=1; QTRAN .sum(dim=-2), :384,:414) */
-int marl_agent_sum(const float* in, float* out, long rows, int N, int D, void* stream);
+/* out[r,d] = sum_n in[r,n,d]   (VDNMixer, mixer.py:15-16 with D=1; QTRAN .sum(dim=-2), :384,:414); ld_in / ld_out =
+ * row strides (>= D) of the (rows*N, D) input and the (rows, D) output */
+int marl_agent_sum(const float* in, long ld_in, float* out, long ld_out, long rows, int N, int D, void* stream);
 /* out[r,n,d] = in[r,d] (+ out if accumulate): autograd of the sum above */
-int marl_agent_bcast(const float* in, float* out, long rows, int N, int D, int accumulate, void* stream);
+int marl_agent_bcast(const float* in, long ld_in, float* out, long ld_out, long rows, int N, int D, int accumulate,
+                     void* stream);
 
 /* QMixMixer.forward after the hypernet layers (mixer.py:64-80).  hy row = [w1raw (N*E, agent-major)
  * | b1 (E) | w2raw (E) | relu(hyper_b2.0) (E)], b2 = hyper_b2.2 output. */

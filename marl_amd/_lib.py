@@ -73,8 +73,8 @@ SIGNATURES = {
     "marl_q_double_select": (I, [P, P, P, F, P, P, L, I, P]),
     "marl_q_scatter": (I, [P, P, P, P, P, L, I, I, P]),
     "marl_vec_add": (I, [P, P, P, L, P]),
-    "marl_agent_sum": (I, [P, P, L, I, I, P]),
-    "marl_agent_bcast": (I, [P, P, L, I, I, I, P]),
+    "marl_agent_sum": (I, [P, L, P, L, L, I, I, P]),
+    "marl_agent_bcast": (I, [P, L, P, L, L, I, I, I, P]),
     "marl_qmix_mix_fwd": (I, [P, L, P, P, P, L, I, I, P]),
     "marl_qmix_mix_bwd": (I, [P, L, P, P, P, P, P, L, I, I, P]),
     "marl_qmix_fused_supported": (I, [I, I, I]),

@@ -363,6 +363,203 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
+// Full-width weight gradient for narrow layers (N <= 80 outputs, K + 1 <= 80 inputs: QTRAN's 78 x 78 encoders and the
+// 64 x 64 head layers): ONE workgroup column, so G and X are read from HBM exactly once (the 64 x 64-block kernel
+// above re-reads G per 64 input columns and X per 64 outputs: 1.26 GB for 0.38 GB of operands on the encoders).
+// Staging as above (16-byte coalesced, one chunk of 64 rows ahead, double-buffered LDS); the ROWS of a chunk are split
+// over the four waves - wave w multiplies rows [16w, 16w+16) into all NTN x NTK output tiles (<= 25 accumulators) - and
+// the waves' partial sums meet once at the end, in wave order, through LDS.
+constexpr int WF = 80;           // tile width (columns) of both operands
+constexpr int WFS = 84;          // LDS row stride: 4 rows apart = 16 banks apart (half-wave conflict-free)
+
+template <bool GATE>
+__global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];       // [G|X][64][WFS] (43 KB: two workgroups per CU); reused for the reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = lane & 15;
+  const int Kext = a.K + 1;
+  const int ntn = (a.N + 15) / 16, ntk = (Kext + 15) / 16;
+  const float* G = a.G;
+  const float* Ya = GATE ? a.Yact : nullptr;
+  const ConcatSrc& x = a.x;
+  f32x4 acc[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const long chunks = ((long)a.M + WCH - 1) / WCH;
+  const long per = (chunks + a.slabs - 1) / a.slabs;
+  const long c_begin = (long)blockIdx.x * per;
+  long c_end = c_begin + per; if (c_end > chunks) c_end = chunks;
+  auto tile = [&](int, int which) { return lds + (which * WCH) * WFS; };
+
+  // item e = tid + 256 * i (i < 5): row e / 20 of the chunk, columns 4 * (e % 20) .. + 3 of G and of X.
+  // The columns of an item are the same in every chunk, so what they ARE is resolved once: kind 1 = four dense0
+  // columns as one 16-byte load; otherwise one row base (2 action indices, 3 dense1, 4 dense0 element-wise, 0 none) +
+  // four byte offsets + four codes (0xffff zero, 0xfffe one = the bias column, 0xfffd the loaded float, else the
+  // action that makes a one-hot column 1).  The host only picks this kernel when no item needs two bases.
+  // fetch() only ISSUES loads (raw bits): nothing selects on a loaded value before stash() - the first use of a value
+  // makes the compiler wait for its load, which serialised every element load of the 64 x 64-block kernel's tail path.
+  int it_kind[5];
+  unsigned it_off[5][2], it_cmp[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int e = tid + 256 * i;
+    const int c4 = (e % 20) * 4;
+    int kind = 0;
+    unsigned off[4], cmp[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      int k = c4 + cc;
+      off[cc] = 0; cmp[cc] = 0xffffu;
+      if (k > a.K) continue;
+      if (k == a.K) { cmp[cc] = 0xfffeu; continue; }
+      if (k < x.k0) { kind = 4; off[cc] = 4u * k; cmp[cc] = 0xfffdu; }
+      else if (k - x.k0 < x.k1) { kind = 3; off[cc] = 4u * (k - x.k0); cmp[cc] = 0xfffdu; }
+      else {
+        k -= x.k0 + x.k1;
+        const int j = k / x.hot_w;
+        kind = 2; off[cc] = 4u * j; cmp[cc] = (unsigned)(k - j * x.hot_w);
+      }
+    }
+    if (kind == 4 && a.xvec && c4 + 3 < x.k0) kind = 1;
+    it_kind[i] = kind;
+    it_off[i][0] = off[0] | (off[1] << 16); it_off[i][1] = off[2] | (off[3] << 16);
+    it_cmp[i][0] = cmp[0] | (cmp[1] << 16); it_cmp[i][1] = cmp[2] | (cmp[3] << 16);
+  }
+  f32x4 gq[5], yq[GATE ? 5 : 1], xq[5];        // xq: the 16-byte load of a kind-1 item or the four raw words of the others
+  int fq[5];
+  auto fetch = [&](long c) {
+    // rows first (the episode map of a row remap is itself a load the addresses depend on), then every data load
+    // back to back
+    long rowv[5], r0v[5], riv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i;
+      const int rl = e / 20;
+      long row = c * WCH + rl;
+      const bool live = row < a.M;
+      if (!live) row = a.M - 1;
+      const ConcatRow cr = concat_row(x, row);
+      fq[i] = (live ? 1 : 0) | (cr.ok0 ? 2 : 0) | (cr.oki ? 4 : 0);
+      rowv[i] = row; r0v[i] = cr.ok0 ? cr.r0 : 0; riv[i] = cr.oki ? cr.ri : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i;
+      const int rl = e / 20, c4 = (e - rl * 20) * 4;
+      const long row = rowv[i];
+      const int cg = c4 < a.N ? c4 : 0;                 // column groups past N re-read group 0 and are zeroed in stash()
+      gq[i] = *reinterpret_cast<const f32x4*>(G + row * a.ldg + cg);
+      if (GATE) yq[GATE ? i : 0] = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + cg);
+      const char* d0 = reinterpret_cast<const char*>(x.p0 + r0v[i] * x.ld0);
+      const int kind = it_kind[i];
+      if (kind == 1) {
+        xq[i] = *reinterpret_cast<const f32x4*>(d0 + 4 * c4);
+      } else if (kind >= 2) {
+        const char* d1 = x.p1 ? reinterpret_cast<const char*>(x.p1 + row * x.ld1) : d0;
+        const char* di = x.idx ? reinterpret_cast<const char*>(x.idx + riv[i] * x.nhot) : d0;
+        const char* base = kind == 2 ? di : (kind == 3 ? d1 : d0);
+        xq[i][0] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][0] & 0xffffu)));
+        xq[i][1] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][0] >> 16)));
+        xq[i][2] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][1] & 0xffffu)));
+        xq[i][3] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][1] >> 16)));
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    float* Gs = tile(buf, 0);
+    float* Xs = tile(buf, 1);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i;
+      const int rl = e / 20, c4 = (e - rl * 20) * 4;
+      f32x4 gv = gq[i];
+      if (GATE) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) gv[cc] = yq[GATE ? i : 0][cc] > 0.f ? gv[cc] : 0.f;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) gv[cc] = c4 + cc < a.N ? gv[cc] : 0.f;
+      if (!(fq[i] & 1)) gv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int kind = it_kind[i];
+      const bool ok0 = (fq[i] & 2) != 0, oki = (fq[i] & 4) != 0;
+      f32x4 xv;
+      if (kind == 1) {
+        xv = ok0 ? xq[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+        const bool okd = kind == 3 || (kind == 4 && ok0);
+        const unsigned cm[4] = {it_cmp[i][0] & 0xffffu, it_cmp[i][0] >> 16, it_cmp[i][1] & 0xffffu, it_cmp[i][1] >> 16};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int raw = kind >= 2 ? __float_as_int(xq[i][cc]) : 0;
+          float v = 0.f;
+          if (cm[cc] == 0xfffeu) v = 1.f;
+          else if (cm[cc] == 0xfffdu) v = okd ? __int_as_float(raw) : 0.f;
+          else if (cm[cc] != 0xffffu) v = (oki && (unsigned)raw == cm[cc]) ? 1.f : 0.f;
+          xv[cc] = v;
+        }
+      }
+      *reinterpret_cast<f32x4*>(Gs + rl * WFS + c4) = gv;
+      *reinterpret_cast<f32x4*>(Xs + rl * WFS + c4) = xv;
+    }
+  };
+
+  // single LDS tile: registers -> LDS, barrier, next chunk's loads issued, MFMAs, barrier.  The loads of chunk c+1
+  // fly during the MFMAs of chunk c and the second workgroup of the CU fills the barrier / latency gaps (one
+  // double-buffered workgroup per CU left the memory system at 1.2 TB/s).
+  if (c_begin < c_end) fetch(c_begin);
+  for (long c = c_begin; c < c_end; ++c) {
+    stash(0);
+    __syncthreads();
+    if (c + 1 < c_end) fetch(c + 1);
+    const float* Gs = tile(0, 0) + (16 * wave + 4 * q) * WFS + m;
+    const float* Xs = tile(0, 1) + (16 * wave + 4 * q) * WFS + m;
+    f32x4 bf[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bf[t][i] = t < ntk ? Xs[i * WFS + 16 * t] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      if (nt < ntn) {
+        f32x4 af;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = Gs[i * WFS + 16 * nt];
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+          if (kt < ntk) acc[nt][kt] = mfma16x4(af, bf[kt], acc[nt][kt]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // the four waves' partial sums, added in wave order through LDS (the staging buffers are free now)
+  float* red = lds;                        // [WF][WFS]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+          if (nt < ntn && kt < ntk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float* d = red + (16 * nt + 4 * q + i) * WFS + 16 * kt + m;
+              *d = (w == 0 ? 0.f : *d) + acc[nt][kt][i];
+            }
+          }
+    }
+    __syncthreads();
+  }
+  float* ws = a.ws + (long)blockIdx.x * a.N * Kext;
+  for (int e = tid; e < a.N * Kext; e += 256) {
+    const int n = e / Kext, k = e - n * Kext;
+    ws[e] = red[n * WFS + k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Direct weight gradient for N == 64 outputs (fc1 of the agent: dW1 = dxp^T [obs | one-hot(u) | id] over
 // B*T*N rows, the largest reduction of an update).  No LDS staging: the reduction index of dW = G^T X is
 // the ROW, and fp32 MFMA 16x16x4 takes one k (= row) per lane quarter, so lane (q, m) feeds the matrix
@@ -636,6 +833,7 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
 
 extern "C" size_t marl_linear_wgrad_workspace(int M, int N, int K, int groups) {
   int slabs = marl_wgrad_slabs(M);
+  if (N <= 80 && K + 1 <= 80 && groups == 1) slabs *= 2;           // the full-width kernel runs two workgroups per CU
   return (size_t)slabs * groups * N * (K + 4) * sizeof(float);      // + 3: column passes of the direct kernel each carry a bias column
 }
 
@@ -698,7 +896,24 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
       return 0;
     }
   }
-  if (bf || try_wgrad_direct(a, s) != 0) {
+  int done = bf ? -1 : try_wgrad_direct(a, s);
+  bool one_base = a.x.p0 && !a.x.m0 && !a.x.nid && a.x.k0 < 16384 && a.x.k1 < 16384 && a.x.nhot < 16384 && a.x.hot_w < 0xfff0;
+  for (int c4 = 0; one_base && c4 < K; c4 += 4) {       // segment of the first and the last real column of each item
+    auto seg = [&](int k) { return k < a.x.k0 ? 0 : (k - a.x.k0 < a.x.k1 ? 1 : 2); };
+    const int kl = c4 + 3 < K ? c4 + 3 : K - 1;
+    if (seg(c4) != seg(kl)) one_base = false;
+  }
+  if (done != 0 && !bf && groups == 1 && N <= WF && K + 1 <= WF && a.gvec && ldg >= (N + 3) / 4 * 4 &&
+      (!Yact || ldya >= (N + 3) / 4 * 4) && M >= 2048 && one_base) {
+    // narrow layer: one pass over G and X
+    const size_t lds = (size_t)2 * WCH * WFS * sizeof(float);
+    const long chunks = ((long)M + WCH - 1) / WCH;
+    a.slabs = (int)(2L * a.slabs < chunks ? 2L * a.slabs : (chunks < 1 ? 1 : chunks));
+    if (Yact) hipLaunchKernelGGL(wgrad_full_kernel<true>, dim3(a.slabs), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(wgrad_full_kernel<false>, dim3(a.slabs), dim3(256), lds, s, a);
+    done = 0;
+  }
+  if (done != 0) {
     dim3 grid(a.slabs, a.nyb * groups, (K + 1 + 63) / 64), block(256);
     if (bf) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, s, a);

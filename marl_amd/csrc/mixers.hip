@@ -106,25 +106,27 @@ __global__ void vec_add_kernel(const float* a, const float* b, float* out, long 
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) out[i] = a[i] + b[i];
 }
 
-__global__ void agent_sum_kernel(const float* in, float* out, long rows, int N, int D) {
+// in rows (r*N + n) of stride ld_in, out rows r of stride ld_out (strides >= D: intermediates are padded to 16-byte rows)
+__global__ void agent_sum_kernel(const float* in, long ld_in, float* out, long ld_out, long rows, int N, int D) {
   const long total = rows * D;
   for (long e = (long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long)gridDim.x * TPB) {
     const long r = e / D;
     const int d = (int)(e - r * D);
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += in[(r * N + n) * D + d];
-    out[e] = s;
+    for (int n = 0; n < N; ++n) s += in[(r * N + n) * ld_in + d];
+    out[r * ld_out + d] = s;
   }
 }
 
-__global__ void agent_bcast_kernel(const float* in, float* out, long rows, int N, int D, int acc) {
+__global__ void agent_bcast_kernel(const float* in, long ld_in, float* out, long ld_out, long rows, int N, int D, int acc) {
   const long total = rows * N * D;
   for (long e = (long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long)gridDim.x * TPB) {
     const long rn = e / D;
     const int d = (int)(e - rn * D);
     const long r = rn / N;
-    const float v = in[r * D + d];
-    out[e] = acc ? out[e] + v : v;
+    const float v = in[r * ld_in + d];
+    float* o = out + rn * ld_out + d;
+    *o = acc ? *o + v : v;
   }
 }
 
@@ -513,17 +515,20 @@ extern "C" int marl_vec_add(const float* a, const float* b, float* out, long n, 
   return 0;
 }
 
-extern "C" int marl_agent_sum(const float* in, float* out, long rows, int N, int D, void* stream) {
+extern "C" int marl_agent_sum(const float* in, long ld_in, float* out, long ld_out, long rows, int N, int D, void* stream) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(agent_sum_kernel, dim3(nblk(rows * D)), dim3(TPB), 0, (hipStream_t)stream, in, out, rows, N, D);
+  if (ld_in < D || ld_out < D) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(agent_sum_kernel, dim3(nblk(rows * D)), dim3(TPB), 0, (hipStream_t)stream, in, ld_in, out, ld_out, rows, N, D);
   MARL_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int marl_agent_bcast(const float* in, float* out, long rows, int N, int D, int accumulate, void* stream) {
+extern "C" int marl_agent_bcast(const float* in, long ld_in, float* out, long ld_out, long rows, int N, int D, int accumulate,
+                                void* stream) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(agent_bcast_kernel, dim3(nblk(rows * N * D)), dim3(TPB), 0, (hipStream_t)stream, in, out, rows,
-                     N, D, accumulate);
+  if (ld_in < D || ld_out < D) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(agent_bcast_kernel, dim3(nblk(rows * N * D)), dim3(TPB), 0, (hipStream_t)stream, in, ld_in, out, ld_out,
+                     rows, N, D, accumulate);
   MARL_CHECK_LAUNCH();
   return 0;
 }

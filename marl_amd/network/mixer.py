@@ -29,6 +29,12 @@ class _Scratch:
             self.d[key] = t
         return t
 
+    def get_rows(self, name, rows, width, device):
+        """(rows, width) fp32 view whose row stride is rounded up to 4 floats: every row starts on a 16-byte boundary,
+        so the GEMM kernels take their vector-load paths (QTRAN's 78-wide intermediates)."""
+        ld = (width + 3) // 4 * 4
+        return self.get(name, (rows, ld), device)[:, :width]
+
 
 def _mlp(dims, sizes):
     """nn.Sequential(Linear, ReLU, Linear, ...) with the reference's index names 0,2,4."""
@@ -452,9 +458,9 @@ class QtranQBase(nn.Module):
         e0, e2 = _linears(self.hidden_action_encoding)
         q0, q2, q4 = _linears(self.q)
         x_ha = ops.src(hidden, idx=u_idx.view(R, 1), nhot=1, hot_w=A)
-        e1 = self._s.get("e1" + tag, (R, ae), dev)
-        e2b = self._s.get("e2" + tag, (R, ae), dev)
-        esum = self._s.get("esum" + tag, (BT, ae), dev)
+        e1 = self._s.get_rows("e1" + tag, R, ae, dev)
+        e2b = self._s.get_rows("e2" + tag, R, ae, dev)
+        esum = self._s.get_rows("esum" + tag, BT, ae, dev)
         y1 = self._s.get("y1" + tag, (BT, Q), dev)
         y2 = self._s.get("y2" + tag, (BT, Q), dev)
         out = self._s.get("out" + tag, (BT, 1), dev)
@@ -481,9 +487,9 @@ class QtranQBase(nn.Module):
         g = d_out.view(BT, 1)
         dy2 = self._s.get("dy2", (BT, Q), dev)
         dy1 = self._s.get("dy1", (BT, Q), dev)
-        desum = self._s.get("desum", (BT, ae), dev)
-        de2 = self._s.get("de2", (R, ae), dev)
-        de1 = self._s.get("de1", (R, ae), dev)
+        desum = self._s.get_rows("desum", BT, ae, dev)
+        de2 = self._s.get_rows("de2", R, ae, dev)
+        de1 = self._s.get_rows("de1", R, ae, dev)
         lin_of(q4).wgrad(g, ops.src(y2), BT)
         lin_of(q4).bwd_x(g, dy2, BT)
         lin_of(q2).wgrad(dy2, ops.src(y1), BT, Yact=y2)

@@ -216,13 +216,19 @@ def vec_add(a, b, out, n):
     check(_lib.load().marl_vec_add(_p(_f32(a)), _p(_f32(b)), _p(_f32(out)), n, _stream()), "marl_vec_add")
 
 
+def _ld(t, D):
+    """row stride of a (rows, D) view (padded intermediates), D for flat / differently shaped tensors"""
+    return t.stride(0) if (t.dim() == 2 and t.shape[1] == D and t.stride(1) == 1) else D
+
+
 def agent_sum(inp, out, rows, N, D):
-    check(_lib.load().marl_agent_sum(_p(_f32(inp)), _p(_f32(out)), rows, N, D, _stream()), "marl_agent_sum")
+    check(_lib.load().marl_agent_sum(_p(_f32(inp)), _ld(inp, D), _p(_f32(out)), _ld(out, D), rows, N, D, _stream()),
+          "marl_agent_sum")
 
 
 def agent_bcast(inp, out, rows, N, D, accumulate=False):
-    check(_lib.load().marl_agent_bcast(_p(_f32(inp)), _p(_f32(out)), rows, N, D, 1 if accumulate else 0, _stream()),
-          "marl_agent_bcast")
+    check(_lib.load().marl_agent_bcast(_p(_f32(inp)), _ld(inp, D), _p(_f32(out)), _ld(out, D), rows, N, D,
+                                       1 if accumulate else 0, _stream()), "marl_agent_bcast")
 
 
 def qmix_mix_fwd(hy, b2, q, q_tot, rows, N, E):

@@ -180,6 +180,34 @@ def test_linear_concat_and_groups(dev):
         close(gflat[k * per + N * Kg:(k + 1) * per], Gk.sum(0), 3e-4)
 
 
+@pytest.mark.parametrize("M,N,K0,HW,gate", [(5000, 78, 64, 14, True), (3000, 78, 78, 0, False), (2500, 64, 64, 0, True),
+                                            (4097, 80, 79, 0, False), (2100, 33, 20, 5, True), (9000, 1, 64, 0, False)])
+def test_wgrad_full_width(dev, M, N, K0, HW, gate):
+    """Narrow layers (N <= 80, K + 1 <= 80; QTRAN's 78-wide encoders, 64-wide heads) take the one-pass full-width
+    weight-gradient kernel when dY rows are 16-byte aligned (row stride padded to 4 floats): dW, db vs torch."""
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K0)
+    K = K0 + HW
+    ld = lambda w: (w + 3) // 4 * 4
+    X0 = torch.randn(M, K0, generator=g)
+    idx = torch.randint(-1, HW, (M, 1), generator=g) if HW else None
+    Xfull = X0
+    if HW:
+        oh = torch.zeros(M, HW)
+        v = idx[:, 0] >= 0
+        oh[v, idx[v, 0]] = 1
+        Xfull = torch.cat([X0, oh], 1)
+    dY = torch.randn(M, N, generator=g)
+    Ya = torch.randn(M, N, generator=g)
+    pad = lambda t: cu(torch.cat([t, torch.zeros(t.shape[0], ld(t.shape[1]) - t.shape[1])], 1), dev)[:, :t.shape[1]]
+    xs = ops.src(pad(X0), idx=cu(idx, dev, torch.int32) if HW else None, nhot=1 if HW else 0, hot_w=HW)
+    dW, db = torch.full((N, K), 0.5, device=dev), torch.full((N,), 0.25, device=dev)
+    ops.linear_wgrad(pad(dY), xs, dW, db, M, N, K, Yact=pad(Ya) if gate else None)
+    Gm = dY * (Ya > 0) if gate else dY
+    close(dW - 0.5, Gm.t() @ Xfull, 2e-3, 1e-3)
+    close(db - 0.25, Gm.sum(0), 2e-3, 1e-3)
+
+
 @pytest.mark.parametrize("rows,S,NH,HW,N3,G,remap,nl", [(333, 120, 0, 0, 1, 10, False, 3), (1000, 120, 5, 11, 5, 10, False, 3),
                                                         (70, 24, 2, 3, 2, 3, False, 3), (4100, 120, 5, 11, 5, 4, True, 3),
                                                         (129, 72, 0, 0, 16, 2, False, 3), (50, 36, 4, 9, 3, 1, False, 3),
