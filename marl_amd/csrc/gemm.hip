@@ -26,13 +26,14 @@ struct LinArgs {
   long gs_x0, gs_x1, gs_w, gs_b, gs_y, gs_m0;
 };
 
-// block = 256 threads = 4 waves; wave tile = 32 rows x 64 cols (2 x 4 MFMA tiles).
+// block = 256 threads = 4 waves; wave tile = 32 rows x 16*NC cols (2 x NC MFMA tiles; NC = 5 for 64 < N <= 80: QTRAN's
+// 78-wide encoders in ONE column block - X is read once instead of twice).
 // K is walked in chunks of 16.  Chunks that lie entirely inside dense segment 0 (no relu gate) take the FAST path:
 // operands go straight to VGPRs (AMODE 1: one 16-byte load per lane and row tile; AMODE 2: four dword loads, for
 // row strides / bases that are not 16-byte aligned, e.g. S = 322) and are software-pipelined one chunk ahead in a
 // second register set (static ping-pong, no copies).  The remaining chunks (other segments of the virtual concat,
 // segment boundaries, gated inputs) take the guarded element path.
-template <int AMODE, bool W_KMAJOR, bool BF, bool GATE>
+template <int AMODE, bool W_KMAJOR, bool BF, bool GATE, int NC>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -46,10 +47,10 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   float* Y = a.Y + g * a.gs_y;
 
   const long row0 = (long)blockIdx.x * 128 + wave * 32;
-  const int col0 = blockIdx.y * 64;
+  const int col0 = blockIdx.y * (16 * NC);
   if (row0 >= a.M) return;
   int ct_used = (a.N - col0 + 15) / 16;
-  if (ct_used > 4) ct_used = 4;
+  if (ct_used > NC) ct_used = NC;
 
   long arow[2];
 #pragma unroll
@@ -57,18 +58,18 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
     long rr = row0 + r * 16 + m;
     arow[r] = rr < a.M ? rr : a.M - 1;
   }
-  int bcol[4];
+  int bcol[NC];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < NC; ++c) {
     int cc = col0 + c * 16 + m;
     bcol[c] = cc < a.N ? cc : a.N - 1;      // clamped: tiles past N compute garbage that is never stored
   }
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][NC];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int K = a.K;
   const int kfast = AMODE ? (x.k0 & ~15) : 0;     // chunks [0, kfast) are whole chunks of dense segment 0
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   const bool wvec = !W_KMAJOR && (a.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   // load() issues a FIXED number of unpredicated loads (invalid rows read row 0 and are zeroed in mma(), column
   // tiles past N read a clamped column): predicated or conditional loads keep the compiler from counting them
-  auto load = [&](f32x4 (&av)[2], f32x4 (&mv)[2], f32x4 (&bv)[4], int k0) __attribute__((always_inline)) {
+  auto load = [&](f32x4 (&av)[2], f32x4 (&mv)[2], f32x4 (&bv)[NC], int k0) __attribute__((always_inline)) {
     const int kk = k0 + 4 * q;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (!W_KMAJOR) {
         const float* wp = W + (long)bcol[c] * a.ldw + kk;
         if (wvec) bv[c] = *reinterpret_cast<const f32x4*>(wp);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
       }
     }
   };
-  auto mma = [&](const f32x4 (&av)[2], const f32x4 (&mv)[2], const f32x4 (&bv)[4]) __attribute__((always_inline)) {
+  auto mma = [&](const f32x4 (&av)[2], const f32x4 (&mv)[2], const f32x4 (&bv)[NC]) __attribute__((always_inline)) {
     f32x4 am[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (c >= ct_used) continue;
 #pragma unroll
       for (int r = 0; r < 2; ++r) acc[r][c] = mm16x4<BF>(am[r], bv[c], acc[r][c]);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   if (AMODE && kfast > 0) {
     // the prefetch is issued unconditionally (the last chunk is simply loaded again): a conditional issue makes the
     // compiler wait vmcnt(0) - for the prefetch it has just issued - in front of every MFMA block
-    f32x4 aA[2], bA[4], aB[2], bB[4], mA[2], mB[2];
+    f32x4 aA[2], bA[NC], aB[2], bB[NC], mA[2], mB[2];
     const int klast = kfast - 16;
     load(aA, mA, bA, 0);
     int k0 = 0;
@@ -146,13 +147,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   }
   for (int k0 = kfast; k0 < K; k0 += 16) {   // generic path: guarded element loads
     const int kk = k0 + 4 * q;
-    f32x4 av[2], bv[4];
+    f32x4 av[2], bv[NC];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i) av[r][i] = (kk + i < K) ? concat_at(x, crow[r], kk + i) : 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (c < ct_used) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (c < ct_used) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) acc[r][c] = mm16x4<BF>(av[r], bv[c], acc[r][c]);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 
   // epilogue: D-layout -> Y (16 lanes = 64 contiguous bytes per row)
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < NC; ++c) {
     if (c >= ct_used) continue;
     const int col = col0 + c * 16 + m;
     if (col >= a.N) continue;
@@ -812,20 +813,20 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
     if (gate) al = al && (a.x.ldm0 % 4 == 0) && aligned16(a.x.m0) && (a.gs_m0 % 4 == 0);
     amode = al ? 1 : 2;
   }
-  dim3 grid((M + 127) / 128, (N + 63) / 64, a.groups), block(256);
-  hipStream_t s = (hipStream_t)stream;
   const bool bf = (act & 0x100) != 0;        // bf16 operands, fp32 accumulate (mixer GEMMs, opt-in)
+  const int nc = (!bf && N > 64 && N <= 80) ? 5 : 4;
+  dim3 grid((M + 127) / 128, (N + 16 * nc - 1) / (16 * nc), a.groups), block(256);
+  hipStream_t s = (hipStream_t)stream;
   a.act = act & 0xff;
-#define LIN_GT(AM, KM, BFV) do { if (gate) hipLaunchKernelGGL((linear_kernel<AM, KM, BFV, true>), grid, block, 0, s, a); \
-                                else hipLaunchKernelGGL((linear_kernel<AM, KM, BFV, false>), grid, block, 0, s, a); } while (0)
-#define LIN_GO(AM, KM, BFV) LIN_GT(AM, KM, BFV)
-#define LIN_KM(AM, BFV) do { if (w_kmajor) LIN_GO(AM, true, BFV); else LIN_GO(AM, false, BFV); } while (0)
-#define LIN_AM(BFV) do { if (amode == 1) LIN_KM(1, BFV); else if (amode == 2) LIN_KM(2, BFV); else LIN_KM(0, BFV); } while (0)
-  if (bf) LIN_AM(true);
-  else LIN_AM(false);
+#define LIN_GT(AM, KM, BFV, NCV) do { if (gate) hipLaunchKernelGGL((linear_kernel<AM, KM, BFV, true, NCV>), grid, block, 0, s, a); \
+                                     else hipLaunchKernelGGL((linear_kernel<AM, KM, BFV, false, NCV>), grid, block, 0, s, a); } while (0)
+#define LIN_KM(AM, BFV, NCV) do { if (w_kmajor) LIN_GT(AM, true, BFV, NCV); else LIN_GT(AM, false, BFV, NCV); } while (0)
+#define LIN_AM(BFV, NCV) do { if (amode == 1) LIN_KM(1, BFV, NCV); else if (amode == 2) LIN_KM(2, BFV, NCV); else LIN_KM(0, BFV, NCV); } while (0)
+  if (bf) LIN_AM(true, 4);
+  else if (nc == 5) LIN_AM(false, 5);
+  else LIN_AM(false, 4);
 #undef LIN_AM
 #undef LIN_KM
-#undef LIN_GO
 #undef LIN_GT
   MARL_CHECK_LAUNCH();
   return 0;
