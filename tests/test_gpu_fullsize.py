@@ -100,3 +100,37 @@ def test_learner_linearity_and_oracle_samples(world):
         a_ = dbg[k].reshape(E, Tm)[idx]
         b_ = inter[k].detach().numpy().reshape(len(idx), Tm)
         np.testing.assert_allclose(a_[live], b_[live], atol=2e-4, err_msg=k)
+
+
+def test_qplex_linearity_and_oracle_samples(world):
+    """QPLEX (BASELINE config 3 shape) at the full 4096 x 120 batch: the fused lambda-net head kernels walk 30 720
+    row tiles per head here.  Same properties as above: the full batch's un-normalised gradient equals the sum over
+    its halves, and q_tot / target q_tot of sampled episodes equal the CPU oracle's."""
+    from marl_amd.hostutil import DeviceBatch
+    from marl_amd.rollout import EpisodeBatch
+    from test_gpu_learners import build_product
+    from golden_cases import case_states
+    case = ("fullq", "2s3z", "qplex", E, T, None, {})
+    args, mac, learner = build_product(case)
+    rec = world["ep"].record
+    Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
+    full, dbg = _grads(learner, rec, Tm)
+    half = E // 2
+    ga, _ = _grads(learner, rec.slice(0, half), Tm)
+    gb, _ = _grads(learner, rec.slice(half, E), Tm)
+    tot = ga + gb
+    n = learner._flat.n
+    assert tot[n + 1] == full[n + 1]
+    np.testing.assert_allclose(full[n], tot[n], rtol=5e-5)
+    scale = np.abs(full[:n]).max()
+    np.testing.assert_allclose(full[:n] / scale, tot[:n] / scale, atol=5e-5)
+    _, agent, mixer, _, _ = case_states(case)
+    st = learners.LearnerState(args, agent, mixer)
+    idx = [0, 1, 2047, 2048, 4095]
+    sub = EpisodeBatch(rec.index_select(torch.as_tensor(idx, device=rec.obs.device))).numpy()
+    _, inter = learners.q_forward(st, sub, T=Tm)
+    live = sub["padded"][:, :Tm, 0] == 0
+    for k in ("q_tot", "q_tot_target"):
+        a_ = dbg[k].reshape(E, Tm)[idx]
+        b_ = inter[k].detach().numpy().reshape(len(idx), Tm)
+        np.testing.assert_allclose(a_[live], b_[live], atol=3e-4, rtol=1e-4, err_msg=k)
