@@ -401,8 +401,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradArgs a) {
   // action that makes a one-hot column 1).  The host only picks this kernel when no item needs two bases.
   // fetch() only ISSUES loads (raw bits): nothing selects on a loaded value before stash() - the first use of a value
   // makes the compiler wait for its load, which serialised every element load of the 64 x 64-block kernel's tail path.
+  // (kept in LDS, 16 bytes per item: with 25 accumulator tiles the register file has no room for them - spilled
+  // registers are reloaded through the same vmcnt queue as the prefetch and drain it)
+  int* itab = reinterpret_cast<int*>(lds + 2 * WCH * WFS) + 2 * 2 * WCH * 4;      // behind the row table: [5][256] int4
   int it_kind[5];
-  unsigned it_off[5][2], it_cmp[5][2];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int e = tid + 256 * i;
@@ -425,46 +427,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradArgs a) {
     }
     if (kind == 4 && a.xvec && c4 + 3 < x.k0) kind = 1;
     it_kind[i] = kind;
-    it_off[i][0] = off[0] | (off[1] << 16); it_off[i][1] = off[2] | (off[3] << 16);
-    it_cmp[i][0] = cmp[0] | (cmp[1] << 16); it_cmp[i][1] = cmp[2] | (cmp[3] << 16);
+    int* t = itab + (i * 256 + tid) * 4;
+    t[0] = (int)(off[0] | (off[1] << 16)); t[1] = (int)(off[2] | (off[3] << 16));
+    t[2] = (int)(cmp[0] | (cmp[1] << 16)); t[3] = (int)(cmp[2] | (cmp[3] << 16));
   }
   f32x4 gq[5], yq[GATE ? 5 : 1], xq[5];        // xq: the 16-byte load of a kind-1 item or the four raw words of the others
   int fq[5];
-  auto fetch = [&](long c) {
-    // rows first (the episode map of a row remap is itself a load the addresses depend on), then every data load
-    // back to back
-    long rowv[5], r0v[5], riv[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + 256 * i;
-      const int rl = e / 20;
-      long row = c * WCH + rl;
+  // Row arithmetic (clamp, row remap, episode map, index remap) ONCE PER ROW of a chunk, not once per 16-byte item:
+  // 64 threads fill a small LDS table {G row offset, x.p0 row offset, idx row offset, p1 row offset (bytes), flags}
+  // two chunks ahead; every item then starts from two 16-byte LDS reads.  (Done per item it was ~110 vector
+  // instructions against the item's 20 MFMAs - the kernel ran at 1.3 TB/s, bound by that arithmetic.)
+  long* rtab = reinterpret_cast<long*>(lds + 2 * WCH * WFS);      // [2 slots][64 rows][4 longs]; flags in the top byte of [3]
+  auto rowinfo = [&](long c, int slot) {
+    if (tid < WCH) {
+      long row = c * WCH + tid;
       const bool live = row < a.M;
       if (!live) row = a.M - 1;
       const ConcatRow cr = concat_row(x, row);
-      fq[i] = (live ? 1 : 0) | (cr.ok0 ? 2 : 0) | (cr.oki ? 4 : 0);
-      rowv[i] = row; r0v[i] = cr.ok0 ? cr.r0 : 0; riv[i] = cr.oki ? cr.ri : 0;
+      const long fl = (live ? 1 : 0) | (cr.ok0 ? 2 : 0) | (cr.oki ? 4 : 0);
+      long* t = rtab + (slot * WCH + tid) * 4;
+      t[0] = row;
+      t[1] = (cr.ok0 ? cr.r0 : 0) * x.ld0 * 4;
+      t[2] = (cr.oki ? cr.ri : 0) * (long)x.nhot * 4;
+      t[3] = fl;
     }
+  };
+  auto fetch = [&](long c) {
+    const long* tb = rtab + (int)(c & 1) * WCH * 4;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int e = tid + 256 * i;
       const int rl = e / 20, c4 = (e - rl * 20) * 4;
-      const long row = rowv[i];
+      const long row = tb[rl * 4 + 0], o0 = tb[rl * 4 + 1], oi = tb[rl * 4 + 2];
+      fq[i] = (int)tb[rl * 4 + 3];
       const int cg = c4 < a.N ? c4 : 0;                 // column groups past N re-read group 0 and are zeroed in stash()
       gq[i] = *reinterpret_cast<const f32x4*>(G + row * a.ldg + cg);
       if (GATE) yq[GATE ? i : 0] = *reinterpret_cast<const f32x4*>(Ya + row * a.ldya + cg);
-      const char* d0 = reinterpret_cast<const char*>(x.p0 + r0v[i] * x.ld0);
+      const char* d0 = reinterpret_cast<const char*>(x.p0) + o0;
       const int kind = it_kind[i];
       if (kind == 1) {
         xq[i] = *reinterpret_cast<const f32x4*>(d0 + 4 * c4);
       } else if (kind >= 2) {
         const char* d1 = x.p1 ? reinterpret_cast<const char*>(x.p1 + row * x.ld1) : d0;
-        const char* di = x.idx ? reinterpret_cast<const char*>(x.idx + riv[i] * x.nhot) : d0;
+        const char* di = x.idx ? reinterpret_cast<const char*>(x.idx) + oi : d0;
         const char* base = kind == 2 ? di : (kind == 3 ? d1 : d0);
-        xq[i][0] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][0] & 0xffffu)));
-        xq[i][1] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][0] >> 16)));
-        xq[i][2] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][1] & 0xffffu)));
-        xq[i][3] = __int_as_float(*reinterpret_cast<const int*>(base + (it_off[i][1] >> 16)));
+        const unsigned o01 = (unsigned)itab[(i * 256 + tid) * 4 + 0], o23 = (unsigned)itab[(i * 256 + tid) * 4 + 1];
+        xq[i][0] = __int_as_float(*reinterpret_cast<const int*>(base + (o01 & 0xffffu)));
+        xq[i][1] = __int_as_float(*reinterpret_cast<const int*>(base + (o01 >> 16)));
+        xq[i][2] = __int_as_float(*reinterpret_cast<const int*>(base + (o23 & 0xffffu)));
+        xq[i][3] = __int_as_float(*reinterpret_cast<const int*>(base + (o23 >> 16)));
       }
     }
   };
@@ -490,7 +501,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradArgs a) {
         xv = ok0 ? xq[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
       } else {
         const bool okd = kind == 3 || (kind == 4 && ok0);
-        const unsigned cm[4] = {it_cmp[i][0] & 0xffffu, it_cmp[i][0] >> 16, it_cmp[i][1] & 0xffffu, it_cmp[i][1] >> 16};
+        const unsigned c01 = (unsigned)itab[(i * 256 + tid) * 4 + 2], c23 = (unsigned)itab[(i * 256 + tid) * 4 + 3];
+        const unsigned cm[4] = {c01 & 0xffffu, c01 >> 16, c23 & 0xffffu, c23 >> 16};
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int raw = kind >= 2 ? __float_as_int(xq[i][cc]) : 0;
@@ -509,27 +521,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradArgs a) {
   // single LDS tile: registers -> LDS, barrier, next chunk's loads issued, MFMAs, barrier.  The loads of chunk c+1
   // fly during the MFMAs of chunk c and the second workgroup of the CU fills the barrier / latency gaps (one
   // double-buffered workgroup per CU left the memory system at 1.2 TB/s).
-  if (c_begin < c_end) fetch(c_begin);
+  if (c_begin < c_end) {
+    rowinfo(c_begin, (int)(c_begin & 1));
+    rowinfo(c_begin + 1, (int)((c_begin + 1) & 1));
+    __syncthreads();
+    fetch(c_begin);
+  }
   for (long c = c_begin; c < c_end; ++c) {
     stash(0);
-    __syncthreads();
+    __syncthreads();                               // tile of chunk c and the row table of chunk c+1 are in LDS
     if (c + 1 < c_end) fetch(c + 1);
+    rowinfo(c + 2, (int)(c & 1));                  // slot of chunk c: its fetch happened an iteration ago
     const float* Gs = tile(0, 0) + (16 * wave + 4 * q) * WFS + m;
     const float* Xs = tile(0, 1) + (16 * wave + 4 * q) * WFS + m;
-    f32x4 bf[5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int kt = 0; kt < 5; ++kt) {
+      if (kt < ntk) {
+        f32x4 bf;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bf[t][i] = t < ntk ? Xs[i * WFS + 16 * t] : 0.f;
+        for (int i = 0; i < 4; ++i) bf[i] = Xs[i * WFS + 16 * kt];
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-      if (nt < ntn) {
-        f32x4 af;
+        for (int nt = 0; nt < 5; ++nt) {
+          if (nt < ntn) {
+            f32x4 af;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = Gs[i * WFS + 16 * nt];
-#pragma unroll
-        for (int kt = 0; kt < 5; ++kt)
-          if (kt < ntk) acc[nt][kt] = mfma16x4(af, bf[kt], acc[nt][kt]);
+            for (int i = 0; i < 4; ++i) af[i] = Gs[i * WFS + 16 * nt];
+            acc[nt][kt] = mfma16x4(af, bf, acc[nt][kt]);
+          }
+        }
       }
     }
     __syncthreads();
@@ -907,7 +926,7 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
   if (done != 0 && !bf && groups == 1 && N <= WF && K + 1 <= WF && a.gvec && ldg >= (N + 3) / 4 * 4 &&
       (!Yact || ldya >= (N + 3) / 4 * 4) && M >= 2048 && one_base) {
     // narrow layer: one pass over G and X
-    const size_t lds = (size_t)2 * WCH * WFS * sizeof(float);
+    const size_t lds = (size_t)2 * WCH * WFS * sizeof(float) + (size_t)2 * WCH * 4 * sizeof(long) + (size_t)5 * 256 * 16;
     const long chunks = ((long)M + WCH - 1) / WCH;
     a.slabs = (int)(2L * a.slabs < chunks ? 2L * a.slabs : (chunks < 1 ? 1 : chunks));
     if (Yact) hipLaunchKernelGGL(wgrad_full_kernel<true>, dim3(a.slabs), dim3(256), lds, s, a);
