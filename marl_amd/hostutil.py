@@ -188,3 +188,28 @@ class DeviceBatch:
     @avail.setter
     def avail(self, v):
         self._avail = v
+
+
+def pin_to_gpu_numa(device_index=0):
+    """Bind this process to the CPUs of the NUMA node the GPU hangs off (one process per GPU: kernel launches and the
+    small D2H reads of an update are MMIO / PCIe round trips, several times slower from the other socket of a
+    two-socket host).  Returns the node, or None when the topology cannot be read (then nothing is changed)."""
+    import glob
+    import os
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None

@@ -40,6 +40,9 @@ def main():
         w.generate_episodes(o.envs)
     for i in range(o.warmup):
         learner.train(ep, i)
+    import gc
+    gc.collect()
+    gc.disable()            # a generation-2 collection costs 35-60 ms here - several updates (as bench.py / timeit do)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(o.updates):
