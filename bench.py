@@ -105,6 +105,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from marl_amd.hostutil import pin_to_gpu_numa
+    numa = pin_to_gpu_numa(local)            # one process per GPU, on the CPUs of that GPU's NUMA node (two-socket hosts)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("MARL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
@@ -234,7 +236,7 @@ def main():
                        "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
                        "n_actions": args.n_actions, "episode_limit": T, "global_envs": o.envs, "envs_per_gpu": E,
                        "mixer_dtype": o.mixer_dtype,
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "numa_node": numa,
                        "step": "batched rollout (T lock-steps) + replay store/sample + 1 learner.train()"},
             "learner_updates_per_sec": 1.0 / t_learn,
             "learner_transitions_per_sec": o.envs * T / t_learn,
