@@ -136,17 +136,17 @@ class QTRANLearner:
         elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
             # replay sample: big arrays are read in place from the ring through the episode index
             small = batch.ring.select_small(batch.index)
-            T = DeviceBatch.first_terminated_len(small.term, self.args.episode_limit)
-            db = DeviceBatch.from_record(batch.ring, self.args, T=self.reducer.max_int(T, self.device), index=batch.index,
+            T = DeviceBatch.first_terminated_len(small.term, self.args.episode_limit, reducer=self.reducer)
+            db = DeviceBatch.from_record(batch.ring, self.args, T=T, index=batch.index,
                                          small=small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
-            T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit)
-            db = DeviceBatch.from_record(batch.record, self.args, T=self.reducer.max_int(T, self.device))
+            T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit, reducer=self.reducer)
+            db = DeviceBatch.from_record(batch.record, self.args, T=T)
         else:
             T = None
             if self.reducer.enabled:
-                T = self.reducer.max_int(DeviceBatch.first_terminated_len(
-                    torch.as_tensor(np.asarray(batch['terminated'])), self.args.episode_limit), self.device)
+                T = DeviceBatch.first_terminated_len(torch.as_tensor(np.asarray(batch['terminated'])),
+                                                     self.args.episode_limit, reducer=self.reducer)
             db = DeviceBatch.from_dict(batch, self.args, self.device, T=T)
         self.max_episode_len = db.T
         try:

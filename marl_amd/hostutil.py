@@ -101,16 +101,26 @@ class DeviceBatch:
         self.ep_len = None      # per-episode lengths when obs is (T+1)-slot storage
 
     @staticmethod
-    def first_terminated_len(term, episode_limit):
+    def first_terminated_len(term, episode_limit, reducer=None):
         """get_max_episode_len (algorithm/q_learner.py:49-66) on device: max over episodes of the first
-        terminated index + 1; episodes that never terminate are ignored; 0 -> episode_limit."""
+        terminated index + 1; episodes that never terminate are ignored; 0 -> episode_limit.
+        With a data-parallel ``reducer`` the max runs over the episodes of ALL ranks (shards must agree on
+        T): the raw per-rank value (0 = none terminated) is all-reduced on the device before the single readback, so a
+        rank whose episodes never terminate does not force episode_limit on the others."""
+        dist_on = reducer is not None and reducer.enabled
         if term.is_cuda and term.dtype == torch.float32 and term.shape[0] > 0:
-            m = int(ops.first_terminated_len(term, episode_limit).item())      # one kernel + one sync
+            out = ops.first_terminated_len(term, episode_limit)              # one kernel
+            if dist_on:
+                reducer.dist.all_reduce(out, op=reducer.dist.ReduceOp.MAX, group=reducer.group)
+            m = int(out.item())                                              # one sync
             return m if m > 0 else episode_limit
         t = (term.reshape(term.shape[0], -1)[:, :episode_limit] == 1)
         anyt = t.any(dim=1)
         first = t.to(torch.int32).argmax(dim=1) + 1
         m = int(torch.where(anyt, first, torch.zeros_like(first)).max().item()) if t.shape[0] > 0 else 0
+        if dist_on:
+            m = reducer.max_int(m, torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                                else torch.device("cpu"))
         return m if m > 0 else episode_limit
 
     @classmethod

@@ -49,7 +49,16 @@ def _worker(rank, world, port, q):
     g, num, den = _numerator_grads(args, agent, mixer, shard, T)
     buf = torch.cat([g, torch.tensor([num, den] + [0.0] * (N_STATS - 2))])
     red.allreduce_(buf)
-    q.put((rank, T, buf.numpy()))
+    # global max_episode_len: rank 0's episodes never terminate, rank 1's stop after 4 and 2 steps ->
+    # both ranks must get 4 (never-terminating episodes are ignored, quirk Q2), not episode_limit
+    from marl_amd.hostutil import DeviceBatch
+    term = torch.zeros(2, 9, 1)
+    if rank == 1:
+        term[0, 3:] = 1.0
+        term[1, 1:] = 1.0
+    Tg = DeviceBatch.first_terminated_len(term, 9, reducer=red)
+    none = DeviceBatch.first_terminated_len(torch.zeros(2, 9, 1), 9, reducer=red)     # nobody terminates anywhere
+    q.put((rank, (T, Tg, none), buf.numpy()))
     dist.destroy_process_group()
 
 
@@ -65,7 +74,7 @@ def test_sharded_numerators_reduce_to_the_full_batch_gradient():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, T0, b0), (_, T1, b1) = sorted(res, key=lambda x: x[0])
-    assert T0 == T1 == 6
+    assert T0 == T1 == (6, 4, 9)
     np.testing.assert_array_equal(b0, b1)                  # every rank holds the same reduced buffer
     case = ("x", "2s3z", "qmix", 6, 6, None, {})
     args, agent, mixer, _, _ = case_states(case)
