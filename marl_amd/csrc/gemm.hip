@@ -929,6 +929,9 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
     const size_t lds = (size_t)2 * WCH * WFS * sizeof(float) + (size_t)2 * WCH * 4 * sizeof(long) + (size_t)5 * 256 * 16;
     const long chunks = ((long)M + WCH - 1) / WCH;
     a.slabs = (int)(2L * a.slabs < chunks ? 2L * a.slabs : (chunks < 1 ? 1 : chunks));
+    const void* fn = Yact ? (const void*)wgrad_full_kernel<true> : (const void*)wgrad_full_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // 67.5 KB > the 64 KB default
+    if (e != hipSuccess) return (int)e;
     if (Yact) hipLaunchKernelGGL(wgrad_full_kernel<true>, dim3(a.slabs), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(wgrad_full_kernel<false>, dim3(a.slabs), dim3(256), lds, s, a);
     done = 0;
