@@ -108,6 +108,27 @@ class QMixMixer(nn.Module):
                 "w2": pick(self.hyper_w2.weight), "w2_b": pick(self.hyper_w2.bias),
                 "h": pick(b20.weight), "h_b": pick(b20.bias), "b2_w": pick(b22.weight), "b2_b": pick(b22.bias)}
 
+    def _fused_struct(self, grad=False):
+        """marl_qmix_weights_t of the parameters (or their gradients), rebuilt only when a tensor's storage moved"""
+        t = self._fused_tensors(grad)
+        key = tuple(v.data_ptr() for v in t.values())
+        cache = self.__dict__.setdefault("_fs_cache", {})
+        c = cache.get(grad)
+        if c is None or c[0] != key:
+            c = cache[grad] = (key, ops.qmix_weights(t))
+        return c[1]
+
+    def __deepcopy__(self, memo):
+        # the cached ctypes structs point at THIS module's storage: a copy (target mixer) starts without them
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        import copy as _copy
+        for k, v in self.__dict__.items():
+            if k != "_fs_cache":
+                new.__dict__[k] = _copy.deepcopy(v, memo)
+        return new
+
     def hip_forward(self, q, s, rows, ctx=None, tag="e"):
         a = self.args
         N, E, HH = a.n_agents, a.qmix_hidden_dim, a.hyper_hidden_dim
@@ -116,7 +137,7 @@ class QMixMixer(nn.Module):
         if self._fused_ok(xs):
             # one kernel: hypernet GEMMs (weights in registers) + mixing; nothing 256-wide touches HBM
             qtot = self._s.get("qtot" + tag, (rows,), dev)
-            ops.qmix_fused_fwd(ops.qmix_weights(self._fused_tensors()), xs, q, qtot, rows, N, a.state_shape, E)
+            ops.qmix_fused_fwd(self._fused_struct(), xs, q, qtot, rows, N, a.state_shape, E)
             if ctx is not None:
                 ctx.update(q=q, s=s, fused=True)
             return qtot
@@ -152,8 +173,8 @@ class QMixMixer(nn.Module):
         if ctx.get("fused"):
             q, s = ctx["q"], ctx["s"]
             dq = self._s.get("dq", (rows, N), q.device)
-            ops.qmix_fused_bwd(ops.qmix_weights(self._fused_tensors()), ops.src(s), q, dq_tot, dq,
-                               ops.qmix_weights(self._fused_tensors(grad=True)), rows, N, a.state_shape, E)
+            ops.qmix_fused_bwd(self._fused_struct(), ops.src(s), q, dq_tot, dq,
+                               self._fused_struct(grad=True), rows, N, a.state_shape, E)
             return dq
         hy, q, s = ctx["hy"], ctx["q"], ctx["s"]
         dev = q.device

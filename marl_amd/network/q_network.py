@@ -4,11 +4,19 @@ The nn.Linear / nn.GRUCell members are parameter containers only (state_dict key
 fc2.* as in the reference); the arithmetic is the persistent HIP unroll kernel
 (marl_amd/csrc/agent.hip) called with T = 1.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
 from .. import ops
 from ..hostutil import require_cuda
+
+
+# module -> (parameter objects, their data pointers, marl_agent_weights_t): the struct is rebuilt only when a
+# parameter's storage moved (flat-buffer adoption, .to(), load_state_dict into new storage) - walking
+# named_parameters() on every launch cost ~15 us, five times per update
+_WEIGHTS = weakref.WeakKeyDictionary()
 
 
 class RNNQNet(nn.Module):
@@ -24,6 +32,11 @@ class RNNQNet(nn.Module):
 
     def weights(self):
         """marl_agent_weights_t over the current parameter storage."""
+        c = _WEIGHTS.get(self)
+        if c is not None:
+            plist, ptrs, w = c
+            if all(q.data_ptr() == o and q.is_cuda for q, o in zip(plist, ptrs)):
+                return w
         p = dict(self.named_parameters())
         dev = p["fc1.weight"].device
         if dev.type != "cuda":
@@ -33,7 +46,10 @@ class RNNQNet(nn.Module):
         for k, v in p.items():
             if not v.data.is_contiguous():
                 v.data = v.data.contiguous()
-        return ops.agent_weights({k: v.data for k, v in p.items()})
+        w = ops.agent_weights({k: v.data for k, v in p.items()})
+        plist = list(p.values())
+        _WEIGHTS[self] = (plist, [q.data_ptr() for q in plist], w)
+        return w
 
     def forward(self, obs, hidden_state):
         """obs (rows, input_shape) already concatenated; hidden (rows, H) -> (q, h)."""
