@@ -1,4 +1,4 @@
-"""Data-parallel path on the GPU: two ranks (both on GPU 0, gloo backend moving CUDA tensors) must
+"""Data-parallel path on the GPU: two / three ranks (all on GPU 0, gloo backend moving CUDA tensors) must
 reproduce the single-process update on the same global batch - loss, max_episode_len and the
 parameters after 3 updates - and bench.py must run under torch.distributed.run."""
 import json
@@ -26,11 +26,11 @@ def _run(cmd, extra_env):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("alg,shape", [("qmix", "2s3z"), ("qtran_base", "3s5z")])
-def test_two_ranks_equal_one_process(alg, shape):
+@pytest.mark.parametrize("alg,shape,world", [("qmix", "2s3z", 2), ("qtran_base", "3s5z", 2), ("qplex", "2s3z", 3)])
+def test_ranks_equal_one_process(alg, shape, world):
     from test_gpu_learners import build_product
     port = 29500 + (os.getpid() % 400)
-    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                 "--master-addr", "127.0.0.1", "--master-port", str(port), "tests/dist_parity_worker.py", alg, shape],
                {"MARL_BENCH_BACKEND": "gloo"})
     B, T = 6, 6
