@@ -136,12 +136,9 @@ class QTRANLearner:
         elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
             # replay sample: big arrays are read in place from the ring through the episode index
             small = batch.ring.select_small(batch.index)
-            T = DeviceBatch.first_terminated_len(small.term, self.args.episode_limit, reducer=self.reducer)
-            db = DeviceBatch.from_record(batch.ring, self.args, T=T, index=batch.index,
-                                         small=small)
+            db = DeviceBatch.from_record_auto(batch.ring, self.args, reducer=self.reducer, index=batch.index, small=small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
-            T = DeviceBatch.first_terminated_len(batch.record.term, self.args.episode_limit, reducer=self.reducer)
-            db = DeviceBatch.from_record(batch.record, self.args, T=T)
+            db = DeviceBatch.from_record_auto(batch.record, self.args, reducer=self.reducer)
         else:
             T = None
             if self.reducer.enabled:

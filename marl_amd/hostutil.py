@@ -153,6 +153,28 @@ class DeviceBatch:
         return self
 
     @classmethod
+    def from_record_auto(cls, rec, args, reducer=None, index=None, small=None):
+        """from_record with max_episode_len found on the way: the kernel that computes it is launched first, the batch
+        is prepared for the common case T = the record's full length while the GPU works, and only then the value is
+        read back (the one host sync of an update) - the preparation's own launches are not left waiting behind it.
+        A shorter T (every episode of the batch ended early) rebuilds the batch."""
+        src = small if small is not None else rec
+        term = src.term
+        if not (term.is_cuda and term.dtype == torch.float32 and term.shape[0] > 0):
+            T = cls.first_terminated_len(term, args.episode_limit, reducer=reducer)
+            return cls.from_record(rec, args, T=T, index=index, small=small)
+        out = ops.first_terminated_len(term, args.episode_limit)
+        if reducer is not None and reducer.enabled:
+            reducer.dist.all_reduce(out, op=reducer.dist.ReduceOp.MAX, group=reducer.group)
+        guess = min(rec.T, args.episode_limit)
+        db = cls.from_record(rec, args, T=guess, index=index, small=small)
+        m = int(out.item())
+        T = m if m > 0 else args.episode_limit
+        if T != guess:
+            db = cls.from_record(rec, args, T=T, index=index, small=small)
+        return db
+
+    @classmethod
     def from_record(cls, rec, args, T=None, index=None, small=None):
         """Zero-copy view of a device EpisodeRecord ((T+1)-slot storage): observations are read in
         place for both passes; only the small per-step arrays are re-packed when T < episode_limit.
