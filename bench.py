@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: mixer GEMMs on the bf16 matrix cores (config 5)")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the learner's forward/backward schedule as one hipGraph (opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--leg-iters", type=int, default=3, help="iterations of the separately timed learner / rollout legs")
@@ -126,6 +127,7 @@ def main():
 
     args = make_args(o.alg, o.shape, o.T)
     args.mixer_dtype = o.mixer_dtype
+    args.hip_graph = o.hip_graph
     T, N = args.episode_limit, args.n_agents
     E = o.envs // world                      # envs / episodes per rank
     args.buffer_size = 2 * E
@@ -226,8 +228,9 @@ def main():
             n = sum(v["launches"] for v in ks)
             if n and all("hbm_bytes_per_launch" in v for v in ks):
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / n
-        avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        ach = fl / (avg_ms * 1e-3) / 1e12
+        # (with --hip-graph the unrolls are launched from inside the replayed graph: no per-launch events, fields null)
+        avg_ms = float(np.mean(kernel_ms)) if kernel_ms else None
+        ach = fl / (avg_ms * 1e-3) / 1e12 if avg_ms else None
         out = {
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
@@ -235,7 +238,7 @@ def main():
             "config": {"workload": "%s_%s_T%d_envs%d" % (o.alg, o.shape, T, o.envs), "alg": o.alg, "shape": o.shape,
                        "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
                        "n_actions": args.n_actions, "episode_limit": T, "global_envs": o.envs, "envs_per_gpu": E,
-                       "mixer_dtype": o.mixer_dtype,
+                       "mixer_dtype": o.mixer_dtype, "hip_graph": bool(o.hip_graph),
                        "parallelism": "dp%d" % world, "numa_node": numa,
                        "step": "batched rollout (T lock-steps) + replay store/sample + 1 learner.train()"},
             "learner_updates_per_sec": 1.0 / t_learn,
@@ -243,7 +246,7 @@ def main():
             "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
             "last_loss": loss,
             "roofline": {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
-                         "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
+                         "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS if ach else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
                          "separate passes; profiles/r01_pmc.json)", "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
                          "flop_per_launch": fl},

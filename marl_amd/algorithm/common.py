@@ -184,3 +184,67 @@ class PairedUnroll:
             cur.wait_stream(self.side)
         finally:
             ops.agent_set_cu_budget(256)
+
+
+class GraphedUpdate:
+    """hipGraph replay of a learner's forward/backward schedule for replay-ring samples of a fixed shape (opt-in:
+    ``args.hip_graph = True``).  The ~25 kernel launches of ``_forward_backward`` become ONE graph launch; what varies
+    between updates (the sampled episode indices and the small per-step arrays gathered from the ring) lives in
+    persistent buffers the captured kernels point at.  Pays on small per-GPU shards, where an update is a few
+    milliseconds and the host-side launch path is exposed behind the one sync an update needs; the gradient
+    all-reduce and the optimizer stay outside the graph.  Falls back to eager launches whenever the shape differs,
+    max_episode_len is shorter than the record, or capture is not possible."""
+
+    WARMUP = 2          # eager updates on the static buffers before capture (allocations, workspace growth)
+
+    def __init__(self):
+        self.entries = {}
+        self.disabled = False
+
+    def run(self, learner, ring, index):
+        """Returns True when the update's forward/backward was done here (static buffers + graph), else False."""
+        from ..hostutil import DeviceBatch
+        if self.disabled:
+            return False
+        args = learner.args
+        key = (id(ring), int(index.numel()), ring.T)
+        e = self.entries.get(key)
+        dev = ring.obs.device
+        if e is None:
+            idx = index.to(device=dev, dtype=torch.long)
+            small = ring.select_small(idx)
+            db = DeviceBatch.from_record(ring, args, T=min(ring.T, args.episode_limit), index=idx, small=small)
+            e = self.entries[key] = dict(idx=idx.clone(), small=small, db=db, calls=0, graph=None,
+                                         avail_next=db.avail_next.clone(), u_act=db.u_act.clone())
+            db.avail_next, db.u_act = e["avail_next"], e["u_act"]
+            e["T"] = db.T
+        idx, small, db = e["idx"], e["small"], e["db"]
+        idx.copy_(index)
+        db.o_map.copy_(idx)
+        ring.select_small(idx, out=small)
+        T = DeviceBatch.first_terminated_len(small.term, args.episode_limit, reducer=learner.reducer)
+        if T != e["T"]:
+            return False
+        torch.clamp(small.u[:, :T], min=0, out=e["u_act"])
+        e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail[:, 1:T + 1])
+        db.__dict__.pop("_avail", None)
+        learner.max_episode_len = T
+        e["calls"] += 1
+        if e["graph"] is None and e["calls"] > self.WARMUP:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    learner._forward_backward(db)
+                e["graph"] = g
+            except Exception as ex:      # capture not possible on this stack: stay eager for good
+                self.disabled = True
+                self.error = repr(ex)
+                torch.cuda.synchronize()
+                learner._forward_backward(db)
+                return True
+        if e["graph"] is not None:
+            e["graph"].replay()
+        else:
+            learner._forward_backward(db)
+        return True

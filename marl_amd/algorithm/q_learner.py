@@ -19,7 +19,8 @@ from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import VDNMixer, QMixMixer, DMAQer
-from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll)
+from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll,
+                     GraphedUpdate)
 
 
 class QLearner:
@@ -50,6 +51,7 @@ class QLearner:
         self._buf = Scratch()
         self.reducer = GradReducer()
         self.pair = PairedUnroll()
+        self.graphs = GraphedUpdate() if getattr(args, "hip_graph", False) else None
         self.last_stats = None
 
     # ------------------------------------------------------------------ storage
@@ -148,6 +150,10 @@ class QLearner:
         self._dbg = dict(q_evals=q_evals, hs=hs, q_targets=q_tgt, q_tot=q_tot, q_tot_target=q_tot_tgt)
 
     def train(self, batch, train_step):
+        if self.graphs is not None and isinstance(batch, EpisodeBatch) and batch.ring is not None and \
+                self.graphs.run(self, batch.ring, batch.index):
+            ops.set_mixer_dtype("fp32")
+            return self._finish_update(train_step)
         if isinstance(batch, DeviceBatch):
             db = batch
         elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
@@ -167,6 +173,10 @@ class QLearner:
             self._forward_backward(db)
         finally:
             ops.set_mixer_dtype("fp32")        # the opt-in bf16 mode never outlives the call that asked for it
+        return self._finish_update(train_step)
+
+    def _finish_update(self, train_step):
+        """gradient all-reduce, clip + optimizer, target sync, loss readback (reference :168-179)"""
         self.reducer.allreduce_(self._flat.gradx)
         stats = self._flat.stats
         self.optimizer.step(den=stats[1:2])

@@ -93,3 +93,39 @@ def test_first_terminated_len_kernel_matches_reference_rule():
         assert DeviceBatch.first_terminated_len(torch.as_tensor(term), T) == (ref if ref > 0 else T)      # host path
     none = torch.zeros(4, 9, device=dev)
     assert DeviceBatch.first_terminated_len(none, 9) == 9
+
+
+def test_hip_graph_replay_equals_eager():
+    """Opt-in hipGraph replay of the learner's forward/backward (args.hip_graph): same ring, same sampled episodes ->
+    bitwise the same losses and parameters as eager launches, across the capture (update 3) and replays."""
+    import bench
+    from marl_amd.controller.share_params import SharedMAC
+    from marl_amd.algorithm.q_learner import QLearner
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd.common.replaybuffer import ReplayBuffer
+    out = {}
+    for mode in (False, True):
+        args = bench.make_args("qmix", "2s3z", 12)
+        E = 96
+        args.buffer_size, args.batch_size, args.hip_graph = 2 * E, E, mode
+        torch.manual_seed(0)
+        np.random.seed(7)
+        mac = SharedMAC(args)
+        learner = QLearner(mac, args)
+        env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, 12, seed=3, fixed_length=True)
+        w = RolloutWorker(env, mac, args)
+        buf = ReplayBuffer(args)
+        w.record_sink = buf
+        losses = []
+        for i in range(6):
+            ep = w.generate_episodes(E)[0]
+            buf.store_episode(ep)
+            losses.append(learner.train(buf.sample(E), i))
+        out[mode] = (losses, learner._flat.flat.detach().cpu().numpy().copy())
+        if mode:
+            g = learner.graphs
+            assert not g.disabled, getattr(g, "error", "")
+            assert any(e["graph"] is not None for e in g.entries.values()), "no graph was captured"
+    assert out[False][0] == out[True][0]
+    np.testing.assert_array_equal(out[False][1], out[True][1])
