@@ -234,7 +234,8 @@ class GraphedUpdate:
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: API calls of other threads (the NCCL watchdog polling its events) do not break the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     learner._forward_backward(db)
                 e["graph"] = g
             except Exception as ex:      # capture not possible on this stack: stay eager for good
