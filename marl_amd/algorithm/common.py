@@ -2,6 +2,8 @@
 tail, the fused clip+optimizer wrapper, the agent backward pass and data-parallel reduction."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import ops
@@ -209,12 +211,14 @@ class GraphedUpdate:
         args = learner.args
         key = (id(ring), int(index.numel()), ring.T)
         e = self.entries.get(key)
+        if e is not None and e["ring"]() is not ring:      # another record reuses the id of a freed one
+            e = None
         dev = ring.obs.device
         if e is None:
             idx = index.to(device=dev, dtype=torch.long)
             small = ring.select_small(idx)
             db = DeviceBatch.from_record(ring, args, T=min(ring.T, args.episode_limit), index=idx, small=small)
-            e = self.entries[key] = dict(idx=idx.clone(), small=small, db=db, calls=0, graph=None,
+            e = self.entries[key] = dict(ring=weakref.ref(ring), idx=idx.clone(), small=small, db=db, calls=0, graph=None,
                                          avail_next=db.avail_next.clone(), u_act=db.u_act.clone())
             db.avail_next, db.u_act = e["avail_next"], e["u_act"]
             e["T"] = db.T
