@@ -46,11 +46,44 @@ def agent_flops(a):
     return 2 * I * H + 12 * H * H + 2 * H * a.n_actions       # SURVEY 8d F_a
 
 
+def learner_flops_per_transition(a, alg):
+    """dense-layer FLOP (2 x MAC) of one learner update per (episode, step) transition."""
+    N, S, A, H, E = a.n_agents, a.state_shape, a.n_actions, a.rnn_hidden_dim, a.qmix_hidden_dim
+    Fa = agent_flops(a)
+    if alg == "vdn":
+        return 5 * N * Fa
+    if alg == "qmix":
+        Fm = 2 * S * N * E + 3 * 2 * S * E + 2 * E + 2 * N * E + 2 * E
+        return 5 * N * Fa + 4 * Fm
+    if alg == "qplex":
+        K, AE = a.num_kernel, a.adv_hypernet_embed
+        trans = 2 * 2 * (S * AE + AE * N)
+        lam = K * 2 * ((S * AE + AE * AE + AE) + (S * AE + AE * AE + AE * N) + ((S + N * A) * AE + AE * AE + AE * N))
+        return 5 * N * Fa + 4 * (trans + lam)     # = 5 N F_a + 2 (32 000 + 823 040) + 2 * 855 040 = 4.99 M on 2s3z
+    if alg.startswith("qtran"):
+        Q = a.qtran_hidden_dim
+        q = N * 2 * 2 * (H + A) ** 2 + 2 * ((S + H + A) * Q + Q * Q + Q)
+        v = N * 2 * 2 * H * H + 2 * ((S + H) * Q + Q * Q + Q)
+        return 4 * N * Fa + 3 * q + 2 * q + 3 * v
+    raise ValueError(alg)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(alg, shape, T, envs, budget_s):
     """The CPU oracle (port of the reference path, pinned by the golden vectors) on a bounded sample
-    of the same workload, timed on this box's host cores."""
+    of the same workload, timed on this box's host cores: 2 warm-up + 5 timed train() calls."""
     from oracle import seeded, learners, rollout as orl
-    cores = min(os.cpu_count() or 1, 16)     # torch-CPU oversubscribes badly beyond ~16 threads on these small ops
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)     # torch-CPU oversubscribes beyond ~16 threads on these small ops (stated below)
     torch.set_num_threads(cores)
     args = seeded.make_args(shape, alg, episode_limit=T)
     agent = seeded.seeded_state(seeded.agent_param_shapes(args), seed=11)
@@ -63,12 +96,12 @@ def cpu_baseline(alg, shape, T, envs, budget_s):
     t0 = time.time()
     ep, _, _, steps, _ = orl.batched_rollout(agent, args, sy, envs, 0.5, rseed=0)
     t_roll = time.time() - t0
+    for i in range(2):                        # warm-up (allocator, thread pool, first-touch)
+        learners.train(st, ep, i)
     t0 = time.time()
-    learners.train(st, ep, 0)
-    t_train = time.time() - t0
-    reps = 1
-    while (time.time() - t0) < budget_s * 0.5 and reps < 3:
-        learners.train(st, ep, reps)
+    reps = 0
+    while reps < 5 or ((time.time() - t0) < budget_s * 0.25 and reps < 20):
+        learners.train(st, ep, 2 + reps)
         reps += 1
     t_train = (time.time() - t0) / reps
     # the reference's actual serial rollout (one env, one agent at a time), a few episodes
@@ -76,8 +109,10 @@ def cpu_baseline(alg, shape, T, envs, budget_s):
     _, _, _, ssteps, _ = orl.serial_rollout(agent, args, orl.SerialSynthEnv(sy), 8, 0.5)
     t_serial = time.time() - t0
     return {"value": steps / (t_roll + t_train), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%s %s: %d envs x T=%d batched CPU rollout + %d oracle train() calls; serial reference-style "
-                      "rollout of 8 episodes" % (alg, shape, envs, T, reps),
+            "host_cpu_count": host_cores, "cpu_model": cpu_model(), "torch_threads": cores,
+            "sample": "%s %s: %d envs x T=%d batched CPU rollout + 2 warm-up and %d timed oracle train() calls on %d "
+                      "torch threads (of %d host CPUs); serial reference-style rollout of 8 episodes"
+                      % (alg, shape, envs, T, reps, cores, host_cores),
             "learner_updates_per_sec": 1.0 / t_train, "learner_transitions_per_sec": envs * T / t_train,
             "batched_rollout_env_steps_per_sec": steps / t_roll, "serial_rollout_env_steps_per_sec": ssteps / t_serial}
 
@@ -95,7 +130,9 @@ def main():
     ap.add_argument("--hip-graph", action="store_true", help="replay the learner's forward/backward schedule as one hipGraph (opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
-    ap.add_argument("--leg-iters", type=int, default=3, help="iterations of the separately timed learner / rollout legs")
+    ap.add_argument("--leg-iters", type=int, default=5, help="iterations of the separately timed learner / rollout legs")
+    ap.add_argument("--dry", action="store_true", help="multi-GPU pre-flight only: init RCCL, one all-reduce of the real "
+                    "gradient-buffer size, print the result and exit")
     o = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +153,31 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     assert world == o.gpus, "launch with torch.distributed.run --nproc-per-node %d" % o.gpus
+    if world > 1 or o.dry:
+        # pre-flight: the exchange step of an update (one flat fp32 all-reduce, one int32 MAX all-reduce, one broadcast)
+        # BEFORE anything is built, so a broken RCCL / IPC setup fails here, fast and legibly
+        import torch.distributed as dist
+        if world > 1:
+            t0 = time.perf_counter()
+            probe = torch.full((70000,), float(rank + 1), device=dev)         # ~ the QMIX-2s3z gradient buffer (62 896 floats)
+            dist.all_reduce(probe)
+            ti = torch.tensor([rank + 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+            dist.broadcast(probe, src=0)
+            torch.cuda.synchronize()
+            ok = bool(abs(float(probe[0]) - world * (world + 1) / 2) < 1e-3 and int(ti) == world)
+            if rank == 0:
+                print("[bench preflight] backend=%s world=%d all_reduce/max/broadcast %s in %.1f ms (HSA_ENABLE_IPC_MODE_LEGACY=%s)"
+                      % (dist.get_backend(), world, "OK" if ok else "WRONG RESULT", (time.perf_counter() - t0) * 1e3,
+                         os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")), file=sys.stderr, flush=True)
+            assert ok, "RCCL pre-flight returned wrong values"
+        if o.dry:
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            elif rank == 0:
+                print("[bench preflight] single process: nothing to check", file=sys.stderr)
+            return
 
     from marl_amd import ops
     from marl_amd.controller.share_params import SharedMAC
@@ -222,8 +284,8 @@ def main():
     if rank == 0:
         fl = agent_flops(args) * E * N * T                 # algorithmic FLOP of one unroll launch
         traffic = None                                     # HBM bytes/launch from the committed PMC passes (same workload only)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc) and (o.alg, o.shape, o.envs, world, T) == ("qmix", "2s3z", 4096, 1, 120):
+        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), "")
+        if pmc and (o.alg, o.shape, o.envs, world, T) == ("qmix", "2s3z", 4096, 1, 120):
             ks = [v for k, v in json.load(open(pmc))["kernels"].items() if k.startswith("agent_fwd_kernel")]
             n = sum(v["launches"] for v in ks)
             if n and all("hbm_bytes_per_launch" in v for v in ks):
@@ -231,6 +293,8 @@ def main():
         # (with --hip-graph the unrolls are launched from inside the replayed graph: no per-launch events, fields null)
         avg_ms = float(np.mean(kernel_ms)) if kernel_ms else None
         ach = fl / (avg_ms * 1e-3) / 1e12 if avg_ms else None
+        fpt = learner_flops_per_transition(args, o.alg)
+        upd_tflops = fpt * (o.envs * T / t_learn) / 1e12
         out = {
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
@@ -247,9 +311,13 @@ def main():
             "last_loss": loss,
             "roofline": {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
                          "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS if ach else None,
+                         "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and avg_ms) else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                         "separate passes; profiles/r01_pmc.json)", "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "separate passes; %s)" % (os.path.relpath(pmc, ROOT) if pmc else "no PMC file for this workload"), "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
                          "flop_per_launch": fl},
+            "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included)",
+                                "flop_per_transition": fpt, "achieved": upd_tflops, "peak": PEAK_F32_TFLOPS,
+                                "unit": "TFLOP/s", "frac": upd_tflops / PEAK_F32_TFLOPS},
         }
         if not o.no_cpu_baseline and world == 1:      # a reported baseline of the N=1 line only
             out["cpu_baseline"] = cpu_baseline(o.alg, o.shape, T, o.cpu_envs, budget_s=20)

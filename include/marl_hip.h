@@ -85,16 +85,15 @@ int marl_wgrad_slabs(int M);
  *           stay indexed by b
  *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
  *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = [T][B*N][6][64] floats
- *   (time-major; per row-step the 6 vectors hprev,x,r,z,n,hn) for the backward pass or NULL */
+ *   (time-major; per row-step the 6 vectors hprev,x,r,z,n,hn) for the backward pass or NULL
+ *   cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over, 1..256; 0 = 256 = the whole chip.  With 128
+ *           the two independent unrolls of an update - eval current-Q and target next-Q (q_learner.py:97,104) - fit
+ *           on the chip together and can be launched on two HIP streams; results do not depend on it (rows are
+ *           independent).  A per-call argument: the library keeps no process-wide state. */
 int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                           const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                           const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T,
-                          int N, int O, int A, int last_action, int reuse_network, void* stream);
-/* CUs (= workgroups) a T > 1 unroll launch spreads its rows over, 1..256 (default 256 = the whole chip).  With 128
- * the two independent unrolls of an update - eval current-Q and target next-Q (q_learner.py:97,104) - fit on the chip
- * together and can be launched on two HIP streams; results do not depend on it (rows are independent).
- * Process-wide setting. */
-int marl_agent_set_cu_budget(int cus);
+                          int N, int O, int A, int last_action, int reuse_network, int cu_budget, void* stream);
 
 /* Gradient destinations of the recurrent / output layers (accumulated into, torch layouts). */
 typedef struct {

@@ -84,6 +84,40 @@ class FusedOptimizer:
             self.s2.copy_(sd["s2"])
 
 
+class ResumeMixin:
+    """Full-resume state the reference's checkpoints lack: parameters, BOTH target networks, the
+    optimizer's running statistics and step count.  ``save_models`` / ``load_models`` keep the reference's three
+    state-dict files (q_learner.py:193-209); these two methods add one extra file next to them."""
+
+    def _target_flats(self):
+        out = {"target_agent": self.target_net.agent._flat.flat}
+        if self.target_mixer is not None and getattr(self.target_mixer, "_flat", None) is not None and self.target_mixer._flat.n:
+            out["target_mixer"] = self.target_mixer._flat.flat
+        return out
+
+    def resume_state(self):
+        sd = {"alg": self.args.alg, "n_params": int(self._flat.n), "params": self._flat.flat.detach().cpu().clone(),
+              "optimizer": self.optimizer.state_dict()}
+        for k, t in self._target_flats().items():
+            sd[k] = t.detach().cpu().clone()
+        return sd
+
+    def load_resume_state(self, sd):
+        if sd["alg"] != self.args.alg or sd["n_params"] != int(self._flat.n):
+            raise ValueError("resume state of a different learner (%s, %d parameters)" % (sd["alg"], sd["n_params"]))
+        self._flat.flat.copy_(sd["params"])
+        for k, t in self._target_flats().items():
+            t.copy_(sd[k])
+        self.optimizer.load_state_dict(sd["optimizer"])
+        self.sync_replicas()
+
+    def save_resume(self, path):
+        torch.save(self.resume_state(), path)
+
+    def load_resume(self, path):
+        self.load_resume_state(torch.load(path, map_location="cpu"))
+
+
 class Scratch:
     def __init__(self):
         self.d = {}
@@ -132,15 +166,26 @@ class GradReducer:
     the GLOBAL sum(mask) happens afterwards in the optimizer kernel)."""
 
     def __init__(self, group=None):
+        import os
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        up = dist.is_available() and dist.is_initialized()
+        # MARL_FORCE_REDUCER=1: take the collective path with a single rank too (RCCL smoke test on a 1-GPU box)
+        self.enabled = up and (dist.get_world_size(group) > 1 or os.environ.get("MARL_FORCE_REDUCER") == "1")
 
     def allreduce_(self, flat_with_stats):
         if self.enabled:
             self.dist.all_reduce(flat_with_stats, op=self.dist.ReduceOp.SUM, group=self.group)
         return flat_with_stats
+
+    def broadcast_(self, *tensors, src=0):
+        """replicas start from rank `src`'s values (parameters, targets, optimizer state): data-parallel training is
+        only exact when every rank holds the same weights - never rely on identical seeding"""
+        if self.enabled:
+            for t in tensors:
+                if t is not None:
+                    self.dist.broadcast(t, src=src, group=self.group)
 
     def max_int(self, value, device):
         """global max of a host integer (used for the global max_episode_len)."""
@@ -153,7 +198,8 @@ class GradReducer:
 
 class PairedUnroll:
     """Launches two independent agent unrolls (eval current-Q and target next-Q: reference q_learner.py:97,104) side by
-    side: each is limited to half of the CUs (marl_agent_set_cu_budget) and the second runs on a side HIP stream.  A
+    side: each is limited to half of the CUs (the cu_budget argument of marl_agent_unroll_fwd - per call, no process
+    state) and the second runs on a side HIP stream.  A
     T-step unroll is a chain of T dependent steps whose latency barely depends on how many row tiles a workgroup
     carries (0.39 / 0.62 / 0.95 ms at 1 / 2 / 3 tiles), so below ~3000 episodes per GPU - the shards of the multi-GPU
     runs - two half-chip launches finish sooner than two whole-chip launches back to back.  Results do not depend on
@@ -169,23 +215,19 @@ class PairedUnroll:
         return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES
 
     def run(self, rows, T, first, second):
-        """first(), second(): closures that launch one unroll each on the current stream."""
+        """first(cu), second(cu): closures that launch one unroll each on the current stream over `cu` CUs."""
         if not self.applies(rows, T):
-            first()
-            second()
+            first(256)
+            second(256)
             return
         cur = torch.cuda.current_stream()
         if self.side is None or self.side.device != cur.device:
             self.side = torch.cuda.Stream(device=cur.device)
-        ops.agent_set_cu_budget(128)
-        try:
-            self.side.wait_stream(cur)              # inputs written on the main stream are visible to the side launch
-            with torch.cuda.stream(self.side):
-                second()
-            first()
-            cur.wait_stream(self.side)
-        finally:
-            ops.agent_set_cu_budget(256)
+        self.side.wait_stream(cur)              # inputs written on the main stream are visible to the side launch
+        with torch.cuda.stream(self.side):
+            second(128)
+        first(128)
+        cur.wait_stream(self.side)
 
 
 class GraphedUpdate:
@@ -206,9 +248,13 @@ class GraphedUpdate:
     def run(self, learner, ring, index):
         """Returns True when the update's forward/backward was done here (static buffers + graph), else False."""
         from ..hostutil import DeviceBatch
+        self.prepared = None
         if self.disabled:
             return False
         args = learner.args
+        # static buffers alias the ring's (E, T) arrays: only full-length records of the steady-state batch size
+        if ring.T != args.episode_limit or int(index.numel()) != int(args.batch_size):
+            return False
         key = (id(ring), int(index.numel()), ring.T)
         e = self.entries.get(key)
         if e is not None and e["ring"]() is not ring:      # another record reuses the id of a freed one
@@ -228,7 +274,12 @@ class GraphedUpdate:
         ring.select_small(idx, out=small)
         T = DeviceBatch.first_terminated_len(small.term, args.episode_limit, reducer=learner.reducer)
         if T != e["T"]:
+            self.prepared = (small, T)       # the eager path reuses the gathered arrays and the agreed T
             return False
+        if e["graph"] is not None and e["ws_gen"] != ops.WS.gen:
+            # a workspace the captured kernels point at was reallocated (another learner / a larger request):
+            # the graph would write into retired storage - drop it and capture again after a warm-up
+            e["graph"], e["ws_keep"], e["calls"] = None, None, 0
         torch.clamp(small.u[:, :T], min=0, out=e["u_act"])
         e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail[:, 1:T + 1])
         db.__dict__.pop("_avail", None)
@@ -242,6 +293,7 @@ class GraphedUpdate:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     learner._forward_backward(db)
                 e["graph"] = g
+                e["ws_gen"], e["ws_keep"] = ops.WS.gen, ops.WS.snapshot()
             except Exception as ex:      # capture not possible on this stack: stay eager for good
                 self.disabled = True
                 self.error = repr(ex)

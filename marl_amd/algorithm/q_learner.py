@@ -19,11 +19,11 @@ from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import VDNMixer, QMixMixer, DMAQer
-from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll,
+from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll, ResumeMixin,
                      GraphedUpdate)
 
 
-class QLearner:
+class QLearner(ResumeMixin):
     def __init__(self, mac, args):
         self.max_episode_len = args.episode_limit
         self.gamma = args.gamma
@@ -53,6 +53,14 @@ class QLearner:
         self.pair = PairedUnroll()
         self.graphs = GraphedUpdate() if getattr(args, "hip_graph", False) else None
         self.last_stats = None
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Data-parallel replicas start from rank 0's parameters, targets and optimizer state (called after
+        construction and after load_models; a no-op without a process group)."""
+        o = self.optimizer
+        self.reducer.broadcast_(self._flat.flat, self.target_net.agent._flat.flat,
+                                self.target_mixer._flat.flat if self.target_mixer._flat.n else None, o.s1, o.s2)
 
     # ------------------------------------------------------------------ storage
     def cuda(self):
@@ -86,7 +94,6 @@ class QLearner:
 
     def _forward_backward(self, db):
         a = self.args
-        ops.set_mixer_dtype(getattr(a, "mixer_dtype", "fp32"))     # "bf16": mixer GEMMs on the bf16 matrix cores (opt-in)
         dev = self.device
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T
@@ -102,10 +109,10 @@ class QLearner:
         # (independent of each other: on small shards they run side by side on two streams, half of the CUs each)
         emap = getattr(db, 'o_map', None)
         self.pair.run(B * N, T,
-                      lambda: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
-                                                   h0=None, ep_len=db.ep_len, ep_map=emap),
-                      lambda: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None,
-                                                     h0=None, ep_len=db.ep_len, ep_map=emap))
+                      lambda cu: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
+                                                   h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu),
+                      lambda cu: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None,
+                                                     h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu))
         ops.q_gather(q_evals, u_act, q_chosen, R, A)
         cur_max = None
         if a.double_q:
@@ -152,14 +159,18 @@ class QLearner:
     def train(self, batch, train_step):
         if self.graphs is not None and isinstance(batch, EpisodeBatch) and batch.ring is not None and \
                 self.graphs.run(self, batch.ring, batch.index):
-            ops.set_mixer_dtype("fp32")
             return self._finish_update(train_step)
         if isinstance(batch, DeviceBatch):
             db = batch
         elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
             # replay sample: big arrays are read in place from the ring through the episode index
-            small = batch.ring.select_small(batch.index)
-            db = DeviceBatch.from_record_auto(batch.ring, self.args, reducer=self.reducer, index=batch.index, small=small)
+            prep = self.graphs.prepared if self.graphs is not None else None
+            if prep is not None:             # the graph path already gathered the small arrays and agreed on T
+                self.graphs.prepared = None
+                db = DeviceBatch.from_record(batch.ring, self.args, T=prep[1], index=batch.index, small=prep[0])
+            else:
+                small = batch.ring.select_small(batch.index)
+                db = DeviceBatch.from_record_auto(batch.ring, self.args, reducer=self.reducer, index=batch.index, small=small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
             db = DeviceBatch.from_record_auto(batch.record, self.args, reducer=self.reducer)
         else:
@@ -169,10 +180,7 @@ class QLearner:
                                                      self.args.episode_limit, reducer=self.reducer)
             db = DeviceBatch.from_dict(batch, self.args, self.device, T=T)
         self.max_episode_len = db.T
-        try:
-            self._forward_backward(db)
-        finally:
-            ops.set_mixer_dtype("fp32")        # the opt-in bf16 mode never outlives the call that asked for it
+        self._forward_backward(db)
         return self._finish_update(train_step)
 
     def _finish_update(self, train_step):
@@ -201,6 +209,7 @@ class QLearner:
             path_mix = self.model_dir + '/mixer_net_params.pkl'
             self.eval_net.load_models(path_rnn)
             self.mixer.load_state_dict(torch.load(path_mix, map_location='cpu'))
+            self.sync_replicas()
             print('Successfully load the model: {} and {}'.format(path_rnn, path_mix))
         else:
             raise Exception("No model!")

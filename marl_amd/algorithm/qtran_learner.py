@@ -19,10 +19,10 @@ from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import QtranQBase, QtranQAlt, QtranV, QMixMixer
 from .common import (MASK_BIG, MASK_QTRAN_EVAL, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward,
-                     GradReducer, PairedUnroll)
+                     GradReducer, PairedUnroll, ResumeMixin)
 
 
-class QTRANLearner:
+class QTRANLearner(ResumeMixin):
     def __init__(self, mac, args):
         self.max_episode_len = args.episode_limit
         self.gamma = args.gamma
@@ -52,6 +52,15 @@ class QTRANLearner:
         self.reducer = GradReducer()
         self.pair = PairedUnroll()
         self.last_stats = None
+        if getattr(args, "hip_graph", False):
+            import warnings
+            warnings.warn("args.hip_graph is not implemented for QTRANLearner: updates run as eager launches")
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """replicas start from rank 0's parameters, targets and optimizer state (see QLearner.sync_replicas)"""
+        o = self.optimizer
+        self.reducer.broadcast_(self._flat.flat, self.target_net.agent._flat.flat, self.target_mixer._flat.flat, o.s1, o.s2)
 
     def cuda(self):
         dev = self.device
@@ -79,7 +88,6 @@ class QTRANLearner:
 
     def _forward_backward(self, db):
         a = self.args
-        ops.set_mixer_dtype(getattr(a, "mixer_dtype", "fp32"))     # "bf16": mixer GEMMs on the bf16 matrix cores (opt-in)
         dev = self.device
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T
@@ -92,10 +100,10 @@ class QTRANLearner:
 
         emap = getattr(db, 'o_map', None)
         self.pair.run(B * N, T,
-                      lambda: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved,
-                                                   h0=None, ep_len=db.ep_len, ep_map=emap),
-                      lambda: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None,
-                                                     h0=None, ep_len=db.ep_len, ep_map=emap))
+                      lambda cu: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, None, saved,
+                                                   h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu),
+                      lambda cu: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, hs_tgt, None, None,
+                                                     h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu))
 
         # local greedy actions (reference :103-114): eval clone masked with -999999, targets with -9999999
         opt_eval, opt_tgt = g("opt_eval", (R,), torch.int32), g("opt_tgt", (R,), torch.int32)
@@ -146,10 +154,7 @@ class QTRANLearner:
                                                      self.args.episode_limit, reducer=self.reducer)
             db = DeviceBatch.from_dict(batch, self.args, self.device, T=T)
         self.max_episode_len = db.T
-        try:
-            self._forward_backward(db)
-        finally:
-            ops.set_mixer_dtype("fp32")        # the opt-in bf16 mode never outlives the call that asked for it
+        self._forward_backward(db)
         self.reducer.allreduce_(self._flat.gradx)
         st = self._flat.stats
         self.optimizer.step(den=st[3:4])
@@ -176,6 +181,7 @@ class QTRANLearner:
             self.eval_net.load_models(path_rnn)
             self.mixer.load_state_dict(torch.load(path_mix, map_location='cpu'))
             self.v.load_state_dict(torch.load(path_v, map_location='cpu'))
+            self.sync_replicas()
             print('Successfully load the model: {} and {}'.format(path_rnn, path_mix))
         else:
             raise Exception("No model!")

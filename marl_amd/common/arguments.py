@@ -1,6 +1,7 @@
-"""Argument helpers (mirror of reference common/arguments.py:9-45, 86-147) restricted to the fields
-the hot path reads.  Booleans parse properly here (the reference's ``type=bool`` treats any
-non-empty string as True)."""
+"""Argument helpers (mirror of reference common/arguments.py:9-45, 86-147): every function the reference's callers
+import (matrix_game_test.py:9, main.py:3) exists with the same name and effect.  Booleans parse properly here (the
+reference's ``type=bool`` treats any non-empty string as True), and ``--RTW`` / ``--load_model``
+default to False: the RTW research variant is outside the hot path and no checkpoint ships with this build."""
 import argparse
 
 
@@ -60,6 +61,7 @@ def get_mixer_args(args):
     args.lambda_opt = 1
     args.lambda_nopt = 1
     args.grad_norm_clip = 10
+    args.noise_dim, args.lambda_mi, args.lambda_ql, args.entropy_coefficient = 16, 0.001, 1, 0.001   # MAVEN (unused here)
     args.adv_hypernet_embed = 64
     args.num_kernel = 10
     args.adv_hypernet_layers = 3
@@ -69,3 +71,48 @@ def get_mixer_args(args):
     args.mixing_embed_dim = 32
     args.double_q = True
     return args
+
+
+# ---- hyper-parameter tables of the algorithms outside the hot path (reference common/arguments.py:48-83,151-214).
+# Nothing in marl_amd reads these fields; the functions exist because the reference's entry scripts import them
+# (matrix_game_test.py:9, main.py:3) and main.py:12 calls get_RTW_args on every run.
+_ACTOR_CRITIC = dict(rnn_hidden_dim=64, critic_dim=128, lr_actor=1e-4, lr_critic=1e-3, epsilon=0.5,
+                     anneal_epsilon=0.00064, min_epsilon=0.02, epsilon_anneal_scale='episode', save_cycle=5000,
+                     grad_norm_clip=10)
+
+
+def _assign(args, table):
+    for k, v in table.items():
+        setattr(args, k, v)
+    return args
+
+
+def get_RTW_args(args):
+    """reference :48-53 (returns None there as well)"""
+    _assign(args, dict(world_loss_weight=1, teammate_loss_weight=1, hidden_dim=64, attn_dim=64, not_self_model=True))
+
+
+def get_coma_args(args):
+    """reference :56-83"""
+    return _assign(args, dict(_ACTOR_CRITIC, td_lambda=0.8, target_update_cycle=200))
+
+
+def get_centralv_args(args):
+    """reference :151-177"""
+    return _assign(args, dict(_ACTOR_CRITIC, td_lambda=0.8, target_update_cycle=200))
+
+
+def get_reinforce_args(args):
+    """reference :181-200"""
+    return _assign(args, dict(_ACTOR_CRITIC))
+
+
+def get_commnet_args(args):
+    """reference :204-209"""
+    args.k = 2 if args.map == '3m' else 3
+    return args
+
+
+def get_g2anet_args(args):
+    """reference :212-215"""
+    return _assign(args, dict(attention_dim=32, hard=True))

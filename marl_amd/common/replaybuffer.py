@@ -94,8 +94,18 @@ class ReplayBuffer:
                 v = src[k]
                 self.buffers[k][idxs] = v.cpu().numpy() if isinstance(v, torch.Tensor) else v
 
-    def sample(self, batch_size):
-        idx = np.random.randint(0, self.current_size, batch_size)
+    def sample(self, batch_size, exclude=None):
+        """Uniform WITH replacement (reference :54-60, quirk Q13).  ``exclude`` = (first, count): ring slots a rollout
+        in flight is writing (overlapped runner) - never sampled; the draw is the reference's single randint call over
+        the remaining slots."""
+        if exclude is not None and exclude[0] < self.current_size:
+            lo, cnt = int(exclude[0]), int(min(exclude[1], self.current_size - exclude[0]))
+            if self.current_size - cnt <= 0:
+                raise ValueError("every stored episode is being overwritten: nothing to sample")
+            idx = np.random.randint(0, self.current_size - cnt, batch_size)
+            idx = np.where(idx >= lo, idx + cnt, idx)
+        else:
+            idx = np.random.randint(0, self.current_size, batch_size)
         if self.record is not None:
             idx_t = torch.as_tensor(idx, dtype=torch.long, device=self.record.obs.device)
             return EpisodeBatch(ring=self.record, index=idx_t)     # read in place by the learners (no gather copy)

@@ -1150,10 +1150,6 @@ ST_DEFINE_SETTER(marl_debug_stamps_fwd)
 extern "C" int marl_debug_stamps_bwd(void* p) { return marl_debug_stamps_fwd(p); }
 #endif
 
-// CUs one unroll launch may occupy (marl_agent_set_cu_budget): 256 = the whole chip; 128 lets two independent
-// unrolls - eval current-Q and target next-Q, q_learner.py:97,104 - run side by side on two streams
-static int marl_cu_budget = 256;
-
 // choose row tiles per workgroup: fill the CU budget, keep LDS within budget
 inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap, int cus = 256) {
   const long tiles = (R + 15) / 16;
@@ -1169,18 +1165,14 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap,
 
 }  // namespace
 
-extern "C" int marl_agent_set_cu_budget(int cus) {
-  if (cus < 1 || cus > 256) return (int)hipErrorInvalidValue;
-  marl_cu_budget = cus;
-  return 0;
-}
-
 extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                                      const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                                      const float* h0, float* q, float* hs, float* h_last, float* saved, int B,
-                                     int T, int N, int O, int A, int last_action, int reuse_network, void* stream) {
+                                     int T, int N, int O, int A, int last_action, int reuse_network, int cu_budget,
+                                     void* stream) {
   if (B <= 0 || T <= 0) return 0;
-  if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
+  if (w->H != H || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256) return (int)hipErrorInvalidValue;
+  if (cu_budget == 0) cu_budget = 256;      // CUs this launch may occupy: 128 lets two independent unrolls run side by side
   FwdArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
@@ -1202,7 +1194,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   // a single step (rollout) is latency-bound: many small workgroups overlap their prologues better than
   // 256 big ones; a long unroll amortises the prologue and wants one workgroup per CU
   if (T == 1 && rt_cap > marl_fwd_rt_single) rt_cap = marl_fwd_rt_single;
-  a.RT = pick_rt(a.R, per_row, fixed, rt_cap, T > 1 ? marl_cu_budget : 256);
+  a.RT = pick_rt(a.R, per_row, fixed, rt_cap, T > 1 ? cu_budget : 256);
   const size_t lds = fixed + per_row * a.RT * 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const long rows = a.RT * 16;

@@ -56,23 +56,26 @@ def flatten_module(module: nn.Module, device, with_grad=False):
 class Lin:
     """An nn.Linear (weight (N,K), bias (N)) driven through marl_linear / marl_linear_wgrad."""
 
-    def __init__(self, weight, bias):
-        self.w, self.b = weight, bias
+    def __init__(self, weight, bias, bf16=False):
+        self.w, self.b, self.bf16 = weight, bias, bool(bf16)
         self.N, self.K = weight.shape
 
     def fwd(self, x, Y, M, act=0, beta=0.0):
-        ops.linear(x, self.w.data, self.b.data if self.b is not None else None, Y, M, self.N, self.K, act=act, beta=beta)
+        ops.linear(x, self.w.data, self.b.data if self.b is not None else None, Y, M, self.N, self.K, act=act, beta=beta,
+                   bf16=self.bf16)
 
     def bwd_x(self, dY, dX, M, Yact=None, beta=0.0):
         """dX[M,K] (=|+=) (dY * relu'(Yact)) W"""
-        ops.linear(ops.src(dY, gate=Yact), self.w.data, None, dX, M, self.K, self.N, beta=beta, w_kmajor=True)
+        ops.linear(ops.src(dY, gate=Yact), self.w.data, None, dX, M, self.K, self.N, beta=beta, w_kmajor=True,
+                   bf16=self.bf16)
 
     def wgrad(self, dY, x, M, Yact=None):
-        ops.linear_wgrad(dY, x, self.w.grad, self.b.grad if self.b is not None else None, M, self.N, self.K, Yact=Yact)
+        ops.linear_wgrad(dY, x, self.w.grad, self.b.grad if self.b is not None else None, M, self.N, self.K, Yact=Yact,
+                         bf16=self.bf16)
 
 
-def lin_of(module: nn.Linear):
-    return Lin(module.weight, module.bias)
+def lin_of(module: nn.Linear, bf16=False):
+    return Lin(module.weight, module.bias, bf16)
 
 
 def to_dev(x, device, dtype=torch.float32):
@@ -169,7 +172,7 @@ class DeviceBatch:
         guess = min(rec.T, args.episode_limit)
         db = cls.from_record(rec, args, T=guess, index=index, small=small)
         m = int(out.item())
-        T = m if m > 0 else args.episode_limit
+        T = m if m > 0 else guess          # none terminated: episode_limit, never more steps than the record holds
         if T != guess:
             db = cls.from_record(rec, args, T=T, index=index, small=small)
         return db
@@ -191,6 +194,9 @@ class DeviceBatch:
         E = rec.E
         if T is None:
             T = cls.first_terminated_len(rec.term, args.episode_limit)
+        if T > Ta:
+            raise ValueError("max_episode_len %d exceeds the %d steps the episode record holds "
+                             "(args.episode_limit != record length?)" % (T, Ta))
         self.B, self.T, self.N, self.O, self.S, self.A = E, T, N, O, S, A
         self.o_cur = (big.obs, (Ta + 1) * N, 0)
         self.o_next = (big.obs, (Ta + 1) * N, 1)

@@ -36,6 +36,18 @@ class _Scratch:
         return self.get(name, (rows, ld), device)[:, :width]
 
 
+class _Precision:
+    """Operand precision of a mixer's GEMMs, read from ITS args on every call (``args.mixer_dtype``: "fp32" exact -
+    default - or "bf16" operands with fp32 accumulation on the bf16 matrix cores, BASELINE config 5).  Per object:
+    two learners with different settings can live in one process."""
+
+    def _bf16(self):
+        return getattr(self.args, "mixer_dtype", "fp32") == "bf16"
+
+    def _lin(self, module):
+        return self._lin(module, self._bf16())
+
+
 def _mlp(dims, sizes):
     """nn.Sequential(Linear, ReLU, Linear, ...) with the reference's index names 0,2,4."""
     layers = []
@@ -51,7 +63,7 @@ def _linears(seq):
 
 
 # =====================================================================================
-class VDNMixer(nn.Module):
+class VDNMixer(_Precision, nn.Module):
     """reference network/mixer.py:9-16."""
 
     def __init__(self, args):
@@ -77,7 +89,7 @@ class VDNMixer(nn.Module):
 
 
 # =====================================================================================
-class QMixMixer(nn.Module):
+class QMixMixer(_Precision, nn.Module):
     """reference network/mixer.py:21-80 (hypernetwork-generated monotonic mixer)."""
 
     def __init__(self, args):
@@ -96,7 +108,7 @@ class QMixMixer(nn.Module):
 
     def _fused_ok(self, xs):
         a = self.args
-        return (not a.two_hyper_layers and not getattr(self, "no_fused", False) and not ops.MIXER_BF16
+        return (not a.two_hyper_layers and not getattr(self, "no_fused", False) and not self._bf16()
                 and ops.qmix_fused_supported(a.n_agents, a.state_shape, a.qmix_hidden_dim)
                 and xs.ld0 % 4 == 0 and (xs.p0 or 0) % 16 == 0 and not (xs.k1 or xs.nhot or xs.nid or xs.m0))
 
@@ -151,17 +163,17 @@ class QMixMixer(nn.Module):
             hw2 = self._s.get("hw2" + tag, (rows, HH), dev)
             l10, l12 = _linears(self.hyper_w1)
             l20, l22 = _linears(self.hyper_w2)
-            lin_of(l10).fwd(xs, hw1, rows, act=1)
-            lin_of(l12).fwd(ops.src(hw1), hy[:, :N * E], rows)
-            lin_of(l20).fwd(xs, hw2, rows, act=1)
-            lin_of(l22).fwd(ops.src(hw2), hy[:, N * E + E:N * E + 2 * E], rows)
+            self._lin(l10).fwd(xs, hw1, rows, act=1)
+            self._lin(l12).fwd(ops.src(hw1), hy[:, :N * E], rows)
+            self._lin(l20).fwd(xs, hw2, rows, act=1)
+            self._lin(l22).fwd(ops.src(hw2), hy[:, N * E + E:N * E + 2 * E], rows)
         else:
-            lin_of(self.hyper_w1).fwd(xs, hy[:, :N * E], rows)
-            lin_of(self.hyper_w2).fwd(xs, hy[:, N * E + E:N * E + 2 * E], rows)
-        lin_of(self.hyper_b1).fwd(xs, hy[:, N * E:N * E + E], rows)
+            self._lin(self.hyper_w1).fwd(xs, hy[:, :N * E], rows)
+            self._lin(self.hyper_w2).fwd(xs, hy[:, N * E + E:N * E + 2 * E], rows)
+        self._lin(self.hyper_b1).fwd(xs, hy[:, N * E:N * E + E], rows)
         b20, b22 = _linears(self.hyper_b2)
-        lin_of(b20).fwd(xs, hy[:, N * E + 2 * E:], rows, act=1)
-        lin_of(b22).fwd(ops.src(hy[:, N * E + 2 * E:]), b2, rows)
+        self._lin(b20).fwd(xs, hy[:, N * E + 2 * E:], rows, act=1)
+        self._lin(b22).fwd(ops.src(hy[:, N * E + 2 * E:]), b2, rows)
         ops.qmix_mix_fwd(hy, b2, q, qtot, rows, N, E)
         if ctx is not None:
             ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2)
@@ -185,21 +197,21 @@ class QMixMixer(nn.Module):
         xs = ops.src(s)
         hb, dhb = hy[:, N * E + 2 * E:], dhy[:, N * E + 2 * E:]
         b20, b22 = _linears(self.hyper_b2)
-        lin_of(b22).wgrad(db2, ops.src(hb), rows)
-        lin_of(b22).bwd_x(db2, dhb, rows)
-        lin_of(b20).wgrad(dhb, xs, rows, Yact=hb)
-        lin_of(self.hyper_b1).wgrad(dhy[:, N * E:N * E + E], xs, rows)
+        self._lin(b22).wgrad(db2, ops.src(hb), rows)
+        self._lin(b22).bwd_x(db2, dhb, rows)
+        self._lin(b20).wgrad(dhb, xs, rows, Yact=hb)
+        self._lin(self.hyper_b1).wgrad(dhy[:, N * E:N * E + E], xs, rows)
         if a.two_hyper_layers:
             for seq, hbuf, cols in ((self.hyper_w1, ctx["hw1"], slice(0, N * E)),
                                     (self.hyper_w2, ctx["hw2"], slice(N * E + E, N * E + 2 * E))):
                 l0, l2 = _linears(seq)
-                lin_of(l2).wgrad(dhy[:, cols], ops.src(hbuf), rows)
+                self._lin(l2).wgrad(dhy[:, cols], ops.src(hbuf), rows)
                 dh = self._s.get("dhw", (rows, HH), dev)
-                lin_of(l2).bwd_x(dhy[:, cols], dh, rows)
-                lin_of(l0).wgrad(dh, xs, rows, Yact=hbuf)
+                self._lin(l2).bwd_x(dhy[:, cols], dh, rows)
+                self._lin(l0).wgrad(dh, xs, rows, Yact=hbuf)
         else:
-            lin_of(self.hyper_w1).wgrad(dhy[:, :N * E], xs, rows)
-            lin_of(self.hyper_w2).wgrad(dhy[:, N * E + E:N * E + 2 * E], xs, rows)
+            self._lin(self.hyper_w1).wgrad(dhy[:, :N * E], xs, rows)
+            self._lin(self.hyper_w2).wgrad(dhy[:, N * E + E:N * E + 2 * E], xs, rows)
         return dq
 
     def forward(self, q_values, states):
@@ -256,7 +268,7 @@ def _head_stride(mods, attr):
     return d[0] // 4
 
 
-class DMAQer(nn.Module):
+class DMAQer(_Precision, nn.Module):
     """QPLEX duplex dueling mixer (reference network/mixer.py:173-288)."""
 
     def __init__(self, args):
@@ -281,11 +293,11 @@ class DMAQer(nn.Module):
         N_, K_ = lins[0].weight.shape
         if gw is not None and gb is not None:
             grp = ops.group(K, x0=x_gs, w=gw, b=gb, y=y_gs)
-            ops.linear(x, lins[0].weight.data, lins[0].bias.data, Y, rows, N_, K_, act=act, grp=grp)
+            ops.linear(x, lins[0].weight.data, lins[0].bias.data, Y, rows, N_, K_, act=act, grp=grp, bf16=self._bf16())
         else:   # parameters not in one flat buffer: one launch per head
             for k, l in enumerate(lins):
                 xk = x if x_gs == 0 else ops.src(self._xview(x, k, x_gs, K_))
-                ops.linear(xk, l.weight.data, l.bias.data, Y[:, k * y_gs:(k + 1) * y_gs], rows, N_, K_, act=act)
+                ops.linear(xk, l.weight.data, l.bias.data, Y[:, k * y_gs:(k + 1) * y_gs], rows, N_, K_, act=act, bf16=self._bf16())
 
     @staticmethod
     def _xview(x, k, gs, width):
@@ -294,7 +306,7 @@ class DMAQer(nn.Module):
 
     def _fused_family(self, mods, x_in, nout, grad=False):
         """marl_mlp3_weights_t of an extractor family when the fused three-layer kernel covers it, else None."""
-        if ops.MIXER_BF16 or getattr(self, "no_fused", False):
+        if self._bf16() or getattr(self, "no_fused", False):
             return None
         heads = [_linears(m) for m in mods]
         if len(heads[0]) != 3:
@@ -306,7 +318,7 @@ class DMAQer(nn.Module):
 
     def _fused_transform(self, xs, grad=False):
         """hyper_w_final and V (Linear-ReLU-Linear, same shapes) as two heads of the fused kernel, or None."""
-        if ops.MIXER_BF16 or getattr(self, "no_fused", False):
+        if self._bf16() or getattr(self, "no_fused", False):
             return None
         heads = [_linears(self.hyper_w_final), _linears(self.V)]
         if len(heads[0]) != 2 or not ops.mlp3_supported(xs, self.state_dim, heads[0][0].out_features, 0, self.n_agents, 2):
@@ -366,10 +378,10 @@ class DMAQer(nn.Module):
             hv = self._s.get("hv" + tag, (rows, HE), dev)
             w_raw = self._s.get("wraw" + tag, (rows, N), dev)
             v = self._s.get("v" + tag, (rows, N), dev)
-            lin_of(w0).fwd(xs, hw, rows, act=1)
-            lin_of(w2).fwd(ops.src(hw), w_raw, rows)
-            lin_of(v0).fwd(xs, hv, rows, act=1)
-            lin_of(v2).fwd(ops.src(hv), v, rows)
+            self._lin(w0).fwd(xs, hw, rows, act=1)
+            self._lin(w2).fwd(ops.src(hw), w_raw, rows)
+            self._lin(v0).fwd(xs, hv, rows, act=1)
+            self._lin(v2).fwd(ops.src(hv), v, rows)
         v_tot = self._s.get("vtot" + tag, (rows,), dev)
         a_tot = lam = None
         heads = {}
@@ -404,10 +416,10 @@ class DMAQer(nn.Module):
         else:
             for seq, hbuf, dout in ((self.hyper_w_final, ctx["hw"], dw_raw), (self.V, ctx["hv"], dv)):
                 l0, l2 = _linears(seq)
-                lin_of(l2).wgrad(dout, ops.src(hbuf), rows)
+                self._lin(l2).wgrad(dout, ops.src(hbuf), rows)
                 dh = self._s.get("dh_t", (rows, HE), dev)
-                lin_of(l2).bwd_x(dout, dh, rows)
-                lin_of(l0).wgrad(dh, xs, rows, Yact=hbuf)
+                self._lin(l2).bwd_x(dout, dh, rows)
+                self._lin(l0).wgrad(dh, xs, rows, Yact=hbuf)
         # lambda-net, family by family, heads batched
         xsa = ops.src(s, idx=ctx["u_idx"].view(rows, N), nhot=N, hot_w=A)
         for name, mods, nout in self.si_weight.families():
@@ -431,12 +443,12 @@ class DMAQer(nn.Module):
                 ggw = _head_stride(lins, "weight")
                 grp = ops.group(K, x0=xin_gs, w=ggw, b=gb, y=dcur_gs, m0=dcur_gs)
                 # gradient buffers follow the parameter layout (views of the learner's flat grad)
-                ops.linear_wgrad(dcur, xin, lins[0].weight.grad, lins[0].bias.grad, rows, N_, K_, Yact=gate, grp=grp)
+                ops.linear_wgrad(dcur, xin, lins[0].weight.grad, lins[0].bias.grad, rows, N_, K_, Yact=gate, grp=grp, bf16=self._bf16())
                 if li > 0:
                     dprev = self._s.get("dh_%s%d" % (name, li), (rows, K * AE), dev)
                     gx = ops.group(K, x0=dcur_gs, w=gw, y=AE, m0=dcur_gs)
                     ops.linear(ops.src(dcur, gate=gate, k0=N_), lins[0].weight.data, None, dprev, rows, K_, N_,
-                               w_kmajor=True, grp=gx)
+                               w_kmajor=True, grp=gx, bf16=self._bf16())
                     dcur, dcur_gs, gate = dprev, AE, hs[li - 1]
         return dq
 
@@ -453,12 +465,14 @@ class DMAQer(nn.Module):
             return v_tot.clone().view(bs, -1, 1)
         u_idx = onehot_to_index(to_dev(actions, dev).reshape(rows, N, self.n_actions)).reshape(-1)
         mq = to_dev(max_q_i, dev).reshape(-1, N)
-        _, a_tot = self.hip_forward(q, s, rows, u_idx=u_idx, max_q=mq, tag="f")
+        ctx = {}
+        _, a_tot = self.hip_forward(q, s, rows, u_idx=u_idx, max_q=mq, ctx=ctx, tag="f")
+        self.last_lambda = ctx["lam"].clone()          # DMAQ_SI_Weight.forward output (rows, N), reference :155-169
         return a_tot.clone().view(bs, -1, 1)
 
 
 # =====================================================================================
-class QtranQBase(nn.Module):
+class QtranQBase(_Precision, nn.Module):
     """QTRAN-base joint action-value network (reference network/mixer.py:355-388)."""
 
     def __init__(self, args):
@@ -485,13 +499,13 @@ class QtranQBase(nn.Module):
         y1 = self._s.get("y1" + tag, (BT, Q), dev)
         y2 = self._s.get("y2" + tag, (BT, Q), dev)
         out = self._s.get("out" + tag, (BT, 1), dev)
-        lin_of(e0).fwd(x_ha, e1, R, act=1)
-        lin_of(e2).fwd(ops.src(e1), e2b, R)
+        self._lin(e0).fwd(x_ha, e1, R, act=1)
+        self._lin(e2).fwd(ops.src(e1), e2b, R)
         ops.agent_sum(e2b, esum, BT, N, ae)
         x_q = ops.src(s, esum)
-        lin_of(q0).fwd(x_q, y1, BT, act=1)
-        lin_of(q2).fwd(ops.src(y1), y2, BT, act=1)
-        lin_of(q4).fwd(ops.src(y2), out, BT)
+        self._lin(q0).fwd(x_q, y1, BT, act=1)
+        self._lin(q2).fwd(ops.src(y1), y2, BT, act=1)
+        self._lin(q4).fwd(ops.src(y2), out, BT)
         if ctx is not None:
             ctx.update(s=s, hidden=hidden, u_idx=u_idx, e1=e1, esum=esum, y1=y1, y2=y2)
         return out.view(BT)
@@ -511,18 +525,18 @@ class QtranQBase(nn.Module):
         desum = self._s.get_rows("desum", BT, ae, dev)
         de2 = self._s.get_rows("de2", R, ae, dev)
         de1 = self._s.get_rows("de1", R, ae, dev)
-        lin_of(q4).wgrad(g, ops.src(y2), BT)
-        lin_of(q4).bwd_x(g, dy2, BT)
-        lin_of(q2).wgrad(dy2, ops.src(y1), BT, Yact=y2)
-        lin_of(q2).bwd_x(dy2, dy1, BT, Yact=y2)
-        lin_of(q0).wgrad(dy1, ops.src(s, esum), BT, Yact=y1)
-        Lin(q0.weight.data[:, S:], None).bwd_x(dy1, desum, BT, Yact=y1)     # only the enc columns need a gradient
+        self._lin(q4).wgrad(g, ops.src(y2), BT)
+        self._lin(q4).bwd_x(g, dy2, BT)
+        self._lin(q2).wgrad(dy2, ops.src(y1), BT, Yact=y2)
+        self._lin(q2).bwd_x(dy2, dy1, BT, Yact=y2)
+        self._lin(q0).wgrad(dy1, ops.src(s, esum), BT, Yact=y1)
+        Lin(q0.weight.data[:, S:], None, self._bf16()).bwd_x(dy1, desum, BT, Yact=y1)     # only the enc columns need a gradient
         ops.agent_bcast(desum, de2, BT, N, ae)
         x_ha = ops.src(hidden, idx=u_idx.view(R, 1), nhot=1, hot_w=A)
-        lin_of(e2).wgrad(de2, ops.src(e1), R)
-        lin_of(e2).bwd_x(de2, de1, R)
-        lin_of(e0).wgrad(de1, x_ha, R, Yact=e1)
-        Lin(e0.weight.data[:, :H], None).bwd_x(de1, dhidden, R, Yact=e1, beta=1.0 if accumulate else 0.0)
+        self._lin(e2).wgrad(de2, ops.src(e1), R)
+        self._lin(e2).bwd_x(de2, de1, R)
+        self._lin(e0).wgrad(de1, x_ha, R, Yact=e1)
+        Lin(e0.weight.data[:, :H], None, self._bf16()).bwd_x(de1, dhidden, R, Yact=e1, beta=1.0 if accumulate else 0.0)
 
     def forward(self, state, hidden_states, actions):
         dev = require_cuda("QtranQBase")
@@ -543,7 +557,7 @@ class QtranQAlt(nn.Module):
         raise NotImplementedError("qtran_alt is broken in the reference and is not part of the hot path")
 
 
-class QtranV(nn.Module):
+class QtranV(_Precision, nn.Module):
     """QTRAN state-value network (reference network/mixer.py:392-418)."""
 
     def __init__(self, args):
@@ -567,12 +581,12 @@ class QtranV(nn.Module):
         y1 = self._s.get("y1" + tag, (BT, Q), dev)
         y2 = self._s.get("y2" + tag, (BT, Q), dev)
         out = self._s.get("out" + tag, (BT, 1), dev)
-        lin_of(e0).fwd(ops.src(hidden), e1, R, act=1)
-        lin_of(e2).fwd(ops.src(e1), e2b, R)
+        self._lin(e0).fwd(ops.src(hidden), e1, R, act=1)
+        self._lin(e2).fwd(ops.src(e1), e2b, R)
         ops.agent_sum(e2b, esum, BT, N, H)
-        lin_of(v0).fwd(ops.src(s, esum), y1, BT, act=1)
-        lin_of(v2).fwd(ops.src(y1), y2, BT, act=1)
-        lin_of(v4).fwd(ops.src(y2), out, BT)
+        self._lin(v0).fwd(ops.src(s, esum), y1, BT, act=1)
+        self._lin(v2).fwd(ops.src(y1), y2, BT, act=1)
+        self._lin(v4).fwd(ops.src(y2), out, BT)
         if ctx is not None:
             ctx.update(s=s, hidden=hidden, e1=e1, esum=esum, y1=y1, y2=y2)
         return out.view(BT)
@@ -591,17 +605,17 @@ class QtranV(nn.Module):
         desum = self._s.get("desum", (BT, H), dev)
         de2 = self._s.get("de2", (R, H), dev)
         de1 = self._s.get("de1", (R, H), dev)
-        lin_of(v4).wgrad(g, ops.src(y2), BT)
-        lin_of(v4).bwd_x(g, dy2, BT)
-        lin_of(v2).wgrad(dy2, ops.src(y1), BT, Yact=y2)
-        lin_of(v2).bwd_x(dy2, dy1, BT, Yact=y2)
-        lin_of(v0).wgrad(dy1, ops.src(s, esum), BT, Yact=y1)
-        Lin(v0.weight.data[:, S:], None).bwd_x(dy1, desum, BT, Yact=y1)
+        self._lin(v4).wgrad(g, ops.src(y2), BT)
+        self._lin(v4).bwd_x(g, dy2, BT)
+        self._lin(v2).wgrad(dy2, ops.src(y1), BT, Yact=y2)
+        self._lin(v2).bwd_x(dy2, dy1, BT, Yact=y2)
+        self._lin(v0).wgrad(dy1, ops.src(s, esum), BT, Yact=y1)
+        Lin(v0.weight.data[:, S:], None, self._bf16()).bwd_x(dy1, desum, BT, Yact=y1)
         ops.agent_bcast(desum, de2, BT, N, H)
-        lin_of(e2).wgrad(de2, ops.src(e1), R)
-        lin_of(e2).bwd_x(de2, de1, R)
-        lin_of(e0).wgrad(de1, ops.src(hidden), R, Yact=e1)
-        lin_of(e0).bwd_x(de1, dhidden, R, Yact=e1, beta=1.0 if accumulate else 0.0)
+        self._lin(e2).wgrad(de2, ops.src(e1), R)
+        self._lin(e2).bwd_x(de2, de1, R)
+        self._lin(e0).wgrad(de1, ops.src(hidden), R, Yact=e1)
+        self._lin(e0).bwd_x(de1, dhidden, R, Yact=e1, beta=1.0 if accumulate else 0.0)
 
     def forward(self, state, hidden):
         dev = require_cuda("QtranV")

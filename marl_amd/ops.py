@@ -32,10 +32,14 @@ def _i32(t):
 
 
 class Workspace:
-    """Grow-only scratch buffers keyed by name (no allocation in steady state)."""
+    """Grow-only scratch buffers keyed by name (no allocation in steady state).  ``gen`` counts (re)allocations:
+    a captured hipGraph holds raw pointers into these buffers, so its owner records ``gen`` at capture time, keeps
+    ``snapshot()`` alive (the old storage cannot be freed and handed to somebody else under the graph) and drops
+    the graph when ``gen`` has moved (algorithm/common.py:GraphedUpdate)."""
 
     def __init__(self):
         self.bufs = {}
+        self.gen = 0
 
     def get(self, name, nbytes, device):
         n = (int(nbytes) + 3) // 4
@@ -43,7 +47,11 @@ class Workspace:
         if b is None or b.numel() < n or b.device != device:
             b = torch.empty(max(n, 1), dtype=torch.float32, device=device)
             self.bufs[name] = b
+            self.gen += 1
         return b
+
+    def snapshot(self):
+        return list(self.bufs.values())
 
 
 WS = Workspace()
@@ -101,23 +109,11 @@ def group(groups, x0=0, x1=0, w=0, b=0, y=0, m0=0):
     return MarlGroup(groups, x0, x1, w, b, y, m0)
 
 
-# Precision of the MIXER GEMMs (marl_linear / marl_linear_wgrad called by network/mixer.py): "fp32" (exact, default)
-# or "bf16" operands with fp32 accumulation on the bf16 matrix cores (BASELINE config 5).  The agent's layers never
-# use it (their call sites pass bf16=False).
-MIXER_BF16 = False
-
-
-def set_mixer_dtype(name):
-    global MIXER_BF16
-    if name not in ("fp32", "bf16"):
-        raise ValueError("mixer_dtype must be 'fp32' or 'bf16'")
-    MIXER_BF16 = name == "bf16"
-
-
-def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, grp=None, bf16=None):
-    """Y[M,N] = act(X W^T + b) (+beta*Y).  W: (N,K) view, or (K,N) when w_kmajor."""
+def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, grp=None, bf16=False):
+    """Y[M,N] = act(X W^T + b) (+beta*Y).  W: (N,K) view, or (K,N) when w_kmajor.  bf16: round both operands to
+    bf16 and use the bf16 matrix cores with fp32 accumulation (per call; the mixers pass their args.mixer_dtype)."""
     lib = _lib.load()
-    if MIXER_BF16 if bf16 is None else bf16:
+    if bf16:
         act |= 0x100
     if ldw is None:
         ldw = W.stride(0) if W.dim() == 2 else (N if w_kmajor else K)
@@ -128,10 +124,10 @@ def linear(x, W, bias, Y, M, N, K, act=0, beta=0.0, w_kmajor=False, ldw=None, gr
           "marl_linear")
 
 
-def linear_wgrad(dY, x, dW, db, M, N, K, Yact=None, grp=None, lddw=None, bf16=None):
+def linear_wgrad(dY, x, dW, db, M, N, K, Yact=None, grp=None, lddw=None, bf16=False):
     """dW[N,K] += (dY * (Yact>0))^T X ; db[N] += column sums."""
     lib = _lib.load()
-    flags = 1 if (MIXER_BF16 if bf16 is None else bf16) else 0
+    flags = 1 if bf16 else 0
     g = grp.groups if grp is not None else 1
     nbytes = lib.marl_linear_wgrad_workspace(M, N, K, g)
     ws = WS.get("wgrad", nbytes, dY.device)
@@ -160,17 +156,15 @@ def agent_weights(params):
 
 
 def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
-                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None):
+                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None, cu_budget=0):
+    """cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over (0 / 256 = the whole chip); 128 lets two
+    independent unrolls run side by side on two streams (PairedUnroll).  A per-call argument, no process state."""
     lib = _lib.load()
     check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
                                     _p(_i32(ep_map)) if ep_map is not None else None, _p(h0),
                                     _p(_f32(q)), _p(hs), _p(h_last), _p(saved), B, T, N, O, A,
-                                    1 if last_action else 0, 1 if reuse_network else 0, _stream()),
+                                    1 if last_action else 0, 1 if reuse_network else 0, int(cu_budget), _stream()),
           "marl_agent_unroll_fwd")
-
-
-def agent_set_cu_budget(cus):
-    check(_lib.load().marl_agent_set_cu_budget(int(cus)), "marl_agent_set_cu_budget")
 
 
 def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None):

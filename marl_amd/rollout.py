@@ -168,9 +168,13 @@ class RolloutWorker:
         return EpisodeBatch(rec), episodes_reward, wins_tag, steps_tot
 
     def _generate_whole(self, rec, evaluate):
+        return self.finish_episodes(self._launch_whole(rec, evaluate, self.mac))
+
+    def _launch_whole(self, rec, evaluate, mac):
         """One persistent launch for the whole rollout; the epsilon schedule (one anneal per lock-step,
-        reference rollout.py:48-50,100-101) is evaluated on the host and shipped as a T-vector."""
-        env, mac, a = self.env, self.mac, self.args
+        reference rollout.py:48-50,100-101) is evaluated on the host and shipped as a T-vector.  Everything is
+        enqueued on the current HIP stream; nothing here waits for the GPU."""
+        env, a = self.env, self.args
         dev = require_cuda("RolloutWorker")
         E, T, N, H = env.n_envs, self.episode_limit, self.n_agents, a.rnn_hidden_dim
         if a.replay_dir != '' and evaluate:
@@ -183,15 +187,37 @@ class RolloutWorker:
             sched[t] = epsilon
             if a.epsilon_anneal_scale == 'step':
                 epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
-        eps_dev = torch.from_numpy(sched).to(dev)
+        eps_dev = torch.from_numpy(sched).to(dev, non_blocking=True)
         mac.init_hidden(E)
         env.whole_rollout(mac.agent.weights(), eps_dev, self.rseed, rec, a.last_action, a.reuse_network,
                           h_out=mac.hidden_states.view(E * N, H))
         if not evaluate:
             self.epsilon = epsilon
-        if evaluate and a.replay_dir != '':
-            env.save_replay()
-            env.close()
+        return rec, evaluate
+
+    def launch_episodes(self, evaluate=False, mac=None):
+        """Asynchronous form of generate_episodes for batched envs with the whole-rollout kernel: enqueue the rollout
+        on the CURRENT stream (a side stream in the overlapped runner) and return a handle for finish_episodes().
+        ``mac``: the controller whose weights the rollout reads (a snapshot while the learner updates the live one)."""
+        env = self.env
+        if not (getattr(env, "batched", False) and hasattr(env, "whole_rollout") and env.supports_whole_rollout()):
+            raise RuntimeError("launch_episodes needs a batched env with the whole-rollout kernel")
+        dev = require_cuda("RolloutWorker")
+        sink = getattr(self, "record_sink", None)
+        rec = None
+        if sink is not None and not evaluate:
+            rec = sink.next_slot_record(env.n_envs, self.episode_limit, self.n_agents, self.obs_shape, self.state_shape,
+                                        self.n_actions, dev)
+        if rec is None:
+            rec = env.new_record()
+        return self._launch_whole(rec, evaluate, mac if mac is not None else self.mac)
+
+    def finish_episodes(self, pending):
+        """(episodes, rewards, win_tags, steps) of a launched rollout: the one device-to-host copy (and sync)."""
+        rec, evaluate = pending
+        if evaluate and self.args.replay_dir != '':
+            self.env.save_replay()
+            self.env.close()
         stats = torch.stack([rec.r.sum(1), rec.won.float(), rec.length.float()], 0).cpu()
         return EpisodeBatch(rec), stats[0].tolist(), [bool(x) for x in stats[1].tolist()], int(stats[2].sum().item())
 

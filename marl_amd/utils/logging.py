@@ -21,3 +21,15 @@ class Logger:
         self.stats[key].append((t, value))
         if self.use_tb:
             self.writer.add_scalar(key, value, t)
+
+
+def get_logger():
+    """console logger of the reference (utils/logging.py:34-44): root logger, one stream handler, DEBUG"""
+    import logging
+    logger = logging.getLogger()
+    logger.handlers = []
+    ch = logging.StreamHandler()
+    ch.setFormatter(logging.Formatter('[%(levelname)s %(asctime)s] %(name)s %(message)s', '%H:%M:%S'))
+    logger.addHandler(ch)
+    logger.setLevel('DEBUG')
+    return logger

@@ -16,3 +16,21 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter):
+    """achieved parity margins (tests/parity.py): worst error / bound per case"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import parity
+    except ImportError:
+        return
+    lines = parity.summary_lines()
+    if lines:
+        terminalreporter.write_sep("-", "parity margins: max|got-ref| vs tol * max|ref| (north-star 1e-4 fp32)")
+        for l in lines:
+            terminalreporter.write_line(l)
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "parity_margins.txt"), "w") as f:
+                f.write("\n".join(lines) + "\n")

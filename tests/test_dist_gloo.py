@@ -58,6 +58,10 @@ def _worker(rank, world, port, q):
         term[1, 1:] = 1.0
     Tg = DeviceBatch.first_terminated_len(term, 9, reducer=red)
     none = DeviceBatch.first_terminated_len(torch.zeros(2, 9, 1), 9, reducer=red)     # nobody terminates anywhere
+    # replicas start from rank 0's values (learners call this for parameters, targets and optimizer state)
+    w = torch.full((7,), float(rank + 1))
+    red.broadcast_(w, None)
+    assert torch.equal(w, torch.ones(7))
     q.put((rank, (T, Tg, none), buf.numpy()))
     dist.destroy_process_group()
 

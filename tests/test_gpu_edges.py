@@ -9,6 +9,7 @@ import torch
 from oracle import seeded, learners
 
 from test_gpu_learners import build_product, named_product_params
+import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +39,7 @@ def test_train_vs_oracle(case):
         loss = learner.train(learners.clone_batch(batch), ts)
         oloss, ograds, ointer = learners.train(ost, learners.clone_batch(batch), ts)
         assert learner.max_episode_len == ointer["T"]
-        np.testing.assert_allclose(loss, oloss, rtol=1e-4 * (1 + 9 * i), atol=1e-5, err_msg="%s loss, step %d" % (name, i))
+        parity.close("edge:" + name, "loss step %d" % i, loss, oloss, tol=1e-4 * (1 + 9 * i))
         if i == 0:
             den = float(learner.last_stats[-1 if alg.startswith("qtran") else 1].item())
             for n, p in named_product_params(learner):
@@ -47,9 +48,7 @@ def test_train_vs_oracle(case):
                 if og is None:
                     assert np.all(g == 0), n
                     continue
-                og = og.detach().numpy()
-                sc = max(1.0, float(np.abs(og).max()))
-                np.testing.assert_allclose(g / sc, og / sc, atol=1e-4, rtol=2e-3, err_msg="%s grad %s" % (name, n))
+                parity.close("edge:" + name, "grad " + n, g, og.detach().numpy(), tol=1e-4)
 
 
 def test_zero_rows_are_noops():

@@ -8,6 +8,7 @@ import torch
 from oracle import seeded, learners
 
 from golden_cases import CASES, TRAIN_STEPS, load_fixture, case_states, build_oracle_state
+import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +42,9 @@ def named_product_params(learner):
     return out
 
 
-def check_pins(fix, prefix, named, atol, rtol, scale=1.0, none_is_zero=False):
+def check_pins(fix, prefix, named, tol, case, scale=1.0, none_is_zero=False):
+    """sampled entries and the 2-norm of every pinned tensor: max abs error <= tol * max|reference tensor| (the
+    fixture stores 64 strided samples + the norm per tensor; max|ref| is taken over the samples)."""
     names = sorted({k[len(prefix) + 1:].rsplit("/", 1)[0] for k in fix.files if k.startswith(prefix + "/")})
     assert names
     got = dict(named)
@@ -52,9 +55,8 @@ def check_pins(fix, prefix, named, atol, rtol, scale=1.0, none_is_zero=False):
             continue
         ref = fix["%s/%s/samp" % (prefix, n)]
         nrm = float(fix["%s/%s/norm" % (prefix, n)])
-        sc = max(1.0, nrm / np.sqrt(max(a.size, 1)) * 10)
-        np.testing.assert_allclose(a[seeded.sample_indices(a.size)] / sc, ref / sc, atol=atol, rtol=rtol, err_msg=prefix + "/" + n)
-        np.testing.assert_allclose(np.sqrt((a * a).sum()), nrm, rtol=max(rtol, 2e-4), atol=atol, err_msg=prefix + "/" + n)
+        parity.close(case, prefix + "/" + n, a[seeded.sample_indices(a.size)], ref, tol=tol)
+        parity.close(case, prefix + "/" + n + "/norm", np.sqrt((a * a).sum()), nrm, tol=tol)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -69,26 +71,25 @@ def test_forward_pieces_vs_reference(case, golden_dir):
     q_cont, _ = mac.get_next_q_values(batch, T)            # quirk Q1: continues from the final hidden
     mac.init_hidden(B)
     q_nxt, h_nxt = mac.get_next_q_values(batch, T)
-    tol = dict(atol=1e-4, rtol=1e-4)
-    np.testing.assert_allclose(q_cur.cpu().numpy(), fix["fwd/q_cur"], **tol)
-    np.testing.assert_allclose(h_cur.cpu().numpy(), fix["fwd/h_cur"], **tol)
-    np.testing.assert_allclose(q_nxt.cpu().numpy(), fix["fwd/q_next"], **tol)
-    np.testing.assert_allclose(h_nxt.cpu().numpy(), fix["fwd/h_next"], **tol)
-    np.testing.assert_allclose(q_cont.cpu().numpy(), fix["fwd/q_next_cont"], **tol)
+    c = "fwd:" + name
+    P = lambda key, t: parity.close(c, key, t.cpu().numpy(), fix[key])
+    P("fwd/q_cur", q_cur); P("fwd/h_cur", h_cur); P("fwd/q_next", q_nxt); P("fwd/h_next", h_nxt)
+    P("fwd/q_next_cont", q_cont)
     u = torch.tensor(batch["u"])
     qc = torch.gather(q_cur.cpu(), 3, u).squeeze(3)
     s = torch.tensor(batch["s"], dtype=torch.float32)
     uo = torch.tensor(batch["u_onehot"], dtype=torch.float32)
     if alg in ("vdn", "qmix"):
-        np.testing.assert_allclose(learner.mixer(qc, s).cpu().numpy(), fix["fwd/q_tot"], atol=2e-4, rtol=1e-4)
+        P("fwd/q_tot", learner.mixer(qc, s))
     elif alg == "qplex":
         qd = q_cur.cpu().clone(); qd[torch.tensor(batch["avail_u"]) == 0] = -9999999
         mx = qd.max(dim=3)[0]
-        np.testing.assert_allclose(learner.mixer(qc, s, is_v=True).cpu().numpy(), fix["fwd/v_tot"], **tol)
-        np.testing.assert_allclose(learner.mixer(qc, s, actions=uo, max_q_i=mx, is_v=False).cpu().numpy(), fix["fwd/a_tot"], **tol)
+        P("fwd/v_tot", learner.mixer(qc, s, is_v=True))
+        P("fwd/a_tot", learner.mixer(qc, s, actions=uo, max_q_i=mx, is_v=False))
+        P("fwd/lambda", learner.mixer.last_lambda.view(B * T, -1))      # DMAQ_SI_Weight output (mixer.py:155-169)
     else:
-        np.testing.assert_allclose(learner.mixer(s, h_cur, uo).cpu().numpy(), fix["fwd/joint_q"], **tol)
-        np.testing.assert_allclose(learner.v(s, h_cur).cpu().numpy(), fix["fwd/v"], **tol)
+        P("fwd/joint_q", learner.mixer(s, h_cur, uo))
+        P("fwd/v", learner.v(s, h_cur))
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -101,21 +102,23 @@ def test_train_steps_vs_reference_and_oracle(case, golden_dir):
         batch = seeded.make_batch(args, B, seed=100 + i, lengths=lengths)
         loss = learner.train(learners.clone_batch(batch), ts)
         oloss, ograds, ointer = learners.train(ost, learners.clone_batch(batch), ts)
+        # step 0 is held to the north-star 1e-4; later steps amplify fp32 rounding through RMSprop's 1/sqrt(v) (a
+        # parameter whose gradient is ~0 moves by lr * g / (sqrt(v) + 1e-8) with v ~ g^2): loosen progressively
         rt = 1e-4 * (10 ** i)
-        np.testing.assert_allclose(loss, fix["losses"][i], rtol=rt, atol=1e-5, err_msg="loss vs reference, step %d" % i)
-        np.testing.assert_allclose(loss, oloss, rtol=rt, atol=1e-5, err_msg="loss vs oracle, step %d" % i)
+        c = "train:%s/step%d" % (name, ts)
+        parity.close(c, "loss vs reference", loss, fix["losses"][i], tol=rt)
+        parity.close(c, "loss vs oracle", loss, oloss, tol=rt)
         assert learner.max_episode_len == ointer["T"]
         den = float(learner.last_stats[-1 if alg.startswith("qtran") else 1].item())
         named = named_product_params(learner)
         if i <= 1:
             grads = [(n, p.grad) for n, p in named]
-            check_pins(fix, "step%d/grad" % i, grads, atol=1e-4 * (1 + 20 * i), rtol=2e-3 * (1 + 10 * i),
-                       scale=1.0 / den, none_is_zero=True)
+            check_pins(fix, "step%d/grad" % i, grads, rt, c, scale=1.0 / den, none_is_zero=True)
             gn = float(torch.sqrt(learner.optimizer.sumsq[0]).item()) / den
-            np.testing.assert_allclose(gn, float(fix["step%d/grad_norm" % i]), rtol=5e-4 * (1 + 10 * i))
-            check_pins(fix, "step%d/param" % i, named, atol=1e-4 * (1 + 20 * i), rtol=1e-3)
+            parity.close(c, "grad_norm", gn, float(fix["step%d/grad_norm" % i]), tol=rt)
+            check_pins(fix, "step%d/param" % i, named, rt, c)
         check_pins(fix, "step%d/target_agent" % i,
-                   [("agent." + k, p) for k, p in learner.target_net.agent.named_parameters()], atol=2e-3, rtol=2e-3)
+                   [("agent." + k, p) for k, p in learner.target_net.agent.named_parameters()], 2e-3, c + "/target")
 
 
 def test_get_q_and_q_tot_table(golden_dir):

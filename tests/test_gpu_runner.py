@@ -37,3 +37,73 @@ def test_matrix_game_finds_the_optimal_joint_action(alg, iters):
     # the learned value is still approaching 8 after 3000 updates; how close it gets by then depends on fp32 summation
     # order (SGD is chaotic), the greedy joint action does not
     assert abs(q_tot[0, 0] - 8.0) < 2.5
+
+
+def test_matrix_game_qmix_lands_in_the_suboptimal_basin():
+    """QMIX's monotonic mixer cannot represent this payoff: the reference's run ends at reward 0
+    (result/qmix/MatrixGame/episode_rewards.npy: 2001 evaluations, the last ones all 0), i.e. a greedy joint action in
+    the [[0,0],[0,0]] block instead of [0,0] (reward 8) - matrix_game_test.py:101-113."""
+    from marl_amd.matrix_game_test import run, PAYOFF1
+    torch.manual_seed(0)
+    q_tot, joint, individual, loss = run("qmix", 2000, verbose=False)
+    assert PAYOFF1[joint[0]][joint[1]] == 0, (q_tot, joint)
+    assert PAYOFF1[individual[0]][individual[1]] == 0, individual          # what the decentralised greedy agents play
+    assert q_tot[0, 0] < q_tot[joint[0], joint[1]]
+
+
+def _runner(tmp_path, tag, extra=(), seed=3, **over):
+    from marl_amd.main import build
+    from marl_amd.runner import Runner
+    from marl_amd.utils.logging import Logger
+    args, env = build(["--alg", "qmix", "--map", "2s3z", "--n_envs", "16", "--n_steps", "9000",
+                       "--result_dir", str(tmp_path / (tag + "_res")), "--model_dir", str(tmp_path / (tag + "_model")),
+                       "--evaluate_epoch", "0"] + list(extra))
+    args.buffer_size = 48            # 3 rollouts fill the ring: later rollouts overwrite stored episodes
+    args.batch_size = 16
+    args.save_cycle = 10 ** 9
+    for k, v in over.items():
+        setattr(args, k, v)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return Runner(env, Logger(), args)
+
+
+def test_overlapped_rollout_equals_the_same_schedule_on_one_stream(tmp_path):
+    """rollout k+1 on a side stream while update k trains.  The rollout reads a snapshot of the agent
+    taken before update k and the sampler skips the ring slots in flight, so the two-stream run must give exactly the
+    losses of the same lag-1 schedule executed on ONE stream; the reference's lag-0 cadence (default) differs."""
+    a = _runner(tmp_path, "ov", overlap_rollout=True)
+    a.run(0)
+    b = _runner(tmp_path, "ser", overlap_rollout="lag1_serial")
+    b.run(0)
+    c = _runner(tmp_path, "ref")
+    c.run(0)
+    assert len(a.losses) == len(b.losses) == len(c.losses) >= 5
+    assert a.losses == b.losses                      # bitwise: same kernels, same inputs, only the stream differs
+    assert a.losses[:1] == c.losses[:1] and a.losses != c.losses      # lag 1 vs the reference's lag 0
+    assert a.rolloutWorker.epsilon < 1.0 and a._side is not None and b._side is None
+
+
+def test_full_resume_continues_bitwise(tmp_path):
+    """optimizer state, targets, epsilon, loop counters, env episode counter and the numpy RNG state
+    survive save_resume / load_resume: a resumed Runner repeats the original run's next updates bit for bit.  (The
+    replay ring is deliberately not in the file - it refills; the test transplants a snapshot of it.)"""
+    a = _runner(tmp_path, "full")
+    a.args.n_steps = 16 * 120 * 3
+    a.run(0)
+    ck = str(tmp_path / "resume.pt")
+    a.save_resume(ck)
+    ring = (a.buffer.record.clone(), a.buffer.current_idx, a.buffer.current_size)
+    a.args.n_steps = 16 * 120 * 5
+    a.run(0)
+    assert len(a.losses) == 5
+    b = _runner(tmp_path, "resumed", seed=77, resume=ck)      # a different initialisation: everything comes from the file
+    assert (b.time_steps, b.train_steps, b.evaluate_steps) == (16 * 120 * 3, 3, 0)
+    assert b.rolloutWorker.epsilon < 1.0 and b.env.episode == 2
+    b.buffer.record, b.buffer.current_idx, b.buffer.current_size = ring
+    b.args.n_steps = 16 * 120 * 5
+    b.run(0)
+    assert b.losses == a.losses[3:]
+    assert torch.equal(b.learner._flat.flat, a.learner._flat.flat)
+    assert torch.equal(b.learner.optimizer.s1, a.learner.optimizer.s1)
+    assert torch.equal(b.learner.target_net.agent._flat.flat, a.learner.target_net.agent._flat.flat)

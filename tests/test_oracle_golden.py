@@ -145,3 +145,39 @@ def test_max_episode_len_quirk_q2():
     term = np.zeros((2, 6, 1)); term[1, 2, 0] = 1; term[1, 3:, 0] = 1
     assert learners.max_episode_len(term, 6) == 3          # unterminated episode ignored
     assert learners.max_episode_len(np.zeros((2, 6, 1)), 6) == 6
+
+
+@pytest.mark.parametrize("alg", ["vdn", "qplex", "qtran_base"])
+def test_oracle_on_reference_checkpoints(alg, golden_dir):
+    """The oracle fed with the state dicts the reference ships (tests/golden/ref_ckpt/, data) reproduces what the real
+    reference computed from the same files (tests/golden/make_ckpt_golden.py): trained weights, not only seeded ones."""
+    fix = np.load(os.path.join(golden_dir, "ref_ckpt_outputs.npz"))
+    d = os.path.join(golden_dir, "ref_ckpt", alg)
+    ld = lambda k: {n: t.numpy() for n, t in torch.load(os.path.join(d, k + "_params.pkl"), map_location="cpu").items()}
+    B, T = 3, 5
+    args = seeded.make_args("2s3z", alg, episode_limit=T)
+    agent = ld("rnn_net")
+    mixer = ld("mixer_net") if alg != "vdn" else {}
+    v = ld("v_net") if alg == "qtran_base" else None
+    extra = seeded.seeded_state(seeded.qmix_param_shapes(args), seed=14) if alg == "qtran_base" else None
+    st = learners.LearnerState(args, agent, mixer, v, extra)
+    batch = seeded.make_batch(args, B, seed=700, lengths=[5, 3, -1])
+    assert abs(seeded.checksum(batch) - float(fix[alg + "/batch_checksum"])) < 1e-6
+    bt = learners.to_tensors(batch, T)
+    tol = dict(atol=2e-5, rtol=1e-5)
+    with torch.no_grad():
+        h0 = torch.zeros(B * args.n_agents, args.rnn_hidden_dim)
+        q, h, _ = nets.agent_unroll(st.agent, bt["o"], nets.shifted_onehot(bt["u_onehot"]), h0)
+        np.testing.assert_allclose(q.numpy(), fix[alg + "/q_cur"], **tol)
+        np.testing.assert_allclose(h.numpy(), fix[alg + "/h_cur"], **tol)
+        qc = torch.gather(q, 3, bt["u"]).squeeze(3)
+        if alg == "vdn":
+            np.testing.assert_allclose(nets.vdn(qc).numpy(), fix[alg + "/q_tot"], **tol)
+        elif alg == "qplex":
+            qd = q.clone(); qd[bt["avail_u"] == 0] = learners.MASK_BIG
+            np.testing.assert_allclose(nets.qplex(st.mixer, qc, bt["s"], args, is_v=True).numpy(), fix[alg + "/v_tot"], **tol)
+            np.testing.assert_allclose(nets.qplex(st.mixer, qc, bt["s"], args, actions=bt["u_onehot"],
+                                                  max_q_i=qd.max(dim=3)[0]).numpy(), fix[alg + "/a_tot"], **tol)
+        else:
+            np.testing.assert_allclose(nets.qtran_q(st.mixer, bt["s"], h, bt["u_onehot"], args).numpy(), fix[alg + "/joint_q"], **tol)
+            np.testing.assert_allclose(nets.qtran_v(st.v, bt["s"], h, args).numpy(), fix[alg + "/v"], **tol)
