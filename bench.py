@@ -59,7 +59,7 @@ def learner_flops_per_transition(a, alg):
         K, AE = a.num_kernel, a.adv_hypernet_embed
         trans = 2 * 2 * (S * AE + AE * N)
         lam = K * 2 * ((S * AE + AE * AE + AE) + (S * AE + AE * AE + AE * N) + ((S + N * A) * AE + AE * AE + AE * N))
-        return 5 * N * Fa + 4 * (trans + lam)     # = 5 N F_a + 2 (32 000 + 823 040) + 2 * 855 040 = 4.99 M on 2s3z
+        return 5 * N * Fa + 4 * (2 * trans + lam)     # SURVEY's figure: 5 N F_a + 2 (32 000 + 823 040) + 2 * 855 040 = 4.99 M on 2s3z
     if alg.startswith("qtran"):
         Q = a.qtran_hidden_dim
         q = N * 2 * 2 * (H + A) ** 2 + 2 * ((S + H + A) * Q + Q * Q + Q)

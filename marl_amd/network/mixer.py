@@ -45,7 +45,7 @@ class _Precision:
         return getattr(self.args, "mixer_dtype", "fp32") == "bf16"
 
     def _lin(self, module):
-        return self._lin(module, self._bf16())
+        return lin_of(module, self._bf16())
 
 
 def _mlp(dims, sizes):
