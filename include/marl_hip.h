@@ -196,6 +196,36 @@ int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float
                   const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, long M, int K1, int N3,
                   int groups, void* stream);
 
+/* ---- fused QTRAN-base heads (qtran_fused.hip) ------------------------------------------------
+ * QtranQBase.forward (network/mixer.py:378-388, A = n_actions > 0, AE = 64 + A) and QtranV.forward (:411-418, A = 0,
+ * AE = 64):  out[bt] = q( [s | sum_n enc([h_n | onehot(u_n)])] ).  The per-agent encoder activations never leave the
+ * CU; the second encoder layer is applied AFTER the agent sum (it is linear): esum = W_enc2 (sum_n e1_n) + N b_enc2.
+ *   hidden (BT*N, 64) agent rows (bt, n) at bt*N + n; u (BT*N) int32 action index (< 0: all-zero one-hot) or NULL
+ *   when A = 0; sp (BT, 64) = W_q0[:, :S] s + b_q0 - the state part of the head's first layer, one marl_linear call,
+ *   shared by evaluations of the same network on the same states (taken / greedy actions, qtran_learner.py:116,133).
+ *   s1, e2 (BT, AEP), y1, y2 (BT, 64), AEP = AE rounded up to 16 (pad columns are written as zeros): saved
+ *   activations for the backward pass (sum_n relu(e1_n), esum, the two hidden layers), all four or none (NULL).
+ * Backward: given d_out (BT) writes the row-level gradients dy2, dy1 (BT, 64), de2 (BT, AEP) - the callers feed them
+ * to marl_linear_wgrad for W_q4, W_q2, W_q0 and W_enc2 (reductions over BT rows) - and the gradient on hidden
+ * (dhidden = or +=), and ACCUMULATES the gradients the agent-level pass owns: d_enc0_w (AE, AE), d_enc0_b (AE) and
+ * d_enc2_b (AE) (= N * colsum(de2)).  Slabs + fixed-order reduce: bitwise reproducible.
+ * Use when marl_qtran_supported(N, A, AE) (A <= 16, hidden widths 64); otherwise compose marl_linear. */
+typedef struct {
+  const float *enc0_w, *enc0_b;   /* hidden(_action)_encoding.0  (AE, AE), (AE) */
+  const float *enc2_w, *enc2_b;   /* hidden(_action)_encoding.2  (AE, AE), (AE) */
+  const float* q0_w; long q0_ld; int q0_s;   /* q.0 / v.0 weight (64, S + AE), its row stride, S */
+  const float *q2_w, *q2_b;       /* q.2 / v.2  (64, 64), (64) */
+  const float *q4_w, *q4_b;       /* q.4 / v.4  (1, 64), (1)   */
+} marl_qtran_weights_t;
+int marl_qtran_supported(int N, int A, int AE);
+int marl_qtran_head_fwd(const marl_qtran_weights_t* w, const float* hidden, const int* u, const float* sp, float* out,
+                        float* s1, float* e2, float* y1, float* y2, long BT, int N, int A, int AE, void* stream);
+size_t marl_qtran_bwd_workspace(long BT, int AE);
+int marl_qtran_head_bwd(const marl_qtran_weights_t* w, const float* hidden, const int* u, const float* d_out,
+                        const float* y1, const float* y2, float* dy1, float* dy2, float* de2, float* dhidden,
+                        int accumulate, float* d_enc0_w, float* d_enc0_b, float* d_enc2_b, float* ws, size_t ws_bytes,
+                        long BT, int N, int A, int AE, void* stream);
+
 /* QPLEX (DMAQer.forward + calc_v/calc_adv, mixer.py:211-288; DMAQ_SI_Weight tail :158-169).
  *  wv row = [w_raw (N) | v (N)] (outputs of hyper_w_final.2 / V.2);
  *  heads = key (rows,K,1) | agents (rows,K,N) | action (rows,K,N) raw extractor outputs.

@@ -41,6 +41,12 @@ class MarlMlp3Weights(C.Structure):
                 [(n, C.c_long) for n in ("gs_w1", "gs_b1", "gs_w2", "gs_b2", "gs_w3", "gs_b3")])
 
 
+class MarlQtranWeights(C.Structure):
+    _fields_ = [("enc0_w", C.c_void_p), ("enc0_b", C.c_void_p), ("enc2_w", C.c_void_p), ("enc2_b", C.c_void_p),
+                ("q0_w", C.c_void_p), ("q0_ld", C.c_long), ("q0_s", C.c_int),
+                ("q2_w", C.c_void_p), ("q2_b", C.c_void_p), ("q4_w", C.c_void_p), ("q4_b", C.c_void_p)]
+
+
 class MarlAgentGrads(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
                 ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
@@ -57,6 +63,7 @@ SRC, GRP, AW = C.POINTER(MarlSrc), C.POINTER(MarlGroup), C.POINTER(MarlAgentWeig
 AG = C.POINTER(MarlAgentGrads)
 QW = C.POINTER(MarlQmixWeights)
 M3 = C.POINTER(MarlMlp3Weights)
+QT = C.POINTER(MarlQtranWeights)
 
 # name -> (restype, argtypes); must list every symbol of include/marl_hip.h
 SIGNATURES = {
@@ -84,6 +91,10 @@ SIGNATURES = {
     "marl_mlp3_fwd": (I, [M3, SRC, P, L, L, L, I, I, I, P]),
     "marl_mlp3_bwd_workspace": (SZ, [L, I, I, I]),
     "marl_mlp3_bwd": (I, [M3, SRC, P, L, L, M3, P, SZ, L, I, I, I, P]),
+    "marl_qtran_supported": (I, [I, I, I]),
+    "marl_qtran_head_fwd": (I, [QT, P, P, P, P, P, P, P, P, L, I, I, I, P]),
+    "marl_qtran_bwd_workspace": (SZ, [L, I]),
+    "marl_qtran_head_bwd": (I, [QT, P, P, P, P, P, P, P, P, P, I, P, P, P, P, SZ, L, I, I, I, P]),
     "marl_qplex_mix_fwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_qplex_mix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_first_terminated_len": (I, [P, L, I, I, P, P]),

@@ -472,7 +472,82 @@ class DMAQer(_Precision, nn.Module):
 
 
 # =====================================================================================
-class QtranQBase(_Precision, nn.Module):
+class _QtranFusedHead:
+    """Fused path shared by QtranQBase (one-hot actions, A = n_actions) and QtranV (A = 0): csrc/qtran_fused.hip.
+    The subclass provides ``_qt_layers()`` -> (enc.0, enc.2, head.0, head.2, head.4) and ``_qt_actions()``."""
+
+    def _qt_dims(self):
+        a = self.args
+        A = self._qt_actions()
+        AE = a.rnn_hidden_dim + A
+        return a.n_agents, A, AE, (AE + 15) // 16 * 16, a.state_shape
+
+    def _qt_ok(self, hidden):
+        a = self.args
+        N, A, AE, _, _ = self._qt_dims()
+        return (not self._bf16() and not getattr(self, "no_fused", False) and a.rnn_hidden_dim == 64
+                and a.qtran_hidden_dim == 64 and ops.qtran_supported(N, A, AE) and hidden.is_contiguous()
+                and hidden.data_ptr() % 16 == 0)
+
+    def _qt_struct(self):
+        ls = self._qt_layers()
+        key = tuple(p.data_ptr() for l in ls for p in (l.weight, l.bias))
+        c = self.__dict__.get("_qt_cache")
+        if c is None or c[0] != key:
+            c = self.__dict__["_qt_cache"] = (key, ops.qtran_weights(*ls, self.args.state_shape))
+        return c[1]
+
+    def __deepcopy__(self, memo):
+        # the cached ctypes struct points at THIS module's storage: a copy (target mixer) starts without it
+        import copy as _copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_qt_cache":
+                new.__dict__[k] = _copy.deepcopy(v, memo)
+        return new
+
+    def state_part(self, s, BT, tag="e"):
+        """sp = W_0[:, :S] s + b_0 (BT, 64): the state columns of the head's first layer.  Independent of hidden
+        states and actions, so one call serves every evaluation of this network on the same states."""
+        q0 = self._qt_layers()[2]
+        S = self.args.state_shape
+        sp = self._s.get("sp" + tag, (BT, q0.out_features), s.device)
+        Lin(q0.weight.data[:, :S], q0.bias, self._bf16()).fwd(ops.src(s), sp, BT)
+        return sp
+
+    def _qt_forward(self, s, hidden, u_idx, BT, ctx, tag, sp):
+        N, A, AE, AEP, S = self._qt_dims()
+        dev = hidden.device
+        if sp is None:
+            sp = self.state_part(s, BT, tag)
+        out = self._s.get("out" + tag, (BT,), dev)
+        s1 = e2 = y1 = y2 = None
+        if ctx is not None:
+            s1, e2 = self._s.get("s1" + tag, (BT, AEP), dev), self._s.get("e2" + tag, (BT, AEP), dev)
+            y1, y2 = self._s.get("y1" + tag, (BT, 64), dev), self._s.get("y2" + tag, (BT, 64), dev)
+        ops.qtran_head_fwd(self._qt_struct(), hidden, u_idx if A else None, sp, out, s1, e2, y1, y2, BT, N, A, AE)
+        if ctx is not None:
+            ctx.update(fused=True, s=s, hidden=hidden, u_idx=u_idx, s1=s1, e2=e2, y1=y1, y2=y2)
+        return out
+
+    def _qt_backward(self, ctx, d_out, BT, dhidden, accumulate):
+        N, A, AE, AEP, S = self._qt_dims()
+        dev = d_out.device
+        e0, e2l, q0, q2, q4 = self._qt_layers()
+        dy1, dy2 = self._s.get("dy1", (BT, 64), dev), self._s.get("dy2", (BT, 64), dev)
+        de2 = self._s.get("de2", (BT, AEP), dev)
+        # head chain + agent-level pass: dhidden, and the gradients of encoder layer 1 / the bias of layer 2
+        ops.qtran_head_bwd(self._qt_struct(), ctx["hidden"], ctx["u_idx"] if A else None, d_out, ctx["y1"], ctx["y2"],
+                           dy1, dy2, de2, dhidden, accumulate, e0.weight.grad, e0.bias.grad, e2l.bias.grad, BT, N, A, AE)
+        # row-level weight gradients: reductions over BT rows of tensors the kernel above has just written
+        self._lin(q4).wgrad(d_out.view(BT, 1), ops.src(ctx["y2"]), BT)
+        self._lin(q2).wgrad(dy2, ops.src(ctx["y1"]), BT)
+        self._lin(q0).wgrad(dy1, ops.src(ctx["s"], ctx["e2"][:, :AE]), BT)
+        Lin(e2l.weight, None, self._bf16()).wgrad(de2[:, :AE], ops.src(ctx["s1"][:, :AE]), BT)
+
+
+class QtranQBase(_QtranFusedHead, _Precision, nn.Module):
     """QTRAN-base joint action-value network (reference network/mixer.py:355-388)."""
 
     def __init__(self, args):
@@ -484,8 +559,16 @@ class QtranQBase(_Precision, nn.Module):
         self.q = _mlp(None, [q_in, args.qtran_hidden_dim, args.qtran_hidden_dim, 1])
         self._s = _Scratch()
 
-    def hip_forward(self, s, hidden, u_idx, BT, ctx=None, tag="e"):
-        """s (BT,S); hidden (BT*N,H); u_idx (BT*N) int32 -> joint q (BT)."""
+    def _qt_layers(self):
+        return tuple(_linears(self.hidden_action_encoding) + _linears(self.q))
+
+    def _qt_actions(self):
+        return self.args.n_actions
+
+    def hip_forward(self, s, hidden, u_idx, BT, ctx=None, tag="e", sp=None):
+        """s (BT,S); hidden (BT*N,H); u_idx (BT*N) int32 -> joint q (BT).  sp: optional result of state_part(s)."""
+        if self._qt_ok(hidden):
+            return self._qt_forward(s, hidden, u_idx, BT, ctx, tag, sp)
         a = self.args
         N, H, A, Q = a.n_agents, a.rnn_hidden_dim, a.n_actions, a.qtran_hidden_dim
         R, ae = BT * N, H + A
@@ -512,6 +595,8 @@ class QtranQBase(_Precision, nn.Module):
 
     def hip_backward(self, ctx, d_out, BT, dhidden, accumulate):
         """d_out (BT). Adds/writes the gradient wrt hidden into dhidden (BT*N,H)."""
+        if ctx.get("fused"):
+            return self._qt_backward(ctx, d_out, BT, dhidden, accumulate)
         a = self.args
         N, H, A, Q, S = a.n_agents, a.rnn_hidden_dim, a.n_actions, a.qtran_hidden_dim, a.state_shape
         R, ae = BT * N, H + A
@@ -557,7 +642,7 @@ class QtranQAlt(nn.Module):
         raise NotImplementedError("qtran_alt is broken in the reference and is not part of the hot path")
 
 
-class QtranV(_Precision, nn.Module):
+class QtranV(_QtranFusedHead, _Precision, nn.Module):
     """QTRAN state-value network (reference network/mixer.py:392-418)."""
 
     def __init__(self, args):
@@ -568,7 +653,15 @@ class QtranV(_Precision, nn.Module):
         self.v = _mlp(None, [args.state_shape + H, args.qtran_hidden_dim, args.qtran_hidden_dim, 1])
         self._s = _Scratch()
 
-    def hip_forward(self, s, hidden, BT, ctx=None, tag="e"):
+    def _qt_layers(self):
+        return tuple(_linears(self.hidden_encoding) + _linears(self.v))
+
+    def _qt_actions(self):
+        return 0
+
+    def hip_forward(self, s, hidden, BT, ctx=None, tag="e", sp=None):
+        if self._qt_ok(hidden):
+            return self._qt_forward(s, hidden, None, BT, ctx, tag, sp)
         a = self.args
         N, H, Q = a.n_agents, a.rnn_hidden_dim, a.qtran_hidden_dim
         R = BT * N
@@ -592,6 +685,8 @@ class QtranV(_Precision, nn.Module):
         return out.view(BT)
 
     def hip_backward(self, ctx, d_out, BT, dhidden, accumulate):
+        if ctx.get("fused"):
+            return self._qt_backward(ctx, d_out, BT, dhidden, accumulate)
         a = self.args
         N, H, Q, S = a.n_agents, a.rnn_hidden_dim, a.qtran_hidden_dim, a.state_shape
         R = BT * N

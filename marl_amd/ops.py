@@ -10,7 +10,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, MarlQmixWeights, MarlMlp3Weights, check
+from ._lib import (MarlSrc, MarlGroup, MarlAgentWeights, MarlAgentGrads, MarlQmixWeights, MarlMlp3Weights,
+                   MarlQtranWeights, check)
 
 
 def _p(t):
@@ -429,3 +430,36 @@ def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups):
     ws = WS.get("mlp3", lib.marl_mlp3_bwd_workspace(M, K1, N3, groups), dY.device)
     check(lib.marl_mlp3_bwd(C.byref(w), C.byref(x), _p(_f32(dY)), ld, gs, C.byref(grads), _p(ws), ws.numel() * 4,
                             M, K1, N3, groups, _stream()), "marl_mlp3_bwd")
+
+
+# ---- fused QTRAN-base heads (csrc/qtran_fused.hip)
+def qtran_supported(N, A, AE):
+    return bool(_lib.load().marl_qtran_supported(N, A, AE))
+
+
+def qtran_weights(enc0, enc2, q0, q2, q4, S):
+    """nn.Linear layers of hidden(_action)_encoding.{0,2} and q.{0,2,4} (or hidden_encoding / v) -> marl_qtran_weights_t"""
+    w = MarlQtranWeights()
+    for name, lin in (("enc0", enc0), ("enc2", enc2), ("q2", q2), ("q4", q4)):
+        for suf, t in (("_w", lin.weight.data), ("_b", lin.bias.data)):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+            setattr(w, name + suf, t.data_ptr())
+    assert q0.weight.data.is_contiguous()
+    w.q0_w, w.q0_ld, w.q0_s = q0.weight.data.data_ptr(), q0.weight.shape[1], S
+    w._keep = (enc0, enc2, q0, q2, q4)
+    return w
+
+
+def qtran_head_fwd(w, hidden, u, sp, out, s1, e2, y1, y2, BT, N, A, AE):
+    check(_lib.load().marl_qtran_head_fwd(C.byref(w), _p(_f32(hidden)), _p(u), _p(_f32(sp)), _p(_f32(out)), _p(s1), _p(e2),
+                                          _p(y1), _p(y2), BT, N, A, AE, _stream()), "marl_qtran_head_fwd")
+
+
+def qtran_head_bwd(w, hidden, u, d_out, y1, y2, dy1, dy2, de2, dhidden, accumulate, d_enc0_w, d_enc0_b, d_enc2_b,
+                   BT, N, A, AE):
+    lib = _lib.load()
+    ws = WS.get("qtran", lib.marl_qtran_bwd_workspace(BT, AE), hidden.device)
+    check(lib.marl_qtran_head_bwd(C.byref(w), _p(_f32(hidden)), _p(u), _p(_f32(d_out)), _p(_f32(y1)), _p(_f32(y2)),
+                                  _p(_f32(dy1)), _p(_f32(dy2)), _p(_f32(de2)), _p(_f32(dhidden)), 1 if accumulate else 0,
+                                  _p(_f32(d_enc0_w)), _p(_f32(d_enc0_b)), _p(_f32(d_enc2_b)), _p(ws), ws.numel() * 4,
+                                  BT, N, A, AE, _stream()), "marl_qtran_head_bwd")

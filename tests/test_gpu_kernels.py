@@ -693,3 +693,89 @@ def test_rollout_kernels_match_numpy_env(dev):
         np.testing.assert_array_equal(pad[:, t].cpu().numpy(), (~livet).astype(np.float32))
         np.testing.assert_array_equal(term[:, t].cpu().numpy(), np.where(livet, (t + 1 >= L), 1).astype(np.float32))
         assert (alive.cpu().numpy() == (t + 1 < L)).all()
+
+
+@pytest.mark.parametrize("kind,BT,N,A,S", [("q", 37, 8, 14, 216), ("q", 16, 5, 11, 120), ("q", 1, 2, 3, 1), ("q", 300, 3, 16, 40),
+                                            ("v", 37, 8, 14, 216), ("v", 129, 5, 11, 120), ("q", 4100, 8, 14, 216)])
+def test_qtran_fused_heads(dev, kind, BT, N, A, S):
+    """Fused QtranQBase / QtranV kernels (csrc/qtran_fused.hip) behind the mixer classes: forward, gradient on the
+    hidden states and every parameter gradient vs torch-CPU autograd of the reference forward (network/mixer.py:378-388,
+    :411-418: per-agent encoder, THEN the agent sum), plus equality with the generic marl_linear composition."""
+    import types
+    from marl_amd.network.mixer import QtranQBase, QtranV
+    from marl_amd.hostutil import FlatParams
+    args = types.SimpleNamespace(n_agents=N, n_actions=A, state_shape=S, rnn_hidden_dim=64, qtran_hidden_dim=64)
+    torch.manual_seed(BT + N + A)
+    mod = (QtranQBase if kind == "q" else QtranV)(args)
+    ref = (QtranQBase if kind == "q" else QtranV)(args)
+    ref.load_state_dict(mod.state_dict())
+    g = torch.Generator().manual_seed(7 * BT + N)
+    R = BT * N
+    s = torch.randn(BT, S, generator=g)
+    h = (torch.randn(R, 64, generator=g) * 0.7).requires_grad_()
+    u = torch.randint(0, A, (R,), generator=g).int()
+    u[::7] = -1                                              # padding rows: all-zero one-hot
+    d_out = torch.randn(BT, generator=g)
+    # torch-CPU reference (parameters of `ref` get .grad)
+    enc = ref.hidden_action_encoding if kind == "q" else ref.hidden_encoding
+    head = ref.q if kind == "q" else ref.v
+    if kind == "q":
+        oh = torch.zeros(R, A)
+        oh[u >= 0] = F.one_hot(u[u >= 0].long(), A).float()
+        x = torch.cat([h, oh], dim=1)
+    else:
+        x = h
+    esum = enc(x).view(BT, N, -1).sum(1)
+    out_ref = head(torch.cat([s, esum], dim=1)).squeeze(1)
+    e1_pre = enc[0](x).detach()                               # (R, AE) pre-activations of the encoder's relu
+
+    def close_except_kinks(got, msg):
+        """The gradient wrt hidden is discontinuous where an encoder pre-activation crosses 0: a unit whose
+        pre-activation is within fp32 rounding of 0 may be gated differently by two correct summation orders (the
+        kernel adds the one-hot column as a table bias, torch inside the GEMM).  Rows are compared at 2e-5 / 1e-4;
+        a row may only deviate if it HAS such a unit (|pre-activation| < 2e-6), and only a handful of rows may."""
+        a_, b_ = got.detach().cpu().numpy(), h.grad.numpy()
+        bad = np.unique(np.nonzero(np.abs(a_ - b_) > 2e-5 + 1e-4 * np.abs(b_))[0])
+        assert len(bad) <= max(1, R // 10000), (msg, len(bad))
+        for r in bad:
+            assert float(e1_pre[r].abs().min()) < 2e-6, (msg, int(r), float(e1_pre[r].abs().min()))
+    (out_ref * d_out).sum().backward()
+    # product: parameters in one flat buffer with gradient views (as in the learners)
+    mod.to(dev)
+    fp = FlatParams(list(mod.parameters()), dev, with_grad=True)
+    base = torch.randn(fp.n, generator=g).to(dev)            # gradients accumulate into what is there
+    fp.grad.copy_(base)
+    sd, hd, ud, dd = cu(s, dev), cu(h.detach(), dev), cu(u, dev, torch.int32), cu(d_out, dev)
+    assert mod._qt_ok(hd)
+    dh = {}
+    for fused in (True, False):
+        mod.no_fused = not fused
+        fp.grad.copy_(base)
+        ctx = {}
+        out = mod.hip_forward(sd, hd, ud, BT, ctx=ctx) if kind == "q" else mod.hip_forward(sd, hd, BT, ctx=ctx)
+        assert bool(ctx.get("fused")) == fused
+        close(out, out_ref, 2e-5, 1e-4, msg="out fused=%s" % fused)
+        dhid = torch.full((R, 64), 0.5, device=dev)
+        mod.hip_backward(ctx, dd, BT, dhid, accumulate=True)
+        close_except_kinks(dhid - 0.5, "dhidden fused=%s" % fused)
+        dh[fused] = dhid.clone()
+        scale = max(1.0, (R / 64.0) ** 0.5)
+        for (name, p), pr in zip(mod.named_parameters(), ref.parameters()):
+            want = pr.grad
+            got = p.grad - base[fp.offsets[[id(q) for q in fp.params].index(id(p))]:][:p.numel()].view(p.shape)
+            tol = 3e-5 * scale * max(1.0, float(want.abs().max()))
+            close(got, want, tol, 1e-4, msg="%s fused=%s" % (name, fused))
+    # without accumulate the old contents are overwritten
+    mod.no_fused = False
+    ctx = {}
+    out = mod.hip_forward(sd, hd, ud, BT, ctx=ctx) if kind == "q" else mod.hip_forward(sd, hd, BT, ctx=ctx)
+    dhid = torch.full((R, 64), 123.0, device=dev)
+    mod.hip_backward(ctx, dd, BT, dhid, accumulate=False)
+    close_except_kinks(dhid, "dhidden overwrite")
+    # the public forward() (reference signature) takes the fused path too
+    if kind == "q":
+        oh4 = torch.zeros(R, A); oh4[u >= 0] = F.one_hot(u[u >= 0].long(), A).float()
+        pub = mod(s.view(1, BT, S), h.detach().view(1, BT, N, 64), oh4.view(1, BT, N, A))
+    else:
+        pub = mod(s.view(1, BT, S), h.detach().view(1, BT, N, 64))
+    close(pub.view(-1), out_ref, 2e-5, 1e-4, msg="public forward")
