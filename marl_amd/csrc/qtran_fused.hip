@@ -474,24 +474,32 @@ struct QtRedArgs {
   float *dWe1, *dbe1, *dbe2;
   int nwg, AE, AEP, A, N;
 };
-// gradients += slabs summed in workgroup order
+// gradients += slabs: 64 elements per block, 4 slab groups per element (thread (e, sg) sums slabs sg, sg+4, .. in order,
+// the 4 partial sums are added in a fixed order) -> deterministic, and 4x shorter dependent chains
 __global__ __launch_bounds__(256) void qtran_reduce_kernel(QtRedArgs a) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float part[4][64];
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
   const int n2 = a.AEP * KW;
+  float s = 0.f;
+  if (e < n2) {
+    for (int w = sg; w < a.nwg; w += 4) s += a.slab2[(long)w * n2 + e];
+  } else if (e < n2 + a.AEP) {
+    for (int w = sg; w < a.nwg; w += 4) s += a.slab1[(long)w * a.AEP + (e - n2)];
+  }
+  part[sg][el] = s;
+  __syncthreads();
+  if (sg != 0) return;
+  s = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
   if (e < n2) {
     const int f = e / KW, k = e - f * KW;
     if (f >= a.AE || k > HD + 16) return;
-    float s = 0.f;
-    for (int w = 0; w < a.nwg; ++w) s += a.slab2[(long)w * n2 + e];
     if (k < HD) a.dWe1[(long)f * a.AE + k] += s;
     else if (k < HD + 16) { if (k - HD < a.A) a.dWe1[(long)f * a.AE + k] += s; }
     else a.dbe1[f] += s;
   } else if (e < n2 + a.AEP) {
     const int f = e - n2;
-    if (f >= a.AE) return;
-    float s = 0.f;
-    for (int w = 0; w < a.nwg; ++w) s += a.slab1[(long)w * a.AEP + f];
-    a.dbe2[f] += (float)a.N * s;
+    if (f < a.AE) a.dbe2[f] += (float)a.N * s;
   }
 }
 
@@ -587,7 +595,7 @@ extern "C" int marl_qtran_head_bwd(const marl_qtran_weights_t* w, const float* h
   r.slab1 = a.slab1; r.slab2 = a.slab2; r.dWe1 = d_enc0_w; r.dbe1 = d_enc0_b; r.dbe2 = d_enc2_b;
   r.nwg = (int)grid; r.AE = AE; r.AEP = AEP; r.A = A; r.N = N;
   const int total = AEP * KW + AEP;
-  hipLaunchKernelGGL(qtran_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, r);
+  hipLaunchKernelGGL(qtran_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }

@@ -194,9 +194,10 @@ def q_train(state: LearnerState, batch, train_step):
 # ---------------------------------------------------------------------------------
 # QTRANLearner.train  (algorithm/qtran_learner.py:71-163, get_qtran :165-200)
 # ---------------------------------------------------------------------------------
-def qtran_forward(state: LearnerState, batch):
+def qtran_forward(state: LearnerState, batch, T=None):
     args = state.args
-    T = max_episode_len(batch["terminated"], args.episode_limit)
+    if T is None:
+        T = max_episode_len(batch["terminated"], args.episode_limit)
     bt = to_tensors(batch, T)
     B, N, H = bt["o"].shape[0], args.n_agents, args.rnn_hidden_dim
     s, u, r, s_next = bt["s"], bt["u"], bt["r"], bt["s_next"]
@@ -234,7 +235,7 @@ def qtran_forward(state: LearnerState, batch):
     loss = l_td + args.lambda_opt * l_opt + args.lambda_nopt * l_nopt
     inter = dict(T=T, q_evals=q_ind, hs_eval=hs_eval, q_targets=q_ind_tgt, hs_target=hs_tgt,
                  joint_q_evals=joint_q, joint_q_targets=joint_q_tgt, v=v, joint_q_hat_opt=joint_q_hat,
-                 l_td=l_td, l_opt=l_opt, l_nopt=l_nopt, loss=loss)
+                 l_td=l_td, l_opt=l_opt, l_nopt=l_nopt, loss=loss, den=mask.sum())
     return loss, inter
 
 

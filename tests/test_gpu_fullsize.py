@@ -134,3 +134,100 @@ def test_qplex_linearity_and_oracle_samples(world):
         a_ = dbg[k].reshape(E, Tm)[idx]
         b_ = inter[k].detach().numpy().reshape(len(idx), Tm)
         np.testing.assert_allclose(a_[live], b_[live], atol=3e-4, rtol=1e-4, err_msg=k)
+
+
+def _shard_world(shape, alg, envs, T, seed, over=None):
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from test_gpu_learners import build_product
+    case = ("shard", shape, alg, envs, T, None, over or {})
+    args, mac, learner = build_product(case)
+    args.epsilon, args.anneal_epsilon, args.seed = 0.3, 1e-4, seed
+    env = SyntheticSMACEnv(envs, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, T, seed=seed + 1)
+    ep, _, _, _ = RolloutWorker(env, mac, args).generate_episodes(envs)
+    return case, args, learner, ep.record
+
+
+def _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, tol=1e-4):
+    """The product on the sampled episodes alone (full T loop: same trip count, BPTT variant and dispatch as the full
+    batch) vs the CPU oracle on the same episodes: forward tensors, loss numerators and EVERY parameter gradient."""
+    import parity
+    from marl_amd.rollout import EpisodeBatch
+    from golden_cases import case_states
+    from test_gpu_learners import named_product_params
+    sub_rec = rec.index_select(torch.as_tensor(idx, device=rec.obs.device))
+    g_sub, dbg = _grads(learner, sub_rec, Tm)
+    sub = EpisodeBatch(sub_rec).numpy()
+    _, agent, mixer, v, extra = case_states(case)
+    st = learners.LearnerState(args, agent, mixer, v, extra)
+    live = sub["padded"][:, :Tm, 0] == 0
+    n = learner._flat.n
+    if args.alg.startswith("qtran"):
+        loss, inter = learners.qtran_forward(st, sub, T=Tm)
+        den = float(inter["den"])
+        for k, ok in (("joint_q", "joint_q_evals"), ("joint_q_targets", "joint_q_targets"), ("v", "v"),
+                      ("joint_q_hat", "joint_q_hat_opt")):
+            a_ = dbg[k].reshape(len(idx), Tm)
+            b_ = inter[ok].detach().numpy().reshape(len(idx), Tm)
+            parity.close(name, "sampled " + k, a_[live], b_[live], tol=tol)
+        want = [float(inter[k]) * den for k in ("l_td", "l_opt", "l_nopt")] + [den]
+        parity.close(name, "loss numerators", g_sub[n:n + 4], np.array(want), tol=tol)
+    else:
+        loss, inter = learners.q_forward(st, sub, T=Tm)
+        den = float(inter["den"])
+        for k in ("q_tot", "q_tot_target"):
+            a_ = dbg[k].reshape(len(idx), Tm)
+            b_ = inter[k].detach().numpy().reshape(len(idx), Tm)
+            parity.close(name, "sampled " + k, a_[live], b_[live], tol=tol)
+        parity.close(name, "loss numerator", g_sub[n:n + 2], np.array([float(inter["num"]), den]), tol=tol)
+    parity.close(name, "sampled q_evals", dbg["q_evals"], inter["q_evals"].detach().numpy(), tol=tol)
+    ograds = learners._grads(st, loss)
+    for (pn, p) in named_product_params(learner):
+        og = ograds.get(pn)
+        g = p.grad.detach().cpu().numpy() / den
+        if og is None:
+            assert np.all(g == 0), pn
+            continue
+        parity.close(name, "grad " + pn, g, og.detach().numpy(), tol=tol)
+
+
+def _linearity(learner, rec, Tm, E_, nstats, name, tol=5e-5):
+    import parity
+    full, _ = _grads(learner, rec, Tm)
+    half = E_ // 2
+    ga, _ = _grads(learner, rec.slice(0, half), Tm)
+    gb, _ = _grads(learner, rec.slice(half, E_), Tm)
+    tot = ga + gb
+    n = learner._flat.n
+    assert tot[n + nstats - 1] == full[n + nstats - 1] == float((1.0 - rec.padded[:, :Tm]).sum().item())
+    parity.close(name, "loss numerators full vs halves", full[n:n + nstats - 1], tot[n:n + nstats - 1], tol=tol)
+    parity.close(name, "gradient full vs halves", full[:n], tot[:n], tol=tol)
+
+
+def test_config4_qtran_3s5z_shard_fullsize():
+    """BASELINE config 4 at its per-GPU shard (QTRAN-base, 3s5z shape, 2048 envs / 4 GPUs = 512 envs x T = 150):
+    614 400 agent rows through the fused joint-Q / V head kernels and the hidden-state-gradient BPTT variant.
+    (a) the un-normalised [gradients | three loss numerators | sum(mask)] of the shard equal the sum over its halves;
+    (b) on sampled episodes - same T = 150 loop - joint_q, target joint_q, v, joint_q_hat, the three loss numerators
+    and every parameter gradient equal the CPU oracle's within 1e-4 of their scale."""
+    from marl_amd.hostutil import DeviceBatch
+    E4, T4 = 512, 150
+    case, args, learner, rec = _shard_world("3s5z", "qtran_base", E4, T4, seed=23)
+    assert int(rec.padded.sum().item()) > 0
+    Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
+    assert Tm == T4
+    _linearity(learner, rec, Tm, E4, 4, "full:cfg4_qtran_3s5z_512x150")
+    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 255, 256, 300, 511], Tm, "full:cfg4_qtran_3s5z_512x150")
+
+
+def test_config5_qmix_mmm2_shard_fullsize():
+    """BASELINE config 5 at its per-GPU shard (QMIX, MMM2 shape, 8192 envs / 8 GPUs = 1024 envs x T = 120, fp32):
+    S = 322 states (rows not 16-byte aligned in a dense layout), 10 agents, two action tiles in the agent kernels.
+    Same two properties as config 4: shard linearity and oracle parity (forward, loss, all gradients) on samples."""
+    from marl_amd.hostutil import DeviceBatch
+    E5, T5 = 1024, 120
+    case, args, learner, rec = _shard_world("MMM2", "qmix", E5, T5, seed=29)
+    Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
+    assert Tm == T5
+    _linearity(learner, rec, Tm, E5, 2, "full:cfg5_qmix_MMM2_1024x120")
+    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 511, 512, 700, 1023], Tm, "full:cfg5_qmix_MMM2_1024x120")
