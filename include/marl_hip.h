@@ -171,6 +171,22 @@ int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const
                         float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
                         int N, int S, int E, void* stream);
 
+/* Fused QMIX for WIDE states (qmix_wide.hip; MMM2: S = 322, N = 10 -> a 416 x 322 concatenated hypernet that does not fit
+ * the registers-resident design above): the weights are packed per call into MFMA-fragment order (L2 resident) and
+ * streamed against 64-row state tiles in LDS; same arithmetic, same gradient destinations.  `s`: dense segment 0 whose
+ * rows start on 16-byte boundaries and hold S rounded up to 4 readable floats (EpisodeRecord pads the state row stride).
+ * flags & 1: bf16 operands for the hypernet GEMM (v_mfma_f32_16x16x32_bf16, fp32 accumulate; BASELINE config 5 "bf16
+ * mixer with MFMA") - the forward kernel is then bound by reading the states from HBM; mixing arithmetic, gradients and
+ * the weight-gradient GEMM stay fp32.  Workspace: packed weights (+ for backward: d(hypernet output) rows x (N*E+3E)
+ * and the slabs).  Supported when marl_qmix_wide_supported(N, S, E) (E == 32, N <= 10, S <= 352). */
+int marl_qmix_wide_supported(int N, int S, int E);
+size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward);
+int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot, float* ws,
+                       size_t ws_bytes, long rows, int N, int S, int E, int flags, void* stream);
+int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot, float* dq,
+                       const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows, int N, int S, int E,
+                       int flags, void* stream);
+
 /* ---- fused three-layer heads (mlp3_fused.hip) -----------------------------------------------
  * Y[:, g*gs_y + 0..N3) = W3_g relu(W2_g relu(W1_g x + b1_g) + b2_g) + b3_g for `groups` equally shaped heads
  * with hidden width 64 whose parameters sit at constant element strides: the key / agents / action extractors
@@ -280,10 +296,13 @@ int marl_select_actions(const float* q, const float* avail, long avail_es, const
                         unsigned rseed, int env0, const int* tg, int tg0, int* act_out, long act_es,
                         int E, int N, int A, void* stream);
 /* Synthetic SMAC-shaped environment (stands in for StarCraft II, main.py:16-20).
- * Episode storage is (T+1)-slot: obs (E,T+1,N,O), state (E,T+1,S), avail (E,T+1,N,A). */
+ * Episode storage is (T+1)-slot: obs (E,T+1,N,O), state (E,T+1,state_ld >= S), avail (E,T+1,N,A).  state_ld is the
+ * row stride of the state storage in floats: a multiple of 4 keeps every state row 16-byte aligned for any S (MMM2:
+ * S = 322 -> 324), which the GEMM kernels downstream need for their vector loads; pad columns are written as zeros
+ * or left untouched (allocate them zeroed). */
 int marl_synth_lengths(unsigned seed, int env0, int episode, int* len, int* won, int E, int T, void* stream);
 int marl_synth_observe(unsigned seed, int env0, int episode, int t, const int* len, float* obs,
-                       float* state, float* avail, int E, int T, int N, int O, int S, int A, void* stream);
+                       float* state, long state_ld, float* avail, int E, int T, int N, int O, int S, int A, void* stream);
 /* reward / terminated / padded for step t given act (E,N) (rollout.py:86-96,122-133 for padding);
  * u (E,T,N) int32 gets the action or -1 on padding. alive_out[e] = (t+1 < len[e]) */
 int marl_synth_step(unsigned seed, int env0, int episode, int t, const int* len, const int* act,
@@ -293,8 +312,8 @@ int marl_synth_step(unsigned seed, int env0, int episode, int t, const int* len,
 /* select + step + observe(t+1) of the synthetic env in ONE launch per lock-step (same arithmetic as the
  * three calls above; q is the (E,N,A) output of the T=1 agent unroll). */
 int marl_synth_fused_step(unsigned seed, unsigned rseed, int env0, int episode, int t, float eps, const int* len,
-                          const float* q, float* obs, float* state, float* avail, int* u, float* r, float* term,
-                          float* padded, int E, int T, int N, int O, int S, int A, void* stream);
+                          const float* q, float* obs, float* state, long state_ld, float* avail, int* u, float* r,
+                          float* term, float* padded, int E, int T, int N, int O, int S, int A, void* stream);
 
 /* The WHOLE rollout of the synthetic env in one persistent launch (rollout_fused.hip): agent step,
  * epsilon-greedy choice, env step and next observation for all T lock-steps; weights and hidden state
@@ -302,7 +321,7 @@ int marl_synth_fused_step(unsigned seed, unsigned rseed, int env0, int episode, 
  * launch-per-step path.  Needs whole environments per workgroup: marl_synth_rollout_supported(). */
 int marl_synth_rollout_supported(int N, int O, int A);
 int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
-                       int fixed_len, const float* eps, float* obs, float* state, float* avail, int* u,
+                       int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                        float* r, float* term, float* padded, int* length, int* won, float* h_out,
                        int E, int T, int N, int O, int S, int A, int last_action, int reuse_network,
                        void* stream);

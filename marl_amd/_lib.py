@@ -87,6 +87,10 @@ SIGNATURES = {
     "marl_qmix_fused_workspace": (SZ, [L, I, I]),
     "marl_qmix_fused_fwd": (I, [QW, SRC, P, P, L, I, I, I, P]),
     "marl_qmix_fused_bwd": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, P]),
+    "marl_qmix_wide_supported": (I, [I, I, I]),
+    "marl_qmix_wide_workspace": (SZ, [L, I, I, I]),
+    "marl_qmix_wide_fwd": (I, [QW, SRC, P, P, P, SZ, L, I, I, I, I, P]),
+    "marl_qmix_wide_bwd": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, I, P]),
     "marl_mlp3_supported": (I, [SRC, I, I, I, I, I]),
     "marl_mlp3_fwd": (I, [M3, SRC, P, L, L, L, I, I, I, P]),
     "marl_mlp3_bwd_workspace": (SZ, [L, I, I, I]),
@@ -107,11 +111,11 @@ SIGNATURES = {
     "marl_adam_step": (I, [P, P, P, P, L, F, F, F, F, F, F, F, P, P, P]),
     "marl_select_actions": (I, [P, P, L, P, F, U, I, P, I, P, L, I, I, I, P]),
     "marl_synth_lengths": (I, [U, I, I, P, P, I, I, P]),
-    "marl_synth_observe": (I, [U, I, I, I, P, P, P, P, I, I, I, I, I, I, P]),
+    "marl_synth_observe": (I, [U, I, I, I, P, P, P, L, P, I, I, I, I, I, I, P]),
     "marl_synth_step": (I, [U, I, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
-    "marl_synth_fused_step": (I, [U, U, I, I, I, F, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "marl_synth_fused_step": (I, [U, U, I, I, I, F, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, I, P]),
     "marl_synth_rollout_supported": (I, [I, I, I]),
-    "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "marl_hip_version": (C.c_char_p, []),
 }
 

@@ -54,13 +54,13 @@ __global__ void synth_lengths_kernel(unsigned seed, int env0, int episode, int* 
 // one block row per env slot; slot t of the (T+1)-slot storage.  Slots past the episode end are zero
 // (rollout.py:122-133); slot len[e] is the final observation (o_next of the last step).
 __global__ void synth_observe_kernel(unsigned seed, int env0, int episode, int t, const int* len, float* obs,
-                                     float* state, float* avail, int E, int T, int N, int O, int S, int A) {
+                                     float* state, long SL, float* avail, int E, int T, int N, int O, int S, int A) {
   const int e = blockIdx.x;
   const bool live = t <= len[e];
   const unsigned env = (unsigned)(env0 + e), tg = (unsigned)(episode * (T + 1) + t);
   float* o = obs + ((long)e * (T + 1) + t) * N * O;
   for (int i = threadIdx.x; i < N * O; i += TPB) o[i] = live ? 2.0f * u01(hkey(seed, ST_OBS, env, tg, (unsigned)i)) - 1.0f : 0.f;
-  float* s = state + ((long)e * (T + 1) + t) * S;
+  float* s = state + ((long)e * (T + 1) + t) * SL;       // SL = row stride of the state storage (>= S)
   for (int i = threadIdx.x; i < S; i += TPB) s[i] = live ? 2.0f * u01(hkey(seed, ST_STATE, env, tg, (unsigned)i)) - 1.0f : 0.f;
   float* a = avail + ((long)e * (T + 1) + t) * N * A;
   for (int i = threadIdx.x; i < N * A; i += TPB) {
@@ -91,9 +91,9 @@ __global__ void synth_step_kernel(unsigned seed, int env0, int episode, int t, c
 // One launch per lock-step for the synthetic env: epsilon-greedy choice (same rule as select_kernel),
 // env step (reward / terminated / padded / u) and the observation of slot t+1.  One block per env.
 __global__ void synth_fused_step_kernel(unsigned seed, unsigned rseed, int env0, int episode, int t, float eps,
-                                        const int* len, const float* q, float* obs, float* state, float* avail,
-                                        int* u, float* r, float* term, float* padded, int E, int T, int N, int O,
-                                        int S, int A) {
+                                        const int* len, const float* q, float* obs, float* state, long SL,
+                                        float* avail, int* u, float* r, float* term, float* padded, int E, int T, int N,
+                                        int O, int S, int A) {
   __shared__ int act[64];
   const int e = blockIdx.x;
   const int L = len[e];
@@ -142,7 +142,7 @@ __global__ void synth_fused_step_kernel(unsigned seed, unsigned rseed, int env0,
   const unsigned tg1 = tg + 1u;
   float* o = obs + ((long)e * (T + 1) + t1) * N * O;
   for (int i = threadIdx.x; i < N * O; i += TPB) o[i] = live1 ? 2.0f * u01(hkey(seed, ST_OBS, env, tg1, (unsigned)i)) - 1.0f : 0.f;
-  float* sp = state + ((long)e * (T + 1) + t1) * S;
+  float* sp = state + ((long)e * (T + 1) + t1) * SL;
   for (int i = threadIdx.x; i < S; i += TPB) sp[i] = live1 ? 2.0f * u01(hkey(seed, ST_STATE, env, tg1, (unsigned)i)) - 1.0f : 0.f;
   float* ap = avail + ((long)e * (T + 1) + t1) * N * A;
   for (int i = threadIdx.x; i < N * A; i += TPB) {
@@ -154,13 +154,13 @@ __global__ void synth_fused_step_kernel(unsigned seed, unsigned rseed, int env0,
 }  // namespace
 
 extern "C" int marl_synth_fused_step(unsigned seed, unsigned rseed, int env0, int episode, int t, float eps,
-                                     const int* len, const float* q, float* obs, float* state, float* avail, int* u,
-                                     float* r, float* term, float* padded, int E, int T, int N, int O, int S, int A,
-                                     void* stream) {
+                                     const int* len, const float* q, float* obs, float* state, long state_ld,
+                                     float* avail, int* u, float* r, float* term, float* padded, int E, int T, int N,
+                                     int O, int S, int A, void* stream) {
   if (E <= 0) return 0;
-  if (N > 64) return (int)hipErrorInvalidValue;
+  if (N > 64 || state_ld < S) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(synth_fused_step_kernel, dim3(E), dim3(TPB), 0, (hipStream_t)stream, seed, rseed, env0, episode,
-                     t, eps, len, q, obs, state, avail, u, r, term, padded, E, T, N, O, S, A);
+                     t, eps, len, q, obs, state, state_ld, avail, u, r, term, padded, E, T, N, O, S, A);
   MARL_CHECK_LAUNCH();
   return 0;
 }
@@ -186,11 +186,12 @@ extern "C" int marl_synth_lengths(unsigned seed, int env0, int episode, int* len
 }
 
 extern "C" int marl_synth_observe(unsigned seed, int env0, int episode, int t, const int* len, float* obs,
-                                  float* state, float* avail, int E, int T, int N, int O, int S, int A,
+                                  float* state, long state_ld, float* avail, int E, int T, int N, int O, int S, int A,
                                   void* stream) {
   if (E <= 0) return 0;
+  if (state_ld < S) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(synth_observe_kernel, dim3(E), dim3(TPB), 0, (hipStream_t)stream, seed, env0, episode, t, len,
-                     obs, state, avail, E, T, N, O, S, A);
+                     obs, state, state_ld, avail, E, T, N, O, S, A);
   MARL_CHECK_LAUNCH();
   return 0;
 }

@@ -37,7 +37,8 @@ __device__ __forceinline__ float group_max16(float v) {
 struct RollArgs {
   const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;
   const float* eps;       // [T] epsilon of each lock-step (device)
-  float *obs, *state, *avail;   // (E,T+1,N,O) (E,T+1,S) (E,T+1,N,A)
+  float *obs, *state, *avail;   // (E,T+1,N,O) (E,T+1,SL >= S) (E,T+1,N,A)
+  long SL;                // row stride of the state storage (a multiple of 4 gives 16-byte state rows for any S)
   int* u;                 // (E,T,N)
   float *r, *term, *padded;     // (E,T)
   int *length, *won;      // (E)
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     rmeta[r] = make_int4(bn * O, bn * A, elen[el], n);
   }
   for (int el = tid; el < nenv_wg; el += RNT)
-    emeta[el] = make_int4((b0 + el) * (T + 1) * S, elen[el], b0 + el < a.E ? 1 : 0, 0);
+    emeta[el] = make_int4((b0 + el) * (T + 1) * (int)a.SL, elen[el], b0 + el < a.E ? 1 : 0, 0);
 
   // ---- environment observation of slot t -> record (+ LDS input tile / availability when wanted)
   // prefixes of slot t (3 of the 4 hash rounds depend only on (stream, env, t)): one thread per row
@@ -122,14 +123,14 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   // Flattened over the slot's elements: every thread handles independent (row, column group) items - the row
   // lookup is one 16-byte LDS read of the metadata table, so nothing serialises on per-row dependent chains and
   // the stores are 16 bytes per lane (the row-per-wave form of this took 30-55 % of a lock-step).
-  const int O4 = O >> 2, S4 = S >> 2;
+  const int O4 = O >> 2, S4 = (S + 3) >> 2;           // the last state group may run into the row padding (zeros)
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1), invO = 1.0f / (float)O, invA = 1.0f / (float)A;
   const float invS4 = 1.0f / (float)(S4 > 0 ? S4 : 1), invS = 1.0f / (float)S;
-  const bool ovec = (O & 3) == 0, svec = (S & 3) == 0;
+  const bool ovec = (O & 3) == 0, svec = (a.SL & 3) == 0 && a.SL >= 4 * S4 && (reinterpret_cast<uintptr_t>(a.state) & 15) == 0;
   auto gen_slot = [&](int t, bool to_lds, float* Av, int first, int nthr) {
     if (tid < first || tid >= first + nthr) return;
     const int tl = tid - first;
-    const int tNO = t * N * O, tNA = t * N * A, tS = t * S;
+    const int tNO = t * N * O, tNA = t * N * A, tS = t * (int)a.SL;
     if (ovec) {
       for (int e = tl; e < vrows * O4; e += nthr) {
         const int r = (int)(((float)e + 0.5f) * invO4);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
           const bool live = t <= mt.y;
           f32x4 v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = live ? 2.0f * u01(hfin(ps, (unsigned)(k + i))) - 1.0f : 0.f;
+          for (int i = 0; i < 4; ++i) v[i] = (live && k + i < S) ? 2.0f * u01(hfin(ps, (unsigned)(k + i))) - 1.0f : 0.f;
           *reinterpret_cast<f32x4*>(a.state + (long)mt.x + tS + k) = v;
         }
       }
@@ -467,16 +468,16 @@ extern "C" int marl_synth_rollout_supported(int N, int O, int A) {
 }
 
 extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
-                                  int fixed_len, const float* eps, float* obs, float* state, float* avail, int* u,
+                                  int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                                   float* r, float* term, float* padded, int* length, int* won, float* h_out,
                                   int E, int T, int N, int O, int S, int A, int last_action, int reuse_network,
                                   void* stream) {
   if (E <= 0 || T <= 0) return 0;
-  if (w->H != H || A > 32 || A < 1) return (int)hipErrorInvalidValue;
+  if (w->H != H || A > 32 || A < 1 || state_ld < S) return (int)hipErrorInvalidValue;
   RollArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
-  a.eps = eps; a.obs = obs; a.state = state; a.avail = avail; a.u = u; a.r = r; a.term = term; a.padded = padded;
+  a.eps = eps; a.obs = obs; a.state = state; a.SL = state_ld; a.avail = avail; a.u = u; a.r = r; a.term = term; a.padded = padded;
   a.length = length; a.won = won; a.h_out = h_out;
   a.seed = seed; a.rseed = rseed; a.env0 = env0; a.episode = episode; a.fixed_len = fixed_len;
   a.E = E; a.T = T; a.N = N; a.O = O; a.S = S; a.A = A;
@@ -490,7 +491,7 @@ extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, 
   // environments per workgroup: one workgroup per CU when the batch allows it (a lock-step is latency
   // bound, so small batches spread over all CUs with partly filled tiles), capped by the LDS budget
   // record offsets are 32-bit element offsets inside the kernel
-  if ((double)E * (T + 1) * N * (O > A ? O : A) >= 2147483648.0 || (double)E * (T + 1) * S >= 2147483648.0)
+  if ((double)E * (T + 1) * N * (O > A ? O : A) >= 2147483648.0 || (double)E * (T + 1) * state_ld >= 2147483648.0)
     return (int)hipErrorInvalidValue;
   const int rt_max = max_rt(a.I, A);
   if (16 * rt_max < N) return (int)hipErrorInvalidValue;

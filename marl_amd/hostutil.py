@@ -139,8 +139,17 @@ class DeviceBatch:
         o, o_next = cut("o"), cut("o_next")
         self.o_cur = (o, T * N, 0)
         self.o_next = (o_next, T * N, 0)
-        self.s = cut("s").view(B * T, S)
-        self.s_next = cut("s_next").view(B * T, S)
+        def rows16(x):
+            """(B*T, S) view whose rows start on 16-byte boundaries (row stride rounded up to 4 floats, zero pad): the
+            fused mixer kernels take their vector-load paths for any S (MMM2: 322)"""
+            x = x.view(B * T, S)
+            if S % 4 == 0:
+                return x
+            buf = torch.zeros(B * T, (S + 3) // 4 * 4, dtype=x.dtype, device=x.device)
+            buf[:, :S] = x
+            return buf[:, :S]
+        self.s = rows16(cut("s"))
+        self.s_next = rows16(cut("s_next"))
         self.u_act = cut("u", torch.int32).view(B, T, N)
         if "u_idx" in batch:
             self.u_fed = cut("u_idx", torch.int32).view(B, T, N)
@@ -201,7 +210,7 @@ class DeviceBatch:
         self.o_cur = (big.obs, (Ta + 1) * N, 0)
         self.o_next = (big.obs, (Ta + 1) * N, 1)
         self.ep_len = rec.length
-        st2 = big.state.view(big.E * (Ta + 1), S)
+        st2 = big.state_store.view(big.E * (Ta + 1), -1)[:, :S]      # row stride padded to 16 bytes (EpisodeRecord)
         self.s = ops.Rows(st2, (T, Ta + 1, 0), self.o_map)
         self.s_next = ops.Rows(st2, (T, Ta + 1, 1), self.o_map)
         self.u_fed = rec.u

@@ -112,6 +112,15 @@ class QMixMixer(_Precision, nn.Module):
                 and ops.qmix_fused_supported(a.n_agents, a.state_shape, a.qmix_hidden_dim)
                 and xs.ld0 % 4 == 0 and (xs.p0 or 0) % 16 == 0 and not (xs.k1 or xs.nhot or xs.nid or xs.m0))
 
+    def _wide_ok(self, xs):
+        """wide-state path (csrc/qmix_wide.hip): weights streamed from L2, fp32 or bf16 operands (args.mixer_dtype)"""
+        a = self.args
+        S = a.state_shape
+        return (not a.two_hyper_layers and not getattr(self, "no_fused", False)
+                and ops.qmix_wide_supported(a.n_agents, S, a.qmix_hidden_dim)
+                and xs.ld0 % 4 == 0 and xs.ld0 >= (S + 3) // 4 * 4 and (xs.p0 or 0) % 16 == 0
+                and not (xs.k1 or xs.nhot or xs.nid or xs.m0))
+
     def _fused_tensors(self, grad=False):
         b20, b22 = _linears(self.hyper_b2)
         pick = (lambda p: p.grad) if grad else (lambda p: p.data)
@@ -153,6 +162,13 @@ class QMixMixer(_Precision, nn.Module):
             if ctx is not None:
                 ctx.update(q=q, s=s, fused=True)
             return qtot
+        if self._wide_ok(xs):
+            # wide states (MMM2): same fusion with the 416 x 322 hypernet streamed from L2; bf16 operands on request
+            qtot = self._s.get("qtot" + tag, (rows,), dev)
+            ops.qmix_wide_fwd(self._fused_struct(), xs, q, qtot, rows, N, a.state_shape, E, bf16=self._bf16())
+            if ctx is not None:
+                ctx.update(q=q, s=s, wide=True)
+            return qtot
         wid = N * E + 3 * E
         hy = self._s.get("hy" + tag, (rows, wid), dev)
         b2 = self._s.get("b2" + tag, (rows, 1), dev)
@@ -187,6 +203,12 @@ class QMixMixer(_Precision, nn.Module):
             dq = self._s.get("dq", (rows, N), q.device)
             ops.qmix_fused_bwd(self._fused_struct(), ops.src(s), q, dq_tot, dq,
                                self._fused_struct(grad=True), rows, N, a.state_shape, E)
+            return dq
+        if ctx.get("wide"):
+            q, s = ctx["q"], ctx["s"]
+            dq = self._s.get("dq", (rows, N), q.device)
+            ops.qmix_wide_bwd(self._fused_struct(), ops.src(s), q, dq_tot, dq, self._fused_struct(grad=True), rows, N,
+                              a.state_shape, E, bf16=self._bf16())
             return dq
         hy, q, s = ctx["hy"], ctx["q"], ctx["s"]
         dev = q.device

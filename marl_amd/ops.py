@@ -311,7 +311,7 @@ def synth_lengths(seed, env0, episode, length, won, E, T):
 
 def synth_observe(seed, env0, episode, t, length, obs, state, avail, E, T, N, O, S, A):
     check(_lib.load().marl_synth_observe(int(seed) & 0xFFFFFFFF, env0, episode, t, _p(_i32(length)), _p(_f32(obs)),
-                                         _p(_f32(state)), _p(_f32(avail)), E, T, N, O, S, A, _stream()),
+                                         _p(_f32(state)), state.stride(-2), _p(_f32(avail)), E, T, N, O, S, A, _stream()),
           "marl_synth_observe")
 
 
@@ -323,7 +323,8 @@ def synth_step(seed, env0, episode, t, length, act, u, r, term, padded, alive_ne
 
 def synth_fused_step(seed, rseed, env0, episode, t, eps, length, q, obs, state, avail, u, r, term, padded, E, T, N, O, S, A):
     check(_lib.load().marl_synth_fused_step(int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode, t, float(eps),
-                                            _p(_i32(length)), _p(_f32(q)), _p(_f32(obs)), _p(_f32(state)), _p(_f32(avail)),
+                                            _p(_i32(length)), _p(_f32(q)), _p(_f32(obs)), _p(_f32(state)), state.stride(-2),
+                                            _p(_f32(avail)),
                                             _p(_i32(u)), _p(_f32(r)), _p(_f32(term)), _p(_f32(padded)), E, T, N, O, S, A,
                                             _stream()), "marl_synth_fused_step")
 
@@ -335,7 +336,7 @@ def synth_rollout_supported(N, O, A):
 def synth_rollout(w, seed, rseed, env0, episode, fixed_len, eps, rec, h_out, E, T, N, O, S, A, last_action, reuse_network):
     check(_lib.load().marl_synth_rollout(C.byref(w), int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode,
                                          1 if fixed_len else 0, _p(_f32(eps)), _p(_f32(rec.obs)), _p(_f32(rec.state)),
-                                         _p(_f32(rec.avail)), _p(_i32(rec.u)), _p(_f32(rec.r)), _p(_f32(rec.term)),
+                                         rec.state.stride(-2), _p(_f32(rec.avail)), _p(_i32(rec.u)), _p(_f32(rec.r)), _p(_f32(rec.term)),
                                          _p(_f32(rec.padded)), _p(_i32(rec.length)), _p(_i32(rec.won)), _p(h_out),
                                          E, T, N, O, S, A, 1 if last_action else 0, 1 if reuse_network else 0, _stream()),
           "marl_synth_rollout")
@@ -366,6 +367,24 @@ def qmix_fused_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E):
     ws = WS.get("qmix_fused", lib.marl_qmix_fused_workspace(rows, N, S), q.device)
     check(lib.marl_qmix_fused_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads),
                                   _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_bwd")
+
+
+def qmix_wide_supported(N, S, E):
+    return bool(_lib.load().marl_qmix_wide_supported(N, S, E))
+
+
+def qmix_wide_fwd(w, s, q, q_tot, rows, N, S, E, bf16=False):
+    lib = _lib.load()
+    ws = WS.get("qmix_wide", lib.marl_qmix_wide_workspace(rows, N, S, 0), q.device)
+    check(lib.marl_qmix_wide_fwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot)), _p(ws), ws.numel() * 4, rows, N, S, E,
+                                 1 if bf16 else 0, _stream()), "marl_qmix_wide_fwd")
+
+
+def qmix_wide_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E, bf16=False):
+    lib = _lib.load()
+    ws = WS.get("qmix_wide", lib.marl_qmix_wide_workspace(rows, N, S, 1), q.device)
+    check(lib.marl_qmix_wide_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads), _p(ws),
+                                 ws.numel() * 4, rows, N, S, E, 1 if bf16 else 0, _stream()), "marl_qmix_wide_bwd")
 
 
 def _uniform_stride(ts):

@@ -779,3 +779,73 @@ def test_qtran_fused_heads(dev, kind, BT, N, A, S):
     else:
         pub = mod(s.view(1, BT, S), h.detach().view(1, BT, N, 64))
     close(pub.view(-1), out_ref, 2e-5, 1e-4, msg="public forward")
+
+
+def _qmix_reference(P, s, q, gq, N, E, bf16):
+    """QMixMixer.forward (reference network/mixer.py:57-80) on torch-CPU; bf16 = True rounds BOTH operands of the four
+    state-conditioned hypernet GEMMs to bf16 (fp32 accumulation), which is what the bf16 matrix-core path computes"""
+    rnd = (lambda t: t.bfloat16().float()) if bf16 else (lambda t: t)
+    R = s.shape[0]
+    lin = lambda k: F.linear(rnd(s), rnd(P[k]), P[k + "_b"])
+    w1 = lin("w1").abs().view(R, N, E)
+    hid = F.elu((q.unsqueeze(2) * w1).sum(1) + lin("b1"))
+    qt = (hid * lin("w2").abs()).sum(1) + F.linear(torch.relu(lin("h")), P["b2_w"], P["b2_b"]).squeeze(1)
+    (qt * gq).sum().backward()
+    return qt
+
+
+@pytest.mark.parametrize("R,N,S,bf16", [(333, 10, 322, False), (64, 10, 322, False), (5000, 10, 322, False), (100, 3, 50, False),
+                                         (1000, 5, 120, False), (333, 10, 322, True), (5000, 10, 322, True), (130, 4, 352, True)])
+def test_qmix_wide(dev, R, N, S, bf16):
+    """wide-state fused QMIX (csrc/qmix_wide.hip: streamed hypernet weights, d(hypernet output) + tall-skinny weight
+    gradient GEMM) vs torch-CPU autograd.  fp32: 1e-4.  bf16: the reference is torch-CPU with the hypernet operands
+    rounded to bf16 - an EXTERNAL reference for the reduced-precision mode, so the tolerance stays tight (products of
+    bf16 values are exact in fp32; only the accumulation order differs); the weight gradient uses the unrounded states
+    (straight-through), compared at 2e-2 of its scale."""
+    from marl_amd import ops
+    E = 32
+    assert ops.qmix_wide_supported(N, S, E)
+    g = torch.Generator().manual_seed(R + N + S)
+    outs = {"w1": N * E, "b1": E, "w2": E, "h": E}
+    P = {}
+    for k in outs:
+        P[k] = (torch.randn(outs[k], S, generator=g) * 0.2).requires_grad_()
+        P[k + "_b"] = (torch.randn(outs[k], generator=g) * 0.2).requires_grad_()
+    P["b2_w"] = torch.randn(1, E, generator=g).requires_grad_()
+    P["b2_b"] = torch.randn(1, generator=g).requires_grad_()
+    s = torch.randn(R, S, generator=g)
+    q = torch.randn(R, N, generator=g, requires_grad=True)
+    gq = torch.randn(R, generator=g)
+    qt = _qmix_reference(P, s, q, gq, N, E, bf16)
+    Wd = {k: cu(v.detach(), dev) for k, v in P.items()}
+    base = {k: torch.randn(v.shape, generator=g) for k, v in P.items()}      # gradients accumulate
+    Gd = {k: cu(v, dev) for k, v in base.items()}
+    ld = (S + 3) // 4 * 4
+    sd = torch.zeros(R, ld, device=dev)
+    sd[:, :S] = cu(s, dev)
+    xs = ops.src(sd[:, :S])
+    out = torch.full((R,), 9.0, device=dev)
+    qd = cu(q.detach(), dev)
+    ops.qmix_wide_fwd(ops.qmix_weights(Wd), xs, qd, out, R, N, S, E, bf16=bf16)
+    scale_o = max(1.0, float(qt.detach().abs().max()))
+    close(out, qt, 1e-4 * scale_o, 1e-4, msg="q_tot")
+    dq = torch.full((R, N), 9.0, device=dev)
+    ops.qmix_wide_bwd(ops.qmix_weights(Wd), xs, qd, cu(gq, dev), dq, ops.qmix_weights(Gd), R, N, S, E, bf16=bf16)
+    close(dq, q.grad, 1e-4 * max(1.0, float(q.grad.abs().max())), 1e-4, msg="dq")
+    # |.| of the hypernet outputs w1 / w2 and relu of h have kinks at 0: where an output is within fp32 rounding of 0 the two
+    # summation orders may pick different one-sided derivatives (this seed has one: row 669, column 120: 6e-8).  Such
+    # (row, column) pairs change one row of that segment's weight gradient; those rows are excluded (at most 2 per case).
+    with torch.no_grad():
+        rnd = (lambda t: t.bfloat16().float()) if bf16 else (lambda t: t)
+        kink = {k: ((F.linear(rnd(s), rnd(P[k]), P[k + "_b"]).abs() < 2e-6).any(0)) for k in ("w1", "w2", "h")}
+    assert sum(int(v.sum()) for v in kink.values()) <= 2
+    for k, v in P.items():
+        want = v.grad
+        got = (Gd[k] - cu(base[k], dev)).cpu()
+        seg = k[:-2] if k.endswith("_b") else k
+        if seg in kink and kink[seg].any():
+            keep = ~kink[seg]
+            want, got = want[keep], got[keep]
+        sc = max(1.0, float(want.abs().max()))
+        tol = (2e-2 if bf16 and k in outs else 1e-4) * sc
+        close(got, want, tol, 1e-4 if not bf16 else 2e-2, msg=k)
