@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--leg-iters", type=int, default=5, help="iterations of the separately timed learner / rollout legs")
+    ap.add_argument("--roofline-kernel", default="unroll", choices=["unroll", "mixer"],
+                    help="kernel the roofline object describes: the agent unroll (fp32 MFMA bound; headline) or the fused "
+                         "wide-state QMIX forward (config 5: HBM bound on reading the states when --mixer-dtype bf16)")
     ap.add_argument("--dry", action="store_true", help="multi-GPU pre-flight only: init RCCL, one all-reduce of the real "
                     "gradient-buffer size, print the result and exit")
     o = ap.parse_args()
@@ -219,6 +222,19 @@ def main():
         else:
             orig_fwd(*a, **k)
     ops.agent_unroll_fwd = timed_fwd
+    mix_pairs = []
+    orig_wide = ops.qmix_wide_fwd
+
+    def timed_wide(*a, **k):
+        if timing["on"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_wide(*a, **k)
+            e1.record()
+            mix_pairs.append((e0, e1))
+        else:
+            orig_wide(*a, **k)
+    ops.qmix_wide_fwd = timed_wide
 
     train_steps = [0]
 
@@ -295,6 +311,26 @@ def main():
         ach = fl / (avg_ms * 1e-3) / 1e12 if avg_ms else None
         fpt = learner_flops_per_transition(args, o.alg)
         upd_tflops = fpt * (o.envs * T / t_learn) / 1e12
+        roof = {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
+                "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS if ach else None,
+                "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and avg_ms) else None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
+                "separate passes; %s)" % (os.path.relpath(pmc, ROOT) if pmc else "no PMC file for this workload"),
+                "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms), "flop_per_launch": fl}
+        if o.roofline_kernel == "mixer":
+            # fused wide-state QMIX forward: one launch reads every state row once (4 S bytes), the chosen Qs (4 N) and
+            # writes q_tot (4): algorithmic bytes = rows * (4 S + 4 N + 4), rows = envs per GPU * T (with bf16
+            # operands the hypernet GEMM sits below the bf16 ridge, i.e. it is bound by this read)
+            mix_ms = [a_.elapsed_time(b_) for a_, b_ in mix_pairs]
+            rows_l = E * T
+            byts = rows_l * (4 * args.state_shape + 4 * N + 4)
+            m_ms = float(np.mean(mix_ms)) if mix_ms else None
+            gbs = byts / (m_ms * 1e-3) / 1e9 if m_ms else None
+            flm = 2 * args.state_shape * (N * args.qmix_hidden_dim + 3 * args.qmix_hidden_dim) * rows_l
+            roof = {"bound": "hbm", "kernel": "qmix_wide_kernel forward (hypernet GEMM + mixing, %s operands)" % o.mixer_dtype,
+                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS if gbs else None,
+                    "traffic": None, "avg_launch_ms": m_ms, "launches_timed": len(mix_ms), "bytes_per_launch": byts,
+                    "flop_per_launch": flm, "tflops": flm / (m_ms * 1e-3) / 1e12 if m_ms else None}
         out = {
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
@@ -309,12 +345,7 @@ def main():
             "learner_transitions_per_sec": o.envs * T / t_learn,
             "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
             "last_loss": loss,
-            "roofline": {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
-                         "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS if ach else None,
-                         "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and avg_ms) else None,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                         "separate passes; %s)" % (os.path.relpath(pmc, ROOT) if pmc else "no PMC file for this workload"), "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
-                         "flop_per_launch": fl},
+            "roofline": roof,
             "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included)",
                                 "flop_per_transition": fpt, "achieved": upd_tflops, "peak": PEAK_F32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": upd_tflops / PEAK_F32_TFLOPS},

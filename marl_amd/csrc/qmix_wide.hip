@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
           for (int j = 0; j < NTW; ++j)
             if (kind[j] >= 0) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[j], acc[rt][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       };
       bf16x8_t wA[NTW], wB[NTW];
       wload(wA, 0);
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
           for (int j = 0; j < NTW; ++j)
             if (kind[j] >= 0) acc[rt][j] = mfma16x4(av, w[j], acc[rt][j]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       };
       f32x4 wA[NTW], wB[NTW];
       wload(wA, 0);
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
             else if (kind[j] == 3) HBA[r * E + 16 * eh[j] + m] = fmaxf(v, 0.f);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
             else v = o > 0.f ? Gs[r] * wb2c[j] : 0.f;
             if (row0 + r < a.rows) a.dhy[(row0 + r) * C + col] = v;
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       WG_BARRIER();                                      // (D2) both halves of every dq_n are in LDS
@@ -405,16 +409,18 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------- weight gradient
-// dW[c][k] = sum_rows dhy[row][c] s[row][k], db[c] = sum_rows dhy[row][c].  grid = (row slabs, 2 column groups).
+// dW[c][k] = sum_rows dhy[row][c] s[row][k], db[c] = sum_rows dhy[row][c].  grid = (row slabs, column groups of 7 tiles):
+// the groups of one row slab are gridDim.x blocks apart (a multiple of 8: same XCD), so the slab's state rows come from
+// HBM once and hit that XCD's L2 for the other groups.
 constexpr int WCH = 32;           // rows per staged chunk
-constexpr int WNT = 13;           // column tiles per group (2 groups cover C <= 416; checked on the host)
+constexpr int WNT = 7;            // column tiles per group: 7 x 3 accumulator tiles per wave (84 registers; 13 x 3 spilled)
 constexpr int WKT = 3;            // k tiles per wave (8 waves x 3 cover S <= 384)
 
 struct WideWgArgs {
   const float* dhy; ConcatSrc s; float* ws;      // slabs [nslab][C][Kx], Kx = 16 KT + 1 (bias in the last column)
   long rows; int S, C, KT, nslab;
 };
-__host__ __device__ inline int wg_gp() { return 16 * WNT + 32; }               // LDS pitch of the dhy chunk: = 16 (mod 32)
+__host__ __device__ inline int wg_gp() { return 16 * WNT + 32; }               // LDS pitch of the dhy chunk: 144 = 16 (mod 32)
 __host__ __device__ inline int wg_xp(int KT) { const int w = 16 * KT; return (w % 32 == 16) ? w : w + 16; }
 
 __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs a) {
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
   // staging items: dhy chunk 32 rows x 52 float4 (columns of this group), state chunk 32 rows x S4 float4
   constexpr int G4 = 4 * WNT;
   const int gi = WCH * G4, xi = WCH * S4;
-  constexpr int NG = (WCH * G4 + 64 * NW - 1) / (64 * NW);       // 4
+  constexpr int NG = (WCH * G4 + 64 * NW - 1) / (64 * NW);       // 2
   constexpr int NX = 6;                                          // covers S <= 384
   f32x4 pg[NG], px[NX];
   const float invS4 = 1.0f / (float)S4;
@@ -503,23 +509,35 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
     if (ch + 1 < nch) fetch(ch + 1);
     const float* G = Gb[b];
     const float* X = Xb[b];
-#pragma unroll
-    for (int st = 0; st < WCH / 4; ++st) {
+    // operands of step st+1 are read while step st multiplies (two named register sets, no copies)
+    auto ld = [&](float (&gv)[WNT], float (&xv)[WKT], int st) __attribute__((always_inline)) {
       const int row = 4 * st + q;                  // MFMA k index = lane quarter = one row of the chunk
-      float xv[WKT];
 #pragma unroll
       for (int k = 0; k < WKT; ++k) {
         const int kt = wave + NW * k;
         xv[k] = X[row * XP + 16 * (kt < a.KT ? kt : 0) + m];
       }
 #pragma unroll
+      for (int t = 0; t < WNT; ++t) gv[t] = G[row * GP + 16 * t + m];
+    };
+    auto mac = [&](const float (&gv)[WNT], const float (&xv)[WKT]) __attribute__((always_inline)) {
+#pragma unroll
       for (int t = 0; t < WNT; ++t) {
-        const float gv = G[row * GP + 16 * t + m];
-        if (wave == 0) bs[t] += gv;
+        if (wave == 0) bs[t] += gv[t];
 #pragma unroll
         for (int k = 0; k < WKT; ++k)
-          if (wave + NW * k < a.KT) acc[t][k] = mfma16(gv, xv[k], acc[t][k]);
+          if (wave + NW * k < a.KT) acc[t][k] = mfma16(gv[t], xv[k], acc[t][k]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    float gA[WNT], xA[WKT], gB[WNT], xB[WKT];
+    ld(gA, xA, 0);
+#pragma unroll 1
+    for (int st = 0; st < WCH / 4; st += 2) {
+      ld(gB, xB, st + 1);
+      mac(gA, xA);
+      ld(gA, xA, st + 2 < WCH / 4 ? st + 2 : st + 1);
+      mac(gB, xB);
     }
     if (ch + 1 < nch) stash(b ^ 1);
   }
@@ -584,7 +602,7 @@ __global__ __launch_bounds__(64 * RSG) void qmix_wide_reduce_kernel(WideRedArgs 
 
 inline bool supported(int N, int S, int Eq) {
   const int C = N * E + 3 * E;
-  return Eq == E && N >= 1 && N <= 16 && C <= 16 * NW * NTW && C <= 2 * 16 * WNT && S >= 4 && S <= 352;   // S: prefetch registers of the state tile
+  return Eq == E && N >= 1 && N <= 16 && C <= 16 * NW * NTW && N <= 10 && S >= 4 && S <= 352;   // S: prefetch registers of the state tile
 }
 inline ConcatSrc state_src(const marl_src_t* s) {
   ConcatSrc c;
@@ -606,8 +624,9 @@ inline size_t packed_floats(int N, int S) {                  // room for either 
   const int C = N * E + 3 * E, NCT = (C + 15) / 16;
   return (size_t)NCT * ((S + 15) / 16) * 256 + (size_t)((C + 3) / 4 * 4);
 }
-inline int wg_slabs(long rows) { long n = (rows + 8 * WCH - 1) / (8 * WCH); if (n > 128) n = 128; return (int)(n < 1 ? 1 : n); }
-inline int rt_of(bool bf) { return bf ? 4 : 2; }      // row tiles per block: the bf16 GEMM is ~16x shorter per row, so it needs
+inline int wg_groups(int C) { return ((C + 15) / 16 + WNT - 1) / WNT; }
+inline int wg_slabs(long rows) { long n = (rows + 8 * WCH - 1) / (8 * WCH); if (n > 64) n = 64; return (int)(n < 1 ? 1 : n); }
+inline int rt_of(bool bf) { (void)bf; return 2; }      // row tiles per block: the bf16 GEMM is ~16x shorter per row, so it needs
                                                       // bigger blocks to keep the L2 weight stream below the HBM state stream
 inline unsigned grid_for(long rows, int RB) {
   const long nblk = (rows + RB - 1) / RB;
@@ -667,7 +686,7 @@ extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t
   if (rc) return rc;
   a.s = state_src(s); a.q = q; a.q_tot = q_tot; a.rows = rows;
   const unsigned grid = grid_for(rows, 16 * rt_of(bf));
-  return bf ? launch_main(qmix_wide_kernel<false, true, 4>, a, grid, true, st)
+  return bf ? launch_main(qmix_wide_kernel<false, true, 2>, a, grid, true, st)
             : launch_main(qmix_wide_kernel<false, false, 2>, a, grid, false, st);
 }
 
@@ -689,7 +708,7 @@ extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t
   float* bslab = wslab + (size_t)nslab * C * (16 * KT + 1);
   a.s = state_src(s); a.q = q; a.g = dq_tot; a.dq = dq; a.dhy = dhy; a.slab = bslab; a.rows = rows;
   const unsigned grid = grid_for(rows, 16 * rt_of(bf));
-  rc = bf ? launch_main(qmix_wide_kernel<true, true, 4>, a, grid, true, st)
+  rc = bf ? launch_main(qmix_wide_kernel<true, true, 2>, a, grid, true, st)
           : launch_main(qmix_wide_kernel<true, false, 2>, a, grid, false, st);
   if (rc) return rc;
   WideWgArgs g;
@@ -697,7 +716,7 @@ extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t
   const size_t lds = (size_t)2 * WCH * (wg_gp() + wg_xp(KT)) * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)qmix_wide_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(qmix_wide_wgrad_kernel, dim3(nslab, 2), dim3(64 * NW), lds, st, g);
+  hipLaunchKernelGGL(qmix_wide_wgrad_kernel, dim3(nslab, wg_groups(C)), dim3(64 * NW), lds, st, g);
   MARL_CHECK_LAUNCH();
   WideRedArgs r;
   r.ws = wslab; r.slab2 = bslab; r.nslab = nslab; r.nwg = (int)grid; r.N = N; r.S = S; r.C = C; r.KT = KT;
