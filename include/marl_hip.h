@@ -178,7 +178,7 @@ int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const
  * flags & 1: bf16 operands for the hypernet GEMM (v_mfma_f32_16x16x32_bf16, fp32 accumulate; BASELINE config 5 "bf16
  * mixer with MFMA") - the forward kernel is then bound by reading the states from HBM; mixing arithmetic, gradients and
  * the weight-gradient GEMM stay fp32.  Workspace: packed weights (+ for backward: d(hypernet output) rows x (N*E+3E)
- * and the slabs).  Supported when marl_qmix_wide_supported(N, S, E) (E == 32, N <= 10, S <= 352). */
+ * and the slabs).  Supported when marl_qmix_wide_supported(N, S, E) (E == 32, N <= 10, S <= 384). */
 int marl_qmix_wide_supported(int N, int S, int E);
 size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward);
 int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot, float* ws,

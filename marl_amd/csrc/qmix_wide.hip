@@ -2,11 +2,10 @@
 //
 // qmix_fused.hip keeps the hypernet weights in registers, which stops at S <= 128 / 256 output columns; here the
 // concatenated hypernet [ w1 (N*E) | b1 (E) | w2 (E) | h = hyper_b2.0 (E) ] x S is 416 x 322 = 536 KB.  It is packed
-// once per call into MFMA-fragment order (1 KB per (column tile, k-chunk), L2 resident) and STREAMED: a workgroup owns
-// a block of RB = 64 (episode, step) rows - the state tile sits in LDS - and wave w owns column tiles w, w+8, w+16
-// (, w+24): per k-chunk it reads its own fragments straight from L2 (one chunk ahead, two named register sets) and
-// multiplies them into RB/16 row tiles, so every weight byte read from L2 feeds 64 rows.  The 416-wide hypernet
-// output never reaches HBM in the forward pass; the mixing arithmetic runs on the accumulators as in qmix_fused.hip.
+// once per call into MFMA-fragment order (1 KB per (column tile, k-chunk), L2 resident) and STREAMED through LDS: a
+// workgroup owns blocks of 128 (episode, step) rows, every wave one 16-row tile x ALL 26 column tiles (104 accumulator
+// registers), so every weight byte read from L2 feeds 128 rows and the mixing arithmetic of a row is wave local.  The
+// 416-wide hypernet output never reaches HBM in the forward pass.
 //   forward : q_tot = sum_e elu(sum_n q_n |w1[n,e]| + b1_e) |w2_e| + (relu(h) . w_b2 + b_b2)
 //   backward: recomputes the tile, forms d(hypernet output) in accumulator layout and writes it (rows x C) for the
 //             weight-gradient GEMM below; dq and the hyper_b2.2 gradients come out of the same pass.
@@ -24,8 +23,6 @@ namespace {
 
 constexpr int E = 32;
 constexpr int NW = 8;             // waves per workgroup
-constexpr int NTW = 4;            // column tiles per wave (upper bound: C <= 512)
-constexpr int RTMAX = 4;          // row tiles per block (upper bound; the kernel is instantiated for 2 and 4)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -104,300 +101,237 @@ __device__ __forceinline__ float sum16(float v) {
 }
 __device__ __forceinline__ float sum32(float v) { v = sum16(v); v += __shfl_xor(v, 16, 64); return v; }
 
-__host__ __device__ inline int ss_f32(int KC) { return 16 * KC + 4; }          // LDS row pitch of the fp32 state tile (floats)
-__host__ __device__ inline int ss_bf16(int KC) { return 32 * KC + 8; }         // ... of the bf16 tile (bf16 elements)
-__host__ __device__ inline size_t tile_bytes(int KC, bool bf, int RB) {
-  const size_t st = bf ? (size_t)RB * ss_bf16(KC) * 2 : (size_t)RB * ss_f32(KC) * 4;
-  const size_t pa = (size_t)NW * RB * E * 4;                                     // scratch overlaying the state tile
-  return st > pa ? st : pa;
-}
-__host__ __device__ inline size_t wide_lds(int KC, bool bf, int RB) {
-  // state tile / PA | W2A | HBA | DPRE | HID | Qs [RB][16] | DQH [RB][16][2] | Gs [RB] | red [NW][E + 1]
-  return tile_bytes(KC, bf, RB) + (size_t)(4 * RB * E + RB * 16 + RB * 32 + RB + NW * (E + 1)) * 4;
+constexpr int NCTM = 26;          // column tiles of the concatenated hypernet (N <= 10: 16 * 26 = 416 columns)
+constexpr int RB = 16 * NW;       // rows per block: one 16-row tile per wave
+
+__host__ __device__ inline size_t wide_lds(int NCT) {
+  // weight chunk x 2 [NCT][64] f32x4 | Qs [RB][16] | Gs [RB] | red [NW][E + 1]
+  return (size_t)(2 * NCT * 256 + RB * 16 + RB + NW * (E + 1)) * 4;
 }
 
-template <bool BWD, bool BF, int RT>
+// One GEMM-shaped kernel: a workgroup walks blocks of 128 (episode, step) rows; wave w owns rows [16w, 16w + 16) of the
+// block and ALL column tiles (<= 26 accumulator tiles = 104 registers), so the whole mixing arithmetic of a row - the sums
+// over agents and over the 32 embedding units - stays inside one wave: no LDS scratch and no barrier in the epilogue.
+// Per k-chunk the packed weight fragments of all tiles (26 KB) are staged once per workgroup into LDS (double buffered,
+// one barrier per chunk; next chunk's fragments in flight in registers) and read by every wave; the state operand goes
+// straight from HBM to registers (each wave reads only its own 16 rows; one chunk ahead).
+// NCTT: compile-time number of column tiles (26 = MMM2's 10 agents: no per-tile branches, tile roles known statically) or
+// 0 = read it from the arguments.
+template <bool BWD, bool BF, int NCTT>
 __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
-  constexpr int RB = 16 * RT;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q4 = lane >> 4, m = lane & 15;
-  const int N = a.N, S = a.S, C = a.C, NE = N * E, KC = a.KC;
-  float* St = reinterpret_cast<float*>(smem_raw);                       // fp32 state tile [RB][SSF]
-  __bf16* Sb = reinterpret_cast<__bf16*>(smem_raw);                     // bf16 state tile [RB][SSB]
-  float* PA = reinterpret_cast<float*>(smem_raw);                       // [NW][RB][E]  (after the GEMM)
-  float* W2A = reinterpret_cast<float*>(smem_raw + tile_bytes(KC, BF, RB)); // [RB][E] |w2|
-  float* HBA = W2A + RB * E;                                            // [RB][E] relu(h)
-  float* DPRE = HBA + RB * E;                                           // [RB][E] dL/da_e
-  float* HID = DPRE + RB * E;                                           // [RB][E] elu(a_e)
-  float* Qs = HID + RB * E;                                             // [RB][16]
-  float* DQH = Qs + RB * 16;                                            // [RB][16][2] halves of dq
-  float* Gs = DQH + RB * 32;                                            // [RB]
+  const int S = a.S, C = a.C, KC = a.KC;
+  const int NCT = NCTT > 0 ? NCTT : a.NCT;
+  const int N = NCTT > 0 ? (NCTT - 6) / 2 : a.N;
+  float* Wl[2] = {smem, smem + NCT * 256};                              // [NCT][64] f32x4 (fp32) / 8 x bf16
+  float* Qs = smem + 2 * NCT * 256;                                     // [RB][16]
+  float* Gs = Qs + RB * 16;                                             // [RB]
   float* red = Gs + RB;                                                 // [NW][E + 1]
-  const int SSF = ss_f32(KC), SSB = ss_bf16(KC);
-
-  // ---- this wave's column tiles: ct = wave + 8 j
-  int kind[NTW], nn[NTW], eh[NTW];
-  float bias[NTW], wb2c[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int ct = wave + NW * j, col0 = 16 * ct;
-    int k = -1;
-    if (ct < a.NCT) {
-      if (col0 < NE) k = 0;
-      else if (col0 < NE + E) k = 1;
-      else if (col0 < NE + 2 * E) k = 2;
-      else if (col0 < C) k = 3;
-    }
-    kind[j] = k; nn[j] = k == 0 ? col0 / E : 0; eh[j] = ct & 1;
-    bias[j] = k >= 0 ? a.Bc[col0 + m] : 0.f;
-    wb2c[j] = a.wb2[16 * eh[j] + m];
-  }
-  const float wb2_l = a.wb2[lane & 31];
+  const f32x4* Wp4 = reinterpret_cast<const f32x4*>(a.Wp);              // 16 bytes per (tile, chunk, lane) in both modes
+  const int witems = NCT * 64;
+  const int S4x4 = ((S + 3) >> 2) * 4;                                  // readable floats of a state row
+  const float wb2lo = a.wb2[m], wb2hi = a.wb2[16 + m];
   const float bb2 = a.bb2[0];
-  float acc_wb2 = 0.f, acc_bb2 = 0.f;
-
-  // ---- state block staging: thread -> (row, float4 column) items over the WHOLE row pitch of the LDS tile: columns below
-  // S come from HBM (one block ahead, in registers), the k-padding columns are rewritten as zeros with every block (the
-  // epilogue scratch overlays the tile).  Rows past the end of the batch are clamped to the last row.
-  const int S4 = (S + 3) >> 2;
-  const int W4 = (BF ? SSB : SSF) >> 2;      // float4 groups per tile row
-  const int items = RB * W4;
-  constexpr int NPF = 3 * RT;                // prefetch registers (float4) per thread: covers S <= 384
-  f32x4 pf[NPF];
-  const float invW4 = 1.0f / (float)W4;
+  float acc_wb2[2] = {0.f, 0.f}, acc_bb2 = 0.f;
   const long nblk = (a.rows + RB - 1) / RB;
-  auto fetch = [&](long blk) {
+
+  f32x4 wpf[4];                                                         // this thread's share of the next weight chunk
+  auto wfetch = [&](int kc) {
 #pragma unroll
-    for (int i = 0; i < NPF; ++i) {
+    for (int i = 0; i < 4; ++i) {
       int e = tid + 64 * NW * i;
-      if (e > items - 1) e = items - 1;
-      const int r = (int)(((float)e + 0.5f) * invW4);
-      int g4 = e - r * W4;
-      if (g4 > S4 - 1) g4 = S4 - 1;                        // pad groups re-read the last real one (value unused)
-      long row = blk * RB + r;
-      if (row > a.rows - 1) row = a.rows - 1;
-      const ConcatRow cr = concat_row(a.s, row);
-      pf[i] = *reinterpret_cast<const f32x4*>(a.s.p0 + cr.r0 * a.s.ld0 + 4 * g4);   // rows are padded to 16 bytes (host check)
+      if (e > witems - 1) e = witems - 1;
+      wpf[i] = Wp4[((long)(e >> 6) * KC + kc) * 64 + (e & 63)];
     }
   };
-  auto stash = [&]() {
+  auto wstash = [&](int b) {
 #pragma unroll
-    for (int i = 0; i < NPF; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int e = tid + 64 * NW * i;
-      if (e < items) {
-        const int r = (int)(((float)e + 0.5f) * invW4);
-        const int c4 = (e - r * W4) * 4;
-        f32x4 v = pf[i];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) if (c4 + cc >= S) v[cc] = 0.f;      // row padding and k padding
-        if (BF) {
-          const bf16x4_t b = __builtin_convertvector(v, bf16x4_t);
-          *reinterpret_cast<bf16x4_t*>(Sb + r * SSB + c4) = b;
-        } else {
-          *reinterpret_cast<f32x4*>(St + r * SSF + c4) = v;
-        }
-      }
+      if (e < witems) *reinterpret_cast<f32x4*>(Wl[b] + e * 4) = wpf[i];
     }
-  };
-  // q / g of the block: thread -> up to two q elements, threads 0..RB-1 one g element
-  float pq[2] = {0.f, 0.f}, pg = 0.f;
-  auto fetch_qg = [&](long blk) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + 64 * NW * i;
-      pq[i] = 0.f;
-      if (e < RB * N) {
-        const long row = blk * RB + e / N;
-        if (row < a.rows) pq[i] = a.q[row * N + e % N];
-      }
-    }
-    if (BWD) {
-      pg = 0.f;
-      const long row = blk * RB + tid;
-      if (tid < RB && row < a.rows) pg = a.g[row];
-    }
-  };
-  auto stash_qg = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + 64 * NW * i;
-      if (e < RB * N) Qs[(e / N) * 16 + e % N] = pq[i];
-    }
-    if (BWD && tid < RB) Gs[tid] = pg;
   };
 
-  long blk = blockIdx.x;
-  if (blk < nblk) { fetch(blk); fetch_qg(blk); stash(); stash_qg(); }
-
-  for (; blk < nblk; blk += gridDim.x) {
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const long row0 = blk * RB;
-    WG_BARRIER();                                        // (A) state tile, Qs, Gs of this block are in LDS
-    const long nb = blk + gridDim.x;
-    if (nb < nblk) { fetch(nb); fetch_qg(nb); }           // next block's loads fly during the GEMM
-    // ---- hypernet GEMM: acc[rt][j] = out[rows 16rt + 4q + i][cols 16ct_j + m]
-    f32x4 acc[RT][NTW];
+    const long rowm = row0 + 16 * wave + m;                             // the row this lane feeds as A operand
+    const long rowc = rowm < a.rows ? rowm : a.rows - 1;
+    const ConcatRow cr = concat_row(a.s, rowc);
+    const float* srow = a.s.p0 + cr.r0 * a.s.ld0;
+    // state fragments of chunk kc: fp32 4 floats at 16 kc + 4 q, bf16 8 floats at 32 kc + 8 q (zero past the row)
+    auto aload = [&](f32x4 (&v)[2], int kc) __attribute__((always_inline)) {
+      if (BF) {
+        const int k0 = 32 * kc + 8 * q4;
+        v[0] = k0 < S4x4 ? *reinterpret_cast<const f32x4*>(srow + k0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        v[1] = k0 + 4 < S4x4 ? *reinterpret_cast<const f32x4*>(srow + k0 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int k0 = 16 * kc + 4 * q4;
+        v[0] = k0 < S4x4 ? *reinterpret_cast<const f32x4*>(srow + k0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    // the block's q / g tiles (read in the epilogue, after at least one barrier of the chunk loop)
+    for (int e = tid; e < RB * N; e += 64 * NW) {
+      const long row = row0 + e / N;
+      Qs[(e / N) * 16 + e % N] = row < a.rows ? a.q[row * N + e % N] : 0.f;
+    }
+    if (BWD && tid < RB) Gs[tid] = row0 + tid < a.rows ? a.g[row0 + tid] : 0.f;
+
+    f32x4 acc[NCTM];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int ct = 0; ct < NCTM; ++ct) {
+      const float bv = ct < NCT ? a.Bc[16 * ct + m] : 0.f;
+      acc[ct] = (f32x4){bv, bv, bv, bv};
+    }
+    f32x4 aA[2], aB[2];
+    wfetch(0);
+    aload(aA, 0);
+    wstash(0);
+    if (KC > 1) wfetch(1);
+    auto mac = [&](const f32x4 (&av)[2], int b) __attribute__((always_inline)) {
+      const float* wl = Wl[b] + lane * 4;
+      if (BF) {
+        bf16x8_t a8;
+        const bf16x4_t lo = __builtin_convertvector(av[0], bf16x4_t), hi = __builtin_convertvector(av[1], bf16x4_t);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[rt][j] = (f32x4){bias[j], bias[j], bias[j], bias[j]};
-    if (BF) {
-      const bf16x8_t* Wp8 = reinterpret_cast<const bf16x8_t*>(a.Wp);
-      auto wload = [&](bf16x8_t (&w)[NTW], int kc) __attribute__((always_inline)) {
+        for (int i = 0; i < 4; ++i) { a8[i] = lo[i]; a8[4 + i] = hi[i]; }
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          const int ct = wave + NW * j;
-          w[j] = Wp8[((long)(ct < a.NCT ? ct : 0) * KC + kc) * 64 + lane];
+        for (int ct = 0; ct < NCTM; ++ct)
+          if (ct < NCT) {
+            const bf16x8_t w8 = *reinterpret_cast<const bf16x8_t*>(wl + ct * 256);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, w8, acc[ct], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < NCTM; ++ct)
+          if (ct < NCT) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + ct * 256);
+            acc[ct] = mfma16x4(av[0], w4, acc[ct]);
+          }
+      }
+    };
+    // chunk loop: buffer kc & 1 holds chunk kc; chunk kc + 1 is in wpf and goes to the other buffer after the barrier
+    for (int kc = 0; kc < KC; kc += 2) {
+      WG_BARRIER();                                 // chunk kc is in Wl[0]; everybody is done with Wl[1]
+      if (kc + 1 < KC) wstash(1);
+      if (kc + 2 < KC) wfetch(kc + 2);
+      aload(aB, kc + 1 < KC ? kc + 1 : kc);
+      mac(aA, 0);
+      if (kc + 1 < KC) {
+        WG_BARRIER();                               // chunk kc + 1 is in Wl[1]; everybody is done with Wl[0]
+        if (kc + 2 < KC) wstash(0);
+        if (kc + 3 < KC) wfetch(kc + 3);
+        aload(aA, kc + 2 < KC ? kc + 2 : kc + 1);
+        mac(aB, 1);
+      }
+    }
+    // ---- mixing, wave local.  acc[ct][i]: row 16 wave + 4 q + i, column 16 ct + m; column tile ct -> agent ct / 2, e-half
+    // ct & 1 for the w1 tiles; then b1 (2N, 2N+1), w2 (2N+2, 2N+3), h (2N+4, 2N+5)
+    const float* qrow = Qs + (16 * wave + 4 * q4) * 16;
+    float pa[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pa[h][i] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCTM - 6; ++ct)
+      if (ct < 2 * N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[ct & 1][i] += qrow[i * 16 + (ct >> 1)] * fabsf(acc[ct][i]);
+      }
+    // the six tail tiles sit at a runtime position 2N: select them with compile-time indices
+    f32x4 tb1[2], tw2[2], th[2];
+#pragma unroll
+    for (int ct = 0; ct < NCTM; ++ct) {
+      const int rel = ct - 2 * N;
+      if (rel == 0) tb1[0] = acc[ct]; else if (rel == 1) tb1[1] = acc[ct];
+      else if (rel == 2) tw2[0] = acc[ct]; else if (rel == 3) tw2[1] = acc[ct];
+      else if (rel == 4) th[0] = acc[ct]; else if (rel == 5) th[1] = acc[ct];
+    }
+    float dpre[2][4], hidv[2][4], tot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tot[i] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ae = pa[h][i] + tb1[h][i];
+        const float ex = __expf(ae);
+        const float hid = ae > 0.f ? ae : ex - 1.f;                       // elu, alpha = 1
+        const float w2 = fabsf(tw2[h][i]), hb = fmaxf(th[h][i], 0.f);
+        tot[i] += hid * w2 + hb * (h ? wb2hi : wb2lo);
+        if (BWD) {
+          const float gr = Gs[16 * wave + 4 * q4 + i];
+          dpre[h][i] = gr * w2 * (ae > 0.f ? 1.f : ex);
+          hidv[h][i] = hid;
+          acc_wb2[h] += gr * hb;
         }
-      };
-      auto mac = [&](const bf16x8_t (&w)[NTW], int kc) __attribute__((always_inline)) {
+      }
+    const long rbase = row0 + 16 * wave + 4 * q4;
+    if (!BWD) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(Sb + (16 * rt + m) * SSB + 32 * kc + 8 * q4);
-#pragma unroll
-          for (int j = 0; j < NTW; ++j)
-            if (kind[j] >= 0) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[j], acc[rt][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      bf16x8_t wA[NTW], wB[NTW];
-      wload(wA, 0);
-      for (int kc = 0; kc < KC; kc += 2) {
-        wload(wB, kc + 1 < KC ? kc + 1 : KC - 1);
-        mac(wA, kc);
-        if (kc + 1 < KC) {
-          wload(wA, kc + 2 < KC ? kc + 2 : KC - 1);
-          mac(wB, kc + 1);
-        }
+      for (int i = 0; i < 4; ++i) {
+        const float t = sum16(tot[i]);
+        if (m == 0 && rbase + i < a.rows) a.q_tot[rbase + i] = t + bb2;
       }
     } else {
-      const f32x4* Wp4 = reinterpret_cast<const f32x4*>(a.Wp);
-      auto wload = [&](f32x4 (&w)[NTW], int kc) __attribute__((always_inline)) {
+      float gr[4];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          const int ct = wave + NW * j;
-          w[j] = Wp4[((long)(ct < a.NCT ? ct : 0) * KC + kc) * 64 + lane];
-        }
-      };
-      auto mac = [&](const f32x4 (&w)[NTW], int kc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(St + (16 * rt + m) * SSF + 16 * kc + 4 * q4);
-#pragma unroll
-          for (int j = 0; j < NTW; ++j)
-            if (kind[j] >= 0) acc[rt][j] = mfma16x4(av, w[j], acc[rt][j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      f32x4 wA[NTW], wB[NTW];
-      wload(wA, 0);
-      for (int kc = 0; kc < KC; kc += 2) {
-        wload(wB, kc + 1 < KC ? kc + 1 : KC - 1);
-        mac(wA, kc);
-        if (kc + 1 < KC) {
-          wload(wA, kc + 2 < KC ? kc + 2 : KC - 1);
-          mac(wB, kc + 1);
-        }
+      for (int i = 0; i < 4; ++i) {
+        gr[i] = Gs[16 * wave + 4 * q4 + i];
+        if (m == 0) acc_bb2 += gr[i];
       }
-    }
-    WG_BARRIER();                                        // (B) every wave is done with the state tile: PA may overlay it
-    // ---- partial pre-activations a_e = b1_e + sum_n q_n |w1[n,e]| of this wave's tiles; |w2|, relu(h) to LDS
-    {
-      float pa[2][RT][4];
+      // d(hypernet output) in place, dq_n = sum_e |w1[n,e]| dpre_e
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pa[h][rt][i] = 0.f;
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
+      for (int ct = 0; ct < NCTM; ++ct) {
+        if (ct >= NCT) continue;
+        const int rel = ct - 2 * N, h = ct & 1;
+        f32x4 v;
+        if (rel < 0) {
+          float dqp[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int r = 16 * rt + 4 * q4 + i;
-            const float v = acc[rt][j][i];
-            if (kind[j] == 0) pa[eh[j]][rt][i] += Qs[r * 16 + nn[j]] * fabsf(v);
-            else if (kind[j] == 1) pa[eh[j]][rt][i] += v;
-            else if (kind[j] == 2) W2A[r * E + 16 * eh[j] + m] = fabsf(v);
-            else if (kind[j] == 3) HBA[r * E + 16 * eh[j] + m] = fmaxf(v, 0.f);
+            const float o = acc[ct][i];
+            v[i] = qrow[i * 16 + (ct >> 1)] * dpre[h][i] * sgn(o);
+            dqp[i] = fabsf(o) * dpre[h][i];
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+          if (h == 1) {                                   // both halves of agent ct / 2 are in this wave: ct - 1 and ct
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) PA[(wave * RB + 16 * rt + 4 * q4 + i) * E + 16 * h + m] = pa[h][rt][i];
-    }
-    WG_BARRIER();                                        // (C)
-    // ---- finish: wave w takes rows [8w, 8w + 8), two rows per pass (lane = e of its half)
-#pragma unroll
-    for (int p = 0; p < RB / NW / 2; ++p) {
-      const int r = (RB / NW) * wave + 2 * p + (lane >> 5), e = lane & 31;
-      float ae = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) ae += PA[(w * RB + r) * E + e];
-      const float ex = __expf(ae);
-      const float hid = ae > 0.f ? ae : ex - 1.f;                 // elu, alpha = 1
-      const float w2 = W2A[r * E + e], hb = HBA[r * E + e];
-      const float tot = sum32(hid * w2 + hb * wb2_l);
-      if (!BWD) {
-        if (e == 0 && row0 + r < a.rows) a.q_tot[row0 + r] = tot + bb2;
-      } else {
-        const float gr = Gs[r];
-        DPRE[r * E + e] = gr * w2 * (ae > 0.f ? 1.f : ex);
-        HID[r * E + e] = hid;
-        acc_wb2 += gr * hb;
-        if (e == 0) acc_bb2 += gr;
-      }
-    }
-    if (BWD) {
-      WG_BARRIER();                                      // (D)
-      // ---- d(hypernet output) in accumulator layout -> HBM; halves of dq -> LDS
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        if (kind[j] < 0) continue;
-        const int ecol = 16 * eh[j] + m, col = 16 * (wave + NW * j) + m;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 16 * rt + 4 * q4 + i;
-            const float o = acc[rt][j][i];
-            float v = 0.f;
-            if (kind[j] == 0) {
-              const float dp = DPRE[r * E + ecol];
-              v = Qs[r * 16 + nn[j]] * dp * sgn(o);
-              const float hsum = sum16(fabsf(o) * dp);                   // this tile's half of dq_n
-              if (m == 0) DQH[(r * 16 + nn[j]) * 2 + eh[j]] = hsum;
-            } else if (kind[j] == 1) v = DPRE[r * E + ecol];
-            else if (kind[j] == 2) v = Gs[r] * HID[r * E + ecol] * sgn(o);
-            else v = o > 0.f ? Gs[r] * wb2c[j] : 0.f;
-            if (row0 + r < a.rows) a.dhy[(row0 + r) * C + col] = v;
+            for (int i = 0; i < 4; ++i) {
+              const float t = sum16(dqp[i] + fabsf(acc[ct - 1 < 0 ? 0 : ct - 1][i]) * dpre[0][i]);
+              if (m == 0 && rbase + i < a.rows) a.dq[(rbase + i) * N + (ct >> 1)] = t;
+            }
           }
-          __builtin_amdgcn_sched_barrier(0);
+        } else if (rel < 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = dpre[h][i];
+        } else if (rel < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gr[i] * hidv[h][i] * sgn(acc[ct][i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[ct][i] > 0.f ? gr[i] * (h ? wb2hi : wb2lo) : 0.f;
         }
-      }
-      WG_BARRIER();                                      // (D2) both halves of every dq_n are in LDS
-      for (int e = tid; e < RB * N; e += 64 * NW) {
-        const int r = e / N, n = e - r * N;
-        if (row0 + r < a.rows) a.dq[(row0 + r) * N + n] = DQH[(r * 16 + n) * 2] + DQH[(r * 16 + n) * 2 + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rbase + i < a.rows) a.dhy[(rbase + i) * C + 16 * ct + m] = v[i];
       }
     }
-    WG_BARRIER();                                        // (E) scratch is free: the next block's tile may land
-    if (nb < nblk) { stash(); stash_qg(); }
+    WG_BARRIER();                                        // Qs / Gs / both weight buffers are free for the next block
   }
   if (BWD) {
-    // hyper_b2.2 gradient partials: lanes e of both halves, then the waves in fixed order
-    const float v = acc_wb2 + __shfl_xor(acc_wb2, 32, 64);
-    const float b = acc_bb2 + __shfl_xor(acc_bb2, 32, 64);
+    // hyper_b2.2 gradient partials: rows 4q + i summed over the lane quarters, then the waves in fixed order
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      acc_wb2[h] += __shfl_xor(acc_wb2[h], 16, 64);
+      acc_wb2[h] += __shfl_xor(acc_wb2[h], 32, 64);
+    }
+    acc_bb2 += __shfl_xor(acc_bb2, 16, 64);
+    acc_bb2 += __shfl_xor(acc_bb2, 32, 64);
     __syncthreads();
-    if (lane < 32) red[wave * (E + 1) + lane] = v;
-    if (lane == 0) red[wave * (E + 1) + E] = b;
+    if (q4 == 0) { red[wave * (E + 1) + m] = acc_wb2[0]; red[wave * (E + 1) + 16 + m] = acc_wb2[1]; }
+    if (lane == 0) red[wave * (E + 1) + E] = acc_bb2;
     __syncthreads();
     if (tid < E + 1) {
       float tot = 0.f;
@@ -428,8 +362,12 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, m = lane & 15;
   const int GP = wg_gp(), XP = wg_xp(a.KT);
-  float* Gb[2] = {smem, smem + WCH * GP + WCH * XP};
-  float* Xb[2] = {smem + WCH * GP, smem + 2 * WCH * GP + WCH * XP};
+  // buffer b: dhy chunk at smem + b * BUF, state chunk behind it (plain offsets from the LDS base - a runtime-indexed array
+  // of pointers made the compiler fall back to FLAT loads, whose waits also drain the global prefetch)
+  const int BUF = WCH * (GP + XP);
+  // source offset (floats) of every row of a chunk, resolved ONE CHUNK AHEAD by 32 threads: the row remap / episode map
+  // costs a dependent global load per row, and resolving it inside the staging loads serialised six L2 round trips per chunk
+  long* rtab = reinterpret_cast<long*>(smem + 2 * BUF);                     // [2][WCH]
   const int grp = blockIdx.y, col0 = grp * 16 * WNT;
   const int S4 = (a.S + 3) >> 2;
   const long per = (a.rows + a.nslab - 1) / a.nslab;
@@ -464,17 +402,22 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
       if (e > xi - 1) e = xi - 1;
       const int r = (int)(((float)e + 0.5f) * invS4);
       const int c4 = (e - r * S4) * 4;
-      long row = rb + r;
+      px[i] = *reinterpret_cast<const f32x4*>(a.s.p0 + rtab[(ch & 1) * WCH + r] + c4);
+    }
+  };
+  auto resolve = [&](long ch) {                    // threads 0..31: table of chunk ch
+    if (tid < WCH) {
+      long row = r_begin + ch * WCH + tid;
       if (row > a.rows - 1) row = a.rows - 1;
       const ConcatRow cr = concat_row(a.s, row);
-      px[i] = *reinterpret_cast<const f32x4*>(a.s.p0 + cr.r0 * a.s.ld0 + c4);
+      rtab[(ch & 1) * WCH + tid] = cr.r0 * a.s.ld0;
     }
   };
   auto stash = [&](int b) {
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const int e = tid + 64 * NW * i;
-      if (e < gi) { const int r = e / G4, c4 = (e - r * G4) * 4; *reinterpret_cast<f32x4*>(Gb[b] + r * GP + c4) = pg[i]; }
+      if (e < gi) { const int r = e / G4, c4 = (e - r * G4) * 4; *reinterpret_cast<f32x4*>(smem + b * BUF + r * GP + c4) = pg[i]; }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -485,13 +428,14 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
         f32x4 v = px[i];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) if (c4 + cc >= a.S) v[cc] = 0.f;
-        *reinterpret_cast<f32x4*>(Xb[b] + r * XP + c4) = v;
+        *reinterpret_cast<f32x4*>(smem + b * BUF + WCH * GP + r * XP + c4) = v;
       }
     }
   };
   // zero the never-written pad columns of both buffers (k padding of the state chunk)
   for (int b = 0; b < 2; ++b)
-    for (int e = tid; e < WCH * (XP - 4 * S4); e += 64 * NW) Xb[b][(e / (XP - 4 * S4)) * XP + 4 * S4 + e % (XP - 4 * S4)] = 0.f;
+    for (int e = tid; e < WCH * (XP - 4 * S4); e += 64 * NW)
+      smem[b * BUF + WCH * GP + (e / (XP - 4 * S4)) * XP + 4 * S4 + e % (XP - 4 * S4)] = 0.f;
   f32x4 acc[WNT][WKT];
   float bs[WNT];
 #pragma unroll
@@ -500,15 +444,19 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
 #pragma unroll
     for (int k = 0; k < WKT; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  resolve(0);
+  resolve(1);
+  __syncthreads();
   if (nch > 0) fetch(0);
   __syncthreads();
   if (nch > 0) stash(0);
   for (long ch = 0; ch < nch; ++ch) {
     const int b = (int)(ch & 1);
     WG_BARRIER();                                  // chunk ch is in buffer b; buffer b^1 is free (read two chunks ago)
-    if (ch + 1 < nch) fetch(ch + 1);
-    const float* G = Gb[b];
-    const float* X = Xb[b];
+    if (ch + 1 < nch) fetch(ch + 1);               // (row table of chunk ch + 1: written before this barrier)
+    if (ch + 2 < nch) resolve(ch + 2);             // overwrites the table of chunk ch, whose loads were issued long ago
+    const float* G = smem + b * BUF;
+    const float* X = G + WCH * GP;
     // operands of step st+1 are read while step st multiplies (two named register sets, no copies)
     auto ld = [&](float (&gv)[WNT], float (&xv)[WKT], int st) __attribute__((always_inline)) {
       const int row = 4 * st + q;                  // MFMA k index = lane quarter = one row of the chunk
@@ -525,10 +473,9 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
       for (int t = 0; t < WNT; ++t) {
         if (wave == 0) bs[t] += gv[t];
 #pragma unroll
-        for (int k = 0; k < WKT; ++k)
-          if (wave + NW * k < a.KT) acc[t][k] = mfma16(gv[t], xv[k], acc[t][k]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < WKT; ++k) acc[t][k] = mfma16(gv[t], xv[k], acc[t][k]);   // k tiles past KT: a clamped operand,
+      }                                                                                // a never-stored accumulator (no branch:
+      __builtin_amdgcn_sched_barrier(0);                                               // those waves wait at the barrier anyway)
     };
     float gA[WNT], xA[WKT], gB[WNT], xB[WKT];
     ld(gA, xA, 0);
@@ -602,7 +549,7 @@ __global__ __launch_bounds__(64 * RSG) void qmix_wide_reduce_kernel(WideRedArgs 
 
 inline bool supported(int N, int S, int Eq) {
   const int C = N * E + 3 * E;
-  return Eq == E && N >= 1 && N <= 16 && C <= 16 * NW * NTW && N <= 10 && S >= 4 && S <= 352;   // S: prefetch registers of the state tile
+  return Eq == E && N >= 1 && N <= 16 && C <= 16 * NCTM && S >= 4 && S <= 384;       // S: k tiles of the weight-gradient GEMM (8 waves x 3)
 }
 inline ConcatSrc state_src(const marl_src_t* s) {
   ConcatSrc c;
@@ -626,9 +573,7 @@ inline size_t packed_floats(int N, int S) {                  // room for either 
 }
 inline int wg_groups(int C) { return ((C + 15) / 16 + WNT - 1) / WNT; }
 inline int wg_slabs(long rows) { long n = (rows + 8 * WCH - 1) / (8 * WCH); if (n > 64) n = 64; return (int)(n < 1 ? 1 : n); }
-inline int rt_of(bool bf) { (void)bf; return 2; }      // row tiles per block: the bf16 GEMM is ~16x shorter per row, so it needs
-                                                      // bigger blocks to keep the L2 weight stream below the HBM state stream
-inline unsigned grid_for(long rows, int RB) {
+inline unsigned grid_for(long rows) {
   const long nblk = (rows + RB - 1) / RB;
   return (unsigned)(nblk < 256 ? nblk : 256);
 }
@@ -649,7 +594,8 @@ int pack(const marl_qmix_weights_t* w, int N, int S, bool bf, float* ws, hipStre
 
 template <typename K>
 int launch_main(K fn, const WideArgs& a, unsigned grid, bool bf, hipStream_t st) {
-  const size_t lds = wide_lds(a.KC, bf, 16 * rt_of(bf));
+  (void)bf;
+  const size_t lds = wide_lds(a.NCT);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -685,9 +631,11 @@ extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t
   int rc = pack(w, N, S, bf, ws, st, a);
   if (rc) return rc;
   a.s = state_src(s); a.q = q; a.q_tot = q_tot; a.rows = rows;
-  const unsigned grid = grid_for(rows, 16 * rt_of(bf));
-  return bf ? launch_main(qmix_wide_kernel<false, true, 2>, a, grid, true, st)
-            : launch_main(qmix_wide_kernel<false, false, 2>, a, grid, false, st);
+  const unsigned grid = grid_for(rows);
+  if (a.NCT == NCTM) return bf ? launch_main(qmix_wide_kernel<false, true, NCTM>, a, grid, true, st)
+                               : launch_main(qmix_wide_kernel<false, false, NCTM>, a, grid, false, st);
+  return bf ? launch_main(qmix_wide_kernel<false, true, 0>, a, grid, true, st)
+            : launch_main(qmix_wide_kernel<false, false, 0>, a, grid, false, st);
 }
 
 extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot,
@@ -707,13 +655,15 @@ extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t
   float* wslab = dhy + (size_t)rows * C;
   float* bslab = wslab + (size_t)nslab * C * (16 * KT + 1);
   a.s = state_src(s); a.q = q; a.g = dq_tot; a.dq = dq; a.dhy = dhy; a.slab = bslab; a.rows = rows;
-  const unsigned grid = grid_for(rows, 16 * rt_of(bf));
-  rc = bf ? launch_main(qmix_wide_kernel<true, true, 2>, a, grid, true, st)
-          : launch_main(qmix_wide_kernel<true, false, 2>, a, grid, false, st);
+  const unsigned grid = grid_for(rows);
+  if (a.NCT == NCTM) rc = bf ? launch_main(qmix_wide_kernel<true, true, NCTM>, a, grid, true, st)
+                             : launch_main(qmix_wide_kernel<true, false, NCTM>, a, grid, false, st);
+  else rc = bf ? launch_main(qmix_wide_kernel<true, true, 0>, a, grid, true, st)
+               : launch_main(qmix_wide_kernel<true, false, 0>, a, grid, false, st);
   if (rc) return rc;
   WideWgArgs g;
   g.dhy = dhy; g.s = a.s; g.ws = wslab; g.rows = rows; g.S = S; g.C = C; g.KT = KT; g.nslab = nslab;
-  const size_t lds = (size_t)2 * WCH * (wg_gp() + wg_xp(KT)) * sizeof(float);
+  const size_t lds = (size_t)2 * WCH * (wg_gp() + wg_xp(KT)) * sizeof(float) + 2 * WCH * sizeof(long);
   hipError_t e = hipFuncSetAttribute((const void*)qmix_wide_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(qmix_wide_wgrad_kernel, dim3(nslab, wg_groups(C)), dim3(64 * NW), lds, st, g);
