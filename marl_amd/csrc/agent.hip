@@ -60,7 +60,9 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-template <int AC, bool SAVE, bool VL>
+// NL: float4 prefetch registers per thread for the next step's observation tile (4; 6 for wide observations - MMM2's
+// O = 176 - where 4 would cap a workgroup at two row tiles and push a 640-tile shard into a second round of workgroups)
+template <int AC, bool SAVE, bool VL, int NL = NLDW>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,13 +109,13 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const int O = a.O;
   const int O4 = O >> 2, n4 = rows * O4;
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
-  f32x4 pf[NLDW];
+  f32x4 pf[NL];
   int pt = 0;                         // step the prefetch registers belong to
   int pu = -1, pu_lds = -1;           // action fed at the step being prefetched / one-hot column currently set in LDS
   // the element -> (row, column group) map of the prefetch is the same every step: resolve it once
-  long goff[NLDW]; int loff[NLDW], plen[NLDW];
+  long goff[NL]; int loff[NL], plen[NL];
 #pragma unroll
-  for (int i = 0; i < NLDW; ++i) {
+  for (int i = 0; i < NL; ++i) {
     // elements past the tile are clamped to its last one (same value, same address): branch-free step loop
     int e = tid + FNT * i;
     if (e > n4 - 1) e = n4 - 1;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   auto issue = [&](int t) {           // start the loads of step t's observations (vector path)
     const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
-    for (int i = 0; i < NLDW; ++i) {
+    for (int i = 0; i < NL; ++i) {
       // always loaded (the record has every slot); steps past the episode end are zeroed at commit
       pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
     }
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   };
   auto commit = [&]() {               // registers -> LDS tile; the one-hot(last action) column is flipped in place
 #pragma unroll
-    for (int i = 0; i < NLDW; ++i)
+    for (int i = 0; i < NL; ++i)
       *reinterpret_cast<f32x4*>(In + loff[i]) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.has_act && tid < rows) {
       const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
@@ -1187,9 +1189,18 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const size_t fixed = (size_t)4 * a.KC * 64 * 16;
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
-  if (a.vload) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW*512 registers
+  int nl = NLDW;
+  if (a.vload) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in nl * 512 registers
     int cap2 = (NLDW * FNT) / (16 * (O / 4));
-    if (cap2 < 1) { a.vload = 0; } else if (cap2 < rt_cap) rt_cap = cap2;
+    const long tiles = (a.R + 15) / 16;
+    const int cus = T > 1 ? cu_budget : 256;
+    const int want = (int)((tiles + cus - 1) / cus);                 // row tiles per workgroup that fill the CUs in one round
+    if (cap2 < want && cap2 < 8 && T > 1 && !saved) {                // wide observations: two more prefetch registers (the
+                                                                     // activation-saving variant has none to spare: it spills)
+      nl = 6;
+      cap2 = (6 * FNT) / (16 * (O / 4));
+    }
+    if (cap2 < 1) { a.vload = 0; nl = NLDW; } else if (cap2 < rt_cap) rt_cap = cap2;
   }
   // a single step (rollout) is latency-bound: many small workgroups overlap their prologues better than
   // 256 big ones; a long unroll amortises the prologue and wants one workgroup per CU
@@ -1223,6 +1234,9 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const void* fn;
 #define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
   const bool sv = saved != nullptr, vl = a.vload != 0;
+  if (vl && nl == 6) {
+    fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, 6> : (const void*)agent_fwd_kernel<2, false, true, 6>;
+  } else
   if (A <= 16) fn = sv ? (vl ? FWD_PICK(1, true, true) : FWD_PICK(1, true, false)) : (vl ? FWD_PICK(1, false, true) : FWD_PICK(1, false, false));
   else fn = sv ? (vl ? FWD_PICK(2, true, true) : FWD_PICK(2, true, false)) : (vl ? FWD_PICK(2, false, true) : FWD_PICK(2, false, false));
 #undef FWD_PICK
