@@ -87,3 +87,18 @@ if out:
 pmc_summary("_pmcq", ("mlp3_", "qplex_mix"),
             "rocprofv3 --pmc <group> --kernel-trace, four separate passes of tools/prof_learner.py --alg qplex --updates 3 "
             "(QPLEX 2s3z, 4096 envs, T=120, 1x MI355X; tools/pmc_qplex.sh); values are means per launch", "_pmc_qplex.json")
+
+# ---- round-2 additions (tools/refresh_profiles_r02.sh)
+for sub, dst in (("_qtran", "_qtran_kernel_stats.csv"), ("_mmm2_fp32", "_mmm2_fp32_kernel_stats.csv"), ("_mmm2_bf16", "_mmm2_bf16_kernel_stats.csv")):
+    f = os.path.join(G, tag + sub, "p_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, tag + dst))
+for name in ("_bench_mmm2_fp32_line.json", "_bench_mmm2_bf16_line.json", "_learner_rates.txt", "_shard_steps.txt"):
+    src = os.path.join(G, tag + name)
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(P, tag + name))
+pmc_summary("_pmcw", ("qmix_wide",),
+            "rocprofv3 --pmc <group> --kernel-trace, separate passes of tools/prof_learner.py --alg qmix --shape MMM2 --envs 1024 "
+            "--mixer-dtype bf16 (1x MI355X); values are means per launch", "_pmc_qmix_wide.json")
+if os.path.exists(os.path.join(G, "parity_margins.txt")):
+    shutil.copy(os.path.join(G, "parity_margins.txt"), os.path.join(P, tag + "_parity_margins.txt"))
