@@ -107,12 +107,15 @@ typedef struct {
  * accumulators, one partial slab per workgroup in `ws`, fixed-order reduce => reproducible).
  *   dq (B,T,N,A) gradient on q, OR (dq_idx != NULL) its sparse form: row (b,t,n) has the single non-zero
  *   dq_val[b,t,n] in column dq_idx[b,t,n] (the TD loss reaches q only through th.gather, q_learner.py:100;
- *   the dense tile is then never materialised); dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
+ *   the dense tile is then never materialised); dq_idx2 / dq_val2: optional SECOND pair per row (QTRAN reaches q through the
+ *   taken and the greedy action, qtran_learner.py:139,145; equal columns add); dq_gdiv > 1: the values are indexed by
+ *   row / dq_gdiv (N: one value per (episode, step), shared by its agents - autograd of .sum(dim=-1));
+ *   dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
  *   saved, hs: outputs of the forward pass;  dxp (B,T,N,64) = gradient at the fc1 pre-activation
  * The fc1 gradient follows as ONE marl_linear_wgrad over dxp and the virtual input [obs|u|id]. */
 size_t marl_agent_bwd_workspace(int B, int N, int A);
 int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const int* dq_idx,
-                          const float* dq_val, const float* dhs,
+                          const float* dq_val, const int* dq_idx2, const float* dq_val2, int dq_gdiv, const float* dhs,
                           const float* saved, const float* hs, float* dxp, float* dh0,
                           const marl_agent_grads_t* g, float* ws, size_t ws_bytes,
                           int B, int T, int N, int A, void* stream);

@@ -131,7 +131,7 @@ class Scratch:
         return t
 
 
-def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=None):
+def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=None, dq_idx2=None, dq_val2=None, dq_gdiv=1):
     """BPTT of the eval unroll: the fused kernel (delta pass + W_ih/W_hh/W_2 gradients), then the
     fc1 weight gradient as one reduction over the virtual input [obs | one-hot(u_{t-1}) | agent id]
     (autograd of controller/share_params.py:125-146 + network/q_network.py:16-21)."""
@@ -146,7 +146,8 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=
     grads = {"rnn.weight_ih": ag.rnn.weight_ih.grad, "rnn.weight_hh": ag.rnn.weight_hh.grad,
              "rnn.bias_ih": ag.rnn.bias_ih.grad, "rnn.bias_hh": ag.rnn.bias_hh.grad,
              "fc2.weight": ag.fc2.weight.grad, "fc2.bias": ag.fc2.bias.grad}
-    ops.agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, None, grads, B, T, N, A, dq_idx=dq_idx, dq_val=dq_val)
+    ops.agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, None, grads, B, T, N, A, dq_idx=dq_idx, dq_val=dq_val,
+                         dq_idx2=dq_idx2, dq_val2=dq_val2, dq_gdiv=dq_gdiv)
     obs, obs_bs, obs_t0 = db.o_cur if which == "cur" else db.o_next
     remap0 = None if (obs_bs == T * N and obs_t0 == 0) else (T * N, obs_bs, obs_t0 * N)
     kw = {}

@@ -134,9 +134,11 @@ class QTRANLearner(ResumeMixin):
         dhs = g("dhs", (B, T, N, H))
         self.mixer.hip_backward(ctx_q, d_jq, BT, dhs.view(R, H), accumulate=False)
         self.v.hip_backward(ctx_v, d_v, BT, dhs.view(R, H), accumulate=True)
-        dq = g("dq", (B, T, N, A))
-        ops.q_scatter(dq, u_act, d_sn, opt_eval, d_so, R, A, N)
-        agent_backward(self.eval_net, db, "cur", saved, hs, dq, dhs, self._buf)
+        # the losses reach q_evals through two gathers per row - the taken action (L_nopt) and the greedy action (L_opt),
+        # each with one gradient per (episode, step) shared by its agents: BPTT takes the two sparse (action, gradient)
+        # pairs and the dense (B,T,N,A) gradient is never materialised
+        agent_backward(self.eval_net, db, "cur", saved, hs, None, dhs, self._buf, dq_idx=u_act, dq_val=d_sn,
+                       dq_idx2=opt_eval, dq_val2=d_so, dq_gdiv=N)
         self._dbg = dict(q_evals=q_evals, hs=hs, joint_q=joint_q, joint_q_targets=joint_q_tgt, v=v,
                          joint_q_hat=joint_q_hat)
 

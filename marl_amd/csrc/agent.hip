@@ -696,7 +696,10 @@ struct BwdArgs {
   const float *Wih, *Whh, *W2;
   const float* dq;        // (B,T,N,A) dense gradient on q, or (when dq_idx != null) unused
   const int* dq_idx;      // (B,T,N) sparse form: the only non-zero of row (b,t,n) is column dq_idx with value dq_val
-  const float* dq_val;    // (B,T,N)   (the Q-learning losses touch one action per row, q_learner.py:93)
+  const float* dq_val;    // (B,T,N) / gdiv  (the Q-learning losses touch one action per row, q_learner.py:93)
+  const int* dq_idx2;     // optional second (column, value) pair per row (QTRAN: taken action AND greedy action,
+  const float* dq_val2;   //   qtran_learner.py:139,145); values of equal columns add
+  int dq_gdiv;            // value index = row index / dq_gdiv (N: one value per (episode, step) shared by its agents)
   const float* dhs;       // (B,T,N,64) external gradient on hs[t], or null
   const float* saved;     // [T][B*N][6][64]
   const float* hs;        // (B,T,N,64) hidden after each step (for dW_2)
@@ -713,6 +716,9 @@ constexpr int NQ = 4;         // dq prefetch registers per thread
 
 __host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + (long)A * 64 + 2 * 192 + A; }
 
+__device__ __forceinline__ long b_of(long rho, int N) { return rho / N; }
+__device__ __forceinline__ int n_of(long rho, int N) { return (int)(rho % N); }
+
 // 8 waves = 2 teams x 4 hidden-unit slices, two waves per SIMD (<= 256 registers each), so that one wave's
 // loads / pointwise math / LDS traffic overlap the other's MFMAs (the previous 4-wave, 457-register version
 // kept the matrix pipe 53 % busy).
@@ -722,7 +728,8 @@ __host__ __device__ inline long bwd_slab_floats(int A) { return 2L * 192 * 64 + 
 //       team 1 ("hh"): dh_prev = carry + [drp|dzp|dhn] W_hh          ;  dW_hh += [drp|dzp|dhn]^T h_prev ; dW_2 += dq^T h
 //   Both roles run the SAME code on the same register arrays (wT, accW, cur/nxt); only base pointers and
 //   LDS column offsets differ, so the register allocation is that of one role.
-template <int AC, bool DHS, bool SPQ>
+// SPQ: 0 dense dq tile, 1 / 2 sparse (column, value) pairs per row
+template <int AC, bool DHS, int SPQ>
 __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -752,8 +759,15 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     rowrho[r] = (int)rho;
     rowok[r] = ok;
   }
-  for (int e = tid; e < rows * HS; e += BNT) CAR[e] = 0.f;
   const long tstride = a.N;
+  // carried dh of the last step: zero, plus the external gradient on hs[T-1] when there is one.  The external gradient of
+  // the earlier steps is added where the carry is written (team 1, procC): it never occupies a slot of the prefetch sets.
+  for (int e = tid; e < rows * HS; e += BNT) {
+    const int r = e / HS, k = e - r * HS;
+    float v = 0.f;
+    if (DHS && k < H && row0 + r < a.R) v = a.dhs[((long)(b_of(row0 + r, a.N) * a.T + a.T - 1) * a.N + n_of(row0 + r, a.N)) * H + k];
+    CAR[e] = v;
+  }
   const int j = 16 * ws + m;
 
   // role weights: B-fragments of the transposed product, lane (q,m) holds W[k = 16c+4q+i][col 16ws+m]
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   __syncthreads();
 
   // ---- prefetch sets (named registers; cur = tile being processed, nxt = tile in flight)
-  //   B set: [0]=h_prev(own cols) [1]=r [2]=z [3]=n [4]=hn [5]=dhs
+  //   B set: [0]=h_prev(own cols) [1]=r [2]=z [3]=n [4]=hn
   //   C set: [0..3]=x (team 0) / h_prev (team 1), all 64 columns ; [4]=x own cols (team 0) / h_t own cols (team 1)
   // (every load is unconditional: at t = 0 the "next step" loads re-read step 0 and are never consumed - a
   // predicated load makes the compiler zero the register first and that write waits for older loads)
@@ -798,7 +812,6 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       P[2][i] = sp_[3 * H];                                                                              \
       P[3][i] = sp_[4 * H];                                                                              \
       P[4][i] = sp_[5 * H];                                                                              \
-      if (DHS) P[5][i] = a.dhs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j];                       \
     }                                                                                                    \
   }
 #define LOAD_C(P, tt, rr, en)                                                                            \
@@ -819,17 +832,20 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 
   // sparse form: the dq tile is never materialised - per row one (column, value) pair, the MFMA operand
   // fragments are synthesised from it in registers
-  auto sp_load = [&](int t, int r, int& u, float& g) {
+  auto sp_load = [&](int t, int r, int& u, float& g, int& u2, float& g2) {
     const long o = (long)rowidx[r] + (long)t * tstride;
+    const long ov = a.dq_gdiv > 1 ? o / a.dq_gdiv : o;
     u = a.dq_idx[o];
-    g = a.dq_val[o] * rowok[r];
+    g = a.dq_val[ov] * rowok[r];
+    if (SPQ == 2) { u2 = a.dq_idx2[o]; g2 = a.dq_val2[ov] * rowok[r]; }
   };
   if (SPQ) {
     for (int r = tid; r < rows; r += BNT) {
-      int u; float g;
-      sp_load(a.T - 1, r, u, g);
+      int u, u2 = -1; float g, g2 = 0.f;
+      sp_load(a.T - 1, r, u, g, u2, g2);
       reinterpret_cast<int*>(DQ0)[r] = u;
       DQ0[rows + r] = g;
+      if (SPQ == 2) { reinterpret_cast<int*>(DQ0)[2 * rows + r] = u2; DQ0[3 * rows + r] = g2; }
     }
   } else {
     for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
@@ -839,7 +855,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   // Register sets of the software pipeline.  NO set is ever copied into another inside the step loop: a copy
   // needs the loaded values and makes the compiler drain vmcnt right where the prefetch was issued.
   //   both phases alternate their row tiles between sA and sB
-  f32x4 sA[6], sB[6];
+  f32x4 sA[5], sB[5];
   // item 1 of a step (the team's 2nd phase-B tile, or phase-C tile 0 when it has only one) is issued into sB as
   // soon as the previous step's last phase-C tile has released that set - before the end-of-step barrier
 #define LOAD_ITEM1(tt, en)                                         \
@@ -853,19 +869,24 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   __syncthreads();
 
   // ---- phase B body for one row tile: dh = carry + dhs + dq W2^T ; gate gradients -> DG, carry*z -> CAR
-  auto procB = [&](const f32x4 (&P)[6], int rt, const float* DQ) __attribute__((always_inline)) {
+  auto procB = [&](const f32x4 (&P)[5], int rt, const float* DQ) __attribute__((always_inline)) {
     f32x4 dh;
 #pragma unroll
     for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
     const float* dqr = DQ + (rt * 16 + m) * QS + 4 * q;
     const int su = SPQ ? reinterpret_cast<const int*>(DQ)[rt * 16 + m] : 0;
     const float sg = SPQ ? DQ[rows + rt * 16 + m] : 0.f;
+    const int su2 = SPQ == 2 ? reinterpret_cast<const int*>(DQ)[2 * rows + rt * 16 + m] : -1;
+    const float sg2 = SPQ == 2 ? DQ[3 * rows + rt * 16 + m] : 0.f;
 #pragma unroll
     for (int ac = 0; ac < AC; ++ac) {
       f32x4 av;
       if (SPQ) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = (su == 16 * ac + 4 * q + i) ? sg : 0.f;
+        for (int i = 0; i < 4; ++i) {
+          av[i] = (su == 16 * ac + 4 * q + i) ? sg : 0.f;
+          if (SPQ == 2) av[i] += (su2 == 16 * ac + 4 * q + i) ? sg2 : 0.f;
+        }
       } else {
         av = *reinterpret_cast<const f32x4*>(dqr + 16 * ac);
       }
@@ -874,7 +895,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rt * 16 + 4 * q + i;
-      const float d = DHS ? dh[i] + P[5][i] * rowok[r] : dh[i];
+      const float d = dh[i];                        // (an external gradient on hs[t] is already part of the carry)
       const float rg = P[1][i], zg = P[2][i], ng = P[3][i];
       const float dn = d * (1.f - zg);
       const float dz = d * (P[0][i] - ng);
@@ -889,8 +910,14 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     }
   };
   // ---- phase C body for one row tile: this role's products
-  auto procC = [&](const f32x4 (&P)[6], int rt, int t, const float* DQ) __attribute__((always_inline)) {
+  auto procC = [&](const f32x4 (&P)[5], int rt, int t, const float* DQ) __attribute__((always_inline)) {
     const int r0 = rt * 16 + 4 * q;
+    // external gradient on hs[t-1] (QTRAN heads): joins the carry this tile writes for the previous step
+    f32x4 dext = {0.f, 0.f, 0.f, 0.f};
+    if (DHS && team && t > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dext[i] = a.dhs[((long)rowidx[r0 + i] + (long)(t - 1) * tstride) * H + j];
+    }
     f32x4 main;                                   // dx (team 0)  /  dh_prev (team 1)
 #pragma unroll
     for (int i = 0; i < 4; ++i) main[i] = team ? CAR[(r0 + i) * HS + j] : 0.f;
@@ -925,12 +952,16 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     }
     if (team) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = main[i];
-      int4 su4 = {0, 0, 0, 0};
-      f32x4 sg4 = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = DHS ? main[i] + dext[i] * rowok[r0 + i] : main[i];
+      int4 su4 = {0, 0, 0, 0}, tu4 = {-1, -1, -1, -1};
+      f32x4 sg4 = {0.f, 0.f, 0.f, 0.f}, tg4 = {0.f, 0.f, 0.f, 0.f};
       if (SPQ) {                                   // the 4 rows' (action, gradient) pairs: two 16-byte LDS reads
         su4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(DQ) + r0);
         sg4 = *reinterpret_cast<const f32x4*>(DQ + rows + r0);
+      }
+      if (SPQ == 2) {
+        tu4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(DQ) + 2 * rows + r0);
+        tg4 = *reinterpret_cast<const f32x4*>(DQ + 3 * rows + r0);
       }
 #pragma unroll
       for (int ac = 0; ac < AC; ++ac) {
@@ -939,6 +970,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
           const int col = 16 * ac + m;
           dqf[0] = su4.x == col ? sg4[0] : 0.f; dqf[1] = su4.y == col ? sg4[1] : 0.f;
           dqf[2] = su4.z == col ? sg4[2] : 0.f; dqf[3] = su4.w == col ? sg4[3] : 0.f;
+          if (SPQ == 2) {
+            dqf[0] += tu4.x == col ? tg4[0] : 0.f; dqf[1] += tu4.y == col ? tg4[1] : 0.f;
+            dqf[2] += tu4.z == col ? tg4[2] : 0.f; dqf[3] += tu4.w == col ? tg4[3] : 0.f;
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) dqf[i] = DQ[(r0 + i) * QS + 16 * ac + m];
@@ -979,9 +1014,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     float* DQ = par ? DQ1 : DQ0;
     float* DQn = par ? DQ0 : DQ1;
     float dqpre[NQ];
-    int spu = -1; float spg = 0.f;
+    int spu = -1, spu2 = -1; float spg = 0.f, spg2 = 0.f;
     if (SPQ) {
-      if (t > 0 && tid < rows) sp_load(t - 1, tid, spu, spg);
+      if (t > 0 && tid < rows) sp_load(t - 1, tid, spu, spg, spu2, spg2);
     } else {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
@@ -1043,7 +1078,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     if (!in_a) {
       if (hasB) {                     // phase B wants its first tile in sA: one copy per step, a whole tile after the issue
 #pragma unroll
-        for (int k = 0; k < (DHS ? 6 : 5); ++k) sA[k] = sB[k];
+        for (int k = 0; k < 5; ++k) sA[k] = sB[k];
       } else {
         c0A_carry = false;            // a team without phase-B tiles (one row tile per workgroup) just starts from sB
       }
@@ -1052,7 +1087,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     ST_MARK(2);
     if (t > 0) {
       if (SPQ) {
-        if (tid < rows) { reinterpret_cast<int*>(DQn)[tid] = spu; DQn[rows + tid] = spg; }
+        if (tid < rows) {
+          reinterpret_cast<int*>(DQn)[tid] = spu; DQn[rows + tid] = spg;
+          if (SPQ == 2) { reinterpret_cast<int*>(DQn)[2 * rows + tid] = spu2; DQn[3 * rows + tid] = spg2; }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
@@ -1266,7 +1304,8 @@ extern "C" size_t marl_agent_bwd_workspace(int B, int N, int A) {
 }
 
 extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const int* dq_idx,
-                                     const float* dq_val, const float* dhs,
+                                     const float* dq_val, const int* dq_idx2, const float* dq_val2, int dq_gdiv,
+                                     const float* dhs,
                                      const float* saved, const float* hs, float* dxp, float* dh0,
                                      const marl_agent_grads_t* g, float* ws, size_t ws_bytes,
                                      int B, int T, int N, int A, void* stream) {
@@ -1276,7 +1315,8 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;   // 32-bit byte offsets into dxp
   BwdArgs a;
   a.Wih = w->w_ih; a.Whh = w->w_hh; a.W2 = w->fc2_w;
-  a.dq = dq; a.dq_idx = dq_idx; a.dq_val = dq_val; a.dhs = dhs; a.saved = saved; a.hs = hs; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
+  a.dq = dq; a.dq_idx = dq_idx; a.dq_val = dq_val; a.dq_idx2 = dq_idx2; a.dq_val2 = dq_val2; a.dq_gdiv = dq_gdiv > 1 ? dq_gdiv : 1;
+  a.dhs = dhs; a.saved = saved; a.hs = hs; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int AC = A <= 16 ? 1 : 2;
   const int QS = AC * 16 + 4;
@@ -1289,11 +1329,12 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   const void* fn;
-  const bool sp = dq_idx != nullptr;
+  const bool sp = dq_idx != nullptr, sp2 = sp && dq_idx2 != nullptr;
   if (sp && !dq_val) return (int)hipErrorInvalidValue;
-  if (!sp && !dq) return (int)hipErrorInvalidValue;
-#define BWD_PICK(AC_) (dhs ? (sp ? (const void*)agent_bwd_kernel<AC_, true, true> : (const void*)agent_bwd_kernel<AC_, true, false>) \
-                           : (sp ? (const void*)agent_bwd_kernel<AC_, false, true> : (const void*)agent_bwd_kernel<AC_, false, false>))
+  if (!sp && (!dq || dq_idx2)) return (int)hipErrorInvalidValue;
+  if (sp2 && !dq_val2) return (int)hipErrorInvalidValue;
+#define BWD_PICK(AC_) (dhs ? (sp2 ? (const void*)agent_bwd_kernel<AC_, true, 2> : sp ? (const void*)agent_bwd_kernel<AC_, true, 1> : (const void*)agent_bwd_kernel<AC_, true, 0>) \
+                           : (sp2 ? (const void*)agent_bwd_kernel<AC_, false, 2> : sp ? (const void*)agent_bwd_kernel<AC_, false, 1> : (const void*)agent_bwd_kernel<AC_, false, 0>))
   if (AC == 1) fn = BWD_PICK(1);
   else fn = BWD_PICK(2);
 #undef BWD_PICK

@@ -168,7 +168,8 @@ def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last
           "marl_agent_unroll_fwd")
 
 
-def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None):
+def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None, dq_idx2=None,
+                     dq_val2=None, dq_gdiv=1):
     """grads: dict name -> gradient tensor for rnn.weight_ih/hh, rnn.bias_ih/hh, fc2.weight/bias (accumulated)."""
     lib = _lib.load()
     g = MarlAgentGrads()
@@ -181,7 +182,11 @@ def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=
     if dq_idx is not None:
         assert dq is None and dq_val is not None and dq_idx.is_contiguous() and dq_val.is_contiguous()
         _i32(dq_idx); _f32(dq_val)
-    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)) if dq is not None else None, _p(dq_idx), _p(dq_val), _p(dhs),
+    if dq_idx2 is not None:
+        assert dq_idx is not None and dq_val2 is not None and dq_idx2.is_contiguous() and dq_val2.is_contiguous()
+        _i32(dq_idx2); _f32(dq_val2)
+    check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)) if dq is not None else None, _p(dq_idx), _p(dq_val),
+                                    _p(dq_idx2), _p(dq_val2), int(dq_gdiv), _p(dhs),
                                     _p(_f32(saved)), _p(_f32(hs)), _p(_f32(dxp)),
                                     _p(dh0), C.byref(g), _p(ws), ws.numel() * 4, B, T, N, A, _stream()),
           "marl_agent_unroll_bwd")
