@@ -438,6 +438,23 @@ def test_agent_unroll_bwd(dev, shape, B, T):
     close(dxb, dxa, 1e-6, 1e-5)
     for k in names:
         close(gb[k], ga[k], 1e-5, 1e-5, msg="sparse " + k)
+    # two pairs per row with one value per (episode, step) shared by its agents (QTRAN: taken + greedy action, the sums
+    # over agents' gradients; equal columns add) plus an external gradient on hs == the dense tensors they stand for
+    idx2 = torch.randint(0, A, (B, T, N), generator=g)
+    idx2[0, 0] = idx[0, 0]                                    # coinciding columns
+    v1, v2 = torch.randn(B, T, generator=g), torch.randn(B, T, generator=g)
+    dense2 = torch.zeros(B, T, N, A).scatter_add_(3, idx[..., None], v1[..., None, None].expand(B, T, N, 1).contiguous())
+    dense2.scatter_add_(3, idx2[..., None], v2[..., None, None].expand(B, T, N, 1).contiguous())
+    dhs2 = cu(torch.randn(B, T, N, 64, generator=g) * 0.1, dev)
+    gc = {k: torch.zeros_like(pd[k]) for k in names}
+    gd = {k: torch.zeros_like(pd[k]) for k in names}
+    dxc, dxd = torch.empty(B, T, N, 64, device=dev), torch.empty(B, T, N, 64, device=dev)
+    ops.agent_unroll_bwd(w, cu(dense2, dev), dhs2, saved, hs, dxc, None, gc, B, T, N, A)
+    ops.agent_unroll_bwd(w, None, dhs2, saved, hs, dxd, None, gd, B, T, N, A, dq_idx=cu(idx, dev, torch.int32),
+                         dq_val=cu(v1, dev), dq_idx2=cu(idx2, dev, torch.int32), dq_val2=cu(v2, dev), dq_gdiv=N)
+    close(dxd, dxc, 1e-6, 1e-5)
+    for k in names:
+        close(gd[k], gc[k], 1e-5, 1e-5, msg="two-pair sparse " + k)
 
 
 # ------------------------------------------------------------------------------------- per-row
