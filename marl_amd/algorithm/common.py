@@ -209,8 +209,9 @@ class PairedUnroll:
     MAX_TILES = 1024          # 128 workgroups x 8 row tiles of 16 rows (the LDS cap of the unroll kernel)
 
     def __init__(self):
+        import os
         self.side = None
-        self.enabled = True
+        self.enabled = os.environ.get("MARL_NO_PAIR") != "1"      # experiments: MARL_NO_PAIR=1 launches them back to back
 
     def applies(self, rows, T):
         return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES

@@ -9,6 +9,7 @@
 // reference network/mixer.py) is a composition of these plus the per-row kernels in mixers.hip.
 // Operand fragments are loaded straight to VGPRs with the K-permutation of common.h, so no LDS
 // round trip is needed: the weights are small and L2-resident, X is streamed once per column block.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/marl_hip.h"
 
@@ -761,6 +762,269 @@ inline int try_wgrad_direct(const WgradArgs& a, hipStream_t s) {
   return -1;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tall-skinny weight gradient for N == 64 outputs through LDS (fc1 of the agent: dW1 = dxp^T [obs | one-hot(u) | id] over
+// B*T*N rows - 2.5 M rows at the headline workload).  The direct kernel above feeds the MFMAs straight from global loads and
+// ends up paying load time PLUS matrix time.  Here the workgroup is split by role:
+//   waves 4-7 (producers) stream 32-row chunks of G and X into LDS, two chunks of loads in flight (two named register sets),
+//             registers -> LDS into the buffer the consumers are not reading; they also resolve the row remap / episode map /
+//             action index of the rows two chunk pairs ahead into LDS tables (one producer wave per pair, in rotation), so no
+//             dependent global load sits inside the staging loads;
+//   waves 0-3 (consumers, one per SIMD) own output tile row tn = wave and ALL k tiles: per 4-row step one G read + KTT X reads
+//             (plain 32-bit LDS reads, prefetched a step ahead) and KTT MFMAs - the matrix pipe never waits for a load phase.
+// One LDS-only barrier per chunk joins the two roles.  (A first version had every wave load, multiply and store in turn: all
+// waves sit in the same phase, stamps showed multiply 30 %, load issue 20 %, LDS write 15 %, barrier 30 % of a chunk - 0.61 ms
+// against 0.57 ms of the direct kernel.)
+// The reduction index of dW = G^T X is the row, and v_mfma_f32_16x16x4 takes one k (= row) per lane quarter, so lane (q, m)
+// reads G[row 4s+q][16 tn + m] and X[row 4s+q][16 tk + m] from ROW-MAJOR tiles (row pitch = 16 mod 32 floats: the two quarters
+// of a half-wave hit disjoint banks) - no transposition anywhere.  The one-hot / agent-id columns of the virtual concat live in
+// a tail of the X tile that is zeroed once; a chunk sets its (at most two) ones per row and the next chunk landing in the
+// buffer clears them.
+constexpr int TGP = 64 + 16;      // LDS pitch of the G chunk
+constexpr int TCH = 32;           // rows per chunk
+constexpr int TPT = 256;          // producer threads
+
+template <int KTT, int NX>        // k tiles (6: K <= 96, 10: K <= 160, 14: K <= 224); float4 of X a producer thread stages per chunk
+__global__ __launch_bounds__(512, 4) void wgrad_tall_kernel(WgradArgs a, int XP) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool cons = wave < 4;
+  const int ptid = tid - 256;                                   // producer thread index (negative in consumers)
+  const int q = lane >> 4, m = lane & 15;
+  const int K = a.K, k0 = a.x.k0;
+  const int BUF = TCH * (TGP + XP);
+  long* rtab = reinterpret_cast<long*>(tsm + 2 * BUF);          // [8][TCH] source offset (floats) of the dense row, by chunk & 7
+  int* htab = reinterpret_cast<int*>(rtab + 8 * TCH);           // [8][TCH] column of the one-hot 1 (or -1)
+  int* itab = htab + 8 * TCH;                                   // [8][TCH] column of the agent-id 1 (or -1)
+  const long per = ((long)a.M + gridDim.x - 1) / gridDim.x;
+  const long r_begin = (long)blockIdx.x * per;
+  long r_end = r_begin + per; if (r_end > a.M) r_end = a.M;
+  const long nch = r_end > r_begin ? (r_end - r_begin + TCH - 1) / TCH : 0;
+  const int D4 = k0 >> 2;                                       // float4 groups of the dense segment
+  const int T4 = (XP - k0) >> 2;                                // float4 groups of the tail (one-hot, agent id, pad)
+  const int di = TCH * D4, ti = TCH * T4;
+  constexpr int NG = TCH * 16 / TPT;                            // float4 of G a producer thread stages per chunk
+
+  // ---- row tables of a chunk PAIR (64 rows = the lanes of one producer wave): loads issued in the first half of a trip,
+  // consumed at the end of its second half
+  int rs_em = 0, rs_u = -1, rs_w = 0, rs_n = -1;
+  bool rs_ok0 = false, rs_oki = false, rs_live = false;
+  auto resolve_issue = [&](long ch) {                           // ch even: rows of chunks ch, ch + 1
+    long row = r_begin + ch * TCH + lane;
+    rs_live = row < r_end;
+    if (row > (long)a.M - 1) row = (long)a.M - 1;
+    const unsigned ur = (unsigned)row;
+    unsigned e = ur; long w = 0;
+    rs_ok0 = true;
+    if (a.x.rpe0) { e = fastdiv(ur, a.x.fd0); w = (long)(ur - e * (unsigned)a.x.rpe0) + a.x.off0; rs_ok0 = w >= 0; }
+    rs_w = (int)w;
+    rs_em = (a.x.emap0 && a.x.rpe0) ? a.x.emap0[e] : (int)e;
+    long ri = row; rs_oki = true;
+    if (a.x.rpei) { const unsigned ei = fastdiv(ur, a.x.fdi); const long wi = (long)(ur - ei * (unsigned)a.x.rpei) + a.x.offi;
+                    rs_oki = wi >= 0; ri = (long)ei * a.x.bsi + wi; }
+    rs_u = (a.x.nhot && rs_oki) ? a.x.idx[ri * a.x.nhot] : -1;
+    rs_n = a.x.nid ? (int)(ur - fastdiv(ur, a.x.fdn) * (unsigned)a.x.nid) : -1;
+  };
+  auto resolve_commit = [&](long ch) {
+    const int b = (int)(ch & 7) * TCH + lane;                   // ch even: slots ch & 7 and (ch & 7) + 1 are adjacent
+    const long r0 = a.x.rpe0 ? (long)rs_em * a.x.bs0 + rs_w : (long)rs_em;
+    rtab[b] = rs_ok0 ? r0 * a.x.ld0 : -1;
+    htab[b] = (rs_live && rs_u >= 0 && rs_u < a.x.hot_w) ? k0 + rs_u : -1;
+    itab[b] = (rs_live && rs_n >= 0) ? k0 + a.x.nhot * a.x.hot_w + rs_n : -1;
+  };
+
+  // ---- producers: the (row, column) a thread stages is the same in every chunk
+  int xr[NX], xc[NX];
+  const float* gp[NG];
+  int gr[NG], glim[NG];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = ptid + TPT * i;
+    xr[i] = -1; xc[i] = 0;
+    if (ptid >= 0 && e < di) { const int r = e / D4; xr[i] = r; xc[i] = (e - r * D4) * 4; }
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int e = (ptid < 0 ? 0 : ptid) + TPT * i;              // rows x 16 float4
+    gr[i] = e >> 4;
+    long row = r_begin + gr[i];
+    if (row > (long)a.M - 1) row = (long)a.M - 1;
+    gp[i] = a.G + row * a.ldg + (e & 15) * 4;
+    const long left = r_end - r_begin - gr[i];                  // row gr[i] of chunk ch exists while ch * TCH < left
+    glim[i] = left > 0 ? (int)((left + TCH - 1) / TCH) : 0;
+  }
+  const long gstep = (long)TCH * a.ldg;
+  auto fetch = [&](f32x4 (&pg)[NG], f32x4 (&px)[NX], unsigned& zmask, long ch) __attribute__((always_inline)) {
+    const int tb = (int)(ch & 7) * TCH;
+    zmask = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const bool live = (int)ch < glim[i];                      // the last chunk of a slab can be ragged; chunks past it are dead
+      pg[i] = *reinterpret_cast<const f32x4*>(live ? gp[i] + ch * gstep : gp[i]);
+      if (!live) zmask |= 0x100u << i;                          // rows past the slab contribute nothing
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {                              // unconditional (threads past the tile re-read its first float4):
+      const long off = rtab[tb + (xr[i] < 0 ? 0 : xr[i])];      // a lane-conditional load makes hipcc wait for the previous set
+      if (off < 0) zmask |= 1u << i;                            // a remapped row before the first slot reads as zero
+      px[i] = *reinterpret_cast<const f32x4*>(a.x.p0 + (off < 0 ? 0 : off) + xc[i]);
+    }
+  };
+  int old_h[2] = {-1, -1}, old_i[2] = {-1, -1};
+  if (!cons)
+    for (int e = ptid; e < 2 * ti; e += TPT) {                  // zero the tails of both buffers once
+      const int bb = e >= ti ? 1 : 0, ee = e - bb * ti;
+      const int r = ee / T4, c = k0 + (ee - r * T4) * 4;
+      *reinterpret_cast<f32x4*>(tsm + bb * BUF + TCH * TGP + r * XP + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  auto stash = [&](const f32x4 (&pg)[NG], const f32x4 (&px)[NX], unsigned zmask, long ch, int b) __attribute__((always_inline)) {
+    const int tb = (int)(ch & 7) * TCH;
+    float* Gs = tsm + b * BUF;
+    float* Xs = Gs + TCH * TGP;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int e = ptid + TPT * i;
+      f32x4 v = pg[i];
+      if (zmask & (0x100u << i)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Gs + (e >> 4) * TGP + (e & 15) * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      if (xr[i] >= 0) {
+        f32x4 v = px[i];
+        if (zmask & (1u << i)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Xs + xr[i] * XP + xc[i]) = v;
+      }
+    }
+    if (ptid < TCH && T4 > 0) {
+      float* row = Xs + ptid * XP;
+      if (old_h[b] >= 0) row[old_h[b]] = 0.f;
+      if (old_i[b] >= 0) row[old_i[b]] = 0.f;
+      const int hc = htab[tb + ptid], ic = itab[tb + ptid];
+      if (hc >= 0) row[hc] = 1.f;
+      if (ic >= 0) row[ic] = 1.f;
+      old_h[b] = hc; old_i[b] = ic;
+    }
+  };
+
+  if (wave == 4) {
+    resolve_issue(0); resolve_commit(0);
+    resolve_issue(2); resolve_commit(2);
+  }
+  __syncthreads();
+  // The two roles are separate loops (each with ONE barrier per chunk, so the counts match): in a shared loop the register
+  // allocator keeps the accumulators and both staging sets live together and spills.
+  if (!cons) {
+    f32x4 gS0[NG], xS0[NX], gS1[NG], xS1[NX];
+    unsigned z0 = 0, z1 = 0;
+    fetch(gS0, xS0, z0, 0); stash(gS0, xS0, z0, 0, 0);
+    fetch(gS0, xS0, z0, 1);
+    ST_DECL(2);
+    // Nothing in the loop is conditional but the resolver's turn: a skipped fetch or stash leaves hipcc's scoreboard with
+    // "maybe pending" registers at the loop head, and it then drains the other set before issuing the next loads.  Chunks past
+    // the slab are therefore staged like any other (dead rows: clamped addresses, zeros) into a buffer nobody reads.
+    for (long ch = 0; ch < nch; ch += 2) {
+      const bool mine = wave == 4 + (int)((ch >> 1) & 3);       // this trip's table resolver
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // chunk ch is in buffer 0; buffer 1 is free
+      ST_MARK(0);
+      if (mine) resolve_issue(ch + 4);                          // BEFORE the fetch: vmcnt retires in order
+      fetch(gS1, xS1, z1, ch + 2);
+      stash(gS0, xS0, z0, ch + 1, 1);
+      ST_MARK(1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // chunk ch + 1 is in buffer 1; buffer 0 is free
+      ST_MARK(0);
+      fetch(gS0, xS0, z0, ch + 3);
+      stash(gS1, xS1, z1, ch + 2, 0);
+      if (mine) resolve_commit(ch + 4);
+      ST_MARK(1);
+    }
+    ST_DUMP(2);
+    return;
+  }
+
+  // ---- consumers
+  const int tn = wave & 3;
+  f32x4 acc[KTT];
+#pragma unroll
+  for (int j = 0; j < KTT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bs = 0.f;
+  ST_DECL(2);
+  for (long ch = 0; ch < ((nch + 1) & ~1L); ++ch) {             // the producers' loop runs in pairs of chunks
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ST_MARK(0);
+    if (ch >= nch) break;
+    // running LDS offsets (no multiply in the loop: hipcc turns `row * pitch` into a 64-bit mad whose unused high half can
+    // land on a register with a global load pending, and then waits vmcnt(0) inside the MFMA loop)
+    const float* Gs = tsm + (int)(ch & 1) * BUF + tn * 16 + m + q * TGP;
+    const float* Xs = tsm + (int)(ch & 1) * BUF + TCH * TGP + m + q * XP;
+    auto ld = [&](float& gv, float (&xv)[KTT]) __attribute__((always_inline)) {
+      gv = Gs[0];
+#pragma unroll
+      for (int j = 0; j < KTT; ++j) xv[j] = Xs[16 * j];
+      Gs += 4 * TGP; Xs += 4 * XP;
+    };
+    auto mac = [&](float gv, const float (&xv)[KTT]) __attribute__((always_inline)) {
+      bs += gv;
+#pragma unroll
+      for (int j = 0; j < KTT; ++j) acc[j] = mfma16(gv, xv[j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    float gA, gB, xA[KTT], xB[KTT];
+    ld(gA, xA);
+#pragma unroll 1
+    for (int st = 0; st < TCH / 4 - 2; st += 2) {
+      ld(gB, xB);
+      mac(gA, xA);
+      ld(gA, xA);
+      mac(gB, xB);
+    }
+    ld(gB, xB);
+    mac(gA, xA);
+    mac(gB, xB);
+    ST_MARK(1);
+  }
+  ST_DUMP(2);
+  const int Kx = K + 1;
+  float* slab = a.ws + (long)blockIdx.x * 64 * Kx;
+#pragma unroll
+  for (int j = 0; j < KTT; ++j) {
+    const int k = 16 * j + m;
+    if (k < K) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slab[(long)(16 * tn + 4 * q + i) * Kx + k] = acc[j][i];
+    }
+  }
+  bs += __shfl_xor(bs, 16, 64);
+  bs += __shfl_xor(bs, 32, 64);
+  if (q == 0) slab[(long)(16 * tn + m) * Kx + K] = bs;
+}
+
+inline int tall_xp(int K) { const int w = (K + 15) / 16 * 16; return (w % 32 == 16) ? w : w + 16; }
+// returns -1 when the shape is not covered
+inline int try_wgrad_tall(WgradArgs& a, size_t ws_bytes, hipStream_t s) {
+  static const bool off = getenv("MARL_WGRAD_TALL") && getenv("MARL_WGRAD_TALL")[0] == '0';      // A/B switch for measurements
+  if (off) return -1;
+  if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || !a.xvec || a.M < 4096 || a.x.k1 || a.x.m0 || !a.x.p0) return -1;
+  if (a.x.nhot > 1 || (a.x.k0 & 3) || a.x.k0 < 16 || a.x.k0 > 192) return -1;
+  const int KT = (a.K + 15) / 16;
+  if (KT > 14) return -1;
+  const int XP = tall_xp(a.K);
+  const size_t lds = (size_t)2 * TCH * (TGP + XP) * sizeof(float) + 8 * TCH * (sizeof(long) + 2 * sizeof(int));
+  if (lds > 80 * 1024) return -1;
+  // two slabs per CU when the caller's workspace holds them (marl_linear_wgrad_workspace sizes it so for N == 64)
+  int slabs = a.slabs;
+  if (slabs == 256 && ws_bytes >= (size_t)512 * 64 * (a.K + 1) * sizeof(float)) slabs = 512;
+  a.slabs = slabs;
+  const void* fn = KT <= 6 ? (const void*)wgrad_tall_kernel<6, 3> : KT <= 10 ? (const void*)wgrad_tall_kernel<10, 5> : (const void*)wgrad_tall_kernel<14, 6>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  int xp = XP;
+  void* kargs[] = {(void*)&a, (void*)&xp};
+  e = hipLaunchKernel(fn, dim3(slabs), dim3(512), kargs, lds, s);
+  if (e != hipSuccess) return (int)e;
+  return 0;
+}
+
 struct WredArgs {
   const float* ws; float* dW; long lddw; float* db;
   int N, K, slabs, groups; long gs_dw, gs_db;
@@ -812,6 +1076,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+ST_DEFINE_SETTER(marl_debug_stamps_wgrad)
+
 extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_kmajor, const float* bias,
                            float* Y, long ldy, int M, int N, int K, int act, float beta,
                            const marl_group_t* grp, void* stream) {
@@ -853,7 +1119,7 @@ extern "C" int marl_linear(const marl_src_t* x, const float* W, long ldw, int w_
 
 extern "C" size_t marl_linear_wgrad_workspace(int M, int N, int K, int groups) {
   int slabs = marl_wgrad_slabs(M);
-  if (N <= 80 && K + 1 <= 80 && groups == 1) slabs *= 2;           // the full-width kernel runs two workgroups per CU
+  if (groups == 1 && ((N <= 80 && K + 1 <= 80) || N == 64)) slabs *= 2;   // the full-width and the tall kernel run two workgroups per CU
   return (size_t)slabs * groups * N * (K + 4) * sizeof(float);      // + 3: column passes of the direct kernel each carry a bias column
 }
 
@@ -883,6 +1149,21 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
   a.xvec = a.x.p0 && !a.x.m0 && (a.x.ld0 % 4 == 0) && aligned16(a.x.p0) && (a.gs_x0 % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const bool bf = (flags & 1) != 0;           // bf16 operands, fp32 accumulate (mixer GEMMs, opt-in)
+  if (!bf) {                                  // 64-output layers over many rows (fc1 of the agent): LDS-staged tall kernel
+    const int slabs0 = a.slabs;
+    const int rc = try_wgrad_tall(a, ws_bytes, s);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      MARL_CHECK_LAUNCH();
+      WredArgs r;
+      r.ws = ws; r.dW = dW; r.lddw = lddw; r.db = db; r.N = N; r.K = K; r.slabs = a.slabs; r.groups = 1; r.gs_dw = 0; r.gs_db = 0;
+      const long total = (long)N * (K + 1);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, r);
+      MARL_CHECK_LAUNCH();
+      return 0;
+    }
+    a.slabs = slabs0;
+  }
   // Wide inputs of a 64-output layer (fc1 of the agent on 3s5z / MMM2: 150 / 204 columns - more accumulator tiles than
   // one pass of the direct kernel holds): column passes [0,64), [64,128) as permuted blocks and the rest as plain
   // tiles, each a direct launch over its own sub-source with its own slabs; G is re-read per pass (3 x 315 MB at

@@ -14,6 +14,7 @@ SEGS = {
     "fwd": ["fc1", "bar1", "commit", "gru", "bar2", "fc2"],
     "fwd_pipe": ["side", "gru", "commit", "bar"],
     "qmix": ["top+fetch", "bar1", "mfma", "pa", "bar2", "finish", "bwd", "stash"],
+    "wgrad": ["barrier", "work"],
     "bwd": ["phaseB", "bar1", "phaseC", "dqwrite", "bar2"],
 }
 
