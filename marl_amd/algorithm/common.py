@@ -212,6 +212,7 @@ class PairedUnroll:
         import os
         self.side = None
         self.enabled = os.environ.get("MARL_NO_PAIR") != "1"      # experiments: MARL_NO_PAIR=1 launches them back to back
+        self.chain = os.environ.get("MARL_NO_CHAIN") != "1"       # experiments: MARL_NO_CHAIN=1 keeps the plain pair + continuation
 
     def applies(self, rows, T):
         return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES
@@ -222,14 +223,60 @@ class PairedUnroll:
             first(256)
             second(256)
             return
+        self._fork(lambda: first(128), lambda: second(128))
+
+    def _fork(self, main, side):
         cur = torch.cuda.current_stream()
         if self.side is None or self.side.device != cur.device:
             self.side = torch.cuda.Stream(device=cur.device)
         self.side.wait_stream(cur)              # inputs written on the main stream are visible to the side launch
         with torch.cuda.stream(self.side):
-            second(128)
-        first(128)
+            side()
+        main()
         cur.wait_stream(self.side)
+
+    # measured step time of the unroll kernel by row tiles per workgroup (us per step, 2s3z-sized agent): one tile runs the
+    # software-pipelined kernel; beyond that ~1.3 + 2.1 per tile (5.5 at 2, 7.6 at 3, 11.7 at 5)
+    @staticmethod
+    def _step_us(rt):
+        return 3.3 if rt <= 1 else 1.3 + 2.1 * rt
+
+    def chain_split(self, rows, T, obs_dim):
+        """CU split (chain, side) for run_chain, or None when the plain schedule (pair, then the continuation over the
+        whole chip) is at least as fast by the step-time model."""
+        if not self.chain or not self.applies(rows, T):
+            return None
+        tiles = (rows + 15) // 16
+        cap = max(1, min(8, 2048 // (4 * max(obs_dim, 4))))          # row tiles per workgroup the unroll kernel can hold
+        ceil = lambda a, b: -(-a // b)
+        plain = self._step_us(ceil(tiles, 128)) + self._step_us(ceil(tiles, 256))
+        best = None
+        for cu_a in (128, 144, 160, 176, 192):
+            cu_b = 256 - cu_a
+            rt_a, rt_b = ceil(tiles, cu_a), ceil(tiles, cu_b)
+            if rt_a > cap or rt_b > cap:
+                continue
+            cost = max(2 * self._step_us(rt_a), self._step_us(rt_b))
+            if best is None or cost < best[0]:
+                best = (cost, cu_a, cu_b)
+        if best is None or best[0] > 0.95 * plain:
+            return None
+        return best[1], best[2]
+
+    def run_chain(self, rows, T, obs_dim, first, cont, second):
+        """first -> cont is a dependent chain of two unrolls (eval current-Q, then its continuation over the next
+        observations: quirk Q1), second is independent of both (target next-Q).  On small shards the chain runs on one
+        stream over most of the CUs - few row tiles per workgroup, so the short-step kernel - while `second` runs beside
+        it on the rest with more tiles per workgroup; nothing waits for a launch gap in the middle.  Larger shards keep
+        the plain schedule (pair first/second, then cont over the whole chip)."""
+        split = self.chain_split(rows, T, obs_dim) if cont is not None else None
+        if split is None:
+            self.run(rows, T, first, second)
+            if cont is not None:
+                cont(256)
+            return
+        cu_a, cu_b = split
+        self._fork(lambda: (first(cu_a), cont(cu_a)), lambda: second(cu_b))
 
 
 class GraphedUpdate:

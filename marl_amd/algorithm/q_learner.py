@@ -108,16 +108,20 @@ class QLearner(ResumeMixin):
         # eval current-Q unroll (keeps activations), target next-Q unroll
         # (independent of each other: on small shards they run side by side on two streams, half of the CUs each)
         emap = getattr(db, 'o_map', None)
-        self.pair.run(B * N, T,
-                      lambda cu: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
-                                                   h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu),
-                      lambda cu: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None,
-                                                     h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu))
+        # quirk Q1: no init_hidden between the two eval passes (reference :96-110) - the double-Q pass continues the eval chain
+        cont = None
+        if a.double_q:
+            cont = lambda cu: self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last,
+                                                   ep_len=db.ep_len, ep_map=emap, cu_budget=cu)
+        self.pair.run_chain(B * N, T, a.obs_shape,
+                            lambda cu: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
+                                                            h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu),
+                            cont,
+                            lambda cu: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None,
+                                                              h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu))
         ops.q_gather(q_evals, u_act, q_chosen, R, A)
         cur_max = None
         if a.double_q:
-            # quirk Q1: no init_hidden between the two eval passes (reference :96-110)
-            self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last, ep_len=db.ep_len, ep_map=getattr(db, 'o_map', None))
             cur_max = g("cur_max", (R,), torch.int32)
             ops.q_double_select(q_en, q_tgt, db.avail_next, MASK_BIG, q_tgt_chosen, cur_max, R, A)
         else:

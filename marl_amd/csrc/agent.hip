@@ -14,6 +14,7 @@
 //   * GRU pointwise math is done on the accumulator (D) layout in registers; activations that the
 //     backward pass needs are written once, coalesced per 16-lane group.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/marl_hip.h"
 
 namespace {
@@ -1149,6 +1150,357 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   }
 }
 
+#undef LOAD_B
+#undef LOAD_C
+#undef LOAD_ITEM1
+#undef LOAD_NEXT_STEP
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined BPTT for few row tiles per workgroup (RT <= 4: the small shards of the multi-GPU runs).
+// With one or two row tiles nothing hides the pointwise phase B of agent_bwd_kernel (16 % of a step with the matrix
+// pipe idle, half of the waves parked at its barrier), and only a quarter of a step's multiplies are on the dependent
+// chain   carry(t) -> gate gradients(t) -> [drp|dzp|dhn](t) W_hh -> carry(t-1).   Here ONE barrier separates the steps:
+//     team 1 ("hh"): per row tile  dh_prev = carry z + [drp|dzp|dhn](t) W_hh   -> straight on (same lanes, no barrier)
+//                    the gate gradients of step t-1 -> the OTHER gate-gradient buffer;  then the products that are off
+//                    the chain: dW_hh += [..](t)^T h_prev, dW_2 += dq(t)^T h
+//     team 0 ("ih"): dx = [drp|dzp|dnp](t) W_ih -> relu gate -> dxp ;  dW_ih += [..](t)^T x
+// so the pointwise math of one wave runs under the multiplies of its SIMD partner.  The gate-gradient tile is double
+// buffered in LDS (which is what limits RT), the sparse dq pairs triple buffered (steps t, t-1 in use, t-2 arriving).
+// One prefetch set per kind (saved planes of the tile's step / of the step before), re-issued as soon as its
+// consumer is done: the other half of the item hides the latency.  Same MFMA sequences per output element as
+// agent_bwd_kernel -> bitwise the same dxp / dh0; the weight-gradient slabs too (same per-workgroup accumulation order).
+template <int AC, bool DHS, int SPQ>
+__global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
+  static_assert(SPQ == 1 || SPQ == 2, "sparse dq only");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, ws = wave & 3;
+  const int q = lane >> 4, m = lane & 15;
+  const int rows = a.RT * 16;
+  float* DGb = smem;                        // [2][rows][DGS]  drp|dzp|dnp|dhn of step parity
+  float* CAR = DGb + 2 * rows * DGS;        // [rows][HS] carried dh (touched by team 1 only, each lane its own cells)
+  float* DQt = CAR + rows * HS;             // [3][4][rows]: (column, value[, column2, value2]) per row, by step % 3
+  float* RED = DQt + 12 * rows;             // [4][64]
+  int* rowidx = reinterpret_cast<int*>(RED + 4 * 64);
+  int* rowrho = rowidx + rows;
+  float* rowok = reinterpret_cast<float*>(rowrho + rows);
+
+  const long row0 = (long)blockIdx.x * rows;
+  for (int r = tid; r < rows; r += BNT) {
+    long rho = row0 + r;
+    const float ok = rho < a.R ? 1.f : 0.f;
+    if (rho > a.R - 1) rho = a.R - 1;
+    const long b = rho / a.N;
+    const int n = (int)(rho % a.N);
+    rowidx[r] = (int)(b * a.T * a.N + n);
+    rowrho[r] = (int)rho;
+    rowok[r] = ok;
+  }
+  const long tstride = a.N;
+  for (int e = tid; e < rows * HS; e += BNT) {
+    const int r = e / HS, k = e - r * HS;
+    float v = 0.f;
+    if (DHS && k < H && row0 + r < a.R) v = a.dhs[((long)(b_of(row0 + r, a.N) * a.T + a.T - 1) * a.N + n_of(row0 + r, a.N)) * H + k];
+    CAR[e] = v;
+  }
+  const int j = 16 * ws + m;
+  const float* Wrole = team ? a.Whh : a.Wih;
+  f32x4 wT[12], w2T[AC];
+#pragma unroll
+  for (int c = 0; c < 12; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wT[c][i] = Wrole[(long)(16 * c + 4 * q + i) * H + j];
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 16 * ac + 4 * q + i;
+      w2T[ac][i] = k < a.A ? a.W2[(long)k * H + j] : 0.f;
+    }
+  f32x4 accW[3][4], accW2[AC];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accW[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac) accW2[ac] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_hn = 0.f, sb2[AC];
+#pragma unroll
+  for (int ac = 0; ac < AC; ++ac) sb2[ac] = 0.f;
+  __syncthreads();                          // row tables
+
+  auto sp_load = [&](int t, int r, int& u, float& g, int& u2, float& g2) {
+    const long o = (long)rowidx[r] + (long)t * tstride;
+    const long ov = a.dq_gdiv > 1 ? o / a.dq_gdiv : o;
+    u = a.dq_idx[o];
+    g = a.dq_val[ov] * rowok[r];
+    if (SPQ == 2) { u2 = a.dq_idx2[o]; g2 = a.dq_val2[ov] * rowok[r]; }
+  };
+  auto sp_store = [&](int t, int r, int u, float g, int u2, float g2) {
+    float* D = DQt + (t % 3) * 4 * rows;
+    reinterpret_cast<int*>(D)[r] = u; D[rows + r] = g;
+    if (SPQ == 2) { reinterpret_cast<int*>(D)[2 * rows + r] = u2; D[3 * rows + r] = g2; }
+  };
+  for (int s = 0; s < 2; ++s) {
+    const int tt = a.T - 1 - s;
+    if (tt >= 0)
+      for (int r = tid; r < rows; r += BNT) {
+        int u, u2 = -1; float g, g2 = 0.f;
+        sp_load(tt, r, u, g, u2, g2);
+        sp_store(tt, r, u, g, u2, g2);
+      }
+  }
+  __syncthreads();
+
+  // saved planes of (step tt, row tile rr), this wave's 16 columns: [0]=h_prev [1]=r [2]=z [3]=n [4]=hn
+  auto load_b = [&](f32x4 (&P)[5], int tt, int rr) __attribute__((always_inline)) {
+    const float* svt = a.saved + (long)tt * a.R * (6 * H);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* sp = svt + (long)rowrho[rr * 16 + 4 * q + i] * (6 * H) + j;
+      P[0][i] = sp[0]; P[1][i] = sp[2 * H]; P[2][i] = sp[3 * H]; P[3][i] = sp[4 * H]; P[4][i] = sp[5 * H];
+    }
+  };
+  // [0..3] = x (team 0) / h_prev (team 1) of step tt, all 64 columns ; [4] = x own columns (team 0) / h(tt) own columns (team 1)
+  auto load_c = [&](f32x4 (&P)[5], int tt, int rr) __attribute__((always_inline)) {
+    const float* svt = a.saved + (long)tt * a.R * (6 * H) + (team ? 0 : H);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr * 16 + 4 * q + i;
+      const float* sp = svt + (long)rowrho[r] * (6 * H);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) P[c][i] = sp[16 * c + m];
+      if (team) P[4][i] = a.hs[((long)rowidx[r] + (long)tt * tstride) * H + j];
+      else P[4][i] = sp[j];
+    }
+  };
+  // dh = carry + dq W2^T ; gate gradients -> DG, carry z -> CAR   (agent_bwd_kernel's phase B for one row tile)
+  auto proc_b = [&](const f32x4 (&P)[5], int rt, const float* DQ, float* DG) __attribute__((always_inline)) {
+    f32x4 dh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dh[i] = CAR[(rt * 16 + 4 * q + i) * HS + j];
+    const int su = reinterpret_cast<const int*>(DQ)[rt * 16 + m];
+    const float sg = DQ[rows + rt * 16 + m];
+    const int su2 = SPQ == 2 ? reinterpret_cast<const int*>(DQ)[2 * rows + rt * 16 + m] : -1;
+    const float sg2 = SPQ == 2 ? DQ[3 * rows + rt * 16 + m] : 0.f;
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      f32x4 av;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = (su == 16 * ac + 4 * q + i) ? sg : 0.f;
+        if (SPQ == 2) av[i] += (su2 == 16 * ac + 4 * q + i) ? sg2 : 0.f;
+      }
+      dh = mfma16x4(av, w2T[ac], dh);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rt * 16 + 4 * q + i;
+      const float d = dh[i];
+      const float rg = P[1][i], zg = P[2][i], ng = P[3][i];
+      const float dn = d * (1.f - zg);
+      const float dz = d * (P[0][i] - ng);
+      const float dnp = dn * (1.f - ng * ng);
+      const float dzp = dz * zg * (1.f - zg);
+      const float drp = dnp * P[4][i] * rg * (1.f - rg);
+      const float dhn = dnp * rg;
+      float* l = DG + r * DGS + j;
+      l[0] = drp; l[64] = dzp; l[128] = dnp; l[192] = dhn;
+      CAR[r * HS + j] = d * zg;
+      sb_r += drp; sb_z += dzp; sb_n += dnp; sb_hn += dhn;
+    }
+  };
+  // this role's transposed product over one row tile: three independent chains (one per gate block)
+  auto product = [&](int rt, const float* DG, f32x4 init) __attribute__((always_inline)) -> f32x4 {
+    const float* gr = DG + (rt * 16 + m) * DGS + 4 * q;
+    f32x4 main = init, m1 = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int c2off = team ? 192 + 16 * c : 128 + 16 * c;                  // team 1 reads dhn instead of dnp
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(gr + 16 * c);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(gr + 64 + 16 * c);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(gr + c2off);
+      main = mfma16x4(a0, wT[c], main);
+      m1 = mfma16x4(a1, wT[4 + c], m1);
+      m2 = mfma16x4(a2, wT[8 + c], m2);
+    }
+    main += m1 + m2;
+    return main;
+  };
+  // dW_role += [gate gradients of this wave's 16 columns]^T P   (accumulator layout = the A^T fragments)
+  auto accum = [&](const f32x4 (&P)[5], int rt, const float* DG) __attribute__((always_inline)) {
+    const int r0 = rt * 16 + 4 * q;
+    f32x4 g0, g1, g2;
+    const int g2off = team ? 192 : 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* l = DG + (r0 + i) * DGS + j;
+      g0[i] = l[0]; g1[i] = l[64]; g2[i] = l[g2off];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      accW[0][c] = mfma16x4(g0, P[c], accW[0][c]);
+      accW[1][c] = mfma16x4(g1, P[c], accW[1][c]);
+      accW[2][c] = mfma16x4(g2, P[c], accW[2][c]);
+    }
+  };
+  const bool full_wg = row0 + rows <= a.R;
+  const int T = a.T, RT = a.RT;
+
+  if (team) {
+    // the chain wave wins the matrix pipe against its SIMD partner (which has 44 % of a step to spare): at equal
+    // priority the two products run interleaved and the chain takes twice its pipe time
+    __builtin_amdgcn_s_setprio(3);
+    f32x4 bS[5], cS[5];
+    // gate gradients of the last step (its carry is the external gradient on hs[T-1], or zero)
+    for (int k = 0; k < RT; ++k) {
+      load_b(bS, T - 1, k);
+      proc_b(bS, k, DQt + ((T - 1) % 3) * 4 * rows, DGb + ((T - 1) & 1) * rows * DGS);
+    }
+    load_b(bS, T > 1 ? T - 2 : 0, 0);
+    load_c(cS, T - 1, 0);
+    WG_BARRIER();
+    ST_DECL(4);
+    for (int t = T - 1; t >= 0; --t) {
+      const float* DGc = DGb + (t & 1) * rows * DGS;
+      float* DGn = DGb + ((t & 1) ^ 1) * rows * DGS;
+      const float* DQc = DQt + (t % 3) * 4 * rows;
+      const float* DQp = DQt + ((t + 2) % 3) * 4 * rows;        // step t-1
+      for (int k = 0; k < RT; ++k) {
+        const int r0 = k * 16 + 4 * q;
+        // ---- on the chain: dh_prev, then the gate gradients of step t-1
+        f32x4 dext = {0.f, 0.f, 0.f, 0.f};
+        if (DHS && t > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dext[i] = a.dhs[((long)rowidx[r0 + i] + (long)(t - 1) * tstride) * H + j];
+        }
+        f32x4 car;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) car[i] = CAR[(r0 + i) * HS + j];
+        const f32x4 main = product(k, DGc, car);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) CAR[(r0 + i) * HS + j] = DHS ? main[i] + dext[i] * rowok[r0 + i] : main[i];
+        ST_MARK(0);
+        if (t > 0) proc_b(bS, k, DQp, DGn);
+        ST_MARK(1);
+        // the next item's step-before planes: the rest of this item and the next product hide the latency
+        const int nk = k + 1 < RT ? k + 1 : 0, nt = k + 1 < RT ? t : t - 1;
+        load_b(bS, nt > 0 ? nt - 1 : 0, nk);
+        // ---- off the chain
+        accum(cS, k, DGc);
+        {
+          const int4 su4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(DQc) + r0);
+          const f32x4 sg4 = *reinterpret_cast<const f32x4*>(DQc + rows + r0);
+          int4 tu4 = {-1, -1, -1, -1};
+          f32x4 tg4 = {0.f, 0.f, 0.f, 0.f};
+          if (SPQ == 2) {
+            tu4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(DQc) + 2 * rows + r0);
+            tg4 = *reinterpret_cast<const f32x4*>(DQc + 3 * rows + r0);
+          }
+#pragma unroll
+          for (int ac = 0; ac < AC; ++ac) {
+            f32x4 dqf;
+            const int col = 16 * ac + m;
+            dqf[0] = su4.x == col ? sg4[0] : 0.f; dqf[1] = su4.y == col ? sg4[1] : 0.f;
+            dqf[2] = su4.z == col ? sg4[2] : 0.f; dqf[3] = su4.w == col ? sg4[3] : 0.f;
+            if (SPQ == 2) {
+              dqf[0] += tu4.x == col ? tg4[0] : 0.f; dqf[1] += tu4.y == col ? tg4[1] : 0.f;
+              dqf[2] += tu4.z == col ? tg4[2] : 0.f; dqf[3] += tu4.w == col ? tg4[3] : 0.f;
+            }
+            accW2[ac] = mfma16x4(dqf, cS[4], accW2[ac]);
+            sb2[ac] += dqf[0] + dqf[1] + dqf[2] + dqf[3];
+          }
+        }
+        load_c(cS, nt > 0 ? nt : 0, nk);
+        ST_MARK(2);
+      }
+      WG_BARRIER();
+      ST_MARK(3);
+    }
+    ST_DUMP_AT(4, 8);
+  } else {
+    f32x4 cS[5];
+    load_c(cS, T - 1, 0);
+    WG_BARRIER();
+    ST_DECL(4);
+    for (int t = T - 1; t >= 0; --t) {
+      const float* DGc = DGb + (t & 1) * rows * DGS;
+      // the dq pairs of step t-2 travel through this team (it has time to spare; hipcc waits for ALL outstanding loads
+      // where the registers are stored, which on the chain team exposed a full memory latency per step)
+      int spu = -1, spu2 = -1; float spg = 0.f, spg2 = 0.f;
+      if (t >= 2 && tid < rows) sp_load(t - 2, tid, spu, spg, spu2, spg2);
+      for (int k = 0; k < RT; ++k) {
+        const int r0 = k * 16 + 4 * q;
+        const f32x4 main = product(k, DGc, (f32x4){0.f, 0.f, 0.f, 0.f});
+        ST_MARK(0);
+        const int4 ri = *reinterpret_cast<const int4*>(rowidx + r0);
+        const unsigned trow = (unsigned)t * (unsigned)a.N, jb = (unsigned)j * 4u;
+        const unsigned o0 = ((unsigned)ri.x + trow) * 256u + jb, o1 = ((unsigned)ri.y + trow) * 256u + jb;
+        const unsigned o2 = ((unsigned)ri.z + trow) * 256u + jb, o3 = ((unsigned)ri.w + trow) * 256u + jb;
+        const float v0 = cS[4][0] > 0.f ? main[0] : 0.f, v1 = cS[4][1] > 0.f ? main[1] : 0.f;
+        const float v2 = cS[4][2] > 0.f ? main[2] : 0.f, v3 = cS[4][3] > 0.f ? main[3] : 0.f;
+        if (full_wg) {
+          st32(a.dxp, o0, v0); st32(a.dxp, o1, v1); st32(a.dxp, o2, v2); st32(a.dxp, o3, v3);
+        } else {
+          if (rowok[r0] != 0.f) st32(a.dxp, o0, v0);
+          if (rowok[r0 + 1] != 0.f) st32(a.dxp, o1, v1);
+          if (rowok[r0 + 2] != 0.f) st32(a.dxp, o2, v2);
+          if (rowok[r0 + 3] != 0.f) st32(a.dxp, o3, v3);
+        }
+        ST_MARK(1);
+        accum(cS, k, DGc);
+        const int nk = k + 1 < RT ? k + 1 : 0, nt = k + 1 < RT ? t : t - 1;
+        load_c(cS, nt > 0 ? nt : 0, nk);
+        ST_MARK(2);
+      }
+      if (t >= 2 && tid < rows) sp_store(t - 2, tid, spu, spg, spu2, spg2);
+      WG_BARRIER();
+      ST_MARK(3);
+    }
+    ST_DUMP_AT(4, 8);
+  }
+
+  if (a.dh0 && team) {
+    for (int r = 4 * q; r < rows; r += 16)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rowok[r + i] != 0.f) a.dh0[(row0 + r + i) * H + j] = CAR[(r + i) * HS + j];
+  }
+  float* slab = a.ws + (long)blockIdx.x * bwd_slab_floats(a.A);
+  float* s_role = slab + (team ? 192 * 64 : 0);
+  float* s_w2 = slab + 2 * 192 * 64;
+  float* s_bih = s_w2 + (long)a.A * 64;
+  float* s_bhh = s_bih + 192;
+  float* s_b2 = s_bhh + 192;
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        s_role[(g * 64 + 16 * ws + 4 * q + i) * 64 + 16 * c + m] = accW[g][c][i];
+  auto red4 = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+  sb_r = red4(sb_r); sb_z = red4(sb_z); sb_n = red4(sb_n); sb_hn = red4(sb_hn);
+  if (team) {
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int arow = 16 * ac + 4 * q + i;
+        if (arow < a.A) s_w2[arow * 64 + j] = accW2[ac][i];
+      }
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      const float v = red4(sb2[ac]);
+      if (ws == 0 && q == 0 && 16 * ac + m < a.A) s_b2[16 * ac + m] = v;
+    }
+    if (q == 0) {            // every gate-gradient tile went through team 1
+      s_bih[j] = sb_r; s_bih[64 + j] = sb_z; s_bih[128 + j] = sb_n;
+      s_bhh[j] = sb_r; s_bhh[64 + j] = sb_z; s_bhh[128 + j] = sb_hn;
+    }
+  }
+}
+
 struct BwdRedArgs {
   const float* ws; int nwg; int A;
   float *dWih, *dWhh, *dW2, *dbih, *dbhh, *db2;
@@ -1338,10 +1690,23 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
   if (AC == 1) fn = BWD_PICK(1);
   else fn = BWD_PICK(2);
 #undef BWD_PICK
-  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  size_t lds_used = lds;
+  // few row tiles per workgroup (small shards), sparse dq: the one-barrier pipelined variant
+  static const int pipe_max_rt = getenv("MARL_BWD_PIPE_MAX_RT") ? atoi(getenv("MARL_BWD_PIPE_MAX_RT")) : 4;   // A/B switch for measurements (helps at every RT its LDS allows: +15 % per update at 1 tile, +1 % at 4)
+  if (sp && a.RT <= pipe_max_rt && T >= 2) {
+    const size_t lds_p = ((size_t)(2 * DGS + HS + 12) * 4 + 12) * rows + 4 * 64 * 4;
+    if (lds_p <= 160 * 1024) {
+#define BWDP_PICK(AC_) (dhs ? (sp2 ? (const void*)agent_bwd_pipe_kernel<AC_, true, 2> : (const void*)agent_bwd_pipe_kernel<AC_, true, 1>) \
+                            : (sp2 ? (const void*)agent_bwd_pipe_kernel<AC_, false, 2> : (const void*)agent_bwd_pipe_kernel<AC_, false, 1>))
+      fn = AC == 1 ? BWDP_PICK(1) : BWDP_PICK(2);
+#undef BWDP_PICK
+      lds_used = lds_p;
+    }
+  }
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
   if (e != hipSuccess) return (int)e;
   void* kargs[] = {(void*)&a};
-  e = hipLaunchKernel(fn, grid, block, kargs, lds, s);
+  e = hipLaunchKernel(fn, grid, block, kargs, lds_used, s);
   if (e != hipSuccess) return (int)e;
   MARL_CHECK_LAUNCH();
   BwdRedArgs r;

@@ -15,6 +15,7 @@ SEGS = {
     "fwd_pipe": ["side", "gru", "commit", "bar"],
     "qmix": ["top+fetch", "bar1", "mfma", "pa", "bar2", "finish", "bwd", "stash"],
     "wgrad": ["barrier", "work"],
+    "bwd_pipe": ["product", "gates/dxp", "accum", "barrier"],
     "bwd": ["phaseB", "bar1", "phaseC", "dqwrite", "bar2"],
 }
 
@@ -43,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     v = buf.cpu().view(16, 16).numpy()
     names = SEGS[which]
-    if which == "bwd":
+    if which in ("bwd", "bwd_pipe"):
         v = v[:, 8:]
     print("segment shares per wave of workgroup 0 (%s, %d envs); cycles/step in the last column" % (which, E))
     print("wave " + " ".join("%9s" % n for n in names) + "   total/step")
