@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: mixer GEMMs on the bf16 matrix cores (config 5)")
+    ap.add_argument("--blocking-loss", action="store_true",
+                    help="read every update's loss back at once (default: the copy is enqueued and read at the end of the timed region - same work, no host stall between steps)")
     ap.add_argument("--hip-graph", action="store_true", help="replay the learner's forward/backward schedule as one hipGraph (opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
@@ -193,6 +195,7 @@ def main():
     args = make_args(o.alg, o.shape, o.T)
     args.mixer_dtype = o.mixer_dtype
     args.hip_graph = o.hip_graph
+    args.lazy_loss = not o.blocking_loss
     T, N = args.episode_limit, args.n_agents
     E = o.envs // world                      # envs / episodes per rank
     args.buffer_size = 2 * E
@@ -344,7 +347,7 @@ def main():
             "learner_updates_per_sec": 1.0 / t_learn,
             "learner_transitions_per_sec": o.envs * T / t_learn,
             "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
-            "last_loss": loss,
+            "last_loss": float(loss), "loss_readback": "blocking" if o.blocking_loss else "deferred",
             "roofline": roof,
             "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included)",
                                 "flop_per_transition": fpt, "achieved": upd_tflops, "peak": PEAK_F32_TFLOPS,

@@ -118,6 +118,45 @@ class ResumeMixin:
         self.load_resume_state(torch.load(path, map_location="cpu"))
 
 
+class LossReadback:
+    """The loss of an update as a host float.  Default: read now (one blocking copy, as the reference's `loss.item()`
+    use).  With ``args.lazy_loss = True`` train() returns a handle instead: the statistics are copied to pinned memory
+    in stream order and `float(handle)` waits only for that copy - the host goes on to enqueue the next rollout / update
+    while this one still runs, which is worth ~0.2 ms per step on small shards (nothing idles between the updates).
+    The arithmetic is the same either way (fp32 on the host)."""
+
+    class Handle:
+        __slots__ = ("buf", "event", "fn", "_v")
+
+        def __init__(self, buf, event, fn):
+            self.buf, self.event, self.fn, self._v = buf, event, fn, None
+
+        def __float__(self):
+            if self._v is None:
+                self.event.synchronize()
+                self._v = float(self.fn(self.buf))
+            return self._v
+
+    RING = 8      # an un-read handle stays valid for this many later updates
+
+    def __init__(self, args):
+        self.lazy = bool(getattr(args, "lazy_loss", False))
+        self.slots, self.k = [], 0
+
+    def read(self, stats, fn):
+        """stats: device vector; fn: host tensor -> loss value."""
+        if not self.lazy:
+            return float(fn(stats.cpu()))        # one copy + sync; the division runs on the host in fp32
+        if len(self.slots) < self.RING:
+            self.slots.append(torch.empty(stats.numel(), dtype=stats.dtype).pin_memory())
+        buf = self.slots[self.k % self.RING]
+        self.k += 1
+        buf.copy_(stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return LossReadback.Handle(buf, ev, fn)
+
+
 class Scratch:
     def __init__(self):
         self.d = {}

@@ -19,7 +19,7 @@ from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import VDNMixer, QMixMixer, DMAQer
-from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll, ResumeMixin,
+from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll, ResumeMixin, LossReadback,
                      GraphedUpdate)
 
 
@@ -51,6 +51,7 @@ class QLearner(ResumeMixin):
         self._buf = Scratch()
         self.reducer = GradReducer()
         self.pair = PairedUnroll()
+        self.loss_readback = LossReadback(args)
         self.graphs = GraphedUpdate() if getattr(args, "hip_graph", False) else None
         self.last_stats = None
         self.sync_replicas()
@@ -195,8 +196,7 @@ class QLearner(ResumeMixin):
         if train_step > 0 and train_step % self.args.target_update_cycle == 0:
             self._update_targets()
         self.last_stats = stats
-        s = stats[:2].cpu()                  # one copy + sync; the division runs on the host in fp32 as before
-        return float(s[0] / s[1])
+        return self.loss_readback.read(stats[:2], lambda s: s[0] / s[1])
 
     # ------------------------------------------------------------------ checkpoints (reference :193-209)
     def save_models(self, train_step):

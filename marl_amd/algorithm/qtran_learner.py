@@ -19,7 +19,7 @@ from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import QtranQBase, QtranQAlt, QtranV, QMixMixer
 from .common import (MASK_BIG, MASK_QTRAN_EVAL, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward,
-                     GradReducer, PairedUnroll, ResumeMixin)
+                     GradReducer, PairedUnroll, ResumeMixin, LossReadback)
 
 
 class QTRANLearner(ResumeMixin):
@@ -51,6 +51,7 @@ class QTRANLearner(ResumeMixin):
         self._buf = Scratch()
         self.reducer = GradReducer()
         self.pair = PairedUnroll()
+        self.loss_readback = LossReadback(args)
         self.last_stats = None
         if getattr(args, "hip_graph", False):
             import warnings
@@ -165,8 +166,8 @@ class QTRANLearner(ResumeMixin):
         if train_step > 0 and train_step % self.args.target_update_cycle == 0:
             self._update_targets()
         self.last_stats = st
-        s = st.cpu()
-        return float((s[0] + self.args.lambda_opt * s[1] + self.args.lambda_nopt * s[2]) / s[3])
+        lo, ln = self.args.lambda_opt, self.args.lambda_nopt
+        return self.loss_readback.read(st[:4], lambda s: (s[0] + lo * s[1] + ln * s[2]) / s[3])
 
     def save_models(self, train_step):
         num = str(train_step // self.args.save_cycle)

@@ -391,9 +391,11 @@ def test_agent_unroll_shifted_storage(dev):
         close(q, q_ref, 1e-4)
 
 
-@pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6)])
+@pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
 def test_agent_unroll_bwd(dev, shape, B, T):
-    """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll."""
+    """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll.  Up to four row tiles per workgroup a
+    sparse dq runs the one-barrier pipelined kernel and a dense one the two-phase kernel (compared with each other below);
+    B = 3300 (16 500 rows = five row tiles per workgroup, the headline layout) runs the two-phase kernel for both."""
     from marl_amd import ops
     args, p_np, obs, ufed, h0 = _agent_case(shape, B, T, dev, seed=1)
     N, O, A = args.n_agents, args.obs_shape, args.n_actions

@@ -170,3 +170,21 @@ def test_bf16_mixer_config5_tolerance():
     assert np.abs(q16 - q32).max() <= 2e-2 * max(1.0, np.abs(q32).max())
     cos = float((g16 * g32).sum() / np.sqrt((g16 * g16).sum() * (g32 * g32).sum()))
     assert cos > 0.999, cos
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("qmix_2s3z", "qtran_3s5z")], ids=lambda c: c[0])
+def test_deferred_loss_readback_gives_the_same_floats(case):
+    """args.lazy_loss: train() returns a handle whose float() is the loss the blocking path returns (same fp32 host
+    arithmetic on the same device statistics); handles stay valid while later updates run."""
+    name, shape, alg, B, T, lengths, over = case
+    args_a, _, la = build_product(case)
+    args_b, _, lb = build_product(case)
+    lb.loss_readback.lazy = True
+    handles, blocking = [], []
+    for i in range(4):
+        batch = seeded.make_batch(args_a, B, seed=300 + i, lengths=lengths)
+        blocking.append(la.train(learners.clone_batch(batch), i))
+        handles.append(lb.train(learners.clone_batch(batch), i))
+    assert not isinstance(handles[0], float)
+    assert [float(h) for h in handles] == blocking
+    assert float(handles[0]) == blocking[0]                  # cached after the first read
