@@ -89,11 +89,19 @@ int marl_wgrad_slabs(int M);
  *   cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over, 1..256; 0 = 256 = the whole chip.  With 128
  *           the two independent unrolls of an update - eval current-Q and target next-Q (q_learner.py:97,104) - fit
  *           on the chip together and can be launched on two HIP streams; results do not depend on it (rows are
- *           independent).  A per-call argument: the library keeps no process-wide state. */
+ *           independent).  A per-call argument: the library keeps no process-wide state.
+ *   x_saved: NULL, or the `saved` buffer an EARLIER unroll of the same weights wrote for the same rows whose step t+1
+ *           input equals this unroll's step t input for t < T-1 (the double-Q pass after the eval pass,
+ *           q_learner.py:97-110: observations shifted by one step, same last actions): the fc1 outputs of those steps
+ *           are read from its x plane instead of being recomputed (bit-identical).  Ragged episodes: at step
+ *           ep_len[b]-1 the earlier unroll saw the zero padding where this one would see the final observation, so q at
+ *           that (terminated) step differs from a recomputation - a position every Q-learning target multiplies by
+ *           (1 - terminated) = 0.  Ignored where the kernel chosen for the shape has no such variant. */
 int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                           const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                           const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T,
-                          int N, int O, int A, int last_action, int reuse_network, int cu_budget, void* stream);
+                          int N, int O, int A, int last_action, int reuse_network, int cu_budget,
+                          const float* x_saved, void* stream);
 
 /* Gradient destinations of the recurrent / output layers (accumulated into, torch layouts). */
 typedef struct {

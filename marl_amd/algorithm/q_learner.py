@@ -112,8 +112,11 @@ class QLearner(ResumeMixin):
         # quirk Q1: no init_hidden between the two eval passes (reference :96-110) - the double-Q pass continues the eval chain
         cont = None
         if a.double_q:
+            # its inputs at steps 0..T-2 are the eval pass's inputs at steps 1..T-1 (same observations, same last actions,
+            # same weights): the fc1 outputs saved there are reused (x_saved)
+            shifted = on is oc and on_bs == oc_bs and on_t0 == oc_t0 + 1
             cont = lambda cu: self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last,
-                                                   ep_len=db.ep_len, ep_map=emap, cu_budget=cu)
+                                                   ep_len=db.ep_len, ep_map=emap, cu_budget=cu, x_saved=saved if shifted else None)
         self.pair.run_chain(B * N, T, a.obs_shape,
                             lambda cu: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
                                                             h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu),

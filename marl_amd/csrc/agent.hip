@@ -39,6 +39,7 @@ struct FwdArgs {
   int B, T, N, O, A, I, KC, RT;
   int has_act, has_id;
   int vload;              // obs rows are 16-B aligned multiples of 4 floats: vector prefetch path
+  const float* xsrc;      // XS kernels: saved planes of an earlier unroll of the SAME weights whose step t+1 input is this unroll's step t input
   long R;                 // B*N rows
 };
 
@@ -63,8 +64,16 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
 
 // NL: float4 prefetch registers per thread for the next step's observation tile (4; 6 for wide observations - MMM2's
 // O = 176 - where 4 would cap a workgroup at two row tiles and push a 640-tile shard into a second round of workgroups)
-template <int AC, bool SAVE, bool VL, int NL = NLDW>
+// XS: the fc1 output of steps 0..T-2 is READ from the x plane another unroll saved (a.xsrc, its step t+1) instead of being
+// recomputed: the double-Q pass of a Q-learning update (q_learner.py:104-110) feeds the eval network the observations
+// of steps 1..T right after the eval pass fed it steps 0..T-1 - same weights, same inputs, so 96 of a row tile's 496
+// multiplies per step are the ones the eval pass just did (bit-identical: same kernel code wrote them).  Exceptions, where
+// the whole workgroup runs fc1 as usual: the last step (a new observation), and any step t at which one of its rows has
+// ep_len - 1 == t - there the earlier unroll (its step t+1 = ep_len) saw the zero padding and this one sees the final
+// observation.  The observation prefetch therefore keeps running; what is saved is the multiplies.
+template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
+  static_assert(!XS || (VL && !SAVE && NL == NLDW), "XS: vector path, no saving");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int team = wave >> 2, ws = wave & 3;
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   int* rown = rowidx + rows;                                 // [rows]: n
   int* rowlen = rown + rows;                                 // [rows]: episode length (INT_MAX if none)
   int* rowrho = rowlen + rows;                               // [rows]: b*N + n
+  int* xneed = rowrho + rows;                                // [2] (XS): some row of this workgroup has ep_len - 1 == t, by step parity
 
   // Rows past the end of the batch (last workgroup only) are CLAMPED to the last valid row: they load
   // the same inputs, compute the same values and store them to the same addresses, so no per-lane
@@ -128,6 +138,30 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     plen[i] = rowlen[r];
   }
   const long urow = tid < rows ? rowu[tid] : 0;
+  // XS: this thread's float4 items of the x tile (rows x 16), same every step
+  int xl[NL]; long xg[NL];
+  if (XS) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int e = tid + FNT * i;
+      if (e > rows * 16 - 1) e = rows * 16 - 1;      // clamped duplicates: same value to the same address
+      const int r = e >> 4, c4 = (e & 15) * 4;
+      xl[i] = r * HS + c4;
+      xg[i] = (long)rowrho[r] * (6 * H) + H + c4;    // plane 1 of [T][R][6][64]
+    }
+  }
+  f32x4 xf[XS ? NL : 1];
+  auto xissue = [&](int ts) {         // start the loads of the x tile the other unroll saved at its step ts
+    const long toff = (long)ts * a.R * (6 * H);
+#pragma unroll
+    for (int i = 0; i < (XS ? NL : 1); ++i) xf[i] = *reinterpret_cast<const f32x4*>(a.xsrc + xg[i] + toff);
+  };
+  auto xcommit = [&]() {
+#pragma unroll
+    for (int i = 0; i < (XS ? NL : 1); ++i) *reinterpret_cast<f32x4*>(Xt + xl[i]) = xf[i];
+  };
+  const int mylen = tid < rows ? rowlen[tid] : 0x7fffffff;
+  if (XS && tid < 2) xneed[tid] = 0;
   auto issue = [&](int t) {           // start the loads of step t's observations (vector path)
     const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
@@ -183,6 +217,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   // the prefetch registers a phi of (loaded, old) and the compiler then drains vmcnt right after the loads to copy
   if (VL) { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
   else load_generic(0);
+  if (XS) {
+    xissue(1);
+    if (mylen - 1 == 0) xneed[0] = 1;             // (cleared above, before the barrier of the constant columns)
+  }
 
   // ---- stage weights: fc1 slice -> LDS fragments (team 0 writes, both teams read); GRU / fc2 -> registers
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
@@ -234,7 +272,12 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     const unsigned trow = (unsigned)t * (unsigned)a.N;
     float* const svt = SAVE ? a.saved + (long)t * a.R * (6 * H) : nullptr;
     // ---------------- phase 1: x = relu(fc1(in))  (two of the team's row tiles in flight)
-    for (int rt = team; rt < a.RT; rt += 4) {
+    const bool xread = XS && t < a.T - 1 && xneed[t & 1] == 0;
+    if (XS) {
+      if (xread) xcommit();
+      xissue(t + 2 < a.T ? t + 2 : a.T - 1);      // unconditional (the last one is never consumed)
+    }
+    for (int rt = xread ? a.RT : team; rt < a.RT; rt += 4) {
       const bool two = rt + 2 < a.RT;
       f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
       const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
@@ -281,6 +324,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     WG_BARRIER();
     ST_MARK(1);
     // the input tile has been consumed: refill it for step t+1, start the loads of step t+2
+    if (XS) {                                     // flag of the next step; this step's flag was read before the barrier
+      if (mylen - 1 == t + 1) xneed[(t + 1) & 1] = 1;
+      if (tid == 0) xneed[t & 1] = 0;
+    }
     if (VL) {
       commit();                                   // (after the last step this writes a tile nobody reads)
       issue(t + 2 < a.T ? t + 2 : a.T - 1);
@@ -1561,7 +1608,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
                                      const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                                      const float* h0, float* q, float* hs, float* h_last, float* saved, int B,
                                      int T, int N, int O, int A, int last_action, int reuse_network, int cu_budget,
-                                     void* stream) {
+                                     const float* x_saved, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256) return (int)hipErrorInvalidValue;
   if (cu_budget == 0) cu_budget = 256;      // CUs this launch may occupy: 128 lets two independent unrolls run side by side
@@ -1569,14 +1616,14 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
   a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.ep_len = ep_len; a.ep_map = ep_map; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
-  a.B = B; a.T = T; a.N = N; a.O = O; a.A = A;
+  a.B = B; a.T = T; a.N = N; a.O = O; a.A = A; a.xsrc = x_saved;
   a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   a.KC = (a.I + 15) / 16;
   a.R = (long)B * N;
   const int KS = a.KC * 16 + 4;
   const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;   // + row tables: 2 long + 4 int
-  const size_t fixed = (size_t)4 * a.KC * 64 * 16;
+  const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16;   // fc1 fragments + the two step flags of the x-reusing variant
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
   int nl = NLDW;
@@ -1624,7 +1671,10 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const void* fn;
 #define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
   const bool sv = saved != nullptr, vl = a.vload != 0;
-  if (vl && nl == 6) {
+  static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
+  if (vl && nl == NLDW && !sv && x_saved && T >= 2 && !xs_off) {
+    fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, true>;
+  } else if (vl && nl == 6) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, 6> : (const void*)agent_fwd_kernel<2, false, true, 6>;
   } else
   if (A <= 16) fn = sv ? (vl ? FWD_PICK(1, true, true) : FWD_PICK(1, true, false)) : (vl ? FWD_PICK(1, false, true) : FWD_PICK(1, false, false));

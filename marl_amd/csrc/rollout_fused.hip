@@ -127,41 +127,52 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1), invO = 1.0f / (float)O, invA = 1.0f / (float)A;
   const float invS4 = 1.0f / (float)(S4 > 0 ? S4 : 1), invS = 1.0f / (float)S;
   const bool ovec = (O & 3) == 0, svec = (a.SL & 3) == 0 && a.SL >= 4 * S4 && (reinterpret_cast<uintptr_t>(a.state) & 15) == 0;
+  // Branch-free: every element is hashed and then masked (bitwise AND with all-ones / zero keeps +0.0 exactly) - with
+  // `live ? hash : 0` hipcc emits a branch per ELEMENT, each re-reading its row metadata from LDS and waiting for it
+  // (four basic blocks with three waits each per float4; the generation then takes as long as the gate MFMAs beside it).
+  auto bits = [](float v) { return __builtin_bit_cast(unsigned, v); };
   auto gen_slot = [&](int t, bool to_lds, float* Av, int first, int nthr) {
     if (tid < first || tid >= first + nthr) return;
     const int tl = tid - first;
     const int tNO = t * N * O, tNA = t * N * A, tS = t * (int)a.SL;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     if (ovec) {
       for (int e = tl; e < vrows * O4; e += nthr) {
         const int r = (int)(((float)e + 0.5f) * invO4);
         const int k = 4 * (e - r * O4);
         const int4 mt = rmeta[r];
         const unsigned po = pfx[r];
-        const bool live = t <= mt.z, feed = t < mt.z;
+        const unsigned lm = t <= mt.z ? 0xffffffffu : 0u, fm = t < mt.z ? 0xffffffffu : 0u;
         const unsigned idx = (unsigned)(mt.w * O + k);
-        f32x4 v;
+        u32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = live ? 2.0f * u01(hfin(po, idx + (unsigned)i)) - 1.0f : 0.f;
-        *reinterpret_cast<f32x4*>(a.obs + (long)mt.x + tNO + k) = v;
-        if (to_lds) *reinterpret_cast<f32x4*>(In + r * KS + k) = feed ? v : (f32x4){0.f, 0.f, 0.f, 0.f};   // padded steps feed zeros (rollout.py:122-133)
+        for (int i = 0; i < 4; ++i) v[i] = bits(2.0f * u01(hfin(po, idx + (unsigned)i)) - 1.0f) & lm;
+        *reinterpret_cast<u32x4*>(a.obs + (long)mt.x + tNO + k) = v;
+        if (to_lds) {                              // padded steps feed zeros (rollout.py:122-133)
+          u32x4 w;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = v[i] & fm;
+          *reinterpret_cast<u32x4*>(In + r * KS + k) = w;
+        }
       }
     } else {
       for (int e = tl; e < vrows * O; e += nthr) {
         const int r = (int)(((float)e + 0.5f) * invO);
         const int k = e - r * O;
         const int4 mt = rmeta[r];
-        const bool live = t <= mt.z, feed = t < mt.z;
-        const float v = live ? 2.0f * u01(hfin(pfx[r], (unsigned)(mt.w * O + k))) - 1.0f : 0.f;
-        a.obs[(long)mt.x + tNO + k] = v;
-        if (to_lds) In[r * KS + k] = feed ? v : 0.f;
+        const unsigned lm = t <= mt.z ? 0xffffffffu : 0u, fm = t < mt.z ? 0xffffffffu : 0u;
+        const unsigned v = bits(2.0f * u01(hfin(pfx[r], (unsigned)(mt.w * O + k))) - 1.0f) & lm;
+        reinterpret_cast<unsigned*>(a.obs)[(long)mt.x + tNO + k] = v;
+        if (to_lds) reinterpret_cast<unsigned*>(In)[r * KS + k] = v & fm;
       }
     }
     for (int e = tl; e < vrows * A; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invA);
       const int k = e - r * A;
       const int4 mt = rmeta[r];
-      const bool live = t <= mt.z;
-      const float v = live ? ((k == 0 || u01(hfin(pfx[rows + r], (unsigned)(mt.w * A + k))) < 0.7f) ? 1.f : 0.f) : 0.f;
+      const float uu = u01(hfin(pfx[rows + r], (unsigned)(mt.w * A + k)));
+      const bool on = (t <= mt.z) & ((k == 0) | (uu < 0.7f));
+      const float v = on ? 1.f : 0.f;
       a.avail[(long)mt.y + tNA + k] = v;
       if (Av) Av[r * A + k] = v;
     }
@@ -170,21 +181,21 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
         const int el = (int)(((float)e + 0.5f) * invS4);
         const int k = 4 * (e - el * S4);
         const int4 mt = emeta[el];
-        if (mt.z) {
-          const unsigned ps = pfx[2 * rows + el];
-          const bool live = t <= mt.y;
-          f32x4 v;
+        const unsigned ps = pfx[2 * rows + el];
+        const unsigned lm = t <= mt.y ? 0xffffffffu : 0u;
+        u32x4 v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = (live && k + i < S) ? 2.0f * u01(hfin(ps, (unsigned)(k + i))) - 1.0f : 0.f;
-          *reinterpret_cast<f32x4*>(a.state + (long)mt.x + tS + k) = v;
-        }
+        for (int i = 0; i < 4; ++i) v[i] = bits(2.0f * u01(hfin(ps, (unsigned)(k + i))) - 1.0f) & (k + i < S ? lm : 0u);
+        if (mt.z) *reinterpret_cast<u32x4*>(a.state + (long)mt.x + tS + k) = v;
       }
     } else {
       for (int e = tl; e < nenv_wg * S; e += nthr) {
         const int el = (int)(((float)e + 0.5f) * invS);
         const int k = e - el * S;
         const int4 mt = emeta[el];
-        if (mt.z) a.state[(long)mt.x + tS + k] = (t <= mt.y) ? 2.0f * u01(hfin(pfx[2 * rows + el], (unsigned)k)) - 1.0f : 0.f;
+        const unsigned lm = t <= mt.y ? 0xffffffffu : 0u;
+        const unsigned v = bits(2.0f * u01(hfin(pfx[2 * rows + el], (unsigned)k)) - 1.0f) & lm;
+        if (mt.z) reinterpret_cast<unsigned*>(a.state)[(long)mt.x + tS + k] = v;
       }
     }
   };

@@ -157,14 +157,17 @@ def agent_weights(params):
 
 
 def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
-                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None, cu_budget=0):
+                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None, cu_budget=0, x_saved=None):
     """cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over (0 / 256 = the whole chip); 128 lets two
-    independent unrolls run side by side on two streams (PairedUnroll).  A per-call argument, no process state."""
+    independent unrolls run side by side on two streams (PairedUnroll).  A per-call argument, no process state.
+    x_saved: the `saved` buffer of an earlier unroll of the same weights whose step t+1 input is this one's step t input
+    (include/marl_hip.h): its fc1 outputs are reused."""
     lib = _lib.load()
     check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
                                     _p(_i32(ep_map)) if ep_map is not None else None, _p(h0),
                                     _p(_f32(q)), _p(hs), _p(h_last), _p(saved), B, T, N, O, A,
-                                    1 if last_action else 0, 1 if reuse_network else 0, int(cu_budget), _stream()),
+                                    1 if last_action else 0, 1 if reuse_network else 0, int(cu_budget),
+                                    _p(_f32(x_saved)) if x_saved is not None else None, _stream()),
           "marl_agent_unroll_fwd")
 
 
