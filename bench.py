@@ -127,8 +127,9 @@ def main():
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: mixer GEMMs on the bf16 matrix cores (config 5)")
-    ap.add_argument("--blocking-loss", action="store_true",
-                    help="read every update's loss back at once (default: the copy is enqueued and read at the end of the timed region - same work, no host stall between steps)")
+    ap.add_argument("--blocking-loss", "--blocking-readbacks", dest="blocking_loss", action="store_true",
+                    help="read every update's loss and every rollout's statistics back at once (default: the copies are enqueued "
+                         "and read at the end of the timed region - same device work, no host stall between steps)")
     ap.add_argument("--hip-graph", action="store_true", help="replay the learner's forward/backward schedule as one hipGraph (opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
@@ -241,8 +242,17 @@ def main():
 
     train_steps = [0]
 
+    lazy_stats = []
+
     def one_step():
-        episodes, _, _, steps = worker.generate_episodes(E)
+        if o.blocking_loss:
+            episodes, _, _, steps = worker.generate_episodes(E)
+        else:
+            # same rollout, same device-side statistics; their copy to the host is enqueued instead of awaited (the env
+            # steps are summed from the handles after the timed region's final barrier)
+            episodes, st = worker.finish_episodes(worker.launch_episodes(), lazy=True)
+            lazy_stats.append(st)
+            steps = 0
         buf.store_episode(episodes)
         batch = buf.sample(min(buf.current_size, args.batch_size))
         loss = learner.train(batch, train_steps[0])
@@ -278,6 +288,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timing["on"] = False
+    env_steps += sum(st.steps() for st in lazy_stats[o.warmup:o.warmup + o.steps])
     tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tt.clone()

@@ -16,6 +16,7 @@ import torch
 
 from ..env.synthetic_smac import EpisodeRecord
 from ..rollout import EpisodeBatch
+from ..hostutil import h2d_async
 
 
 class ReplayBuffer:
@@ -107,7 +108,7 @@ class ReplayBuffer:
         else:
             idx = np.random.randint(0, self.current_size, batch_size)
         if self.record is not None:
-            idx_t = torch.as_tensor(idx, dtype=torch.long, device=self.record.obs.device)
+            idx_t = h2d_async(idx, self.record.obs.device, torch.long)   # pinned staging: no host stall behind the queue
             return EpisodeBatch(ring=self.record, index=idx_t)     # read in place by the learners (no gather copy)
         return {k: self.buffers[k][idx] for k in self.buffers}
 

@@ -595,11 +595,14 @@ extern "C" int marl_qplex_mix_bwd(const float* w_raw, const float* q, const floa
 
 // get_max_episode_len (algorithm/q_learner.py:49-66) in one launch: per episode the first step with terminated == 1,
 // max over episodes of (that step + 1); episodes that never terminate contribute nothing (quirk Q2).  One wave per
-// episode scans its row 64 steps at a time (ballot + first set bit), one atomicMax per episode.
+// episode at a time scans its row 64 steps at a time (ballot + first set bit) and keeps a running max; ONE atomicMax per
+// workgroup (4096 episodes each with its own atomic on the one output word took 48 us).
 __global__ __launch_bounds__(TPB) void first_term_kernel(const float* term, long ld, int E, int T, int* out) {
-  const int lane = threadIdx.x & 63;
+  __shared__ int wmax[TPB / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long wave_id = ((long)blockIdx.x * TPB + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * TPB) >> 6;
+  int best = 0;
   for (long e = wave_id; e < E; e += nwaves) {
     int first = 0;
     for (int t0 = 0; t0 < T && first == 0; t0 += 64) {
@@ -608,7 +611,14 @@ __global__ __launch_bounds__(TPB) void first_term_kernel(const float* term, long
       const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
       if (m) first = t0 + __builtin_ctzll(m) + 1;
     }
-    if (lane == 0 && first > 0) atomicMax(out, first);
+    best = first > best ? first : best;
+  }
+  if (lane == 0) wmax[wv] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int b = wmax[0];
+    for (int i = 1; i < TPB / 64; ++i) b = wmax[i] > b ? wmax[i] : b;
+    if (b > 0) atomicMax(out, b);
   }
 }
 
@@ -617,7 +627,7 @@ extern "C" int marl_first_terminated_len(const float* term, long ld, int E, int 
   hipError_t e = hipMemsetAsync(out, 0, sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   if (E <= 0 || T <= 0) return 0;
-  long nb = ((long)E * 64 + TPB - 1) / TPB; if (nb > 1024) nb = 1024;
+  long nb = ((long)E * 64 + TPB - 1) / TPB; if (nb > 256) nb = 256;
   hipLaunchKernelGGL(first_term_kernel, dim3((unsigned)nb), dim3(TPB), 0, s, term, ld, E, T, out);
   MARL_CHECK_LAUNCH();
   return 0;

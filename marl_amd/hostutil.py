@@ -85,6 +85,46 @@ def to_dev(x, device, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(x)).to(device=device, dtype=dtype).contiguous()
 
 
+class _PinnedRing:
+    """Host -> device copies that do not stall the host: a pageable source makes the copy wait (on the host) until
+    everything queued before it has run, which keeps the host from enqueuing the next kernels behind a long one.
+    Small arrays go through a ring of pinned staging buffers instead; a slot is reused only after its copy finished."""
+    SLOTS = 8
+
+    def __init__(self):
+        self.rings = {}
+
+    def to_device(self, arr, device, dtype):
+        a = np.ascontiguousarray(arr)
+        t = torch.from_numpy(a)
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        key = (dtype, t.numel())
+        ring = self.rings.setdefault(key, {"k": 0, "slots": []})
+        if len(ring["slots"]) < self.SLOTS:
+            ring["slots"].append([torch.empty(t.numel(), dtype=dtype).pin_memory(), None])
+        slot = ring["slots"][ring["k"] % len(ring["slots"])] if len(ring["slots"]) == self.SLOTS else ring["slots"][-1]
+        ring["k"] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(t.reshape(-1))
+        out = slot[0].to(device, non_blocking=True).reshape(t.shape)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[1] = ev
+        return out
+
+
+_PINNED = _PinnedRing()
+
+
+def h2d_async(arr, device, dtype):
+    """numpy array -> device tensor through pinned staging (see _PinnedRing); CPU targets just convert."""
+    if torch.device(device).type != "cuda":
+        return torch.as_tensor(np.asarray(arr), dtype=dtype, device=device)
+    return _PINNED.to_device(arr, device, dtype)
+
+
 def onehot_to_index(u_onehot):
     """(…,A) one-hot or all-zero rows -> int32 index, -1 for all-zero rows (padding / t=0)."""
     s = u_onehot.sum(-1)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .hostutil import require_cuda
+from .hostutil import h2d_async, require_cuda
 
 
 class EpisodeBatch(dict):
@@ -81,6 +81,30 @@ class EpisodeBatch(dict):
             v = self[k].cpu().numpy()
             out[k] = v.astype(np.int64) if k == "u" else v.astype(np.float64)
         return out
+
+
+class RolloutStats:
+    """Per-episode reward / win flag / length of one rollout, copied to pinned host memory in stream order; the
+    accessors wait for that copy only (finish_episodes(lazy=True))."""
+
+    def __init__(self, stats_dev):
+        self.buf = torch.empty(stats_dev.shape, dtype=stats_dev.dtype).pin_memory()
+        self.buf.copy_(stats_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def _host(self):
+        self.event.synchronize()
+        return self.buf
+
+    def rewards(self):
+        return self._host()[0].tolist()
+
+    def wins(self):
+        return [bool(x) for x in self._host()[1].tolist()]
+
+    def steps(self):
+        return int(self._host()[2].sum().item())
 
 
 class RolloutWorker:
@@ -187,7 +211,7 @@ class RolloutWorker:
             sched[t] = epsilon
             if a.epsilon_anneal_scale == 'step':
                 epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
-        eps_dev = torch.from_numpy(sched).to(dev, non_blocking=True)
+        eps_dev = h2d_async(sched, dev, torch.float32)       # pinned staging: the host does not wait for the queue
         mac.init_hidden(E)
         env.whole_rollout(mac.agent.weights(), eps_dev, self.rseed, rec, a.last_action, a.reuse_network,
                           h_out=mac.hidden_states.view(E * N, H))
@@ -212,13 +236,18 @@ class RolloutWorker:
             rec = env.new_record()
         return self._launch_whole(rec, evaluate, mac if mac is not None else self.mac)
 
-    def finish_episodes(self, pending):
-        """(episodes, rewards, win_tags, steps) of a launched rollout: the one device-to-host copy (and sync)."""
+    def finish_episodes(self, pending, lazy=False):
+        """(episodes, rewards, win_tags, steps) of a launched rollout: the one device-to-host copy (and sync).
+        ``lazy``: the statistics are still reduced on the device and copied out, but into pinned memory in stream order;
+        returns (episodes, RolloutStats) and the host does not wait - RolloutStats.rewards() / wins() / steps() do."""
         rec, evaluate = pending
         if evaluate and self.args.replay_dir != '':
             self.env.save_replay()
             self.env.close()
-        stats = torch.stack([rec.r.sum(1), rec.won.float(), rec.length.float()], 0).cpu()
+        stats = torch.stack([rec.r.sum(1), rec.won.float(), rec.length.float()], 0)
+        if lazy:
+            return EpisodeBatch(rec), RolloutStats(stats)
+        stats = stats.cpu()
         return EpisodeBatch(rec), stats[0].tolist(), [bool(x) for x in stats[1].tolist()], int(stats[2].sum().item())
 
     # ------------------------------------------------------------------ serial path (reference loop)
