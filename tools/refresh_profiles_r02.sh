@@ -27,8 +27,13 @@ done
   echo -n "qmix MMM2 envs=1024 mixer bf16 : "; python3 tools/prof_learner.py --alg qmix --shape MMM2 --envs 1024 --warmup 5 --updates 20 --mixer-dtype bf16 2>/dev/null | grep updates ) > $OUT/${TAG}_learner_rates.txt
 # single-GPU step times at the shard sizes of the 2 / 4 / 8-GPU strong-scaling runs
 ( for E in 512 1024 2048 4096; do
-    python3 bench.py --envs $E --steps 20 --warmup 6 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c "
+    python3 bench.py --envs $E --steps 20 --warmup 6 --no-cpu-baseline $SHARD_FLAGS 2>/dev/null | grep '^{"metric"' | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('envs_per_gpu=%d : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['global_envs'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"
   done ) > $OUT/${TAG}_shard_steps.txt
+# hardware probes: HBM read ceiling; fp32 MFMA vs VALU / LDS issue on one SIMD (built in the container: tools/probe/)
+( [ -x tools/probe/bw_probe ] && timeout 120 tools/probe/bw_probe ) > $OUT/${TAG}_bw_probe.txt 2>&1
+( [ -x tools/probe/coissue_probe ] && timeout 120 tools/probe/coissue_probe ) > $OUT/${TAG}_coissue_probe.txt 2>&1
+# device idle gaps of the default bench step
+bash tools/prof_gaps.sh > $OUT/${TAG}_gaps.txt 2>&1
 cat $OUT/${TAG}_learner_rates.txt $OUT/${TAG}_shard_steps.txt

@@ -75,7 +75,7 @@ def pmc_summary(sub, names, source, dest):
     return out
 
 
-out = pmc_summary("_pmc", ("agent_", "qmix_fused_kernel", "wgrad_direct", "synth_rollout"),
+out = pmc_summary("_pmc", ("agent_", "qmix_fused_kernel", "wgrad_direct", "wgrad_tall", "synth_rollout"),
                   "rocprofv3 --pmc <group> --kernel-trace, four separate passes of tools/prof_learner.py --updates 3 --rollouts 2 "
                   "(QMIX 2s3z, 4096 envs, T=120, 1x MI355X); values are means per launch", "_pmc.json")
 if out:
@@ -93,7 +93,8 @@ for sub, dst in (("_qtran", "_qtran_kernel_stats.csv"), ("_mmm2_fp32", "_mmm2_fp
     f = os.path.join(G, tag + sub, "p_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, tag + dst))
-for name in ("_bench_mmm2_fp32_line.json", "_bench_mmm2_bf16_line.json", "_learner_rates.txt", "_shard_steps.txt"):
+for name in ("_bench_mmm2_fp32_line.json", "_bench_mmm2_bf16_line.json", "_learner_rates.txt", "_shard_steps.txt",
+             "_bw_probe.txt", "_coissue_probe.txt", "_gaps.txt"):
     src = os.path.join(G, tag + name)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(P, tag + name))
