@@ -337,9 +337,16 @@ def main():
             # the double-Q unroll reads the fc1 outputs the eval unroll saved (all steps but the last): it executes fewer
             # FLOP than the algorithmic count and is kept out of `achieved`
             I_ = args.obs_shape + args.n_actions + N
-            fl_x = fl - 2 * I_ * args.rnn_hidden_dim * E * N * (T - 1)
+            # (one row tile per workgroup runs the software-pipelined kernel, which has no reusing variant; wide
+            # observations that need six prefetch registers neither - marl_agent_unroll_fwd ignores x_saved there)
+            tiles = (E * N + 15) // 16
+            split = learner.pair.chain_split(E * N, T, args.obs_shape)
+            rt = -(-tiles // (split[0] if split else 256))
+            applies = rt >= 2 and args.obs_shape % 4 == 0 and 2048 // (4 * args.obs_shape) >= min(rt, 8)
+            fl_x = fl - (2 * I_ * args.rnn_hidden_dim * E * N * (T - 1) if applies else 0)
             roof["reuse_launch"] = {"what": "double-Q unroll reusing the eval unroll's fc1 outputs", "avg_launch_ms": float(np.mean(xs_ms)),
-                                    "launches_timed": len(xs_ms), "flop_executed": fl_x, "flop_algorithmic": fl}
+                                    "launches_timed": len(xs_ms), "reuse_applies": bool(applies), "flop_executed": fl_x,
+                                    "flop_algorithmic": fl}
         if o.roofline_kernel == "mixer":
             # fused wide-state QMIX forward: one launch reads every state row once (4 S bytes), the chosen Qs (4 N) and
             # writes q_tot (4): algorithmic bytes = rows * (4 S + 4 N + 4), rows = envs per GPU * T (with bf16

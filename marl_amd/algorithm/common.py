@@ -157,6 +157,34 @@ class LossReadback:
         return LossReadback.Handle(buf, ev, fn)
 
 
+class SpeculativeBatchMixin:
+    """Learners with `_forward_backward(db)`, `args`, `reducer`, `max_episode_len`."""
+    _full_len_streak = 0      # consecutive updates whose max_episode_len was the record's full length
+
+    def _device_batch(self, rec, index, small):
+        """DeviceBatch of a device record with max_episode_len agreed.  While the last updates all ran at the record's
+        full length, the forward / backward is launched for that length BEFORE the value is read back (the read-back waits
+        only for the kernel that computes it): the host never waits for the device in front of an update, and the device
+        never waits for the host's first launches after the sync.  A different length - every episode of the batch ended
+        early - redoes the pass (forward / backward overwrite their outputs and zero the gradient buffer themselves).
+        Returns None when the pass has already been launched."""
+        from ..hostutil import DeviceBatch
+        term = (small if small is not None else rec).term
+        if not (term.is_cuda and term.dtype == torch.float32 and term.shape[0] > 0) or self._full_len_streak < 2:
+            db = DeviceBatch.from_record_auto(rec, self.args, reducer=self.reducer, index=index, small=small)
+            full = db.T == min(rec.T, self.args.episode_limit)
+            self._full_len_streak = self._full_len_streak + 1 if full else 0
+            return db
+        db, pending = DeviceBatch.from_record_begin(rec, self.args, reducer=self.reducer, index=index, small=small)
+        self.max_episode_len = db.T
+        self._forward_backward(db)
+        T = pending()
+        if T == db.T:
+            return None
+        self._full_len_streak = 0
+        return DeviceBatch.from_record(rec, self.args, T=T, index=index, small=small)
+
+
 class Scratch:
     def __init__(self):
         self.d = {}

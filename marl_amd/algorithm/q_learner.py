@@ -19,11 +19,11 @@ from .. import ops
 from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import VDNMixer, QMixMixer, DMAQer
-from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll, ResumeMixin, LossReadback,
+from .common import (MASK_BIG, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward, GradReducer, PairedUnroll, ResumeMixin, LossReadback, SpeculativeBatchMixin,
                      GraphedUpdate)
 
 
-class QLearner(ResumeMixin):
+class QLearner(ResumeMixin, SpeculativeBatchMixin):
     def __init__(self, mac, args):
         self.max_episode_len = args.episode_limit
         self.gamma = args.gamma
@@ -178,9 +178,13 @@ class QLearner(ResumeMixin):
                 db = DeviceBatch.from_record(batch.ring, self.args, T=prep[1], index=batch.index, small=prep[0])
             else:
                 small = batch.ring.select_small(batch.index)
-                db = DeviceBatch.from_record_auto(batch.ring, self.args, reducer=self.reducer, index=batch.index, small=small)
+                db = self._device_batch(batch.ring, batch.index, small)
+                if db is None:
+                    return self._finish_update(train_step)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
-            db = DeviceBatch.from_record_auto(batch.record, self.args, reducer=self.reducer)
+            db = self._device_batch(batch.record, None, None)
+            if db is None:
+                return self._finish_update(train_step)
         else:
             T = None
             if self.reducer.enabled:   # shards must agree on T

@@ -19,10 +19,10 @@ from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import QtranQBase, QtranQAlt, QtranV, QMixMixer
 from .common import (MASK_BIG, MASK_QTRAN_EVAL, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward,
-                     GradReducer, PairedUnroll, ResumeMixin, LossReadback)
+                     GradReducer, PairedUnroll, ResumeMixin, LossReadback, SpeculativeBatchMixin)
 
 
-class QTRANLearner(ResumeMixin):
+class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
     def __init__(self, mac, args):
         self.max_episode_len = args.episode_limit
         self.gamma = args.gamma
@@ -149,17 +149,18 @@ class QTRANLearner(ResumeMixin):
         elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
             # replay sample: big arrays are read in place from the ring through the episode index
             small = batch.ring.select_small(batch.index)
-            db = DeviceBatch.from_record_auto(batch.ring, self.args, reducer=self.reducer, index=batch.index, small=small)
+            db = self._device_batch(batch.ring, batch.index, small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
-            db = DeviceBatch.from_record_auto(batch.record, self.args, reducer=self.reducer)
+            db = self._device_batch(batch.record, None, None)
         else:
             T = None
             if self.reducer.enabled:
                 T = DeviceBatch.first_terminated_len(torch.as_tensor(np.asarray(batch['terminated'])),
                                                      self.args.episode_limit, reducer=self.reducer)
             db = DeviceBatch.from_dict(batch, self.args, self.device, T=T)
-        self.max_episode_len = db.T
-        self._forward_backward(db)
+        if db is not None:               # (None: _device_batch already launched the pass for the record's full length)
+            self.max_episode_len = db.T
+            self._forward_backward(db)
         self.reducer.allreduce_(self._flat.gradx)
         st = self._flat.stats
         self.optimizer.step(den=st[3:4])

@@ -125,6 +125,35 @@ def h2d_async(arr, device, dtype):
     return _PINNED.to_device(arr, device, dtype)
 
 
+class AsyncInt:
+    """Read-back of a one-element device tensor that does not wait for what was enqueued AFTER its producer: the copy runs
+    on a side stream behind an event recorded right after the producing kernel.  `wait()` blocks on that copy only."""
+    _side = {}
+    _bufs = {}
+
+    def __init__(self, dev_tensor):
+        cur = torch.cuda.current_stream()
+        key = dev_tensor.device
+        side = AsyncInt._side.get(key)
+        if side is None:
+            side = AsyncInt._side[key] = torch.cuda.Stream(device=key)
+            AsyncInt._bufs[key] = [[torch.empty(1, dtype=dev_tensor.dtype).pin_memory() for _ in range(8)], 0]
+        ring = AsyncInt._bufs[key]
+        self.buf = ring[0][ring[1] % 8]
+        ring[1] += 1
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            self.buf.copy_(dev_tensor, non_blocking=True)
+            self.done = torch.cuda.Event()
+            self.done.record(side)
+
+    def wait(self):
+        self.done.synchronize()
+        return int(self.buf[0])
+
+
 def onehot_to_index(u_onehot):
     """(…,A) one-hot or all-zero rows -> int32 index, -1 for all-zero rows (padding / t=0)."""
     s = u_onehot.sum(-1)
@@ -215,16 +244,30 @@ class DeviceBatch:
         if not (term.is_cuda and term.dtype == torch.float32 and term.shape[0] > 0):
             T = cls.first_terminated_len(term, args.episode_limit, reducer=reducer)
             return cls.from_record(rec, args, T=T, index=index, small=small)
-        out = ops.first_terminated_len(term, args.episode_limit)
+        db, pending = cls.from_record_begin(rec, args, reducer=reducer, index=index, small=small)
+        T = pending()
+        if T != db.T:
+            db = cls.from_record(rec, args, T=T, index=index, small=small)
+        return db
+
+    @classmethod
+    def from_record_begin(cls, rec, args, reducer=None, index=None, small=None):
+        """First half of from_record_auto for device records: launches the max_episode_len kernel, starts its read-back on a
+        side stream and builds the batch for the common case T = the record's full length.  Returns (db, pending);
+        pending() is the agreed T (blocks only until the kernel and its copy are done, NOT on work enqueued since - a learner
+        may launch its forward / backward on `db` first and redo it in the rare case T differs)."""
+        src = small if small is not None else rec
+        out = ops.first_terminated_len(src.term, args.episode_limit)
         if reducer is not None and reducer.enabled:
             reducer.dist.all_reduce(out, op=reducer.dist.ReduceOp.MAX, group=reducer.group)
         guess = min(rec.T, args.episode_limit)
+        handle = AsyncInt(out)
         db = cls.from_record(rec, args, T=guess, index=index, small=small)
-        m = int(out.item())
-        T = m if m > 0 else guess          # none terminated: episode_limit, never more steps than the record holds
-        if T != guess:
-            db = cls.from_record(rec, args, T=T, index=index, small=small)
-        return db
+
+        def pending():
+            m = handle.wait()
+            return m if m > 0 else guess      # none terminated: episode_limit, never more steps than the record holds
+        return db, pending
 
     @classmethod
     def from_record(cls, rec, args, T=None, index=None, small=None):

@@ -265,9 +265,11 @@ def first_terminated_len(term, T):
     (0 = no episode terminates).  term: (E, >=T[, 1]) CUDA float32 with unit inner stride."""
     t2 = term.reshape(term.shape[0], -1)
     assert t2.dtype == torch.float32 and t2.is_cuda and t2.stride(1) == 1
-    out = _FT_OUT.get(t2.device)
-    if out is None:
-        out = _FT_OUT[t2.device] = torch.zeros(1, dtype=torch.int32, device=t2.device)
+    ring = _FT_OUT.get(t2.device)
+    if ring is None:         # a ring of output words: an asynchronous read-back of one call may still be pending at the next
+        ring = _FT_OUT[t2.device] = [torch.zeros(8, dtype=torch.int32, device=t2.device), 0]
+    out = ring[0][ring[1] % 8:ring[1] % 8 + 1]
+    ring[1] += 1
     check(_lib.load().marl_first_terminated_len(_p(t2), t2.stride(0), t2.shape[0], min(T, t2.shape[1]), _p(out), _stream()),
           "marl_first_terminated_len")
     return out

@@ -128,3 +128,39 @@ def test_hip_graph_replay_equals_eager():
             assert any(e["graph"] is not None for e in g.entries.values()), "no graph was captured"
     assert out[False][0] == out[True][0]
     np.testing.assert_array_equal(out[False][1], out[True][1])
+
+
+def test_speculative_full_length_launch_redoes_a_short_batch():
+    """QLearner launches forward / backward for the record's full length before max_episode_len is read back once the
+    last updates all ran at full length; a batch whose episodes ALL ended early must then be redone at its own length -
+    same losses and parameters as a learner that always reads the length first."""
+    import bench
+    from marl_amd.controller.share_params import SharedMAC
+    from marl_amd.algorithm.q_learner import QLearner
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    out = {}
+    for spec in (False, True):
+        args = bench.make_args("qmix", "2s3z", 12)
+        E = 40
+        torch.manual_seed(0)
+        mac = SharedMAC(args)
+        learner = QLearner(mac, args)
+        env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, 12, seed=5, fixed_length=True)
+        w = RolloutWorker(env, mac, args)
+        losses, lens = [], []
+        for i in range(6):
+            ep = w.generate_episodes(E)[0]
+            if i == 4:                          # every episode of this batch ends after 5 steps
+                rec = ep.record
+                rec.term[:, 4:] = 1.0
+                rec.padded[:, 5:] = 1.0
+                rec.length.fill_(5)
+            if not spec:
+                learner._full_len_streak = 0     # never speculate
+            losses.append(learner.train(ep, i))
+            lens.append(learner.max_episode_len)
+        out[spec] = (losses, lens, learner._flat.flat.detach().cpu().numpy().copy())
+    assert out[True][1] == out[False][1] == [12, 12, 12, 12, 5, 12]
+    assert out[True][0] == out[False][0]
+    np.testing.assert_array_equal(out[True][2], out[False][2])
