@@ -272,6 +272,16 @@ int marl_qplex_mix_bwd(const float* w_raw, const float* q, const float* max_q, c
  * episode_limit); episodes that never terminate are ignored (quirk Q2).  term: (E, >=T) fp32, row stride ld. */
 int marl_first_terminated_len(const float* term, long ld, int E, int T, int* out, void* stream);
 
+/* ReplayBuffer.sample (common/replaybuffer.py:54-60) for a ring that lives in HBM: the per-step arrays of the B sampled
+ * episodes idx[b] (int64) in one launch.  Sources are the ring's arrays: u (E,T,N) int32, r / terminated / padded (E,T)
+ * fp32, length / won (E) int32, avail (E,T+1,N,A) fp32 ((T+1)-slot storage).  Outputs: o_map (B) = idx as int32 (the
+ * episode map the unroll / mixer kernels read obs and state through), u and u_act = max(u, 0) (B,T,N), r / term / padded
+ * (B,T), length / won (B), avail_next (B,T,N,A) = avail slots 1..T.  obs and state are NOT copied. */
+int marl_replay_gather(const long long* idx, int B, int T, int N, int A, const int* u_src, const float* r_src,
+                       const float* term_src, const float* padded_src, const int* length_src, const int* won_src,
+                       const float* avail_src, int* o_map, int* u, int* u_act, float* r, float* term, float* padded,
+                       int* length, int* won, float* avail_next, void* stream);
+
 /* TD target + masked squared error (q_learner.py:165-168).  Writes the UN-normalised gradient
  * dq_tot = -2 mask^2 td and out2 = {sum (mask td)^2, sum mask}; the 1/sum(mask) factor is applied
  * in the optimizer so that data-parallel ranks can all-reduce numerators. */

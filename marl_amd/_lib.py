@@ -74,6 +74,7 @@ SIGNATURES = {
     "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "marl_agent_bwd_workspace": (SZ, [I, I, I]),
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, I, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
+    "marl_replay_gather": (I, [P, I, I, I, I] + [P] * 16 + [P]),
     "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),
     "marl_q_masked_max": (I, [P, P, F, P, P, L, I, P]),
     "marl_q_double_select": (I, [P, P, P, F, P, P, L, I, P]),

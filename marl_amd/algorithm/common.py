@@ -397,7 +397,7 @@ class GraphedUpdate:
             # the graph would write into retired storage - drop it and capture again after a warm-up
             e["graph"], e["ws_keep"], e["calls"] = None, None, 0
         torch.clamp(small.u[:, :T], min=0, out=e["u_act"])
-        e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail[:, 1:T + 1])
+        e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail_next[:, :T] if small.avail is None else small.avail[:, 1:T + 1])
         db.__dict__.pop("_avail", None)
         learner.max_episode_len = T
         e["calls"] += 1

@@ -633,6 +633,62 @@ extern "C" int marl_first_terminated_len(const float* term, long ld, int E, int 
   return 0;
 }
 
+// ReplayBuffer.sample (common/replaybuffer.py:54-60) for a device-resident ring: the per-step arrays of the sampled
+// episodes in ONE launch (was seven index_select launches + an int32 cast + a clamp + the re-packing of next-step avail).
+// Block (b, chunk): a 1024-element chunk of episode idx[b]'s avail slots 1..T; chunk 0 also copies the small arrays.
+namespace {
+struct GatherArgs {
+  const long long* idx;
+  const int *u_src, *length_src, *won_src;
+  const float *r_src, *term_src, *padded_src, *avail_src;
+  int *o_map, *u, *u_act, *length, *won;
+  float *r, *term, *padded, *avail_next;
+  int B, T, N, A;
+};
+__global__ __launch_bounds__(TPB) void replay_gather_kernel(GatherArgs a) {
+  const int b = blockIdx.x;
+  const long e = (long)a.idx[b];
+  const int TNA = a.T * a.N * a.A;
+  const float* av = a.avail_src + (e * (a.T + 1) + 1) * (long)a.N * a.A;
+  float* ao = a.avail_next + (long)b * TNA;
+  for (int i = blockIdx.y * 1024 + threadIdx.x; i < TNA && i < (blockIdx.y + 1) * 1024; i += TPB) ao[i] = av[i];
+  if (blockIdx.y != 0) return;
+  const int TN = a.T * a.N;
+  for (int i = threadIdx.x; i < TN; i += TPB) {
+    const int v = a.u_src[e * TN + i];
+    a.u[(long)b * TN + i] = v;
+    a.u_act[(long)b * TN + i] = v < 0 ? 0 : v;
+  }
+  for (int i = threadIdx.x; i < a.T; i += TPB) {
+    a.r[(long)b * a.T + i] = a.r_src[e * a.T + i];
+    a.term[(long)b * a.T + i] = a.term_src[e * a.T + i];
+    a.padded[(long)b * a.T + i] = a.padded_src[e * a.T + i];
+  }
+  if (threadIdx.x == 0) {
+    a.o_map[b] = (int)e;
+    a.length[b] = a.length_src[e];
+    a.won[b] = a.won_src[e];
+  }
+}
+}  // namespace
+
+extern "C" int marl_replay_gather(const long long* idx, int B, int T, int N, int A, const int* u_src, const float* r_src,
+                                  const float* term_src, const float* padded_src, const int* length_src,
+                                  const int* won_src, const float* avail_src, int* o_map, int* u, int* u_act, float* r,
+                                  float* term, float* padded, int* length, int* won, float* avail_next, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  GatherArgs a;
+  a.idx = idx; a.u_src = u_src; a.length_src = length_src; a.won_src = won_src;
+  a.r_src = r_src; a.term_src = term_src; a.padded_src = padded_src; a.avail_src = avail_src;
+  a.o_map = o_map; a.u = u; a.u_act = u_act; a.length = length; a.won = won;
+  a.r = r; a.term = term; a.padded = padded; a.avail_next = avail_next;
+  a.B = B; a.T = T; a.N = N; a.A = A;
+  const int chunks = (T * N * A + 1023) / 1024;
+  hipLaunchKernelGGL(replay_gather_kernel, dim3((unsigned)B, (unsigned)(chunks > 0 ? chunks : 1)), dim3(TPB), 0, (hipStream_t)stream, a);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" size_t marl_loss_workspace(long rows) { return (size_t)1024 * 4 * sizeof(float); }
 
 extern "C" int marl_td_loss(const float* q_tot, const float* q_tot_tgt, const float* r, const float* term,

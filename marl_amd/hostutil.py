@@ -279,10 +279,11 @@ class DeviceBatch:
         Ta, N, O, S, A = rec.T, rec.N, rec.O, rec.S, rec.A
         big = rec
         self.o_map = None
+        idx = None
         if index is not None:
             idx = index.to(device=rec.obs.device, dtype=torch.long)
-            self.o_map = idx.to(torch.int32).contiguous()
             rec = small if small is not None else rec.select_small(idx)
+            self.o_map = rec.o_map if getattr(rec, "o_map", None) is not None else idx.to(torch.int32).contiguous()
         E = rec.E
         if T is None:
             T = cls.first_terminated_len(rec.term, args.episode_limit)
@@ -300,19 +301,26 @@ class DeviceBatch:
         self.u_bs = Ta * N
         cutc = lambda x: x[:, :T].contiguous()
         self.u_taken = cutc(rec.u)
-        self.u_act = self.u_taken.clamp(min=0)
+        fused = getattr(rec, "avail_next", None) is not None       # select_small on the device (one launch) made these
+        self.u_act = cutc(rec.u_act) if fused else self.u_taken.clamp(min=0)
         self.r, self.term, self.padded = cutc(rec.r).view(-1), cutc(rec.term).view(-1), cutc(rec.padded).view(-1)
-        self._avail_src = (rec, T)            # `avail` (current-step availability, QPLEX / QTRAN only) is built lazily
-        self.avail_next = rec.avail[:, 1:T + 1].reshape(E * T * N, A)
+        # `avail` (current-step availability, QPLEX / QTRAN only) is built lazily; a fused gather did not copy it
+        self._avail_src = (rec, T) if rec.avail is not None else (big, T, idx, rec.length)
+        self.avail_next = (rec.avail_next[:, :T] if fused else rec.avail[:, 1:T + 1]).reshape(E * T * N, A)
         return self
 
     @property
     def avail(self):
         if "_avail" not in self.__dict__:
-            rec, T = self._avail_src
-            t_idx = torch.arange(T, device=rec.avail.device)[None, :, None, None]
-            live = t_idx < rec.length[:, None, None, None]
-            self._avail = torch.where(live, rec.avail[:, :T], torch.zeros((), device=rec.avail.device)).reshape(-1, rec.A)
+            if len(self._avail_src) == 2:
+                rec, T = self._avail_src
+                av, length = rec.avail[:, :T], rec.length
+            else:
+                big, T, idx, length = self._avail_src
+                av = big.avail.index_select(0, idx)[:, :T]
+            t_idx = torch.arange(T, device=av.device)[None, :, None, None]
+            live = t_idx < length[:, None, None, None]
+            self._avail = torch.where(live, av, torch.zeros((), device=av.device)).reshape(-1, av.shape[-1])
         return self._avail
 
     @avail.setter

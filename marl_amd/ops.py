@@ -260,6 +260,21 @@ def qplex_mix_bwd(w_raw, q, max_q, key, ag, ac, g, dq, dw_raw, dv, dkey, dag, da
 _FT_OUT = {}
 
 
+def replay_gather(idx, src, out):
+    """src / out: objects with u, r, term, padded, length, won (+ src.avail, out.o_map, out.u_act, out.avail_next)."""
+    assert idx.dtype == torch.int64 and idx.is_cuda and idx.is_contiguous()
+    B, T, N, A = int(idx.numel()), src.T, src.N, src.A
+    for t in (src.u, src.r, src.term, src.padded, src.length, src.won, src.avail, out.u, out.u_act, out.r, out.term, out.padded,
+              out.length, out.won, out.avail_next, out.o_map):
+        assert t.is_cuda and t.is_contiguous()
+    assert src.u.dtype == torch.int32 and src.length.dtype == torch.int32 and src.won.dtype == torch.int32
+    check(_lib.load().marl_replay_gather(_p(idx), B, T, N, A, _p(src.u), _p(_f32(src.r)), _p(_f32(src.term)), _p(_f32(src.padded)),
+                                         _p(src.length), _p(src.won), _p(_f32(src.avail)), _p(_i32(out.o_map)), _p(_i32(out.u)),
+                                         _p(_i32(out.u_act)), _p(_f32(out.r)), _p(_f32(out.term)), _p(_f32(out.padded)),
+                                         _p(_i32(out.length)), _p(_i32(out.won)), _p(_f32(out.avail_next)), _stream()),
+          "marl_replay_gather")
+
+
 def first_terminated_len(term, T):
     """max over episodes of (first terminated step + 1) within the first T steps as a 1-element int32 device tensor
     (0 = no episode terminates).  term: (E, >=T[, 1]) CUDA float32 with unit inner stride."""
