@@ -222,7 +222,7 @@ def main():
             e0.record()
             orig_fwd(*a, **k)
             e1.record()
-            (xs_pairs if k.get("x_saved") is not None else ev_pairs).append((e0, e1))
+            (xs_pairs if k.get("gi_in") is not None else ev_pairs).append((e0, e1))
         else:
             orig_fwd(*a, **k)
     ops.agent_unroll_fwd = timed_fwd
@@ -337,14 +337,10 @@ def main():
             # the double-Q unroll reads the fc1 outputs the eval unroll saved (all steps but the last): it executes fewer
             # FLOP than the algorithmic count and is kept out of `achieved`
             I_ = args.obs_shape + args.n_actions + N
-            # (one row tile per workgroup runs the software-pipelined kernel, which has no reusing variant; wide
-            # observations that need six prefetch registers neither - marl_agent_unroll_fwd ignores x_saved there)
-            tiles = (E * N + 15) // 16
-            split = learner.pair.chain_split(E * N, T, args.obs_shape)
-            rt = -(-tiles // (split[0] if split else 256))
-            applies = rt >= 2 and args.obs_shape % 4 == 0 and 2048 // (4 * args.obs_shape) >= min(rt, 8)
-            fl_x = fl - (2 * I_ * args.rnn_hidden_dim * E * N * (T - 1) if applies else 0)
-            roof["reuse_launch"] = {"what": "double-Q unroll reusing the eval unroll's fc1 outputs", "avg_launch_ms": float(np.mean(xs_ms)),
+            # fc1 and the input-side gate products (x W_ih) of all steps but the last are read, not computed
+            fl_x = fl - (2 * I_ * args.rnn_hidden_dim + 6 * args.rnn_hidden_dim ** 2) * E * N * (T - 1)
+            applies = True          # the learner passes gi_in only where marl_agent_unroll_reuse_supported says so
+            roof["reuse_launch"] = {"what": "double-Q unroll reusing the eval unroll's fc1 outputs and input-side gate sums", "avg_launch_ms": float(np.mean(xs_ms)),
                                     "launches_timed": len(xs_ms), "reuse_applies": bool(applies), "flop_executed": fl_x,
                                     "flop_algorithmic": fl}
         if o.roofline_kernel == "mixer":

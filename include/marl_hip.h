@@ -84,24 +84,29 @@ int marl_wgrad_slabs(int M);
  *           ep_map[b] (replay samples read in place, common/replaybuffer.py:54-60); ufed / ep_len / outputs
  *           stay indexed by b
  *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
- *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = [T][B*N][6][64] floats
- *   (time-major; per row-step the 6 vectors hprev,x,r,z,n,hn) for the backward pass or NULL
+ *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = T * R16 * 6 * 64 floats (R16 = B*N rounded up to
+ *   16) or NULL: per row-step the 6 vectors hprev,x,r,z,n,hn for the backward pass, in a tile layout private to the two
+ *   kernels ([T][16-row tile][plane][16-column tile][lane][4]: one 16-byte access per lane and plane on both sides)
  *   cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over, 1..256; 0 = 256 = the whole chip.  With 128
  *           the two independent unrolls of an update - eval current-Q and target next-Q (q_learner.py:97,104) - fit
  *           on the chip together and can be launched on two HIP streams; results do not depend on it (rows are
  *           independent).  A per-call argument: the library keeps no process-wide state.
- *   x_saved: NULL, or the `saved` buffer an EARLIER unroll of the same weights wrote for the same rows whose step t+1
- *           input equals this unroll's step t input for t < T-1 (the double-Q pass after the eval pass,
- *           q_learner.py:97-110: observations shifted by one step, same last actions): the fc1 outputs of those steps
- *           are read from its x plane instead of being recomputed (bit-identical).  Ragged episodes: at step
- *           ep_len[b]-1 the earlier unroll saw the zero padding where this one would see the final observation, so q at
- *           that (terminated) step differs from a recomputation - a position every Q-learning target multiplies by
- *           (1 - terminated) = 0.  Ignored where the kernel chosen for the shape has no such variant. */
+ *   gi_out: NULL, or T * R16 * 3 * 64 floats (same tile layout): with `saved`, the input-side gate sums bias + x W_ih (r | z | n blocks) of every
+ *           row-step are stored as well.
+ *   gi_in : NULL, or the gi_out buffer an EARLIER unroll of the same weights wrote for the same rows whose step t+1 input
+ *           equals this unroll's step t input for t < T-1 (the double-Q pass after the eval pass, q_learner.py:97-110:
+ *           observations shifted by one step, same last actions): fc1 and the input-side gate products of those steps - 288
+ *           of a row tile's 496 multiplies per step - are not recomputed; every GRU kernel here accumulates the input-side
+ *           products before the hidden-side ones, so the result is bit-identical.  Ragged episodes stay exact: a step t at
+ *           which a row of the workgroup has ep_len - 1 == t (the earlier unroll saw the zero padding there, this one sees
+ *           the final observation) and the last step are computed in full.  Both pointers are ignored where the kernel
+ *           chosen for the shape has no such variant (marl_agent_unroll_reuse_supported). */
 int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                           const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                           const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T,
                           int N, int O, int A, int last_action, int reuse_network, int cu_budget,
-                          const float* x_saved, void* stream);
+                          float* gi_out, const float* gi_in, void* stream);
+int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int A, int cu_budget);
 
 /* Gradient destinations of the recurrent / output layers (accumulated into, torch layouts). */
 typedef struct {

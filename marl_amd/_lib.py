@@ -71,7 +71,8 @@ SIGNATURES = {
     "marl_linear_wgrad": (I, [P, L, P, L, SRC, P, L, P, I, I, I, I, GRP, P, SZ, P]),
     "marl_linear_wgrad_workspace": (SZ, [I, I, I, I]),
     "marl_wgrad_slabs": (I, [I]),
-    "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P, P]),
+    "marl_agent_unroll_reuse_supported": (I, [I, I, I, I, I, I]),
     "marl_agent_bwd_workspace": (SZ, [I, I, I]),
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, I, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_replay_gather": (I, [P, I, I, I, I] + [P] * 16 + [P]),

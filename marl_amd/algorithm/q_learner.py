@@ -99,7 +99,7 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T
         g = lambda name, shape, dt=torch.float32: self._buf.get(name, shape, dev, dt)
-        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", (T, B * N, 6, H))
+        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", ops.saved_shape(T, B, N))
         h_last, h_scr = g("h_last", (B * N, H)), g("h_scr", (B * N, H))
         q_tgt, q_en = g("q_tgt", (B, T, N, A)), g("q_en", (B, T, N, A))
         q_chosen, q_tgt_chosen = g("q_chosen", (R,)), g("q_tgt_chosen", (R,))
@@ -109,17 +109,20 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         # eval current-Q unroll (keeps activations), target next-Q unroll
         # (independent of each other: on small shards they run side by side on two streams, half of the CUs each)
         emap = getattr(db, 'o_map', None)
-        # quirk Q1: no init_hidden between the two eval passes (reference :96-110) - the double-Q pass continues the eval chain
-        cont = None
+        # quirk Q1: no init_hidden between the two eval passes (reference :96-110) - the double-Q pass continues the eval chain.
+        # Its inputs at steps 0..T-2 are the eval pass's inputs at steps 1..T-1 (same observations, same last actions, same
+        # weights): fc1 and the input-side gate sums stored there are reused (gi), where the kernels of this shape can
+        cont, gi = None, None
         if a.double_q:
-            # its inputs at steps 0..T-2 are the eval pass's inputs at steps 1..T-1 (same observations, same last actions,
-            # same weights): the fc1 outputs saved there are reused (x_saved)
             shifted = on is oc and on_bs == oc_bs and on_t0 == oc_t0 + 1
+            split = self.pair.chain_split(B * N, T, a.obs_shape)
+            if shifted and ops.agent_unroll_reuse_supported(B, T, N, a.obs_shape, A, split[0] if split else 256):
+                gi = g("gi", ops.saved_shape(T, B, N, planes=3))
             cont = lambda cu: self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last,
-                                                   ep_len=db.ep_len, ep_map=emap, cu_budget=cu, x_saved=saved if shifted else None)
+                                                   ep_len=db.ep_len, ep_map=emap, cu_budget=cu, gi_in=gi)
         self.pair.run_chain(B * N, T, a.obs_shape,
                             lambda cu: self.eval_net.unroll(oc, oc_bs, oc_t0, db.u_fed, db.u_bs, -1, B, T, q_evals, hs, h_last, saved,
-                                                            h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu),
+                                                            h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu, gi_out=gi),
                             cont,
                             lambda cu: self.target_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_tgt, None, None, None,
                                                               h0=None, ep_len=db.ep_len, ep_map=emap, cu_budget=cu))

@@ -93,7 +93,7 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T
         g = lambda name, shape, dt=torch.float32: self._buf.get(name, shape, dev, dt)
-        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", (T, B * N, 6, H))
+        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", ops.saved_shape(T, B, N))
         q_tgt, hs_tgt = g("q_tgt", (B, T, N, A)), g("hs_tgt", (B, T, N, H))
         (oc, oc_bs, oc_t0), (on, on_bs, on_t0) = db.o_cur, db.o_next
         u_act = db.u_act.reshape(-1)

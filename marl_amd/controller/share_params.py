@@ -107,7 +107,7 @@ class SharedMAC:
 
     # ------------------------------------------------------------------ batched primitives
     def unroll(self, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, B, T, q, hs=None, h_last=None, saved=None, h0="state",
-               ep_len=None, ep_map=None, cu_budget=0, x_saved=None):
+               ep_len=None, ep_map=None, cu_budget=0, gi_out=None, gi_in=None):
         """T-step unroll over B episodes starting from self.hidden_states (or zeros if None)."""
         dev = self.device()
         N, A, O = self.n_agents, self.n_actions, self.obs_shape
@@ -115,7 +115,7 @@ class SharedMAC:
             h0 = None if self.hidden_states is None else self.hidden_states.reshape(B * N, -1).contiguous()
         ops.agent_unroll_fwd(self.agent.weights(), obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
                              B, T, N, O, A, self.args.last_action, self.args.reuse_network, ep_len=ep_len, ep_map=ep_map,
-                             cu_budget=cu_budget, x_saved=x_saved)
+                             cu_budget=cu_budget, gi_out=gi_out, gi_in=gi_in)
 
     def _batch_unroll(self, batch, T, which):
         dev = self.device()

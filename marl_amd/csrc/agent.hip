@@ -39,7 +39,8 @@ struct FwdArgs {
   int B, T, N, O, A, I, KC, RT;
   int has_act, has_id;
   int vload;              // obs rows are 16-B aligned multiples of 4 floats: vector prefetch path
-  const float* xsrc;      // XS kernels: saved planes of an earlier unroll of the SAME weights whose step t+1 input is this unroll's step t input
+  float* gi_out;          // [T][R][3][64] or null: the input-side gate sums bias + x W_ih (r | z | n) of every row-step are stored
+  const float* gi_in;     // XS kernels: gi_out of an earlier unroll of the SAME weights whose step t+1 input is this unroll's step t input
   long R;                 // B*N rows
 };
 
@@ -56,6 +57,17 @@ constexpr int NLDW = 4;        // float4 prefetch registers per thread (one step
 // GRU math / LDS waits / global stores overlap the other's MFMAs (measured with one wave per SIMD:
 // MFMA pipe 40 % busy, 28 % of wave time parked, 30 % VALU).  Every thread also carries 1/512 of the
 // NEXT step's observation tile in 4 float4 registers, issued a full step ahead.
+// Saved activations (and the input-side gate sums), TILE layout: [T][row tile][plane][column tile c][lane = 16 q + m][i].
+// Lane (q, m) of a wave holds rows 4q+i (i = 0..3) at column 16c+m of a 16-row tile in its accumulator registers, so every
+// plane of a tile is ONE 16-byte store / load per lane (1 KB per wave-instruction, fully coalesced) in the forward AND in the
+// backward kernels - the row-major layout cost four 4-byte accesses per plane (36 stores per row tile in the saving unroll,
+// 40 loads per row tile in BPTT; on a part where fp32 MFMAs and everything else issue one after the other that is time).
+// Row tiles are global (row / 16), so kernels with different rows-per-workgroup agree; rows past the batch in the last tile
+// have slots of their own.
+__device__ __forceinline__ long sv_off(long tile_t /* t * n_tiles + tile */, int planes, int plane, int c, int lane) {
+  return ((tile_t * planes + plane) * 4 + c) * 256 + lane * 4;
+}
+
 // store helpers: uniform base pointer (SGPR pair) + 32-bit byte offset -> saddr-form global stores,
 // one v_lshl_add per element instead of 64-bit address arithmetic per store
 __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
@@ -64,13 +76,15 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
 
 // NL: float4 prefetch registers per thread for the next step's observation tile (4; 6 for wide observations - MMM2's
 // O = 176 - where 4 would cap a workgroup at two row tiles and push a 640-tile shard into a second round of workgroups)
-// XS: the fc1 output of steps 0..T-2 is READ from the x plane another unroll saved (a.xsrc, its step t+1) instead of being
-// recomputed: the double-Q pass of a Q-learning update (q_learner.py:104-110) feeds the eval network the observations
-// of steps 1..T right after the eval pass fed it steps 0..T-1 - same weights, same inputs, so 96 of a row tile's 496
-// multiplies per step are the ones the eval pass just did (bit-identical: same kernel code wrote them).  Exceptions, where
-// the whole workgroup runs fc1 as usual: the last step (a new observation), and any step t at which one of its rows has
-// ep_len - 1 == t - there the earlier unroll (its step t+1 = ep_len) saw the zero padding and this one sees the final
-// observation.  The observation prefetch therefore keeps running; what is saved is the multiplies.
+// XS: everything that depends only on the INPUT of a step - fc1 and the input-side gate sums bias + x W_ih, 288 of a row tile's
+// 496 multiplies per step - is READ from what another unroll stored (a.gi_in = that unroll's gi_out, its step t+1) instead of
+// being recomputed: the double-Q pass of a Q-learning update (q_learner.py:104-110) feeds the eval network the observations of
+// steps 1..T right after the eval pass fed it steps 0..T-1 - same weights, same inputs, and every GRU kernel accumulates the
+// input-side products before the hidden-side ones, so the stored sums are exactly the accumulators this pass would hold after
+// its own input-side products (bit-identical).  Exceptions, where the whole workgroup computes the step as usual: the last
+// step (a new observation), and any step t at which one of its rows has ep_len - 1 == t - there the earlier unroll (its step
+// t+1 = ep_len) saw the zero padding and this one sees the final observation.  The observation prefetch therefore keeps
+// running; what is saved is the multiplies.
 template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   static_assert(!XS || (VL && !SAVE && NL == NLDW), "XS: vector path, no saving");
@@ -78,6 +92,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int team = wave >> 2, ws = wave & 3;
   const int q = lane >> 4, m = lane & 15;
+  const long NTILES = (a.R + 15) >> 4;               // global 16-row tiles (saved-activation layout)
+  const int RTW = (int)((NTILES - (long)blockIdx.x * a.RT) < a.RT ? (NTILES - (long)blockIdx.x * a.RT) : a.RT);   // REAL row tiles of this workgroup: the last one may hold fewer (whole tiles past the batch are not processed)
   const int rows = a.RT * 16;
   const int KP = a.KC * 16, KS = KP + 4;
   // LDS carve (all offsets multiples of 4 floats)
@@ -138,27 +154,14 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     plen[i] = rowlen[r];
   }
   const long urow = tid < rows ? rowu[tid] : 0;
-  // XS: this thread's float4 items of the x tile (rows x 16), same every step
-  int xl[NL]; long xg[NL];
-  if (XS) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      int e = tid + FNT * i;
-      if (e > rows * 16 - 1) e = rows * 16 - 1;      // clamped duplicates: same value to the same address
-      const int r = e >> 4, c4 = (e & 15) * 4;
-      xl[i] = r * HS + c4;
-      xg[i] = (long)rowrho[r] * (6 * H) + H + c4;    // plane 1 of [T][R][6][64]
-    }
-  }
-  f32x4 xf[XS ? NL : 1];
-  auto xissue = [&](int ts) {         // start the loads of the x tile the other unroll saved at its step ts
-    const long toff = (long)ts * a.R * (6 * H);
-#pragma unroll
-    for (int i = 0; i < (XS ? NL : 1); ++i) xf[i] = *reinterpret_cast<const f32x4*>(a.xsrc + xg[i] + toff);
-  };
-  auto xcommit = [&]() {
-#pragma unroll
-    for (int i = 0; i < (XS ? NL : 1); ++i) *reinterpret_cast<f32x4*>(Xt + xl[i]) = xf[i];
+  // XS: the stored input-side sums of the NEXT row tile this wave will process, in accumulator layout (rows 4q+i, column j);
+  // issued a whole tile ahead and moved into the accumulators at the top of the tile (by then they have landed)
+  f32x4 gB[3];
+  auto gissue = [&](int ts, int rt) {
+    const float* gp = a.gi_in + sv_off((long)ts * NTILES + (long)blockIdx.x * a.RT + rt, 3, 0, ws, lane);
+    gB[0] = *reinterpret_cast<const f32x4*>(gp);
+    gB[1] = *reinterpret_cast<const f32x4*>(gp + 1024);
+    gB[2] = *reinterpret_cast<const f32x4*>(gp + 2 * 1024);
   };
   const int mylen = tid < rows ? rowlen[tid] : 0x7fffffff;
   if (XS && tid < 2) xneed[tid] = 0;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   if (VL) { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
   else load_generic(0);
   if (XS) {
-    xissue(1);
+    if (team < RTW) gissue(1, team);
     if (mylen - 1 == 0) xneed[0] = 1;             // (cleared above, before the barrier of the constant columns)
   }
 
@@ -270,15 +273,11 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   ST_DECL(6);
   for (int t = 0; t < a.T; ++t) {
     const unsigned trow = (unsigned)t * (unsigned)a.N;
-    float* const svt = SAVE ? a.saved + (long)t * a.R * (6 * H) : nullptr;
+    const long svt = SAVE ? (long)t * NTILES + (long)blockIdx.x * a.RT : 0;      // (step, first row tile of this workgroup)
     // ---------------- phase 1: x = relu(fc1(in))  (two of the team's row tiles in flight)
-    const bool xread = XS && t < a.T - 1 && xneed[t & 1] == 0;
-    if (XS) {
-      if (xread) xcommit();
-      xissue(t + 2 < a.T ? t + 2 : a.T - 1);      // unconditional (the last one is never consumed)
-    }
-    for (int rt = xread ? a.RT : team; rt < a.RT; rt += 4) {
-      const bool two = rt + 2 < a.RT;
+    const bool xread = XS && t < a.T - 1 && xneed[t & 1] == 0;      // this step's input-side work is read, not computed
+    for (int rt = xread ? RTW : team; rt < RTW; rt += 4) {
+      const bool two = rt + 2 < RTW;
       f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
       const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
       const float* in1 = in0 + 32 * KS;
@@ -298,26 +297,14 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         acc0[i] = fmaxf(acc0[i], 0.f);
         Xt[(r0 + i) * HS + j] = acc0[i];
       }
-      if (SAVE) {
-        const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
-        st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc0[0]);
-        st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc0[1]);
-        st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc0[2]);
-        st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc0[3]);
-      }
+      if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off(svt + rt, 6, 1, ws, lane)) = acc0;
       if (two) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc1[i] = fmaxf(acc1[i], 0.f);
           Xt[(r0 + 32 + i) * HS + j] = acc1[i];
         }
-        if (SAVE) {
-          const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0 + 32);
-          st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc1[0]);
-          st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc1[1]);
-          st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc1[2]);
-          st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc1[3]);
-        }
+        if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off(svt + rt + 2, 6, 1, ws, lane)) = acc1;
       }
     }
     ST_MARK(0);
@@ -337,25 +324,55 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     ST_MARK(2);
     // ---------------- phase 2: GRU gates + pointwise update
     const bool last = (t == a.T - 1) && a.h_last;
-    for (int rt = team; rt < a.RT; rt += 2) {
+    for (int rt = team; rt < RTW; rt += 2) {
       f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
       f32x4 az = {bias_z, bias_z, bias_z, bias_z};
       f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
       f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
       const float* xr = Xt + (rt * 16 + m) * HS + 4 * q;
       const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+      const int r0 = rt * 16 + 4 * q;
+      if (XS) {
+        if (xread) { ar = gB[0]; az = gB[1]; ain = gB[2]; }
+        // the tile after this one: the same step's next tile of this team, or the team's first tile of the next step (the
+        // stored step index is one ahead of this unroll's; the last ones issued are never consumed)
+        const bool same = rt + 2 < RTW;
+        const int nts = same ? t + 1 : t + 2;
+        gissue(nts < a.T ? nts : a.T - 1, same ? rt + 2 : team);
+      }
+      // input-side products first, hidden-side products after them (the SAME order in every GRU kernel: the input-side
+      // sums bias + x W_ih of one unroll can then stand in for another unroll's - the XS variant)
+      // (the candidate's hidden-side product h W_hn has an accumulator of its own and rides along with the input-side
+      // products: four independent accumulation chains in the first loop as before the reordering, two in the second)
+      if (!xread) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
+          ahn = mfma16x4(ah, whh[2][c], ahn);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+          ahn = mfma16x4(ah, whh[2][c], ahn);
+        }
+      }
+      if (SAVE && a.gi_out) {
+        float* const gp = a.gi_out + sv_off(svt + rt, 3, 0, ws, lane);
+        *reinterpret_cast<f32x4*>(gp) = ar;
+        *reinterpret_cast<f32x4*>(gp + 1024) = az;
+        *reinterpret_cast<f32x4*>(gp + 2 * 1024) = ain;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-        ar = mfma16x4(ax, wih[0][c], ar);
-        az = mfma16x4(ax, wih[1][c], az);
-        ain = mfma16x4(ax, wih[2][c], ain);
-        ahn = mfma16x4(ah, whh[2][c], ahn);
         ar = mfma16x4(ah, whh[0][c], ar);
         az = mfma16x4(ah, whh[1][c], az);
       }
-      const int r0 = rt * 16 + 4 * q;
       f32x4 vhp, vr, vz, vn, vh;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -373,13 +390,12 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       }
       const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
       if (SAVE) {
-        const unsigned e0 = (unsigned)rr.x * 1536u + jb, e1 = (unsigned)rr.y * 1536u + jb;
-        const unsigned e2 = (unsigned)rr.z * 1536u + jb, e3 = (unsigned)rr.w * 1536u + jb;
-        st32(svt, e0, vhp[0]); st32(svt, e1, vhp[1]); st32(svt, e2, vhp[2]); st32(svt, e3, vhp[3]);
-        st32(svt, e0 + 512u, vr[0]); st32(svt, e1 + 512u, vr[1]); st32(svt, e2 + 512u, vr[2]); st32(svt, e3 + 512u, vr[3]);
-        st32(svt, e0 + 768u, vz[0]); st32(svt, e1 + 768u, vz[1]); st32(svt, e2 + 768u, vz[2]); st32(svt, e3 + 768u, vz[3]);
-        st32(svt, e0 + 1024u, vn[0]); st32(svt, e1 + 1024u, vn[1]); st32(svt, e2 + 1024u, vn[2]); st32(svt, e3 + 1024u, vn[3]);
-        st32(svt, e0 + 1280u, ahn[0]); st32(svt, e1 + 1280u, ahn[1]); st32(svt, e2 + 1280u, ahn[2]); st32(svt, e3 + 1280u, ahn[3]);
+        float* const sp = a.saved + sv_off(svt + rt, 6, 0, ws, lane);       // plane k at sp + 1024 k
+        *reinterpret_cast<f32x4*>(sp) = vhp;
+        *reinterpret_cast<f32x4*>(sp + 2 * 1024) = vr;
+        *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
+        *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
+        *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
       }
       if (last) {
         st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     WG_BARRIER();
     ST_MARK(4);
     // ---------------- phase 3: q = fc2(h')   (row tiles dealt round-robin to the 8 waves)
-    for (int rt = wave; rt < a.RT; rt += 8) {
+    for (int rt = wave; rt < RTW; rt += 8) {
       f32x4 acc[AC];
 #pragma unroll
       for (int ac = 0; ac < AC; ++ac) acc[ac] = (f32x4){bias2[ac], bias2[ac], bias2[ac], bias2[ac]};
@@ -438,6 +454,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, ws = wave & 3;
   const int q = lane >> 4, m = lane & 15;
+  const long NTILES = (a.R + 15) >> 4;               // global 16-row tiles (saved-activation layout)
+  const int RTW = (int)((NTILES - (long)blockIdx.x * a.RT) < a.RT ? (NTILES - (long)blockIdx.x * a.RT) : a.RT);   // REAL row tiles of this workgroup: the last one may hold fewer (whole tiles past the batch are not processed)
   const int rows = a.RT * 16;
   const int KP = a.KC * 16, KS = KP + 4;
   float* W1s = smem;                                  // [4][KC][64] f32x4
@@ -567,9 +585,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
 
   // x(ts) = relu(fc1(in)) for row tiles rt, rt+stride.. of this wave's slice (pairs share the B fragments)
   auto fc1 = [&](const float* In, float* Xt, int ts, int rt_first, int rt_stride) __attribute__((always_inline)) {
-    float* const svt = SAVE ? a.saved + (long)ts * a.R * (6 * H) : nullptr;
-    for (int rt = rt_first; rt < a.RT; rt += 2 * rt_stride) {
-      const bool two = rt + rt_stride < a.RT;
+    const long svt = SAVE ? (long)ts * NTILES + (long)blockIdx.x * a.RT : 0;
+    for (int rt = rt_first; rt < RTW; rt += 2 * rt_stride) {
+      const bool two = rt + rt_stride < RTW;
       f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
       const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
       const float* in1 = in0 + rt_stride * 16 * KS;
@@ -589,13 +607,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
         acc0[i] = fmaxf(acc0[i], 0.f);
         Xt[(r0 + i) * HS + j] = acc0[i];
       }
-      if (SAVE) {
-        const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
-        st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc0[0]);
-        st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc0[1]);
-        st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc0[2]);
-        st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc0[3]);
-      }
+      if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off(svt + rt, 6, 1, ws, lane)) = acc0;
       if (two) {
         const int r1 = r0 + rt_stride * 16;
 #pragma unroll
@@ -603,13 +615,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
           acc1[i] = fmaxf(acc1[i], 0.f);
           Xt[(r1 + i) * HS + j] = acc1[i];
         }
-        if (SAVE) {
-          const int4 rr = *reinterpret_cast<const int4*>(rowrho + r1);
-          st32(svt, (unsigned)rr.x * 1536u + jb + 256u, acc1[0]);
-          st32(svt, (unsigned)rr.y * 1536u + jb + 256u, acc1[1]);
-          st32(svt, (unsigned)rr.z * 1536u + jb + 256u, acc1[2]);
-          st32(svt, (unsigned)rr.w * 1536u + jb + 256u, acc1[3]);
-        }
+        if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off(svt + rt + rt_stride, 6, 1, ws, lane)) = acc1;
       }
     }
   };
@@ -650,13 +656,13 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   for (int t = 0; t < a.T; ++t) {
     const int par = t & 1;
     const unsigned trow = (unsigned)t * (unsigned)a.N;
-    float* const svt = SAVE ? a.saved + (long)t * a.R * (6 * H) : nullptr;
+    const long svt = SAVE ? (long)t * NTILES + (long)blockIdx.x * a.RT : 0;      // (step, first row tile of this workgroup)
     float* Xc = Xt0 + par * rows * HS;                 // x(t), written in the previous step
     float* Inn = In0 + (par ^ 1) * rows * KS;           // input of step t+1 (committed during step t-1)
     if (team == 1) {
       if (t + 1 < a.T) fc1(Inn, Xt0 + (par ^ 1) * rows * HS, t + 1, 0, 1);
       if (t > 0)
-        for (int rt = ws; rt < a.RT; rt += 4) fc2(Hp, t - 1, rt);
+        for (int rt = ws; rt < RTW; rt += 4) fc2(Hp, t - 1, rt);
     }
     ST_MARK(0);
     if (tid < 4) tilecnt[(par ^ 1) * 4 + tid] = 0;      // counters of the NEXT step (nobody grabs them before the barrier)
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
       return __builtin_amdgcn_readfirstlane(v);
     };
     int rt_next = grab();
-    while (rt_next < a.RT) {
+    while (rt_next < RTW) {
       const int rt = rt_next;
       rt_next = grab();
       f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
@@ -677,13 +683,18 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
       f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
       const float* xr = Xc + (rt * 16 + m) * HS + 4 * q;
       const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+      // input-side products first, hidden-side products after them (the SAME order in every GRU kernel: the input-side
+      // sums bias + x W_ih of one unroll can then stand in for another unroll's - see the GI variants of agent_fwd_kernel)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
         ar = mfma16x4(ax, wih[0][c], ar);
         az = mfma16x4(ax, wih[1][c], az);
         ain = mfma16x4(ax, wih[2][c], ain);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
         ahn = mfma16x4(ah, whh[2][c], ahn);
         ar = mfma16x4(ah, whh[0][c], ar);
         az = mfma16x4(ah, whh[1][c], az);
@@ -706,13 +717,12 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
       }
       const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
       if (SAVE) {
-        const unsigned e0 = (unsigned)rr.x * 1536u + jb, e1 = (unsigned)rr.y * 1536u + jb;
-        const unsigned e2 = (unsigned)rr.z * 1536u + jb, e3 = (unsigned)rr.w * 1536u + jb;
-        st32(svt, e0, vhp[0]); st32(svt, e1, vhp[1]); st32(svt, e2, vhp[2]); st32(svt, e3, vhp[3]);
-        st32(svt, e0 + 512u, vr[0]); st32(svt, e1 + 512u, vr[1]); st32(svt, e2 + 512u, vr[2]); st32(svt, e3 + 512u, vr[3]);
-        st32(svt, e0 + 768u, vz[0]); st32(svt, e1 + 768u, vz[1]); st32(svt, e2 + 768u, vz[2]); st32(svt, e3 + 768u, vz[3]);
-        st32(svt, e0 + 1024u, vn[0]); st32(svt, e1 + 1024u, vn[1]); st32(svt, e2 + 1024u, vn[2]); st32(svt, e3 + 1024u, vn[3]);
-        st32(svt, e0 + 1280u, ahn[0]); st32(svt, e1 + 1280u, ahn[1]); st32(svt, e2 + 1280u, ahn[2]); st32(svt, e3 + 1280u, ahn[3]);
+        float* const sp = a.saved + sv_off(svt + rt, 6, 0, ws, lane);       // plane k at sp + 1024 k
+        *reinterpret_cast<f32x4*>(sp) = vhp;
+        *reinterpret_cast<f32x4*>(sp + 2 * 1024) = vr;
+        *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
+        *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
+        *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
       }
       if (last) {
         st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
@@ -730,7 +740,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     float* tmp = Hp; Hp = Hn; Hn = tmp;
   }
   ST_DUMP(6);
-  for (int rt = wave; rt < a.RT; rt += 8) fc2(Hp, a.T - 1, rt);      // q of the last step
+  for (int rt = wave; rt < RTW; rt += 8) fc2(Hp, a.T - 1, rt);      // q of the last step
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -808,6 +818,8 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     rowok[r] = ok;
   }
   const long tstride = a.N;
+  const long NTILES = (a.R + 15) >> 4, tile0 = (long)blockIdx.x * a.RT;      // global 16-row tiles (saved-activation layout)
+  const int RTW = (int)((NTILES - tile0) < a.RT ? (NTILES - tile0) : a.RT);     // REAL row tiles of this workgroup (the last one may hold fewer)
   // carried dh of the last step: zero, plus the external gradient on hs[T-1] when there is one.  The external gradient of
   // the earlier steps is added where the carry is written (team 1, procC): it never occupies a slot of the prefetch sets.
   for (int e = tid; e < rows * HS; e += BNT) {
@@ -851,26 +863,23 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   // predicated load makes the compiler zero the register first and that write waits for older loads)
 #define LOAD_B(P, tt, rr, en)                                                                            \
   {                                                                                                      \
-    const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H);                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-      const int r_ = (rr) * 16 + 4 * q + i;                                                              \
-      const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H) + j;                                          \
-      P[0][i] = sp_[0];                                                                                  \
-      P[1][i] = sp_[2 * H];                                                                              \
-      P[2][i] = sp_[3 * H];                                                                              \
-      P[3][i] = sp_[4 * H];                                                                              \
-      P[4][i] = sp_[5 * H];                                                                              \
-    }                                                                                                    \
+    const float* sp_ = a.saved + sv_off((long)(tt) * NTILES + tile0 + (rr), 6, 0, ws, lane);             \
+    P[0] = *reinterpret_cast<const f32x4*>(sp_);                                                         \
+    P[1] = *reinterpret_cast<const f32x4*>(sp_ + 2 * 1024);                                              \
+    P[2] = *reinterpret_cast<const f32x4*>(sp_ + 3 * 1024);                                              \
+    P[3] = *reinterpret_cast<const f32x4*>(sp_ + 4 * 1024);                                              \
+    P[4] = *reinterpret_cast<const f32x4*>(sp_ + 5 * 1024);                                              \
   }
 #define LOAD_C(P, tt, rr, en)                                                                            \
   {                                                                                                      \
-    const float* svt_ = a.saved + (long)(tt) * a.R * (6 * H) + (team ? 0 : H);                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-      const int r_ = (rr) * 16 + 4 * q + i;                                                              \
-      const float* sp_ = svt_ + (long)rowrho[r_] * (6 * H);                                              \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c][i] = sp_[16 * c + m];                           \
-      if (team) P[4][i] = a.hs[((long)rowidx[r_] + (long)(tt) * tstride) * H + j];                       \
-      else P[4][i] = sp_[j];                                                                             \
+    const float* sp_ = a.saved + sv_off((long)(tt) * NTILES + tile0 + (rr), 6, team ? 0 : 1, 0, lane);   \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c] = *reinterpret_cast<const f32x4*>(sp_ + 256 * c); \
+    if (!team) P[4] = *reinterpret_cast<const f32x4*>(sp_ + 256 * ws);                                   \
+    else if ((tt) + 1 < a.T)     /* h(tt) = the hidden state fed into step tt+1: plane 0 of that step */  \
+      P[4] = *reinterpret_cast<const f32x4*>(sp_ + NTILES * (6 * 1024) + 256 * ws);                      \
+    else {                                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+        P[4][i] = a.hs[((long)rowidx[(rr) * 16 + 4 * q + i] + (long)(tt) * tstride) * H + j];            \
     }                                                                                                    \
   }
   auto dq_elem = [&](int t, int e) -> float {
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   } else {
     for (int e = tid; e < rows * QP; e += BNT) DQ0[(e / QP) * QS + (e % QP)] = dq_elem(a.T - 1, e);
   }
-  const bool hasB = team < a.RT;                   // this team owns at least one row tile in phase B
+  const bool hasB = team < RTW;                   // this team owns at least one row tile in phase B
   const bool full_wg = row0 + rows <= a.R;         // no rows past the batch in this workgroup
   // Register sets of the software pipeline.  NO set is ever copied into another inside the step loop: a copy
   // needs the loaded values and makes the compiler drain vmcnt right where the prefetch was issued.
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   // soon as the previous step's last phase-C tile has released that set - before the end-of-step barrier
 #define LOAD_ITEM1(tt, en)                                         \
   {                                                                \
-    if (team + 2 < a.RT) LOAD_B(sB, tt, team + 2, en)              \
+    if (team + 2 < RTW) LOAD_B(sB, tt, team + 2, en)              \
     else LOAD_C(sB, tt, 0, en)                                     \
   }
   if (hasB) LOAD_B(sA, a.T - 1, team, true)
@@ -1080,7 +1089,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       int rt = team;
       bool pre = true;               // sB already holds (in flight) the item after the first tile
       while (true) {
-        bool more = rt + 2 < a.RT;
+        bool more = rt + 2 < RTW;
         if (!pre) {
           if (more) LOAD_B(sB, t, rt + 2, true)
           else LOAD_C(sB, t, 0, true)
@@ -1089,7 +1098,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
         procB(sA, rt, DQ);
         if (!more) { c0A = false; break; }
         rt += 2;
-        more = rt + 2 < a.RT;
+        more = rt + 2 < RTW;
         if (more) LOAD_B(sA, t, rt + 2, true)
         else LOAD_C(sA, t, 0, true)
         procB(sB, rt, DQ);
@@ -1107,17 +1116,17 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     int rt0 = 0;
     bool in_a = true;                 // next-step item 0 landed in sA
     if (!c0A) {
-      if (1 < a.RT) LOAD_C(sA, t, 1, true)
+      if (1 < RTW) LOAD_C(sA, t, 1, true)
       else LOAD_NEXT_STEP(sA, t)
       procC(sB, 0, t, DQ);
       rt0 = 1;
     }
-    for (int rt = rt0; rt < a.RT; rt += 2) {
-      if (rt + 1 < a.RT) LOAD_C(sB, t, rt + 1, true)
+    for (int rt = rt0; rt < RTW; rt += 2) {
+      if (rt + 1 < RTW) LOAD_C(sB, t, rt + 1, true)
       else { LOAD_NEXT_STEP(sB, t) in_a = false; }
       procC(sA, rt, t, DQ);
-      if (rt + 1 < a.RT) {
-        if (rt + 2 < a.RT) LOAD_C(sA, t, rt + 2, true)
+      if (rt + 1 < RTW) {
+        if (rt + 2 < RTW) LOAD_C(sA, t, rt + 2, true)
         else LOAD_NEXT_STEP(sA, t)
         procC(sB, rt + 1, t, DQ);
       }
@@ -1244,6 +1253,8 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
     rowok[r] = ok;
   }
   const long tstride = a.N;
+  const long NTILES = (a.R + 15) >> 4, tile0 = (long)blockIdx.x * a.RT;      // global 16-row tiles (saved-activation layout)
+  const int RTW = (int)((NTILES - tile0) < a.RT ? (NTILES - tile0) : a.RT);     // REAL row tiles of this workgroup (the last one may hold fewer)
   for (int e = tid; e < rows * HS; e += BNT) {
     const int r = e / HS, k = e - r * HS;
     float v = 0.f;
@@ -1301,24 +1312,25 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
 
   // saved planes of (step tt, row tile rr), this wave's 16 columns: [0]=h_prev [1]=r [2]=z [3]=n [4]=hn
   auto load_b = [&](f32x4 (&P)[5], int tt, int rr) __attribute__((always_inline)) {
-    const float* svt = a.saved + (long)tt * a.R * (6 * H);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* sp = svt + (long)rowrho[rr * 16 + 4 * q + i] * (6 * H) + j;
-      P[0][i] = sp[0]; P[1][i] = sp[2 * H]; P[2][i] = sp[3 * H]; P[3][i] = sp[4 * H]; P[4][i] = sp[5 * H];
-    }
+    const float* sp = a.saved + sv_off((long)tt * NTILES + tile0 + rr, 6, 0, ws, lane);
+    P[0] = *reinterpret_cast<const f32x4*>(sp);
+    P[1] = *reinterpret_cast<const f32x4*>(sp + 2 * 1024);
+    P[2] = *reinterpret_cast<const f32x4*>(sp + 3 * 1024);
+    P[3] = *reinterpret_cast<const f32x4*>(sp + 4 * 1024);
+    P[4] = *reinterpret_cast<const f32x4*>(sp + 5 * 1024);
   };
   // [0..3] = x (team 0) / h_prev (team 1) of step tt, all 64 columns ; [4] = x own columns (team 0) / h(tt) own columns (team 1)
   auto load_c = [&](f32x4 (&P)[5], int tt, int rr) __attribute__((always_inline)) {
-    const float* svt = a.saved + (long)tt * a.R * (6 * H) + (team ? 0 : H);
+    const float* sp = a.saved + sv_off((long)tt * NTILES + tile0 + rr, 6, team ? 0 : 1, 0, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = rr * 16 + 4 * q + i;
-      const float* sp = svt + (long)rowrho[r] * (6 * H);
+    for (int c = 0; c < 4; ++c) P[c] = *reinterpret_cast<const f32x4*>(sp + 256 * c);
+    if (!team) {
+      P[4] = *reinterpret_cast<const f32x4*>(sp + 256 * ws);
+    } else if (tt + 1 < a.T) {       // h(tt) = the hidden state fed into step tt+1: plane 0 of that step
+      P[4] = *reinterpret_cast<const f32x4*>(sp + NTILES * (6 * 1024) + 256 * ws);
+    } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) P[c][i] = sp[16 * c + m];
-      if (team) P[4][i] = a.hs[((long)rowidx[r] + (long)tt * tstride) * H + j];
-      else P[4][i] = sp[j];
+      for (int i = 0; i < 4; ++i) P[4][i] = a.hs[((long)rowidx[rr * 16 + 4 * q + i] + (long)tt * tstride) * H + j];
     }
   };
   // dh = carry + dq W2^T ; gate gradients -> DG, carry z -> CAR   (agent_bwd_kernel's phase B for one row tile)
@@ -1392,7 +1404,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
     }
   };
   const bool full_wg = row0 + rows <= a.R;
-  const int T = a.T, RT = a.RT;
+  const int T = a.T, RT = RTW;
 
   if (team) {
     // the chain wave wins the matrix pipe against its SIMD partner (which has 44 % of a step to spare): at equal
@@ -1604,11 +1616,28 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap,
 
 }  // namespace
 
+// 1 when a T-step unroll of these dimensions over cu_budget CUs runs the kernel family that stores (gi_out) / reads (gi_in)
+// the input-side gate sums; the software-pipelined kernel (one row tile per workgroup) and wide observations that need six
+// prefetch registers do not.  (Alignment of the actual pointers is checked at launch; a launch that cannot reuse computes.)
+extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int A, int cu_budget) {
+  if (B <= 0 || T < 2 || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256 || (O % 4) != 0 || O < 4) return 0;
+  if (getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0') return 0;
+  if (cu_budget == 0) cu_budget = 256;
+  const long tiles = ((long)B * N + 15) / 16;
+  const int want = (int)((tiles + cu_budget - 1) / cu_budget);
+  const int cap2 = (NLDW * FNT) / (16 * (O / 4));
+  if (cap2 < 1 || (cap2 < want && cap2 < 8)) return 0;          // six-register variant (or no vector path)
+  int rt = want < 1 ? 1 : want;
+  if (rt > 8) rt = 8;
+  if (rt > cap2) rt = cap2;
+  return rt > marl_fwd_pipe_max_rt ? 1 : 0;
+}
+
 extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                                      const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                                      const float* h0, float* q, float* hs, float* h_last, float* saved, int B,
                                      int T, int N, int O, int A, int last_action, int reuse_network, int cu_budget,
-                                     const float* x_saved, void* stream) {
+                                     float* gi_out, const float* gi_in, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256) return (int)hipErrorInvalidValue;
   if (cu_budget == 0) cu_budget = 256;      // CUs this launch may occupy: 128 lets two independent unrolls run side by side
@@ -1616,7 +1645,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
   a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.ep_len = ep_len; a.ep_map = ep_map; a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved;
-  a.B = B; a.T = T; a.N = N; a.O = O; a.A = A; a.xsrc = x_saved;
+  a.B = B; a.T = T; a.N = N; a.O = O; a.A = A; a.gi_out = saved ? gi_out : nullptr; a.gi_in = gi_in;
   a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   a.KC = (a.I + 15) / 16;
@@ -1672,7 +1701,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
 #define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
   const bool sv = saved != nullptr, vl = a.vload != 0;
   static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
-  if (vl && nl == NLDW && !sv && x_saved && T >= 2 && !xs_off) {
+  if (vl && nl == NLDW && !sv && gi_in && T >= 2 && !xs_off) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, true>;
   } else if (vl && nl == 6) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, 6> : (const void*)agent_fwd_kernel<2, false, true, 6>;

@@ -321,13 +321,18 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
       f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
       const float* xr = Xt + (rt * 16 + m) * HS + 4 * q;
       const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+      // input-side products first, hidden-side products after them (the SAME order in every GRU kernel: the input-side
+      // sums bias + x W_ih of one unroll can then stand in for another unroll's - see the GI variants of agent_fwd_kernel)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
         ar = mfma16x4(ax, wih[0][c], ar);
         az = mfma16x4(ax, wih[1][c], az);
         ain = mfma16x4(ax, wih[2][c], ain);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
         ahn = mfma16x4(ah, whh[2][c], ahn);
         ar = mfma16x4(ah, whh[0][c], ar);
         az = mfma16x4(ah, whh[1][c], az);

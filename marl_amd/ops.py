@@ -157,18 +157,38 @@ def agent_weights(params):
 
 
 def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
-                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None, cu_budget=0, x_saved=None):
+                     B, T, N, O, A, last_action=True, reuse_network=True, ep_len=None, ep_map=None, cu_budget=0, gi_out=None,
+                     gi_in=None):
     """cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over (0 / 256 = the whole chip); 128 lets two
     independent unrolls run side by side on two streams (PairedUnroll).  A per-call argument, no process state.
-    x_saved: the `saved` buffer of an earlier unroll of the same weights whose step t+1 input is this one's step t input
-    (include/marl_hip.h): its fc1 outputs are reused."""
+    gi_out / gi_in: (T, B*N, 3, 64) buffer of input-side gate sums written by one unroll and read by a later unroll of the
+    same weights whose step t input is the earlier one's step t+1 input (include/marl_hip.h)."""
     lib = _lib.load()
     check(lib.marl_agent_unroll_fwd(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
                                     _p(_i32(ep_map)) if ep_map is not None else None, _p(h0),
                                     _p(_f32(q)), _p(hs), _p(h_last), _p(saved), B, T, N, O, A,
                                     1 if last_action else 0, 1 if reuse_network else 0, int(cu_budget),
-                                    _p(_f32(x_saved)) if x_saved is not None else None, _stream()),
+                                    _p(_f32(gi_out)) if gi_out is not None else None,
+                                    _p(_f32(gi_in)) if gi_in is not None else None, _stream()),
           "marl_agent_unroll_fwd")
+
+
+def saved_shape(T, B, N, planes=6, H=64):
+    """Shape of the activation buffer an unroll saves for BPTT (planes = 6) or of its input-side gate sums (planes = 3):
+    the kernels use a tile layout [T][16-row tile][plane][column tile][lane][4] (csrc/agent.hip: sv_off), so the row count is
+    rounded up to whole tiles.  The buffer is opaque to the host; `saved_plane` decodes one plane."""
+    return (T, (B * N + 15) // 16 * 16, planes, H)
+
+
+def saved_plane(saved, plane, rows):
+    """(T, rows, 64) view-copy of one plane of a buffer in the tile layout (tests / debugging)."""
+    T, R16, P, H = saved.shape
+    t = saved.reshape(T, R16 // 16, P, 4, 4, 16, 4)[:, :, plane]          # (T, tile, c, q, m, i)
+    return t.permute(0, 1, 3, 5, 2, 4).reshape(T, R16, H)[:, :rows]       # row = 16 tile + 4 q + i ; column = 16 c + m
+
+
+def agent_unroll_reuse_supported(B, T, N, O, A, cu_budget=0):
+    return bool(_lib.load().marl_agent_unroll_reuse_supported(B, T, N, O, A, int(cu_budget)))
 
 
 def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None, dq_idx2=None,

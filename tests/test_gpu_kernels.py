@@ -355,7 +355,7 @@ def test_agent_unroll_fwd(dev, shape, B, T, with_h0):
     q = torch.empty(B, T, N, A, device=dev)
     hs = torch.empty(B, T, N, 64, device=dev)
     hl = torch.empty(B * N, 64, device=dev)
-    saved = torch.empty(T, B * N, 6, 64, device=dev)        # time-major, 6 planes per row-step
+    saved = torch.empty(ops.saved_shape(T, B, N), device=dev)  # opaque tile layout, 6 planes per row-step
     ops.agent_unroll_fwd(w, cu(obs, dev), T * N, 0, cu(ufed, dev, torch.int32), T * N, 0,
                          cu(h0, dev) if h0 is not None else None, q, hs, hl, saved, B, T, N, O, A)
     close(q, q_ref, 1e-4, msg="q")
@@ -363,7 +363,7 @@ def test_agent_unroll_fwd(dev, shape, B, T, with_h0):
     close(hl, hl_ref, 1e-4, msg="h_last")
     # saved plane 0 is the hidden state fed INTO each step
     hprev = torch.cat([(torch.zeros(B, 1, N, 64) if h0 is None else torch.tensor(h0).view(B, 1, N, 64)), hs_ref[:, :-1]], 1)
-    close(saved[:, :, 0].reshape(T, B, N, 64).permute(1, 0, 2, 3), hprev, 1e-4, msg="hprev")
+    close(ops.saved_plane(saved, 0, B * N).reshape(T, B, N, 64).permute(1, 0, 2, 3), hprev, 1e-4, msg="hprev")
 
 
 def test_agent_unroll_shifted_storage(dev):
@@ -410,7 +410,7 @@ def test_agent_unroll_bwd(dev, shape, B, T):
     w = ops.agent_weights(pd)
     q = torch.empty(B, T, N, A, device=dev)
     hs = torch.empty(B, T, N, 64, device=dev)
-    saved = torch.empty(T, B * N, 6, 64, device=dev)
+    saved = torch.empty(ops.saved_shape(T, B, N), device=dev)
     obs_d, u_d = cu(obs, dev), cu(ufed, dev, torch.int32)
     ops.agent_unroll_fwd(w, obs_d, T * N, 0, u_d, T * N, 0, None, q, hs, None, saved, B, T, N, O, A)
     dxp = torch.empty(B, T, N, 64, device=dev)
