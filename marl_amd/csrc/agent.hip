@@ -344,7 +344,15 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       // sums bias + x W_ih of one unroll can then stand in for another unroll's - the XS variant)
       // (the candidate's hidden-side product h W_hn has an accumulator of its own and rides along with the input-side
       // products: four independent accumulation chains in the first loop as before the reordering, two in the second)
-      if (!xread) {
+      if (!xread && AC == 2) {           // register-tight variant: the hidden-side operands are live in one loop only
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
+        }
+      } else if (!xread) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+        if (!xread && AC == 2) ahn = mfma16x4(ah, whh[2][c], ahn);
         ar = mfma16x4(ah, whh[0][c], ar);
         az = mfma16x4(ah, whh[1][c], az);
       }
