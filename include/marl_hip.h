@@ -84,7 +84,7 @@ int marl_wgrad_slabs(int M);
  *           ep_map[b] (replay samples read in place, common/replaybuffer.py:54-60); ufed / ep_len / outputs
  *           stay indexed by b
  *   h0    : (B*N,64) or NULL = zeros (init_hidden, :74-76); h_last may alias h0
- *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = T * R16 * 6 * 64 floats (R16 = B*N rounded up to
+ *   q (B,T,N,A); hs (B,T,N,64) hidden AFTER each step or NULL; saved = (T+1) * R16 * 6 * 64 floats (R16 = B*N rounded up to
  *   16) or NULL: per row-step the 6 vectors hprev,x,r,z,n,hn for the backward pass, in a tile layout private to the two
  *   kernels ([T][16-row tile][plane][16-column tile][lane][4]: one 16-byte access per lane and plane on both sides)
  *   cu_budget: CUs (= workgroups) a T > 1 launch spreads its rows over, 1..256; 0 = 256 = the whole chip.  With 128
@@ -124,7 +124,8 @@ typedef struct {
  *   taken and the greedy action, qtran_learner.py:139,145; equal columns add); dq_gdiv > 1: the values are indexed by
  *   row / dq_gdiv (N: one value per (episode, step), shared by its agents - autograd of .sum(dim=-1));
  *   dhs (B,T,N,64) extra gradient on hs or NULL (QTRAN heads)
- *   saved, hs: outputs of the forward pass;  dxp (B,T,N,64) = gradient at the fc1 pre-activation
+ *   saved: output of the forward pass (it holds h(t) as well; `hs` is not read any more and may be NULL);
+ *   dxp (B,T,N,64) = gradient at the fc1 pre-activation
  * The fc1 gradient follows as ONE marl_linear_wgrad over dxp and the virtual input [obs|u|id]. */
 size_t marl_agent_bwd_workspace(int B, int N, int A);
 int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float* dq, const int* dq_idx,

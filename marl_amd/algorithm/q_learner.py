@@ -99,7 +99,8 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         B, T, N, A, H = db.B, db.T, db.N, db.A, a.rnn_hidden_dim
         R, BT = B * T * N, B * T
         g = lambda name, shape, dt=torch.float32: self._buf.get(name, shape, dev, dt)
-        q_evals, hs, saved = g("q_evals", (B, T, N, A)), g("hs", (B, T, N, H)), g("saved", ops.saved_shape(T, B, N))
+        # (no (B,T,N,H) hidden-state output: the Q-learning losses do not read it and BPTT finds h(t) in `saved`)
+        q_evals, hs, saved = g("q_evals", (B, T, N, A)), None, g("saved", ops.saved_shape(T, B, N))
         h_last, h_scr = g("h_last", (B * N, H)), g("h_scr", (B * N, H))
         q_tgt, q_en = g("q_tgt", (B, T, N, A)), g("q_en", (B, T, N, A))
         q_chosen, q_tgt_chosen = g("q_chosen", (R,)), g("q_tgt_chosen", (R,))
@@ -165,7 +166,7 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         # instead of scattering them into a dense (B,T,N,A) tensor
         agent_backward(self.eval_net, db, "cur", saved, hs, None, None, self._buf,
                        dq_idx=u_act, dq_val=dq_chosen.reshape(-1).contiguous())
-        self._dbg = dict(q_evals=q_evals, hs=hs, q_targets=q_tgt, q_tot=q_tot, q_tot_target=q_tot_tgt)
+        self._dbg = dict(q_evals=q_evals, q_targets=q_tgt, q_tot=q_tot, q_tot_target=q_tot_tgt)
 
     def train(self, batch, train_step):
         if self.graphs is not None and isinstance(batch, EpisodeBatch) and batch.ring is not None and \

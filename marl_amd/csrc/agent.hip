@@ -405,6 +405,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
         *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
         *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
+        // the hidden state AFTER the last step, where the backward pass looks for h(t): plane 0 of step t+1
+        if (t == a.T - 1) *reinterpret_cast<f32x4*>(sp + NTILES * (6 * 1024)) = vh;
       }
       if (last) {
         st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
@@ -732,6 +734,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
         *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
         *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
         *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
+        // the hidden state AFTER the last step, where the backward pass looks for h(t): plane 0 of step t+1
+        if (t == a.T - 1) *reinterpret_cast<f32x4*>(sp + NTILES * (6 * 1024)) = vh;
       }
       if (last) {
         st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
@@ -769,7 +773,7 @@ struct BwdArgs {
   int dq_gdiv;            // value index = row index / dq_gdiv (N: one value per (episode, step) shared by its agents)
   const float* dhs;       // (B,T,N,64) external gradient on hs[t], or null
   const float* saved;     // [T][B*N][6][64]
-  const float* hs;        // (B,T,N,64) hidden after each step (for dW_2)
+  const float* hs;        // unused since the forward pass stores h(t) with the saved planes (kept in the ABI)
   float* dxp;             // (B,T,N,64): gradient at fc1 pre-activation
   float* dh0;             // (B*N,64) gradient wrt the initial hidden state, or null
   float* ws;              // [n_wg][slab]: dW_ih | dW_hh | dW_2 | db_ih | db_hh | db_2 partials
@@ -883,13 +887,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
   {                                                                                                      \
     const float* sp_ = a.saved + sv_off((long)(tt) * NTILES + tile0 + (rr), 6, team ? 0 : 1, 0, lane);   \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) P[c] = *reinterpret_cast<const f32x4*>(sp_ + 256 * c); \
-    if (!team) P[4] = *reinterpret_cast<const f32x4*>(sp_ + 256 * ws);                                   \
-    else if ((tt) + 1 < a.T)     /* h(tt) = the hidden state fed into step tt+1: plane 0 of that step */  \
-      P[4] = *reinterpret_cast<const f32x4*>(sp_ + NTILES * (6 * 1024) + 256 * ws);                      \
-    else {                                                                                               \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
-        P[4][i] = a.hs[((long)rowidx[(rr) * 16 + 4 * q + i] + (long)(tt) * tstride) * H + j];            \
-    }                                                                                                    \
+    /* team 1: h(tt) = the hidden state fed into step tt+1 = plane 0 of that step (the forward pass also */ \
+    /* writes a plane 0 for step T) */                                                                   \
+    P[4] = *reinterpret_cast<const f32x4*>(sp_ + (team ? NTILES * (6 * 1024) : 0) + 256 * ws);           \
   }
   auto dq_elem = [&](int t, int e) -> float {
     const int r = e / QP, k = e - r * QP;
@@ -1333,14 +1333,8 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
     const float* sp = a.saved + sv_off((long)tt * NTILES + tile0 + rr, 6, team ? 0 : 1, 0, lane);
 #pragma unroll
     for (int c = 0; c < 4; ++c) P[c] = *reinterpret_cast<const f32x4*>(sp + 256 * c);
-    if (!team) {
-      P[4] = *reinterpret_cast<const f32x4*>(sp + 256 * ws);
-    } else if (tt + 1 < a.T) {       // h(tt) = the hidden state fed into step tt+1: plane 0 of that step
-      P[4] = *reinterpret_cast<const f32x4*>(sp + NTILES * (6 * 1024) + 256 * ws);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) P[4][i] = a.hs[((long)rowidx[rr * 16 + 4 * q + i] + (long)tt * tstride) * H + j];
-    }
+    // team 1: h(tt) = the hidden state fed into step tt+1 = plane 0 of that step (the forward pass also writes one for step T)
+    P[4] = *reinterpret_cast<const f32x4*>(sp + (team ? NTILES * (6 * 1024) : 0) + 256 * ws);
   };
   // dh = carry + dq W2^T ; gate gradients -> DG, carry z -> CAR   (agent_bwd_kernel's phase B for one row tile)
   auto proc_b = [&](const f32x4 (&P)[5], int rt, const float* DQ, float* DG) __attribute__((always_inline)) {

@@ -177,14 +177,14 @@ def saved_shape(T, B, N, planes=6, H=64):
     """Shape of the activation buffer an unroll saves for BPTT (planes = 6) or of its input-side gate sums (planes = 3):
     the kernels use a tile layout [T][16-row tile][plane][column tile][lane][4] (csrc/agent.hip: sv_off), so the row count is
     rounded up to whole tiles.  The buffer is opaque to the host; `saved_plane` decodes one plane."""
-    return (T, (B * N + 15) // 16 * 16, planes, H)
+    return (T + (1 if planes == 6 else 0), (B * N + 15) // 16 * 16, planes, H)     # (+ the hidden state after the last step)
 
 
 def saved_plane(saved, plane, rows):
     """(T, rows, 64) view-copy of one plane of a buffer in the tile layout (tests / debugging)."""
     T, R16, P, H = saved.shape
     t = saved.reshape(T, R16 // 16, P, 4, 4, 16, 4)[:, :, plane]          # (T, tile, c, q, m, i)
-    return t.permute(0, 1, 3, 5, 2, 4).reshape(T, R16, H)[:, :rows]       # row = 16 tile + 4 q + i ; column = 16 c + m
+    return t.permute(0, 1, 3, 5, 2, 4).reshape(T, R16, H)[:, :rows]       # row = 16 tile + 4 q + i ; column = 16 c + m  (T+1 slabs for 6 planes)
 
 
 def agent_unroll_reuse_supported(B, T, N, O, A, cu_budget=0):
@@ -210,7 +210,7 @@ def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=
         _i32(dq_idx2); _f32(dq_val2)
     check(lib.marl_agent_unroll_bwd(C.byref(w), _p(_f32(dq)) if dq is not None else None, _p(dq_idx), _p(dq_val),
                                     _p(dq_idx2), _p(dq_val2), int(dq_gdiv), _p(dhs),
-                                    _p(_f32(saved)), _p(_f32(hs)), _p(_f32(dxp)),
+                                    _p(_f32(saved)), _p(hs), _p(_f32(dxp)),
                                     _p(dh0), C.byref(g), _p(ws), ws.numel() * 4, B, T, N, A, _stream()),
           "marl_agent_unroll_bwd")
 

@@ -363,7 +363,9 @@ def test_agent_unroll_fwd(dev, shape, B, T, with_h0):
     close(hl, hl_ref, 1e-4, msg="h_last")
     # saved plane 0 is the hidden state fed INTO each step
     hprev = torch.cat([(torch.zeros(B, 1, N, 64) if h0 is None else torch.tensor(h0).view(B, 1, N, 64)), hs_ref[:, :-1]], 1)
-    close(ops.saved_plane(saved, 0, B * N).reshape(T, B, N, 64).permute(1, 0, 2, 3), hprev, 1e-4, msg="hprev")
+    # (and one more slab: the hidden state after the last step, where the backward pass looks for h(T-1))
+    hprev = torch.cat([hprev, hs_ref[:, -1:]], 1)
+    close(ops.saved_plane(saved, 0, B * N).reshape(T + 1, B, N, 64).permute(1, 0, 2, 3), hprev, 1e-4, msg="hprev")
 
 
 def test_agent_unroll_shifted_storage(dev):
