@@ -187,6 +187,14 @@ int marl_qmix_fused_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const
 int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot,
                         float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
                         int N, int S, int E, void* stream);
+/* The same backward with the TD loss of q_learner.py:112-127 folded in (the backward pass recomputes q_tot anyway, so the eval
+ * mixer's forward launch, marl_td_loss and its reduction are not needed): per row target = r + gamma q_tot_tgt (1 - term),
+ * td = mask (target - q_tot), dL/dq_tot = -2 mask td with mask = 1 - padded.  loss2[0] += sum td^2, loss2[1] += sum mask
+ * (un-normalised; fixed summation order); q_tot (rows) is written when not NULL. */
+int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* q_tot_tgt,
+                             const float* r, const float* term, const float* padded, float gamma, float* q_tot,
+                             float* dq, const marl_qmix_weights_t* grads, float* loss2, float* ws, size_t ws_bytes,
+                             long rows, int N, int S, int E, void* stream);
 
 /* Fused QMIX for WIDE states (qmix_wide.hip; MMM2: S = 322, N = 10 -> a 416 x 322 concatenated hypernet that does not fit
  * the registers-resident design above): the weights are packed per call into MFMA-fragment order (L2 resident) and

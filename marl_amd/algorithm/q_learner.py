@@ -152,16 +152,22 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
             else:
                 q_tot_tgt, _ = self.target_mixer.hip_forward(qtc, db.s_next, BT, tag="t")
         else:
-            q_tot = self.mixer.hip_forward(qc, db.s, BT, ctx=ctx)
+            fold = a.alg == 'qmix' and getattr(self.mixer, "loss_backward_fused", None) is not None and \
+                self.mixer.loss_backward_fused(db.s) and not getattr(a, "no_loss_fold", False)
+            q_tot = g("q_tot", (BT,)) if fold else self.mixer.hip_forward(qc, db.s, BT, ctx=ctx)
             q_tot_tgt = self.target_mixer.hip_forward(qtc, db.s_next, BT, tag="t")
 
         # TD loss (un-normalised numerator + sum(mask) land in the tail of the gradient buffer)
         self._flat.zero_grad()
-        dq_tot = g("dq_tot", (BT,))
-        ops.td_loss(q_tot, q_tot_tgt, db.r, db.term, db.padded, self.gamma, dq_tot, self._flat.stats[:2], BT)
-
-        # backward: mixer, gather, BPTT
-        dq_chosen = self.mixer.hip_backward(ctx, dq_tot, BT)
+        if a.alg != 'qplex' and fold:
+            # fused QMIX: eval-mixer forward, TD loss and mixer backward are ONE launch (the backward recomputes q_tot anyway)
+            dq_chosen = self.mixer.hip_loss_backward(qc, db.s, BT, q_tot_tgt, db.r, db.term, db.padded, self.gamma,
+                                                     self._flat.stats[:2], q_tot=q_tot)
+        else:
+            dq_tot = g("dq_tot", (BT,))
+            ops.td_loss(q_tot, q_tot_tgt, db.r, db.term, db.padded, self.gamma, dq_tot, self._flat.stats[:2], BT)
+            # backward: mixer, gather, BPTT
+            dq_chosen = self.mixer.hip_backward(ctx, dq_tot, BT)
         # the loss reaches q_evals only through the gather above: hand BPTT the sparse (action, gradient) pairs
         # instead of scattering them into a dense (B,T,N,A) tensor
         agent_backward(self.eval_net, db, "cur", saved, hs, None, None, self._buf,

@@ -33,11 +33,14 @@ struct QmixArgs {
   float* q_tot;                   // (rows) (forward)
   float* dq;                      // (rows, N) (backward)
   float* ws;                      // [nwg][slab] (backward)
+  // LOSS variant (backward with the TD loss folded in): g is not read; dL/dq_tot is formed per row from these
+  const float *lr, *lterm, *lpadded, *lq_tgt;   // (rows) reward, terminated, padded, target-network q_tot of the next state
+  float gamma;
   long rows;
   int N, S, C;
 };
 
-__host__ __device__ inline long qmix_slab_floats(int C, int S) { return (long)C * (S + 1) + (E + 1); }
+__host__ __device__ inline long qmix_slab_floats(int C, int S) { return (long)C * (S + 1) + (E + 1) + 2; }   // + [sum (mask td)^2 | sum mask] of the LOSS variant
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 __device__ __forceinline__ float sum16(float v) {     // over the 16 lanes of a quarter-wave
@@ -48,8 +51,14 @@ __device__ __forceinline__ float sum32(float v) { v = sum16(v); v += __shfl_xor(
 
 // TPW column tiles per wave, NW = 16/TPW waves.  Two waves share each SIMD (8 waves x 2 tiles, or two 4-wave
 // workgroups per CU): one wave's finishing math / LDS waits / barrier skew hide behind the other's MFMAs.
-template <bool BWD, int TPW>
+// LOSS (with BWD): the TD loss of q_learner.py:112-127 is folded in.  The backward pass recomputes q_tot anyway, so the
+// separate forward launch of the eval mixer, the loss launch and its reduction disappear: per row
+//     target = r + gamma q_tot_target (1 - terminated),  td = mask (target - q_tot),  dL/dq_tot = -2 mask td
+// with mask = 1 - padded (un-normalised: the division by the global sum(mask) is folded into the optimizer step); the loss
+// numerator and sum(mask) go through the slab like the weight gradients (fixed summation order).
+template <bool BWD, int TPW, bool LOSS = false>
 __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs a) {
+  static_assert(!LOSS || BWD, "the loss is folded into the backward kernel");
   constexpr int NW = 16 / TPW, QNT = 64 * NW;
   __shared__ __attribute__((aligned(16))) float Ss[2][16 * SS];   // state tile, double buffered
   __shared__ float PA[NW][16][E];      // per-wave partial sums of the pre-activation a_e
@@ -59,6 +68,7 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
   __shared__ float HID[16][E];        // elu(a_e)         (backward)
   __shared__ float Qs2[2][16][16];    // q tile (double buffered with the state tile)
   __shared__ float Gs2[2][16];        // dL/dq_tot tile   (backward)
+  __shared__ float Ls2[2][4][16];     // reward | terminated | padded | target q_tot of the tile (LOSS)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, m = lane & 15;
   const int N = a.N, S = a.S, C = a.C, NE = N * E;
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
 #pragma unroll
   for (int c = 0; c < TPW; ++c) sbW[c] = 0.f;
   float acc_wb2 = 0.f, acc_bb2 = 0.f;      // hyper_b2.2 gradients (finishing lanes)
+  float acc_ln = 0.f, acc_lm = 0.f;        // LOSS: sum (mask td)^2, sum mask (lanes e == 0 of the finishing rows)
   if (BWD) {
 #pragma unroll
     for (int c = 0; c < TPW; ++c)
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
     }
   };
   // q / g elements of this thread, also one tile ahead (threads 0..16N-1: q, threads 192..207: g)
-  float pq = 0.f, pg = 0.f;
+  float pq = 0.f, pg = 0.f, pl[4] = {0.f, 0.f, 0.f, 0.f};
   const int qr = tid / N, qn = tid - qr * N;
   auto fetch_qg = [&](long tile) {
     pq = 0.f; pg = 0.f;
@@ -142,7 +153,10 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
     }
     if (BWD && tid >= 192 && tid < 208) {
       const long row = tile * 16 + (tid - 192);
-      if (row < a.rows) pg = a.g[row];
+      if (LOSS) {
+        pl[0] = pl[1] = pl[3] = 0.f; pl[2] = 1.f;        // rows past the batch: padded
+        if (row < a.rows) { pl[0] = a.lr[row]; pl[1] = a.lterm[row]; pl[2] = a.lpadded[row]; pl[3] = a.lq_tgt[row]; }
+      } else if (row < a.rows) pg = a.g[row];
     }
   };
   float wb2c[TPW];                                   // hyper_b2.2 weight of this lane's column in each tile
@@ -159,7 +173,12 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
     float (*Qs)[16] = Qs2[buf];
     float* Gs = Gs2[buf];
     if (tid < 16 * N) Qs[qr][qn] = pq;
-    if (BWD && tid >= 192 && tid < 208) Gs[tid - 192] = pg;
+    if (BWD && tid >= 192 && tid < 208) {
+      if (LOSS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Ls2[buf][k][tid - 192] = pl[k];
+      } else Gs[tid - 192] = pg;
+    }
     const long nt = tile + gridDim.x;
     if (nt < tiles) { fetch(nt); fetch_qg(nt); }
     ST_MARK(0);
@@ -216,7 +235,19 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
       if (!BWD) {
         if (e == 0 && row0 + r < a.rows) a.q_tot[row0 + r] = tot + bb2;
       } else {
-        const float gr = Gs[r];
+        float gr;
+        if (LOSS) {
+          const float qt = tot + bb2;
+          const float mask = 1.f - Ls2[buf][2][r];
+          const float target = Ls2[buf][0][r] + a.gamma * Ls2[buf][3][r] * (1.f - Ls2[buf][1][r]);
+          const float mtd = mask * (target - qt);
+          gr = -2.f * mask * mtd;
+          if (e == 0) {
+            acc_ln += mtd * mtd; acc_lm += mask;
+            Gs[r] = gr;                                  // read by every wave after the barrier below
+            if (a.q_tot && row0 + r < a.rows) a.q_tot[row0 + r] = qt;
+          }
+        } else gr = Gs[r];
         DPRE[r][e] = gr * w2 * (ae > 0.f ? 1.f : ex);
         HID[r][e] = hid;
         acc_wb2 += gr * hb;
@@ -305,12 +336,26 @@ __global__ __launch_bounds__(64 * (16 / TPW), 2) void qmix_fused_kernel(QmixArgs
       for (int w = 0; w < NW; ++w) tot += wred[w * (E + 1) + tid];
       slab[(long)C * Sx + tid] = tot;
     }
+    // loss partials: the two finishing lanes (e == 0 of each half) of every wave, waves in fixed order
+    __syncthreads();
+    if (LOSS) {
+      const float ln = acc_ln + __shfl_xor(acc_ln, 32, 64), lm = acc_lm + __shfl_xor(acc_lm, 32, 64);
+      if (lane == 0) { wred[2 * wave] = ln; wred[2 * wave + 1] = lm; }
+      __syncthreads();
+      if (tid < 2) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += wred[2 * w + tid];
+        slab[(long)C * Sx + E + 1 + tid] = tot;
+      }
+    } else if (tid < 2) slab[(long)C * Sx + E + 1 + tid] = 0.f;
   }
 }
 
 struct QmixRedArgs {
   const float* ws; int nwg; int N, S, C;
   float *dW[4], *dB[4], *dwb2, *dbb2;
+  float* loss2;       // [sum (mask td)^2 | sum mask] accumulated into (LOSS variant) or null
 };
 
 constexpr int RSG = 16;            // slab groups per output element (fixed summation order -> deterministic)
@@ -342,7 +387,9 @@ __global__ __launch_bounds__(64 * RSG) void qmix_fused_reduce_kernel(QmixRedArgs
   } else {
     // tail: [dwb2 (E) | dbb2]
     const long tpos = e - (long)a.C * Sx;
-    if (tpos < E) a.dwb2[tpos] += s; else a.dbb2[0] += s;
+    if (tpos < E) a.dwb2[tpos] += s;
+    else if (tpos == E) a.dbb2[0] += s;
+    else if (a.loss2) a.loss2[tpos - E - 1] += s;
   }
 }
 
@@ -396,8 +443,28 @@ extern "C" int marl_qmix_fused_fwd(const marl_qmix_weights_t* w, const marl_src_
   QmixArgs a;
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
   a.g = nullptr; a.q_tot = q_tot; a.dq = nullptr; a.ws = nullptr;
+  a.lr = a.lterm = a.lpadded = a.lq_tgt = nullptr; a.gamma = 0.f;
   hipLaunchKernelGGL((qmix_fused_kernel<false, FWD_TPW>), dim3(grid_for(rows, 2)), dim3(64 * (16 / FWD_TPW)), 0,
                      (hipStream_t)stream, a);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+static int qmix_bwd_launch(QmixArgs& a, const marl_qmix_weights_t* grads, float* loss2, float* ws, long rows, int N, int S,
+                           bool loss, hipStream_t st) {
+  const unsigned nwg = grid_for(rows);
+  if (loss) hipLaunchKernelGGL((qmix_fused_kernel<true, 2, true>), dim3(nwg), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((qmix_fused_kernel<true, 2, false>), dim3(nwg), dim3(512), 0, st, a);
+  MARL_CHECK_LAUNCH();
+  QmixRedArgs r;
+  r.ws = ws; r.nwg = (int)nwg; r.N = N; r.S = S; r.C = a.C; r.loss2 = loss2;
+  r.dW[0] = const_cast<float*>(grads->w1); r.dB[0] = const_cast<float*>(grads->w1_b);
+  r.dW[1] = const_cast<float*>(grads->b1); r.dB[1] = const_cast<float*>(grads->b1_b);
+  r.dW[2] = const_cast<float*>(grads->w2); r.dB[2] = const_cast<float*>(grads->w2_b);
+  r.dW[3] = const_cast<float*>(grads->h); r.dB[3] = const_cast<float*>(grads->h_b);
+  r.dwb2 = const_cast<float*>(grads->b2_w); r.dbb2 = const_cast<float*>(grads->b2_b);
+  const long slab = qmix_slab_floats(a.C, S);
+  hipLaunchKernelGGL(qmix_fused_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(64 * RSG), 0, st, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }
@@ -411,19 +478,21 @@ extern "C" int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_
   QmixArgs a;
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
   a.g = dq_tot; a.q_tot = nullptr; a.dq = dq; a.ws = ws;
-  const unsigned nwg = grid_for(rows);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((qmix_fused_kernel<true, 2>), dim3(nwg), dim3(512), 0, st, a);
-  MARL_CHECK_LAUNCH();
-  QmixRedArgs r;
-  r.ws = ws; r.nwg = (int)nwg; r.N = N; r.S = S; r.C = a.C;
-  r.dW[0] = const_cast<float*>(grads->w1); r.dB[0] = const_cast<float*>(grads->w1_b);
-  r.dW[1] = const_cast<float*>(grads->b1); r.dB[1] = const_cast<float*>(grads->b1_b);
-  r.dW[2] = const_cast<float*>(grads->w2); r.dB[2] = const_cast<float*>(grads->w2_b);
-  r.dW[3] = const_cast<float*>(grads->h); r.dB[3] = const_cast<float*>(grads->h_b);
-  r.dwb2 = const_cast<float*>(grads->b2_w); r.dbb2 = const_cast<float*>(grads->b2_b);
-  const long slab = qmix_slab_floats(a.C, S);
-  hipLaunchKernelGGL(qmix_fused_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(64 * RSG), 0, st, r);
-  MARL_CHECK_LAUNCH();
-  return 0;
+  a.lr = a.lterm = a.lpadded = a.lq_tgt = nullptr; a.gamma = 0.f;
+  return qmix_bwd_launch(a, grads, nullptr, ws, rows, N, S, false, (hipStream_t)stream);
+}
+
+extern "C" int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
+                                        const float* q_tot_tgt, const float* r, const float* term, const float* padded,
+                                        float gamma, float* q_tot, float* dq, const marl_qmix_weights_t* grads,
+                                        float* loss2, float* ws, size_t ws_bytes, long rows, int N, int S, int Eq,
+                                        void* stream) {
+  if (rows <= 0) return 0;
+  if (!supported(N, S, Eq) || !q_tot_tgt || !r || !term || !padded || !loss2) return (int)hipErrorInvalidValue;
+  if (ws_bytes < marl_qmix_fused_workspace(rows, N, S)) return (int)hipErrorInvalidValue;
+  QmixArgs a;
+  if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
+  a.g = nullptr; a.q_tot = q_tot; a.dq = dq; a.ws = ws;
+  a.lr = r; a.lterm = term; a.lpadded = padded; a.lq_tgt = q_tot_tgt; a.gamma = gamma;
+  return qmix_bwd_launch(a, grads, loss2, ws, rows, N, S, true, (hipStream_t)stream);
 }

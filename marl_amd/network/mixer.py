@@ -195,6 +195,22 @@ class QMixMixer(_Precision, nn.Module):
             ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2)
         return qtot
 
+    def loss_backward_fused(self, s):
+        """True when hip_loss_backward covers this shape (the registers-resident fused kernel)."""
+        return self._fused_ok(ops.src(s))
+
+    def hip_loss_backward(self, q, s, rows, q_tot_tgt, r, term, padded, gamma, loss2, q_tot=None):
+        """Forward + TD loss + backward of the mixer in ONE launch (csrc/qmix_fused.hip, LOSS variant): the backward pass
+        recomputes q_tot anyway, so the eval mixer's forward launch, the loss launch and its reduction are not needed
+        (q_learner.py:112-127).  loss2 (2 floats, accumulated into): sum (mask td)^2, sum mask.  Returns dL/dq (rows, N);
+        hypernet gradients are accumulated into .grad; q_tot (rows) is written when given."""
+        a = self.args
+        N, E = a.n_agents, a.qmix_hidden_dim
+        dq = self._s.get("dq", (rows, N), q.device)
+        ops.qmix_fused_loss_bwd(self._fused_struct(), ops.src(s), q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
+                                self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E)
+        return dq
+
     def hip_backward(self, ctx, dq_tot, rows):
         a = self.args
         N, E, HH = a.n_agents, a.qmix_hidden_dim, a.hyper_hidden_dim

@@ -164,3 +164,28 @@ def test_speculative_full_length_launch_redoes_a_short_batch():
     assert out[True][1] == out[False][1] == [12, 12, 12, 12, 5, 12]
     assert out[True][0] == out[False][0]
     np.testing.assert_array_equal(out[True][2], out[False][2])
+
+
+def test_qmix_loss_folded_into_the_mixer_backward():
+    """QMIX on the fused mixer kernels: eval-mixer forward + TD loss + mixer backward as ONE launch (the backward recomputes
+    q_tot anyway) against the three-launch path (args.no_loss_fold) - same loss, sum(mask), gradients and q_tot up to the
+    summation order of the two kernels' pre-activation partial sums (4 vs 8 waves)."""
+    case = ("qmix_fold", "2s3z", "qmix", 37, 9, None, {})
+    name, shape, alg, B, T, lengths, over = case
+    rng = np.random.default_rng(5)
+    lengths = [int(x) for x in rng.integers(1, T + 1, size=B)]
+    lengths[0], lengths[-1] = T, -1
+    case = (name, shape, alg, B, T, lengths, over)
+    out = {}
+    for fold in (True, False):
+        args, mac, learner = build_product(case)
+        args.no_loss_fold = not fold
+        batch = seeded.make_batch(args, B, seed=11, lengths=lengths)
+        loss = learner.train(learners.clone_batch(batch), 0)
+        out[fold] = (loss, learner.last_stats[:2].cpu().numpy().copy(), learner._flat.gradx.detach().cpu().numpy().copy(),
+                     learner._dbg["q_tot"].detach().cpu().numpy().copy())
+    assert out[True][1][1] == out[False][1][1]                         # sum(mask): exact
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-6)
+    np.testing.assert_allclose(out[True][3], out[False][3], rtol=0, atol=2e-6 * np.abs(out[False][3]).max())
+    scale = np.abs(out[False][2]).max()
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=0, atol=2e-6 * scale)

@@ -29,3 +29,24 @@ def test_run_chain_falls_back_to_plain_order_without_continuation():
     calls.clear()
     p.run_chain(100, 8, 80, lambda cu: calls.append(("first", cu)), None, lambda cu: calls.append(("second", cu)))
     assert calls == [("first", 256), ("second", 256)]
+
+
+def test_saved_activation_tile_layout_decode():
+    """ops.saved_plane inverts the kernels' tile layout [T][tile][plane][column tile c][lane = 16 q + m][i]:
+    element (row = 16 tile + 4 q + i, column = 16 c + m) sits at (((t * NT + tile) * P + plane) * 4 + c) * 256 + (16 q + m) * 4 + i
+    (csrc/agent.hip: sv_off)."""
+    import torch
+    from marl_amd import ops
+    T, B, N = 2, 3, 7                    # 21 rows -> two 16-row tiles
+    shape = ops.saved_shape(T, B, N)
+    assert shape == (T + 1, 32, 6, 64)   # one more slab: the hidden state after the last step
+    assert ops.saved_shape(T, B, N, planes=3) == (T, 32, 3, 64)
+    buf = torch.arange(int(torch.tensor(shape).prod()), dtype=torch.float32).reshape(shape)
+    NT, P = 2, 6
+    for plane in (0, 4):
+        got = ops.saved_plane(buf, plane, B * N)
+        assert got.shape == (T + 1, B * N, 64)
+        for (t, row, col) in ((0, 0, 0), (1, 5, 17), (2, 20, 63), (1, 16, 32)):
+            tile, q, i, c, m = row // 16, (row % 16) // 4, row % 4, col // 16, col % 16
+            off = (((t * NT + tile) * P + plane) * 4 + c) * 256 + (16 * q + m) * 4 + i
+            assert float(got[t, row, col]) == float(off)
