@@ -85,9 +85,15 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
 // step (a new observation), and any step t at which one of its rows has ep_len - 1 == t - there the earlier unroll (its step
 // t+1 = ep_len) saw the zero padding and this one sees the final observation.  The observation prefetch therefore keeps
 // running; what is saved is the multiplies.
-template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false>
+// HALF: wide observations (MMM2: O = 176) - the NL prefetch registers hold one COLUMN HALF of the next step's observation
+// tile at a time: the left half is committed (and the right half's loads issued) after the first barrier of a step, the right
+// half committed (and the next step's left half issued) at the end of the gate phase - both inside the window in which the
+// input tile may be rewritten, both with a gate phase or more between issue and use.  The same registers then cover twice
+// the rows (a six-register variant spilled).  Non-saving unrolls only.
+template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false, bool HALF = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
-  static_assert(!XS || (VL && !SAVE && NL == NLDW), "XS: vector path, no saving");
+  static_assert(!XS || (VL && !SAVE && NL == NLDW && !HALF), "XS: vector path, no saving");
+  static_assert(!HALF || VL, "HALF: vector path");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int team = wave >> 2, ws = wave & 3;
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 
   // ---- input tile [obs | onehot(ufed) | id | 0-pad]
   const int O = a.O;
-  const int O4 = O >> 2, n4 = rows * O4;
+  const int O4 = HALF ? O >> 3 : O >> 2, n4 = rows * O4;          // float4 groups per row (HALF: of one column half)
+  const int hoff = HALF ? 4 * O4 : 0;                               // float offset of the right column half
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
   f32x4 pf[NL];
   int pt = 0;                         // step the prefetch registers belong to
@@ -165,22 +172,24 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   };
   const int mylen = tid < rows ? rowlen[tid] : 0x7fffffff;
   if (XS && tid < 2) xneed[tid] = 0;
-  auto issue = [&](int t) {           // start the loads of step t's observations (vector path)
-    const long toff = (long)(t + a.obs_t0) * a.N * O;
+  auto issue = [&](int t, int h = 0) {   // start the loads of step t's observations (vector path; h: column half)
+    const long toff = (long)(t + a.obs_t0) * a.N * O + (h ? hoff : 0);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       // always loaded (the record has every slot); steps past the episode end are zeroed at commit
       pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
     }
     pt = t;
+    if (h) return;
     int u = -1;
     if (tid < rows && a.ufed && t + a.u_t0 >= 0) u = a.ufed[urow + (long)(t + a.u_t0) * a.N];
     pu = u;
   };
-  auto commit = [&]() {               // registers -> LDS tile; the one-hot(last action) column is flipped in place
+  auto commit = [&](int h = 0) {      // registers -> LDS tile; the one-hot(last action) column is flipped in place
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      *reinterpret_cast<f32x4*>(In + loff[i]) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(In + loff[i] + (h ? hoff : 0)) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (h) return;
     if (a.has_act && tid < rows) {
       const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
       if (pn != pu_lds) {
@@ -218,7 +227,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   };
   // NOTE the prefetch is issued UNCONDITIONALLY every step (the step index is clamped): a conditional issue makes
   // the prefetch registers a phi of (loaded, old) and the compiler then drains vmcnt right after the loads to copy
-  if (VL) { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
+  if (HALF) { issue(0, 0); commit(0); issue(0, 1); commit(1); issue(a.T > 1 ? 1 : 0, 0); }
+  else if (VL) { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
   else load_generic(0);
   if (XS) {
     if (team < RTW) gissue(1, team);
@@ -315,7 +325,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       if (mylen - 1 == t + 1) xneed[(t + 1) & 1] = 1;
       if (tid == 0) xneed[t & 1] = 0;
     }
-    if (VL) {
+    if (HALF) {
+      commit(0);                                  // left half of step t+1's input; its right half travels during the gates
+      issue(t + 1 < a.T ? t + 1 : a.T - 1, 1);
+    } else if (VL) {
       commit();                                   // (after the last step this writes a tile nobody reads)
       issue(t + 2 < a.T ? t + 2 : a.T - 1);
     } else if (t + 1 < a.T) {
@@ -412,6 +425,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         st32(a.h_last, (unsigned)rr.x * 256u + jb, vh[0]); st32(a.h_last, (unsigned)rr.y * 256u + jb, vh[1]);
         st32(a.h_last, (unsigned)rr.z * 256u + jb, vh[2]); st32(a.h_last, (unsigned)rr.w * 256u + jb, vh[3]);
       }
+    }
+    if (HALF) {
+      commit(1);                                  // right half of step t+1's input
+      issue(t + 2 < a.T ? t + 2 : a.T - 1, 0);
     }
     ST_MARK(3);
     WG_BARRIER();
@@ -1629,7 +1646,7 @@ extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int
   const long tiles = ((long)B * N + 15) / 16;
   const int want = (int)((tiles + cu_budget - 1) / cu_budget);
   const int cap2 = (NLDW * FNT) / (16 * (O / 4));
-  if (cap2 < 1 || (cap2 < want && cap2 < 8)) return 0;          // six-register variant (or no vector path)
+  if (cap2 < 1 || (cap2 < want && cap2 < 8)) return 0;          // half-tile prefetch variant (or no vector path): no reuse
   int rt = want < 1 ? 1 : want;
   if (rt > 8) rt = 8;
   if (rt > cap2) rt = cap2;
@@ -1658,18 +1675,19 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16;   // fc1 fragments + the two step flags of the x-reusing variant
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
-  int nl = NLDW;
-  if (a.vload) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in nl * 512 registers
+  bool half = false;
+  if (a.vload) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW * 512 registers
     int cap2 = (NLDW * FNT) / (16 * (O / 4));
     const long tiles = (a.R + 15) / 16;
     const int cus = T > 1 ? cu_budget : 256;
     const int want = (int)((tiles + cus - 1) / cus);                 // row tiles per workgroup that fill the CUs in one round
-    if (cap2 < want && cap2 < 8 && T > 1 && !saved) {                // wide observations: two more prefetch registers (the
-                                                                     // activation-saving variant has none to spare: it spills)
-      nl = 6;
-      cap2 = (6 * FNT) / (16 * (O / 4));
-    }
-    if (cap2 < 1) { a.vload = 0; nl = NLDW; } else if (cap2 < rt_cap) rt_cap = cap2;
+    if (cap2 < want && cap2 < 8 && T > 1 && O % 8 == 0 && !saved) {  // wide observations: the registers hold one column
+      half = true;                                                   // half of the tile at a time (HALF kernels).  Not the
+      cap2 = (NLDW * FNT) / (16 * (O / 8));                          // activation-saving variant: hipcc cannot count its
+    }                                                                // stores across the tile loop and waits vmcnt(0) for
+                                                                     // the right half at the end of every gate phase
+                                                                     // (measured 2.2 -> 3.2 ms at MMM2 / 1024 envs)
+    if (cap2 < 1) { a.vload = 0; half = false; } else if (cap2 < rt_cap) rt_cap = cap2;
   }
   // a single step (rollout) is latency-bound: many small workgroups overlap their prologues better than
   // 256 big ones; a long unroll amortises the prologue and wants one workgroup per CU
@@ -1704,10 +1722,10 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
 #define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
   const bool sv = saved != nullptr, vl = a.vload != 0;
   static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
-  if (vl && nl == NLDW && !sv && gi_in && T >= 2 && !xs_off) {
+  if (vl && !half && !sv && gi_in && T >= 2 && !xs_off) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, true>;
-  } else if (vl && nl == 6) {
-    fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, 6> : (const void*)agent_fwd_kernel<2, false, true, 6>;
+  } else if (vl && half) {
+    fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, false, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, false, true>;
   } else
   if (A <= 16) fn = sv ? (vl ? FWD_PICK(1, true, true) : FWD_PICK(1, true, false)) : (vl ? FWD_PICK(1, false, true) : FWD_PICK(1, false, false));
   else fn = sv ? (vl ? FWD_PICK(2, true, true) : FWD_PICK(2, true, false)) : (vl ? FWD_PICK(2, false, true) : FWD_PICK(2, false, false));
