@@ -393,6 +393,42 @@ def test_agent_unroll_shifted_storage(dev):
         close(q, q_ref, 1e-4)
 
 
+@pytest.mark.parametrize("shape,B,T,cus", [("2s3z", 37, 5, 4), ("2s3z", 700, 6, 48), ("3s5z", 40, 4, 8), ("2s3z", 9, 2, 2)])
+def test_double_q_unroll_reuses_input_side_work_bitwise(dev, shape, B, T, cus):
+    """gi_out / gi_in (include/marl_hip.h): an unroll over steps 1..T of (T+1)-slot storage that READS the input-side gate sums
+    an unroll over steps 0..T-1 stored == the same unroll computing everything, bit for bit - with ragged episode lengths
+    (steps ep_len - 1 and T - 1 are computed in full), an episode map, a carried hidden state and a partial last row tile.
+    A small CU budget gives several row tiles per workgroup (the kernel family that has the variant) at test sizes."""
+    from marl_amd import ops
+    args, p_np, _, _, _ = _agent_case(shape, B, T, dev)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    assert ops.agent_unroll_reuse_supported(B, T, N, O, A, cus)
+    rng = np.random.default_rng(B + T)
+    E = B + 3                                                  # storage holds more episodes than the batch
+    store = cu(rng.standard_normal((E, T + 1, N, O)).astype(np.float32), dev)
+    u = cu(rng.integers(-1, A, size=(B, T, N)), dev, torch.int32)
+    emap = cu(rng.permutation(E)[:B], dev, torch.int32)
+    lens = rng.integers(1, T + 1, size=B)
+    lens[0], lens[-1] = T, 1
+    ep_len = cu(lens, dev, torch.int32)
+    w = ops.agent_weights({k: cu(v, dev) for k, v in p_np.items()})
+    H = 64
+    saved = torch.empty(ops.saved_shape(T, B, N), device=dev)
+    gi = torch.full(ops.saved_shape(T, B, N, planes=3), float("nan"), device=dev)
+    q0, h_last = torch.empty(B, T, N, A, device=dev), torch.empty(B * N, H, device=dev)
+    # eval pass: slots 0..T-1, last action = the previous step's (u_t0 = -1), stores activations and gate sums
+    ops.agent_unroll_fwd(w, store, (T + 1) * N, 0, u, T * N, -1, None, q0, None, h_last, saved, B, T, N, O, A,
+                         ep_len=ep_len, ep_map=emap, cu_budget=cus, gi_out=gi)
+    outs = []
+    for reuse in (True, False):
+        q, hl = torch.empty(B, T, N, A, device=dev), torch.empty(B * N, H, device=dev)
+        ops.agent_unroll_fwd(w, store, (T + 1) * N, 1, u, T * N, 0, h_last, q, None, hl, None, B, T, N, O, A,
+                             ep_len=ep_len, ep_map=emap, cu_budget=cus, gi_in=gi if reuse else None)
+        outs.append((q.cpu(), hl.cpu()))
+    assert torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
 def test_agent_unroll_bwd(dev, shape, B, T):
     """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll.  Up to four row tiles per workgroup a
