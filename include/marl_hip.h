@@ -211,6 +211,12 @@ int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const 
 int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot, float* dq,
                        const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows, int N, int S, int E,
                        int flags, void* stream);
+/* marl_qmix_wide_bwd with the TD loss folded in (see marl_qmix_fused_loss_bwd): q_tot of a row is complete inside one wave of
+ * the backward kernel, so dL/dq_tot is formed there; loss2[0] += sum (mask td)^2, loss2[1] += sum mask; q_tot optional. */
+int marl_qmix_wide_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* q_tot_tgt,
+                            const float* r, const float* term, const float* padded, float gamma, float* q_tot, float* dq,
+                            const marl_qmix_weights_t* grads, float* loss2, float* ws, size_t ws_bytes, long rows,
+                            int N, int S, int E, int flags, void* stream);
 
 /* ---- fused three-layer heads (mlp3_fused.hip) -----------------------------------------------
  * Y[:, g*gs_y + 0..N3) = W3_g relu(W2_g relu(W1_g x + b1_g) + b2_g) + b3_g for `groups` equally shaped heads

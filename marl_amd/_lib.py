@@ -94,6 +94,7 @@ SIGNATURES = {
     "marl_qmix_wide_workspace": (SZ, [L, I, I, I]),
     "marl_qmix_wide_fwd": (I, [QW, SRC, P, P, P, SZ, L, I, I, I, I, P]),
     "marl_qmix_wide_bwd": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, I, P]),
+    "marl_qmix_wide_loss_bwd": (I, [QW, SRC, P, P, P, P, P, F, P, P, QW, P, P, SZ, L, I, I, I, I, P]),
     "marl_mlp3_supported": (I, [SRC, I, I, I, I, I]),
     "marl_mlp3_fwd": (I, [M3, SRC, P, L, L, L, I, I, I, P]),
     "marl_mlp3_bwd_workspace": (SZ, [L, I, I, I]),

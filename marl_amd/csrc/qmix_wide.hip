@@ -38,7 +38,10 @@ struct WideArgs {
   float* q_tot;                   // (rows)                      (forward)
   float* dq;                      // (rows, N)                   (backward)
   float* dhy;                     // (rows, C) d(hypernet out)   (backward)
-  float* slab;                    // [grid][E + 1] hyper_b2.2 gradient partials
+  float* slab;                    // [grid][E + 3] hyper_b2.2 gradient partials | loss numerator | sum(mask)
+  // LOSS variant (backward with the TD loss folded in, as qmix_fused.hip): g is not read
+  const float *lr, *lterm, *lpadded, *lq_tgt;
+  float gamma;
   long rows;
   int N, S, C, NCT, KC;           // KC: k-chunks of 16 (fp32) or 32 (bf16)
 };
@@ -105,8 +108,8 @@ constexpr int NCTM = 26;          // column tiles of the concatenated hypernet (
 constexpr int RB = 16 * NW;       // rows per block: one 16-row tile per wave
 
 __host__ __device__ inline size_t wide_lds(int NCT) {
-  // weight chunk x 2 [NCT][64] f32x4 | Qs [RB][16] | Gs [RB] | red [NW][E + 1]
-  return (size_t)(2 * NCT * 256 + RB * 16 + RB + NW * (E + 1)) * 4;
+  // weight chunk x 2 [NCT][64] f32x4 | Qs [RB][16] | Gs [RB] | Ls [4][RB] | red [NW][E + 3]
+  return (size_t)(2 * NCT * 256 + RB * 16 + RB + 4 * RB + NW * (E + 3)) * 4;
 }
 
 // One GEMM-shaped kernel: a workgroup walks blocks of 128 (episode, step) rows; wave w owns rows [16w, 16w + 16) of the
@@ -117,8 +120,12 @@ __host__ __device__ inline size_t wide_lds(int NCT) {
 // straight from HBM to registers (each wave reads only its own 16 rows; one chunk ahead).
 // NCTT: compile-time number of column tiles (26 = MMM2's 10 agents: no per-tile branches, tile roles known statically) or
 // 0 = read it from the arguments.
-template <bool BWD, bool BF, int NCTT>
+// LOSS (with BWD): the TD loss is folded in as in qmix_fused.hip - q_tot of a row is complete inside its wave, so dL/dq_tot is formed
+// there (second pass over the cheap per-element math instead of more live registers) and the eval mixer's forward launch,
+// the loss launch and its reduction are not needed.
+template <bool BWD, bool BF, int NCTT, bool LOSS = false>
 __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
+  static_assert(!LOSS || BWD, "the loss is folded into the backward kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q4 = lane >> 4, m = lane & 15;
@@ -128,13 +135,15 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
   float* Wl[2] = {smem, smem + NCT * 256};                              // [NCT][64] f32x4 (fp32) / 8 x bf16
   float* Qs = smem + 2 * NCT * 256;                                     // [RB][16]
   float* Gs = Qs + RB * 16;                                             // [RB]
-  float* red = Gs + RB;                                                 // [NW][E + 1]
+  float* Ls = Gs + RB;                                                  // [4][RB] reward | terminated | padded | target q_tot (LOSS)
+  float* red = Ls + 4 * RB;                                             // [NW][E + 3]
   const f32x4* Wp4 = reinterpret_cast<const f32x4*>(a.Wp);              // 16 bytes per (tile, chunk, lane) in both modes
   const int witems = NCT * 64;
   const int S4x4 = ((S + 3) >> 2) * 4;                                  // readable floats of a state row
   const float wb2lo = a.wb2[m], wb2hi = a.wb2[16 + m];
   const float bb2 = a.bb2[0];
   float acc_wb2[2] = {0.f, 0.f}, acc_bb2 = 0.f;
+  float acc_ln = 0.f, acc_lm = 0.f;                                     // LOSS: sum (mask td)^2, sum mask (lanes m == 0)
   const long nblk = (a.rows + RB - 1) / RB;
 
   f32x4 wpf[4];                                                         // this thread's share of the next weight chunk
@@ -176,7 +185,14 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
       const long row = row0 + e / N;
       Qs[(e / N) * 16 + e % N] = row < a.rows ? a.q[row * N + e % N] : 0.f;
     }
-    if (BWD && tid < RB) Gs[tid] = row0 + tid < a.rows ? a.g[row0 + tid] : 0.f;
+    if (BWD && tid < RB) {
+      const long row = row0 + tid;
+      if (LOSS) {
+        const bool ok = row < a.rows;                                   // rows past the batch: padded
+        Ls[tid] = ok ? a.lr[row] : 0.f; Ls[RB + tid] = ok ? a.lterm[row] : 0.f;
+        Ls[2 * RB + tid] = ok ? a.lpadded[row] : 1.f; Ls[3 * RB + tid] = ok ? a.lq_tgt[row] : 0.f;
+      } else Gs[tid] = row < a.rows ? a.g[row] : 0.f;
+    }
 
     f32x4 acc[NCTM];
 #pragma unroll
@@ -249,26 +265,33 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
       else if (rel == 2) tw2[0] = acc[ct]; else if (rel == 3) tw2[1] = acc[ct];
       else if (rel == 4) th[0] = acc[ct]; else if (rel == 5) th[1] = acc[ct];
     }
-    float dpre[2][4], hidv[2][4], tot[4];
+    float dpre[2][4], hidv[2][4], tot[4], gr[4] = {0.f, 0.f, 0.f, 0.f};
+    // one pass over the per-element mixing math; with_grad also forms dpre / hid / the hyper_b2.2 gradient from gr
+    auto mix_pass = [&](const bool with_grad) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tot[i] = 0.f;
+      for (int i = 0; i < 4; ++i) tot[i] = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float ae = pa[h][i] + tb1[h][i];
-        const float ex = __expf(ae);
-        const float hid = ae > 0.f ? ae : ex - 1.f;                       // elu, alpha = 1
-        const float w2 = fabsf(tw2[h][i]), hb = fmaxf(th[h][i], 0.f);
-        tot[i] += hid * w2 + hb * (h ? wb2hi : wb2lo);
-        if (BWD) {
-          const float gr = Gs[16 * wave + 4 * q4 + i];
-          dpre[h][i] = gr * w2 * (ae > 0.f ? 1.f : ex);
-          hidv[h][i] = hid;
-          acc_wb2[h] += gr * hb;
+        for (int i = 0; i < 4; ++i) {
+          const float ae = pa[h][i] + tb1[h][i];
+          const float ex = __expf(ae);
+          const float hid = ae > 0.f ? ae : ex - 1.f;                       // elu, alpha = 1
+          const float w2 = fabsf(tw2[h][i]), hb = fmaxf(th[h][i], 0.f);
+          tot[i] += hid * w2 + hb * (h ? wb2hi : wb2lo);
+          if (with_grad) {
+            dpre[h][i] = gr[i] * w2 * (ae > 0.f ? 1.f : ex);
+            hidv[h][i] = hid;
+            acc_wb2[h] += gr[i] * hb;
+          }
         }
-      }
+    };
     const long rbase = row0 + 16 * wave + 4 * q4;
+    if (BWD && !LOSS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gr[i] = Gs[16 * wave + 4 * q4 + i];
+    }
+    mix_pass(BWD && !LOSS);
     if (!BWD) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -276,12 +299,25 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
         if (m == 0 && rbase + i < a.rows) a.q_tot[rbase + i] = t + bb2;
       }
     } else {
-      float gr[4];
+      if (LOSS) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        gr[i] = Gs[16 * wave + 4 * q4 + i];
-        if (m == 0) acc_bb2 += gr[i];
+        for (int i = 0; i < 4; ++i) {
+          const int rl = 16 * wave + 4 * q4 + i;
+          const float qt = sum16(tot[i]) + bb2;
+          const float mask = 1.f - Ls[2 * RB + rl];
+          const float target = Ls[rl] + a.gamma * Ls[3 * RB + rl] * (1.f - Ls[RB + rl]);
+          const float mtd = mask * (target - qt);
+          gr[i] = -2.f * mask * mtd;
+          if (m == 0) {
+            acc_ln += mtd * mtd; acc_lm += mask;
+            if (a.q_tot && rbase + i < a.rows) a.q_tot[rbase + i] = qt;
+          }
+        }
+        mix_pass(true);
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (m == 0) acc_bb2 += gr[i];
       // d(hypernet output) in place, dq_n = sum_e |w1[n,e]| dpre_e
 #pragma unroll
       for (int ct = 0; ct < NCTM; ++ct) {
@@ -329,15 +365,17 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
     }
     acc_bb2 += __shfl_xor(acc_bb2, 16, 64);
     acc_bb2 += __shfl_xor(acc_bb2, 32, 64);
+    acc_ln += __shfl_xor(acc_ln, 16, 64); acc_ln += __shfl_xor(acc_ln, 32, 64);       // lanes m == 0 of the four row groups
+    acc_lm += __shfl_xor(acc_lm, 16, 64); acc_lm += __shfl_xor(acc_lm, 32, 64);
     __syncthreads();
-    if (q4 == 0) { red[wave * (E + 1) + m] = acc_wb2[0]; red[wave * (E + 1) + 16 + m] = acc_wb2[1]; }
-    if (lane == 0) red[wave * (E + 1) + E] = acc_bb2;
+    if (q4 == 0) { red[wave * (E + 3) + m] = acc_wb2[0]; red[wave * (E + 3) + 16 + m] = acc_wb2[1]; }
+    if (lane == 0) { red[wave * (E + 3) + E] = acc_bb2; red[wave * (E + 3) + E + 1] = acc_ln; red[wave * (E + 3) + E + 2] = acc_lm; }
     __syncthreads();
-    if (tid < E + 1) {
+    if (tid < E + 3) {
       float tot = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) tot += red[w * (E + 1) + tid];
-      a.slab[(long)blockIdx.x * (E + 1) + tid] = tot;
+      for (int w = 0; w < NW; ++w) tot += red[w * (E + 3) + tid];
+      a.slab[(long)blockIdx.x * (E + 3) + tid] = tot;
     }
   }
 }
@@ -515,6 +553,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
 struct WideRedArgs {
   const float* ws; const float* slab2; int nslab, nwg, N, S, C, KT;
   float *dW[4], *dB[4], *dwb2, *dbb2;
+  float* loss2;       // [sum (mask td)^2 | sum mask] accumulated into (LOSS variant) or null
 };
 constexpr int RSG = 8;            // slab groups per output element (fixed summation order -> deterministic)
 __global__ __launch_bounds__(64 * RSG) void qmix_wide_reduce_kernel(WideRedArgs a) {
@@ -526,8 +565,8 @@ __global__ __launch_bounds__(64 * RSG) void qmix_wide_reduce_kernel(WideRedArgs 
   float s = 0.f;
   if (e < n1) {
     for (int w = sg; w < a.nslab; w += RSG) s += a.ws[(long)w * n1 + e];
-  } else if (e < n1 + E + 1) {
-    for (int w = sg; w < a.nwg; w += RSG) s += a.slab2[(long)w * (E + 1) + (e - n1)];
+  } else if (e < n1 + E + 3) {
+    for (int w = sg; w < a.nwg; w += RSG) s += a.slab2[(long)w * (E + 3) + (e - n1)];
   }
   part[sg][el] = s;
   __syncthreads();
@@ -541,9 +580,11 @@ __global__ __launch_bounds__(64 * RSG) void qmix_wide_reduce_kernel(WideRedArgs 
     seg_of(col, a.N * E, seg, r);
     if (k < a.S) a.dW[seg][(long)r * a.S + k] += s;
     else if (k == 16 * a.KT) a.dB[seg][r] += s;
-  } else if (e < n1 + E + 1) {
+  } else if (e < n1 + E + 3) {
     const long t = e - n1;
-    if (t < E) a.dwb2[t] += s; else a.dbb2[0] += s;
+    if (t < E) a.dwb2[t] += s;
+    else if (t == E) a.dbb2[0] += s;
+    else if (a.loss2) a.loss2[t - E - 1] += s;
   }
 }
 
@@ -615,7 +656,7 @@ extern "C" size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward
   size_t f = packed_floats(N, S);
   if (backward) {
     const int KT = (S + 15) / 16;
-    f += (size_t)rows * C + (size_t)wg_slabs(rows) * C * (16 * KT + 1) + (size_t)256 * (E + 1) + 64;
+    f += (size_t)rows * C + (size_t)wg_slabs(rows) * C * (16 * KT + 1) + (size_t)256 * (E + 3) + 64;
   }
   return f * sizeof(float);
 }
@@ -638,9 +679,11 @@ extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t
             : launch_main(qmix_wide_kernel<false, false, 0>, a, grid, false, st);
 }
 
-extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot,
-                                  float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
-                                  int N, int S, int Eq, int flags, void* stream) {
+struct WideLoss { const float *q_tot_tgt, *r, *term, *padded; float gamma; float* q_tot; float* loss2; };
+
+static int wide_bwd_impl(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot, const WideLoss* L,
+                         float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
+                         int N, int S, int Eq, int flags, void* stream) {
   if (rows <= 0) return 0;
   if (!supported(N, S, Eq) || !src_ok(s, S)) return (int)hipErrorInvalidValue;
   if (ws_bytes < marl_qmix_wide_workspace(rows, N, S, 1) || (reinterpret_cast<uintptr_t>(ws) & 15)) return (int)hipErrorInvalidValue;
@@ -655,11 +698,19 @@ extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t
   float* wslab = dhy + (size_t)rows * C;
   float* bslab = wslab + (size_t)nslab * C * (16 * KT + 1);
   a.s = state_src(s); a.q = q; a.g = dq_tot; a.dq = dq; a.dhy = dhy; a.slab = bslab; a.rows = rows;
+  if (L) { a.lr = L->r; a.lterm = L->term; a.lpadded = L->padded; a.lq_tgt = L->q_tot_tgt; a.gamma = L->gamma; a.q_tot = L->q_tot; }
   const unsigned grid = grid_for(rows);
-  if (a.NCT == NCTM) rc = bf ? launch_main(qmix_wide_kernel<true, true, NCTM>, a, grid, true, st)
-                             : launch_main(qmix_wide_kernel<true, false, NCTM>, a, grid, false, st);
-  else rc = bf ? launch_main(qmix_wide_kernel<true, true, 0>, a, grid, true, st)
-               : launch_main(qmix_wide_kernel<true, false, 0>, a, grid, false, st);
+  if (L) {
+    if (a.NCT == NCTM) rc = bf ? launch_main(qmix_wide_kernel<true, true, NCTM, true>, a, grid, true, st)
+                               : launch_main(qmix_wide_kernel<true, false, NCTM, true>, a, grid, false, st);
+    else rc = bf ? launch_main(qmix_wide_kernel<true, true, 0, true>, a, grid, true, st)
+                 : launch_main(qmix_wide_kernel<true, false, 0, true>, a, grid, false, st);
+  } else {
+    if (a.NCT == NCTM) rc = bf ? launch_main(qmix_wide_kernel<true, true, NCTM>, a, grid, true, st)
+                               : launch_main(qmix_wide_kernel<true, false, NCTM>, a, grid, false, st);
+    else rc = bf ? launch_main(qmix_wide_kernel<true, true, 0>, a, grid, true, st)
+                 : launch_main(qmix_wide_kernel<true, false, 0>, a, grid, false, st);
+  }
   if (rc) return rc;
   WideWgArgs g;
   g.dhy = dhy; g.s = a.s; g.ws = wslab; g.rows = rows; g.S = S; g.C = C; g.KT = KT; g.nslab = nslab;
@@ -670,13 +721,29 @@ extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t
   MARL_CHECK_LAUNCH();
   WideRedArgs r;
   r.ws = wslab; r.slab2 = bslab; r.nslab = nslab; r.nwg = (int)grid; r.N = N; r.S = S; r.C = C; r.KT = KT;
+  r.loss2 = L ? L->loss2 : nullptr;
   r.dW[0] = const_cast<float*>(grads->w1); r.dB[0] = const_cast<float*>(grads->w1_b);
   r.dW[1] = const_cast<float*>(grads->b1); r.dB[1] = const_cast<float*>(grads->b1_b);
   r.dW[2] = const_cast<float*>(grads->w2); r.dB[2] = const_cast<float*>(grads->w2_b);
   r.dW[3] = const_cast<float*>(grads->h); r.dB[3] = const_cast<float*>(grads->h_b);
   r.dwb2 = const_cast<float*>(grads->b2_w); r.dbb2 = const_cast<float*>(grads->b2_b);
-  const long total = (long)C * (16 * KT + 1) + E + 1;
+  const long total = (long)C * (16 * KT + 1) + E + 3;
   hipLaunchKernelGGL(qmix_wide_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64 * RSG), 0, st, r);
   MARL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int marl_qmix_wide_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot,
+                                  float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
+                                  int N, int S, int Eq, int flags, void* stream) {
+  return wide_bwd_impl(w, s, q, dq_tot, nullptr, dq, grads, ws, ws_bytes, rows, N, S, Eq, flags, stream);
+}
+
+extern "C" int marl_qmix_wide_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* q_tot_tgt,
+                                       const float* r, const float* term, const float* padded, float gamma, float* q_tot,
+                                       float* dq, const marl_qmix_weights_t* grads, float* loss2, float* ws, size_t ws_bytes,
+                                       long rows, int N, int S, int Eq, int flags, void* stream) {
+  if (!q_tot_tgt || !r || !term || !padded || !loss2) return (int)hipErrorInvalidValue;
+  WideLoss L = {q_tot_tgt, r, term, padded, gamma, q_tot, loss2};
+  return wide_bwd_impl(w, s, q, nullptr, &L, dq, grads, ws, ws_bytes, rows, N, S, Eq, flags, stream);
 }

@@ -196,8 +196,9 @@ class QMixMixer(_Precision, nn.Module):
         return qtot
 
     def loss_backward_fused(self, s):
-        """True when hip_loss_backward covers this shape (the registers-resident fused kernel)."""
-        return self._fused_ok(ops.src(s))
+        """True when hip_loss_backward covers this shape (one of the two fused kernel families)."""
+        xs = ops.src(s)
+        return self._fused_ok(xs) or self._wide_ok(xs)
 
     def hip_loss_backward(self, q, s, rows, q_tot_tgt, r, term, padded, gamma, loss2, q_tot=None):
         """Forward + TD loss + backward of the mixer in ONE launch (csrc/qmix_fused.hip, LOSS variant): the backward pass
@@ -207,8 +208,13 @@ class QMixMixer(_Precision, nn.Module):
         a = self.args
         N, E = a.n_agents, a.qmix_hidden_dim
         dq = self._s.get("dq", (rows, N), q.device)
-        ops.qmix_fused_loss_bwd(self._fused_struct(), ops.src(s), q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
-                                self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E)
+        xs = ops.src(s)
+        if self._fused_ok(xs):
+            ops.qmix_fused_loss_bwd(self._fused_struct(), xs, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
+                                    self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E)
+        else:
+            ops.qmix_wide_loss_bwd(self._fused_struct(), xs, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
+                                   self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E, bf16=self._bf16())
         return dq
 
     def hip_backward(self, ctx, dq_tot, rows):

@@ -423,6 +423,15 @@ def qmix_fused_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, g
                                        _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_loss_bwd")
 
 
+def qmix_wide_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, rows, N, S, E, bf16=False):
+    """wide-state fused QMIX backward with the TD loss folded in (include/marl_hip.h)"""
+    lib = _lib.load()
+    ws = WS.get("qmix_wide", lib.marl_qmix_wide_workspace(rows, N, S, 1), q.device)
+    check(lib.marl_qmix_wide_loss_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot_tgt)), _p(_f32(r)), _p(_f32(term)),
+                                      _p(_f32(padded)), float(gamma), _p(q_tot), _p(_f32(dq)), C.byref(grads), _p(_f32(loss2)),
+                                      _p(ws), ws.numel() * 4, rows, N, S, E, 1 if bf16 else 0, _stream()), "marl_qmix_wide_loss_bwd")
+
+
 def qmix_wide_supported(N, S, E):
     return bool(_lib.load().marl_qmix_wide_supported(N, S, E))
 

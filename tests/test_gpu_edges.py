@@ -166,11 +166,12 @@ def test_speculative_full_length_launch_redoes_a_short_batch():
     np.testing.assert_array_equal(out[True][2], out[False][2])
 
 
-def test_qmix_loss_folded_into_the_mixer_backward():
-    """QMIX on the fused mixer kernels: eval-mixer forward + TD loss + mixer backward as ONE launch (the backward recomputes
-    q_tot anyway) against the three-launch path (args.no_loss_fold) - same loss, sum(mask), gradients and q_tot up to the
-    summation order of the two kernels' pre-activation partial sums (4 vs 8 waves)."""
-    case = ("qmix_fold", "2s3z", "qmix", 37, 9, None, {})
+@pytest.mark.parametrize("shape", ["2s3z", "MMM2"])
+def test_qmix_loss_folded_into_the_mixer_backward(shape):
+    """QMIX on the fused mixer kernels (2s3z: registers-resident hypernet; MMM2: wide-state kernel): eval-mixer forward + TD
+    loss + mixer backward as ONE launch (the backward recomputes q_tot anyway) against the three-launch path
+    (args.no_loss_fold) - same loss, sum(mask), gradients and q_tot up to the summation order of the kernels' partial sums."""
+    case = ("qmix_fold", shape, "qmix", 37, 9, None, {})
     name, shape, alg, B, T, lengths, over = case
     rng = np.random.default_rng(5)
     lengths = [int(x) for x in rng.integers(1, T + 1, size=B)]
