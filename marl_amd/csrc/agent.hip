@@ -476,8 +476,12 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 //     team 1 : fc1(t+1) -> Xt[(t+1)&1],  q(t-1) = fc2(h(t-1)),  then joins the GRU tiles (per-slice counter)
 // with the input tile and the fc1 output double-buffered in LDS (which is why it needs RT <= 3-4).
 // Results are bit-identical to agent_fwd_kernel (same MFMA sequences per output element).
-template <int AC, bool SAVE>
+// XS (as in agent_fwd_kernel): the input-side work of steps 0..T-2 is read from what an earlier unroll stored (gi_in); fc1 runs
+// only for the last step and for the steps flagged through xneed (a row with ep_len - 1 == t), known two steps ahead because
+// team 1 computes fc1 a step early.  Team 0 alone walks the row tiles then (static order, so the sums can be prefetched).
+template <int AC, bool SAVE, bool XS = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
+  static_assert(!XS || !SAVE, "XS: no saving");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, ws = wave & 3;
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   int* rowlen = rown + rows;
   int* rowrho = rowlen + rows;
   int* tilecnt = rowrho + rows;                       // [2][4]: next GRU tile of each hidden-unit slice, by step parity
+  int* xneed = tilecnt + 8;                           // [4] (XS): some row of this workgroup has ep_len - 1 == t, by t & 3
 
   const long row0 = (long)blockIdx.x * rows;
   for (int r = tid; r < rows; r += FNT) {
@@ -513,6 +518,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     rowrho[r] = (int)rho;
   }
   if (tid < 8) tilecnt[tid] = 0;
+  if (XS && tid >= 8 && tid < 12) xneed[tid - 8] = 0;
   __syncthreads();
   for (int e = tid; e < rows * H; e += FNT) {
     int r = e / H, k = e % H;
@@ -571,6 +577,20 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   issue(0); commit(In0, pu_lds0);
   issue(Tm1 < 1 ? Tm1 : 1); commit(In0 + rows * KS, pu_lds1);
   issue(Tm1 < 2 ? Tm1 : 2);
+  // XS: stored input-side sums of the next row tile team 0 will process (accumulator layout), a tile ahead; step flags
+  f32x4 gB[3];
+  auto gissue = [&](int ts, int rt) {
+    const float* gp = a.gi_in + sv_off((long)ts * NTILES + (long)blockIdx.x * a.RT + rt, 3, 0, wave & 3, lane);
+    gB[0] = *reinterpret_cast<const f32x4*>(gp);
+    gB[1] = *reinterpret_cast<const f32x4*>(gp + 1024);
+    gB[2] = *reinterpret_cast<const f32x4*>(gp + 2 * 1024);
+  };
+  const int mylen = tid < rows ? rowlen[tid] : 0x7fffffff;
+  if (XS) {
+    if (team == 0) gissue(Tm1 < 1 ? Tm1 : 1, 0);
+    if (mylen - 1 == 0) xneed[0] = 1;
+    if (mylen - 1 == 1) xneed[1] = 1;
+  }
 
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
   float bias_r, bias_z, bias_in, bias_hn, bias1, bias2[AC];
@@ -674,8 +694,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     }
   };
 
-  // prologue: x(0) by both teams (tiles alternate between them)
-  fc1(In0, Xt0, 0, team, 2);
+  // prologue: x(0) by both teams (tiles alternate between them); XS: only when step 0 is computed in full
+  // (the barrier above - staged weights - also published the step flags)
+  if (!XS || Tm1 == 0 || xneed[0]) fc1(In0, Xt0, 0, team, 2);
   WG_BARRIER();
 
   float* Hp = Ha;
@@ -687,10 +708,15 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     const long svt = SAVE ? (long)t * NTILES + (long)blockIdx.x * a.RT : 0;      // (step, first row tile of this workgroup)
     float* Xc = Xt0 + par * rows * HS;                 // x(t), written in the previous step
     float* Inn = In0 + (par ^ 1) * rows * KS;           // input of step t+1 (committed during step t-1)
+    const bool xread = XS && t < Tm1 && xneed[t & 3] == 0;         // this step's input-side work is read, not computed
     if (team == 1) {
-      if (t + 1 < a.T) fc1(Inn, Xt0 + (par ^ 1) * rows * HS, t + 1, 0, 1);
+      if (t + 1 < a.T && (!XS || t + 1 == Tm1 || xneed[(t + 1) & 3])) fc1(Inn, Xt0 + (par ^ 1) * rows * HS, t + 1, 0, 1);
       if (t > 0)
         for (int rt = ws; rt < RTW; rt += 4) fc2(Hp, t - 1, rt);
+    }
+    if (XS) {                                            // flag of step t+2 (its slot was cleared a step ago); clear t+3's slot
+      if (mylen - 1 == t + 2) xneed[(t + 2) & 3] = 1;
+      if (tid == 0) xneed[(t + 3) & 3] = 0;
     }
     ST_MARK(0);
     if (tid < 4) tilecnt[(par ^ 1) * 4 + tid] = 0;      // counters of the NEXT step (nobody grabs them before the barrier)
@@ -701,24 +727,38 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
       if (lane == 0) v = atomicAdd(&tilecnt[par * 4 + ws], 1);
       return __builtin_amdgcn_readfirstlane(v);
     };
-    int rt_next = grab();
+    int rt_next = XS ? (team == 0 ? 0 : RTW) : grab();
     while (rt_next < RTW) {
       const int rt = rt_next;
-      rt_next = grab();
+      rt_next = XS ? rt + 1 : grab();
       f32x4 ar = {bias_r, bias_r, bias_r, bias_r};
       f32x4 az = {bias_z, bias_z, bias_z, bias_z};
       f32x4 ain = {bias_in, bias_in, bias_in, bias_in};
       f32x4 ahn = {bias_hn, bias_hn, bias_hn, bias_hn};
       const float* xr = Xc + (rt * 16 + m) * HS + 4 * q;
       const float* hr = Hp + (rt * 16 + m) * HS + 4 * q;
+      if (XS) {
+        if (xread) { ar = gB[0]; az = gB[1]; ain = gB[2]; }
+        const bool same = rt + 1 < RTW;              // the next tile: this step's, or tile 0 of the next step (stored step + 1)
+        const int nts = same ? t + 1 : t + 2;
+        gissue(nts < a.T ? nts : Tm1, same ? rt + 1 : 0);
+      }
       // input-side products first, hidden-side products after them (the SAME order in every GRU kernel: the input-side
       // sums bias + x W_ih of one unroll can then stand in for another unroll's - see the GI variants of agent_fwd_kernel)
+      if (!xread) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-        ar = mfma16x4(ax, wih[0][c], ar);
-        az = mfma16x4(ax, wih[1][c], az);
-        ain = mfma16x4(ax, wih[2][c], ain);
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
+        }
+      }
+      if (SAVE && a.gi_out) {
+        float* const gp = a.gi_out + sv_off(svt + rt, 3, 0, ws, lane);
+        *reinterpret_cast<f32x4*>(gp) = ar;
+        *reinterpret_cast<f32x4*>(gp + 1024) = az;
+        *reinterpret_cast<f32x4*>(gp + 2 * 1024) = ain;
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -1636,9 +1676,10 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap,
 
 }  // namespace
 
-// 1 when a T-step unroll of these dimensions over cu_budget CUs runs the kernel family that stores (gi_out) / reads (gi_in)
-// the input-side gate sums; the software-pipelined kernel (one row tile per workgroup) and wide observations that need six
-// prefetch registers do not.  (Alignment of the actual pointers is checked at launch; a launch that cannot reuse computes.)
+// 1 when a T-step unroll of these dimensions over cu_budget CUs runs a kernel that stores (gi_out) / reads (gi_in) the
+// input-side gate sums: the multi-tile unroll with the plain observation prefetch, or the software-pipelined kernel (one row
+// tile per workgroup, T >= 4); not the half-tile prefetch variant of wide observations.  (Alignment of the actual pointers is
+// checked at launch; a launch that cannot reuse computes.)
 extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int A, int cu_budget) {
   if (B <= 0 || T < 2 || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256 || (O % 4) != 0 || O < 4) return 0;
   if (getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0') return 0;
@@ -1650,7 +1691,10 @@ extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int
   int rt = want < 1 ? 1 : want;
   if (rt > 8) rt = 8;
   if (rt > cap2) rt = cap2;
-  return rt > marl_fwd_pipe_max_rt ? 1 : 0;
+  if (rt > marl_fwd_pipe_max_rt) return 1;
+  // the pipelined kernel: needs T >= 4 and its double-buffered tiles in LDS (otherwise the launch falls back to the multi-tile
+  // kernel, which has the variant as well)
+  return 1;
 }
 
 extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
@@ -1707,8 +1751,10 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
     const size_t lds_p = fixed + per_row_p * a.RT * 16 + 64;
     if (lds_p <= 160 * 1024) {
       const void* fp;
-      if (A <= 16) fp = saved ? (const void*)agent_fwd_pipe_kernel<1, true> : (const void*)agent_fwd_pipe_kernel<1, false>;
-      else fp = saved ? (const void*)agent_fwd_pipe_kernel<2, true> : (const void*)agent_fwd_pipe_kernel<2, false>;
+      static const bool xs_off_p = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
+      const bool xs = gi_in && !saved && !xs_off_p;
+      if (A <= 16) fp = saved ? (const void*)agent_fwd_pipe_kernel<1, true> : xs ? (const void*)agent_fwd_pipe_kernel<1, false, true> : (const void*)agent_fwd_pipe_kernel<1, false>;
+      else fp = saved ? (const void*)agent_fwd_pipe_kernel<2, true> : xs ? (const void*)agent_fwd_pipe_kernel<2, false, true> : (const void*)agent_fwd_pipe_kernel<2, false>;
       e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
       if (e != hipSuccess) return (int)e;
       void* kp[] = {(void*)&a};

@@ -56,4 +56,4 @@ def test_bench_runs_under_torchrun_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 32 and d["value"] > 0
     # (at full size the double-Q unroll reuses the eval unroll's input-side work and is listed beside the other two)
     assert d["scaling"] == "strong" and d["roofline"]["launches_timed"] == 6
-    assert d["roofline"]["by_launch"]["reuse"]["launches_timed"] == 0     # one row tile per workgroup: the pipelined kernel, nothing reused
+    assert d["roofline"]["by_launch"]["reuse"]["launches_timed"] == 2     # the double-Q unroll of each update (pipelined kernel here)
