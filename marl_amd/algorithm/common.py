@@ -316,17 +316,18 @@ class PairedUnroll:
         tiles = (rows + 15) // 16
         cap = max(1, min(8, 2048 // (4 * max(obs_dim, 4))))          # row tiles per workgroup the unroll kernel can hold
         ceil = lambda a, b: -(-a // b)
-        plain = self._step_us(ceil(tiles, 128)) + self._step_us(ceil(tiles, 256))
+        # (the continuation reads the input-side work the first unroll stored: ~0.6 of a full unroll's step time)
+        plain = self._step_us(ceil(tiles, 128)) + 0.6 * self._step_us(ceil(tiles, 256))
         best = None
         for cu_a in (128, 144, 160, 176, 192):
             cu_b = 256 - cu_a
             rt_a, rt_b = ceil(tiles, cu_a), ceil(tiles, cu_b)
             if rt_a > cap or rt_b > cap:
                 continue
-            cost = max(2 * self._step_us(rt_a), self._step_us(rt_b))
+            cost = max(1.6 * self._step_us(rt_a), self._step_us(rt_b))
             if best is None or cost < best[0]:
                 best = (cost, cu_a, cu_b)
-        if best is None or best[0] > 0.95 * plain:
+        if best is None or best[0] > 0.9 * plain:
             return None
         return best[1], best[2]
 
