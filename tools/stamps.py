@@ -46,6 +46,13 @@ def main():
     names = SEGS[which]
     if which in ("bwd", "bwd_pipe"):
         v = v[:, 8:]
+    if which == "qmix":          # forward (target mixer) in columns 0-7, loss + backward in 8-15
+        show(v[:, :8], names, "qmix forward", E, args.episode_limit)
+        v = v[:, 8:]
+    show(v, names, which, E, args.episode_limit)
+
+
+def show(v, names, which, E, T):
     print("segment shares per wave of workgroup 0 (%s, %d envs); cycles/step in the last column" % (which, E))
     print("wave " + " ".join("%9s" % n for n in names) + "   total/step")
     for wv in range(16):
@@ -53,7 +60,7 @@ def main():
         tot = row.sum()
         if tot == 0:
             continue
-        print("%4d " % wv + " ".join("%8.1f%%" % (100.0 * x / tot) for x in row) + "   %10.0f" % (tot / args.episode_limit))
+        print("%4d " % wv + " ".join("%8.1f%%" % (100.0 * x / tot) for x in row) + "   %10.0f" % (tot / T))
 
 
 if __name__ == "__main__":
