@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
   const int fr = tid >> 5, fc4 = (tid & 31) * 4;
   const bool ones_lane = BWD && ones && fc4 == (S & ~3);
   const int ones_j = S & 3;
-  const unsigned last_row = (unsigned)(a.rows - 1);
+  const int nrows = (int)a.rows;                         // rows < 2^31 (32-bit row arithmetic in the loop)
+  const unsigned last_row = (unsigned)(nrows - 1);
   const unsigned rpe = (unsigned)a.s.rpe0;
   const int roff = rpe ? (int)a.s.off0 : 0;
   const FastDiv fd = a.s.fd0;
@@ -206,24 +207,24 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
   auto fetch_qg = [&](int tile) {
     pq = 0.f; pg = 0.f;
     if (tid < 16 * N) {
-      const long row = (long)tile * 16 + qr;
-      if (row < a.rows) pq = a.q[row * N + qn];
+      const int row = tile * 16 + qr;
+      if (row < nrows) pq = a.q[(unsigned)(row * N + qn)];
     }
     if (BWD && tid >= 192 && tid < 208) {
-      const long row = (long)tile * 16 + (tid - 192);
+      const int row = tile * 16 + (tid - 192);
       if (LOSS) {
         pl[0] = pl[1] = pl[3] = 0.f; pl[2] = 1.f;        // rows past the batch: padded
-        if (row < a.rows) { pl[0] = a.lr[row]; pl[1] = a.lterm[row]; pl[2] = a.lpadded[row]; pl[3] = a.lq_tgt[row]; }
-      } else if (row < a.rows) pg = a.g[row];
+        if (row < nrows) { pl[0] = a.lr[row]; pl[1] = a.lterm[row]; pl[2] = a.lpadded[row]; pl[3] = a.lq_tgt[row]; }
+      } else if (row < nrows) pg = a.g[row];
     }
   };
   // dq of the previous tile: the waves' partials in fixed order (threads 0..16N-1, after the next barrier)
-  auto flush_dq = [&](long prow0) {
+  auto flush_dq = [&](int prow0) {
     if (tid < 16 * N) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += DQP[w][qn][qr];
-      if (prow0 + qr < a.rows) a.dq[(prow0 + qr) * N + qn] = v;
+      if (prow0 + qr < nrows) a.dq[(unsigned)((prow0 + qr) * N + qn)] = v;
     }
   };
   int tile = blockIdx.x;
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
     stash(0);
   }
   int buf = 0;
-  long prow0 = -1;
+  int prow0 = -1;
   ST_DECL(8);
   // barriers below only order LDS traffic (s_waitcnt lgkmcnt): the prefetch loads of the next tile stay in
   // flight across them - a __syncthreads() would drain vmcnt and expose the HBM latency on every tile
   __syncthreads();                                  // constant rows of Qt2
   for (; tile < tiles; tile += gridDim.x, buf ^= 1) {
-    const long row0 = (long)tile * 16;
+    const int row0 = tile * 16;
     if (tid < 16 * N) Qt2[buf][qn][qr] = pq;
     if (BWD && tid >= 192 && tid < 208) {
       if (LOSS) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tot += QT[w][tid];
-        if (row0 + tid < a.rows) a.q_tot[row0 + tid] = tot + bb2;
+        if (row0 + tid < nrows) a.q_tot[row0 + tid] = tot + bb2;
       }
       ST_MARK(5);
     } else {
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
           acc_ln += mtd * mtd; acc_lm += mask;
         }
         if (a.q_tot && wave == 0 && m == 0) {
-          if (row0 + 16 <= a.rows) *reinterpret_cast<f32x4*>(&a.q_tot[row0 + 4 * q4]) = qt;
+          if (row0 + 16 <= nrows) *reinterpret_cast<f32x4*>(&a.q_tot[row0 + 4 * q4]) = qt;
           else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (row0 + 4 * q4 + i < a.rows) a.q_tot[row0 + 4 * q4 + i] = qt[i];
+            for (int i = 0; i < 4; ++i) if (row0 + 4 * q4 + i < nrows) a.q_tot[row0 + 4 * q4 + i] = qt[i];
           }
         }
       } else gr = *reinterpret_cast<const f32x4*>(&Gs2[buf][4 * q4]);
