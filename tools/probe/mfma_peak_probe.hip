@@ -43,8 +43,8 @@ void run(int wgs_per_cu, int iters) {
   hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
   const double per_wave = (double)iters * 4 * NACC;
   const double flops = per_wave * 2048.0 * 4 * grid;
-  printf("  %d waves/SIMD, %d independent accumulators: %.3f ms  %.1f TFLOP/s  | s_memtime %.2f ticks per MFMA per SIMD, shader clock %.0f MHz\n",
-         wgs_per_cu, NACC, ms, flops / ms / 1e9, (double)h[0] / (per_wave * wgs_per_cu), (double)h[0] / (double)h[1] * 100.0);
+  printf("  %d workgroup(s) of 4 waves per CU, %d independent accumulators: %.3f ms  %.1f TFLOP/s  | wave 0: %.2f s_memtime ticks per MFMA it issued, shader clock %.0f MHz\n",
+         wgs_per_cu, NACC, ms, flops / ms / 1e9, (double)h[0] / per_wave, (double)h[0] / (double)h[1] * 100.0);
   hipFree(out); hipFree(ticks);
 }
 
