@@ -89,6 +89,11 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     rowe[r] = (int)(rho / N) - b0;
     rown[r] = (int)(rho % N);
   }
+  // env step: lane -> (env, agent); the N rows of an environment sit in ONE wave (64 / N environments per wave)
+  const int es_epw = 64 / N, es_er = lane / N;
+  const int es_n = lane - es_er * N, es_l0 = es_er * N;
+  const int es_el = wave * es_epw + es_er;
+  const bool es_has = es_er < es_epw && es_el < nenv_wg && b0 + es_el < a.E;
   const int lmin = T / 2 > 1 ? T / 2 : 1;
   for (int e = tid; e < nenv_wg; e += RNT) {
     int b = b0 + e; if (b > a.E - 1) b = a.E - 1;
@@ -433,19 +438,24 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
       uex[r] = u01(hkey(a.rseed, ST_EXPLORE, env, tg + 1u, nn_));
       uex[rows + r] = u01(hkey(a.rseed, ST_PICK, env, tg + 1u, nn_));
     }
-    if (tid < nenv_wg && b0 + tid < a.E) {
-      const int el = tid, L = elen[el];
+    // one lane per (env, agent) hashes its reward term; the env's lane sums them in agent order (the serial form -
+    // one thread per env looping over the agents' hashes - was 4-12 % of a lock-step on the critical path)
+    if (es_has) {
+      const int L = elen[es_el];
       const bool live = t < L;
-      const unsigned env = (unsigned)(a.env0 + b0 + el);
-      float acc = 0.f;
+      float term = 0.f;
       if (live) {
-        const unsigned pre = hprefix(a.seed, ST_REWARD, env, tg);
-        for (int n = 0; n < N; ++n) acc = acc + (u01(hfin(pre, (unsigned)(n * A + act[el * N + n]))) - 0.5f);
+        const unsigned pre = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
+        term = u01(hfin(pre, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
       }
-      const long o = (long)(b0 + el) * T + t;
-      a.r[o] = live ? acc * (1.0f / (float)N) : 0.f;
-      a.term[o] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
-      a.padded[o] = live ? 0.f : 1.f;
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc = acc + __shfl(term, es_l0 + n, 64);
+      if (es_n == 0) {
+        const long o = (long)(b0 + es_el) * T + t;
+        a.r[o] = live ? acc * (1.0f / (float)N) : 0.f;
+        a.term[o] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
+        a.padded[o] = live ? 0.f : 1.f;
+      }
     }
     float* tmp = Hp; Hp = Hn; Hn = tmp;
     tmp = AvC; AvC = AvN; AvN = tmp;
