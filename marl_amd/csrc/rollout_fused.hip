@@ -92,7 +92,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   // env step: lane -> (env, agent); the N rows of an environment sit in ONE wave (64 / N environments per wave)
   const int es_epw = 64 / N, es_er = lane / N;
   const int es_n = lane - es_er * N, es_l0 = es_er * N;
-  const int es_el = wave * es_epw + es_er;
+  const int es_el = ((wave + 4) & 7) * es_epw + es_er;     // team 1's waves first: team 0 goes straight on to fc1 of the next step
   const bool es_has = es_er < es_epw && es_el < nenv_wg && b0 + es_el < a.E;
   const int lmin = T / 2 > 1 ? T / 2 : 1;
   for (int e = tid; e < nenv_wg; e += RNT) {
@@ -279,15 +279,27 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
       const float* in0 = In + (rt * 16 + m) * KS + 4 * q;
       const float* in1 = in0 + 32 * KS;
       const float* wf = W1s + (ws * a.KC * 64 + lane) * 4;
-      for (int c = 0; c < a.KC; ++c) {
-        f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
-        acc0 = mfma16x4(a0, bv, acc0);
-        if (two) {
-          f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
-          acc1 = mfma16x4(a1, bv, acc1);
+      // the k-chunk loop has a runtime trip count: two named operand sets, the loads of chunk c+1 issued before the
+      // multiplies of chunk c (as written before - load, wait, four dependent MFMAs - every chunk paid an LDS round trip)
+#define FC1_LD(B_, A0_, A1_, c_)                                                  \
+      B_ = *reinterpret_cast<const f32x4*>(wf + (c_) * 256);                      \
+      A0_ = *reinterpret_cast<const f32x4*>(in0 + 16 * (c_));                     \
+      if (two) A1_ = *reinterpret_cast<const f32x4*>(in1 + 16 * (c_));
+      f32x4 bA, aA, a1A = acc0, bB, aB, a1B = acc0;
+      FC1_LD(bA, aA, a1A, 0)
+      for (int c = 0; c < a.KC; c += 2) {
+        const bool odd = c + 1 < a.KC;
+        const int cB = odd ? c + 1 : c, cA = c + 2 < a.KC ? c + 2 : c;
+        FC1_LD(bB, aB, a1B, cB)
+        acc0 = mfma16x4(aA, bA, acc0);
+        if (two) acc1 = mfma16x4(a1A, bA, acc1);
+        FC1_LD(bA, aA, a1A, cA)
+        if (odd) {
+          acc0 = mfma16x4(aB, bB, acc0);
+          if (two) acc1 = mfma16x4(a1B, bB, acc1);
         }
       }
+#undef FC1_LD
       const int r0 = rt * 16 + 4 * q;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -449,7 +461,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
         term = u01(hfin(pre, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
       }
       float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc = acc + __shfl(term, es_l0 + n, 64);
+      for (int n0 = 0; n0 < N; n0 += 4) {          // four shuffles in flight; the sum stays in agent order
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __shfl(term, (es_l0 + n0 + k) & 63, 64);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = n0 + k < N ? acc + v[k] : acc;
+      }
       if (es_n == 0) {
         const long o = (long)(b0 + es_el) * T + t;
         a.r[o] = live ? acc * (1.0f / (float)N) : 0.f;
