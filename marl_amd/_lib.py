@@ -119,7 +119,7 @@ SIGNATURES = {
     "marl_synth_step": (I, [U, I, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "marl_synth_fused_step": (I, [U, U, I, I, I, F, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, I, P]),
     "marl_synth_rollout_supported": (I, [I, I, I]),
-    "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "marl_hip_version": (C.c_char_p, []),
 }
 

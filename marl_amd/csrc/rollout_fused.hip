@@ -37,6 +37,7 @@ __device__ __forceinline__ float group_max16(float v) {
 struct RollArgs {
   const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;
   const float* eps;       // [T] epsilon of each lock-step (device)
+  float* stats;           // [3][E] or null: per episode  sum_t r (fp32, in step order) | won | length  (the host's rollout statistics)
   float *obs, *state, *avail;   // (E,T+1,N,O) (E,T+1,SL >= S) (E,T+1,N,A)
   long SL;                // row stride of the state storage (a multiple of 4 gives 16-byte state rows for any S)
   int* u;                 // (E,T,N)
@@ -102,7 +103,9 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     if (a.fixed_len) L = T;
     elen[e] = L;
     a.length[b] = L;
-    a.won[b] = (int)(hkey(a.seed, ST_WON, env, (unsigned)a.episode, 0u) & 1u);
+    const int won_ = (int)(hkey(a.seed, ST_WON, env, (unsigned)a.episode, 0u) & 1u);
+    a.won[b] = won_;
+    if (a.stats && b0 + e < a.E) { a.stats[a.E + b] = (float)won_; a.stats[2L * a.E + b] = (float)L; }
   }
   for (int e = tid; e < rows * H; e += RNT) Ha[(e / H) * HS + (e % H)] = 0.f;     // init_hidden: zeros
   __syncthreads();
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   float* AvC = Av0;
   float* AvN = Av1;
   ST_DECL(10);
+  float ep_r = 0.f;                                // episode reward of this lane's environment (lanes es_n == 0)
   float eps_next = a.eps[0];
   for (int t = 0; t < T; ++t) {
     const float eps = eps_next;                    // scalar load issued a step ahead
@@ -470,7 +474,9 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
       }
       if (es_n == 0) {
         const long o = (long)(b0 + es_el) * T + t;
-        a.r[o] = live ? acc * (1.0f / (float)N) : 0.f;
+        const float rew = live ? acc * (1.0f / (float)N) : 0.f;
+        ep_r = ep_r + rew;
+        a.r[o] = rew;
         a.term[o] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
         a.padded[o] = live ? 0.f : 1.f;
       }
@@ -481,6 +487,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     // no barrier: `act` is next written after three more barriers; In/Xt/H hazards as in agent_fwd_kernel
   }
   ST_DUMP(10);
+  if (a.stats && es_has && es_n == 0) a.stats[b0 + es_el] = ep_r;
   if (a.h_out) {
     WG_BARRIER();
     for (int e = tid; e < rows * H; e += RNT) {
@@ -514,15 +521,15 @@ extern "C" int marl_synth_rollout_supported(int N, int O, int A) {
 extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
                                   int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                                   float* r, float* term, float* padded, int* length, int* won, float* h_out,
-                                  int E, int T, int N, int O, int S, int A, int last_action, int reuse_network,
-                                  void* stream) {
+                                  float* stats, int E, int T, int N, int O, int S, int A, int last_action,
+                                  int reuse_network, void* stream) {
   if (E <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1 || state_ld < S) return (int)hipErrorInvalidValue;
   RollArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
   a.eps = eps; a.obs = obs; a.state = state; a.SL = state_ld; a.avail = avail; a.u = u; a.r = r; a.term = term; a.padded = padded;
-  a.length = length; a.won = won; a.h_out = h_out;
+  a.length = length; a.won = won; a.h_out = h_out; a.stats = stats;
   a.seed = seed; a.rseed = rseed; a.env0 = env0; a.episode = episode; a.fixed_len = fixed_len;
   a.E = E; a.T = T; a.N = N; a.O = O; a.S = S; a.A = A;
   a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;

@@ -87,8 +87,12 @@ class RolloutStats:
     """Per-episode reward / win flag / length of one rollout, copied to pinned host memory in stream order; the
     accessors wait for that copy only (finish_episodes(lazy=True))."""
 
+    _pool = {}        # shape -> free pinned buffers (a fresh pin_memory() per rollout is a host allocation call)
+
     def __init__(self, stats_dev):
-        self.buf = torch.empty(stats_dev.shape, dtype=stats_dev.dtype).pin_memory()
+        self._key = (tuple(stats_dev.shape), stats_dev.dtype)
+        free = RolloutStats._pool.setdefault(self._key, [])
+        self.buf = free.pop() if free else torch.empty(stats_dev.shape, dtype=stats_dev.dtype).pin_memory()
         self.buf.copy_(stats_dev, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
@@ -96,6 +100,12 @@ class RolloutStats:
     def _host(self):
         self.event.synchronize()
         return self.buf
+
+    def __del__(self):            # the buffer goes back to the pool with its owner (nobody reads it any more)
+        try:
+            RolloutStats._pool[self._key].append(self.buf)
+        except Exception:
+            pass
 
     def rewards(self):
         return self._host()[0].tolist()
@@ -244,7 +254,11 @@ class RolloutWorker:
         if evaluate and self.args.replay_dir != '':
             self.env.save_replay()
             self.env.close()
-        stats = torch.stack([rec.r.sum(1), rec.won.float(), rec.length.float()], 0)
+        stats = getattr(rec, "kernel_stats", None)         # written by the whole-rollout kernel (one launch, no reduction pass)
+        if stats is not None:
+            rec.kernel_stats = None
+        else:
+            stats = torch.stack([rec.r.sum(1), rec.won.float(), rec.length.float()], 0)
         if lazy:
             return EpisodeBatch(rec), RolloutStats(stats)
         stats = stats.cpu()

@@ -30,6 +30,11 @@ def test_batched_rollout_matches_oracle(eps, evaluate):
     env = SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=5, env0=2)
     w = RolloutWorker(env, mac, args)
     ep, rew, wins, steps = w.generate_episodes(E, evaluate=evaluate)
+    # the whole-rollout kernel wrote the per-episode statistics itself (reward sums | won | length; compared with the
+    # oracle's below) - and they agree with a reduction of the record it wrote
+    assert getattr(env, "_stats_ring", None) and ep.record.kernel_stats is None
+    np.testing.assert_allclose(rew, ep.record.r.sum(1).cpu().numpy(), atol=1e-5)
+    assert steps == int(ep.record.length.sum().item()) and list(wins) == [bool(x) for x in ep.record.won.cpu().tolist()]
     # three device paths, one record: whole-rollout persistent kernel (default), one fused env kernel per
     # lock-step, and the separate select / step / observe kernels
     for mode in ("fused_step", "unfused"):
