@@ -358,15 +358,16 @@ int marl_synth_fused_step(unsigned seed, unsigned rseed, int env0, int episode, 
 
 /* The WHOLE rollout of the synthetic env in one persistent launch (rollout_fused.hip): agent step,
  * epsilon-greedy choice, env step and next observation for all T lock-steps; weights and hidden state
- * stay on chip.  eps[T] = epsilon per lock-step.  Produces the same (T+1)-slot record as the
+ * stay on chip.  eps[T] = epsilon per lock-step; eps == NULL: eps(0) = eps0 and the reference's per-step anneal
+ * eps(t+1) = eps(t) > eps_min ? eps(t) - eps_anneal : eps(t) (rollout.py:100-101) evaluated in the kernel, in fp64.  Produces the same (T+1)-slot record as the
  * launch-per-step path.  stats (optional, [3][E] floats): per episode  sum_t r | won | length - what
  * RolloutWorker.generate_episodes returns besides the batch (rollout.py:135-140), without extra launches.  Needs whole environments per workgroup: marl_synth_rollout_supported(). */
 int marl_synth_rollout_supported(int N, int O, int A);
 int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
                        int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                        float* r, float* term, float* padded, int* length, int* won, float* h_out,
-                       float* stats, int E, int T, int N, int O, int S, int A, int last_action, int reuse_network,
-                       void* stream);
+                       float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N, int O, int S,
+                       int A, int last_action, int reuse_network, void* stream);
 
 const char* marl_hip_version(void);
 

@@ -58,7 +58,7 @@ class MarlAgentWeights(C.Structure):
                 ("H", C.c_int)]
 
 
-P, I, L, F, U, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size_t
+P, I, L, F, U, SZ, D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size_t, C.c_double
 SRC, GRP, AW = C.POINTER(MarlSrc), C.POINTER(MarlGroup), C.POINTER(MarlAgentWeights)
 AG = C.POINTER(MarlAgentGrads)
 QW = C.POINTER(MarlQmixWeights)
@@ -119,7 +119,7 @@ SIGNATURES = {
     "marl_synth_step": (I, [U, I, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "marl_synth_fused_step": (I, [U, U, I, I, I, F, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, I, P]),
     "marl_synth_rollout_supported": (I, [I, I, I]),
-    "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, D, D, D, I, I, I, I, I, I, I, I, P]),
     "marl_hip_version": (C.c_char_p, []),
 }
 

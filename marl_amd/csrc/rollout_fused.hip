@@ -36,7 +36,9 @@ __device__ __forceinline__ float group_max16(float v) {
 
 struct RollArgs {
   const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;
-  const float* eps;       // [T] epsilon of each lock-step (device)
+  const float* eps;       // [T] epsilon of each lock-step (device), or null: the schedule below
+  double eps0, eps_anneal, eps_min;   // eps(0) = eps0, eps(t+1) = eps(t) > eps_min ? eps(t) - eps_anneal : eps(t), evaluated in
+                          // fp64 like the host loop of rollout.py:100-101 and rounded to fp32 per step
   float* stats;           // [3][E] or null: per episode  sum_t r (fp32, in step order) | won | length  (the host's rollout statistics)
   float *obs, *state, *avail;   // (E,T+1,N,O) (E,T+1,SL >= S) (E,T+1,N,A)
   long SL;                // row stride of the state storage (a multiple of 4 gives 16-byte state rows for any S)
@@ -272,10 +274,12 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   float* AvN = Av1;
   ST_DECL(10);
   float ep_r = 0.f;                                // episode reward of this lane's environment (lanes es_n == 0)
-  float eps_next = a.eps[0];
+  float eps_next = a.eps ? a.eps[0] : (float)a.eps0;
+  double eps_d = a.eps0;
   for (int t = 0; t < T; ++t) {
     const float eps = eps_next;                    // scalar load issued a step ahead
-    if (t + 1 < T) eps_next = a.eps[t + 1];
+    if (a.eps) { if (t + 1 < T) eps_next = a.eps[t + 1]; }
+    else { eps_d = eps_d > a.eps_min ? eps_d - a.eps_anneal : eps_d; eps_next = (float)eps_d; }
     // ---------------- phase 1: x = relu(fc1(in))
     for (int rt = team; rt < a.RT; rt += 4) {
       const bool two = rt + 2 < a.RT;
@@ -521,14 +525,14 @@ extern "C" int marl_synth_rollout_supported(int N, int O, int A) {
 extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
                                   int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                                   float* r, float* term, float* padded, int* length, int* won, float* h_out,
-                                  float* stats, int E, int T, int N, int O, int S, int A, int last_action,
-                                  int reuse_network, void* stream) {
+                                  float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N,
+                                  int O, int S, int A, int last_action, int reuse_network, void* stream) {
   if (E <= 0 || T <= 0) return 0;
   if (w->H != H || A > 32 || A < 1 || state_ld < S) return (int)hipErrorInvalidValue;
   RollArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
-  a.eps = eps; a.obs = obs; a.state = state; a.SL = state_ld; a.avail = avail; a.u = u; a.r = r; a.term = term; a.padded = padded;
+  a.eps = eps; a.eps0 = eps0; a.eps_anneal = eps_anneal; a.eps_min = eps_min; a.obs = obs; a.state = state; a.SL = state_ld; a.avail = avail; a.u = u; a.r = r; a.term = term; a.padded = padded;
   a.length = length; a.won = won; a.h_out = h_out; a.stats = stats;
   a.seed = seed; a.rseed = rseed; a.env0 = env0; a.episode = episode; a.fixed_len = fixed_len;
   a.E = E; a.T = T; a.N = N; a.O = O; a.S = S; a.A = A;

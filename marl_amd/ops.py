@@ -379,12 +379,16 @@ def synth_rollout_supported(N, O, A):
 
 
 def synth_rollout(w, seed, rseed, env0, episode, fixed_len, eps, rec, h_out, E, T, N, O, S, A, last_action, reuse_network,
-                  stats=None):
+                  stats=None, eps_sched=None):
+    """eps: device (T,) epsilon per lock-step, or None with eps_sched = (eps0, anneal, eps_min): the per-step anneal of
+    rollout.py:100-101 is then evaluated inside the kernel (fp64, like the host loop) and no schedule crosses PCIe."""
+    e0, ea, em = (0.0, 0.0, 0.0) if eps_sched is None else eps_sched
+    assert (eps is None) != (eps_sched is None)
     check(_lib.load().marl_synth_rollout(C.byref(w), int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode,
-                                         1 if fixed_len else 0, _p(_f32(eps)), _p(_f32(rec.obs)), _p(_f32(rec.state)),
+                                         1 if fixed_len else 0, _p(_f32(eps)) if eps is not None else None, _p(_f32(rec.obs)), _p(_f32(rec.state)),
                                          rec.state.stride(-2), _p(_f32(rec.avail)), _p(_i32(rec.u)), _p(_f32(rec.r)), _p(_f32(rec.term)),
                                          _p(_f32(rec.padded)), _p(_i32(rec.length)), _p(_i32(rec.won)), _p(h_out),
-                                         _p(_f32(stats)) if stats is not None else None, E, T, N, O, S, A, 1 if last_action else 0, 1 if reuse_network else 0, _stream()),
+                                         _p(_f32(stats)) if stats is not None else None, float(e0), float(ea), float(em), E, T, N, O, S, A, 1 if last_action else 0, 1 if reuse_network else 0, _stream()),
           "marl_synth_rollout")
 
 

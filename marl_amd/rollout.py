@@ -216,15 +216,16 @@ class RolloutWorker:
         epsilon = 0 if evaluate else self.epsilon
         if a.epsilon_anneal_scale == 'episode':
             epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
-        sched = np.empty(T, dtype=np.float32)
-        for t in range(T):
-            sched[t] = epsilon
-            if a.epsilon_anneal_scale == 'step':
+        # the kernel evaluates the same fp64 recurrence per lock-step (no schedule vector crosses PCIe); the host runs it
+        # only to know the epsilon the next rollout starts from
+        step_scale = a.epsilon_anneal_scale == 'step'
+        sched = (float(epsilon), float(self.anneal_epsilon) if step_scale else 0.0, float(self.min_epsilon))
+        if step_scale:
+            for t in range(T):
                 epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
-        eps_dev = h2d_async(sched, dev, torch.float32)       # pinned staging: the host does not wait for the queue
         mac.init_hidden(E)
-        env.whole_rollout(mac.agent.weights(), eps_dev, self.rseed, rec, a.last_action, a.reuse_network,
-                          h_out=mac.hidden_states.view(E * N, H))
+        env.whole_rollout(mac.agent.weights(), None, self.rseed, rec, a.last_action, a.reuse_network,
+                          h_out=mac.hidden_states.view(E * N, H), eps_sched=sched)
         if not evaluate:
             self.epsilon = epsilon
         return rec, evaluate
