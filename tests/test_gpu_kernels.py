@@ -577,7 +577,8 @@ def test_qmix_mix(dev):
     close(dq, q.grad, 1e-4)
 
 
-@pytest.mark.parametrize("R,N,S", [(333, 5, 120), (16, 5, 120), (4099, 3, 48), (50, 2, 4), (1000, 5, 126)])
+@pytest.mark.parametrize("R,N,S", [(333, 5, 120), (16, 5, 120), (4099, 3, 48), (50, 2, 4), (1000, 5, 126), (257, 4, 128), (100, 1, 128),
+                                   (8200, 5, 124)])
 def test_qmix_fused(dev, R, N, S):
     """fused hypernet + mixing kernels (forward, dq, hypernet weight gradients) vs torch-CPU autograd of
     the restated QMixMixer.forward (reference network/mixer.py:57-80); S not a multiple of 4 falls back."""
