@@ -19,7 +19,7 @@ for P in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/${TAG}_pmc/pass$i -o p -- python3 tools/prof_learner.py --updates 3 --rollouts 2 > $OUT/${TAG}_pmc.pass$i.log 2>&1 || true
 done
 make -C marl_amd/csrc stamps > /dev/null 2>&1
-( for k in rollout fwd bwd wgrad; do python3 tools/stamps.py $k 4096 2>/dev/null | grep -v amdgpu.ids; echo; done
+( for k in rollout fwd bwd wgrad qmix; do python3 tools/stamps.py $k 4096 2>/dev/null | grep -v amdgpu.ids; echo; done
   for k in fwd_pipe bwd_pipe rollout; do python3 tools/stamps.py $k 512 2>/dev/null | grep -v amdgpu.ids; echo; done ) > $OUT/${TAG}_stamps.txt
 python3 bench.py > $OUT/${TAG}_bench_full.log 2>&1
 grep '^{"metric"' $OUT/${TAG}_bench_full.log | tail -1 > $OUT/${TAG}_bench_full_line.json
