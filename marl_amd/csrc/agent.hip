@@ -114,7 +114,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   int* rown = rowidx + rows;                                 // [rows]: n
   int* rowlen = rown + rows;                                 // [rows]: episode length (INT_MAX if none)
   int* rowrho = rowlen + rows;                               // [rows]: b*N + n
-  int* xneed = rowrho + rows;                                // [2] (XS): some row of this workgroup has ep_len - 1 == t, by step parity
+  int* xmask = rowrho + rows;                                // [T] (XS): step t is computed in full - the last step, or some row of this workgroup has ep_len - 1 == t
 
   // Rows past the end of the batch (last workgroup only) are CLAMPED to the last valid row: they load
   // the same inputs, compute the same values and store them to the same addresses, so no per-lane
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     gB[2] = *reinterpret_cast<const f32x4*>(gp + 2 * 1024);
   };
   const int mylen = tid < rows ? rowlen[tid] : 0x7fffffff;
-  if (XS && tid < 2) xneed[tid] = 0;
+  if (XS) for (int e = tid; e < a.T; e += FNT) xmask[e] = e == a.T - 1 ? 1 : 0;      // (before the barrier of the constant columns)
   auto issue = [&](int t, int h = 0) {   // start the loads of step t's observations (vector path; h: column half)
     const long toff = (long)(t + a.obs_t0) * a.N * O + (h ? hoff : 0);
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   else load_generic(0);
   if (XS) {
     if (team < RTW) gissue(1, team);
-    if (mylen - 1 == 0) xneed[0] = 1;             // (cleared above, before the barrier of the constant columns)
+    if (mylen >= 1 && mylen - 1 < a.T) xmask[mylen - 1] = 1;      // visible after the barrier below
   }
 
   // ---- stage weights: fc1 slice -> LDS fragments (team 0 writes, both teams read); GRU / fc2 -> registers
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     const unsigned trow = (unsigned)t * (unsigned)a.N;
     const long svt = SAVE ? (long)t * NTILES + (long)blockIdx.x * a.RT : 0;      // (step, first row tile of this workgroup)
     // ---------------- phase 1: x = relu(fc1(in))  (two of the team's row tiles in flight)
-    const bool xread = XS && t < a.T - 1 && xneed[t & 1] == 0;      // this step's input-side work is read, not computed
+    const bool xread = XS && xmask[t] == 0;       // this step's input-side work is read, not computed
     for (int rt = xread ? RTW : team; rt < RTW; rt += 4) {
       const bool two = rt + 2 < RTW;
       f32x4 acc0 = {bias1, bias1, bias1, bias1}, acc1 = acc0;
@@ -318,13 +318,17 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       }
     }
     ST_MARK(0);
-    WG_BARRIER();
+    // XS, step read rather than computed: nothing touched the input tile or Xt, so there is nothing for this barrier to
+    // order (one barrier per step: the hidden tiles are double-buffered, see the note at the end of the loop)
+    if (!xread) WG_BARRIER();
     ST_MARK(1);
     // the input tile has been consumed: refill it for step t+1, start the loads of step t+2
-    if (XS) {                                     // flag of the next step; this step's flag was read before the barrier
-      if (mylen - 1 == t + 1) xneed[(t + 1) & 1] = 1;
-      if (tid == 0) xneed[t & 1] = 0;
-    }
+    if (XS) {
+      // only the steps computed in full read the input tile: its refill and the observation loads run for those alone
+      // (conditional loads cost a register copy + wait where they are issued - here that is the rare path)
+      if (t + 1 < a.T && xmask[t + 1]) commit();
+      if (t + 2 < a.T && xmask[t + 2]) issue(t + 2);
+    } else
     if (HALF) {
       commit(0);                                  // left half of step t+1's input; its right half travels during the gates
       issue(t + 1 < a.T ? t + 1 : a.T - 1, 1);
@@ -1716,7 +1720,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.R = (long)B * N;
   const int KS = a.KC * 16 + 4;
   const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;   // + row tables: 2 long + 4 int
-  const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16;   // fc1 fragments + the two step flags of the x-reusing variant
+  const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16 + (((size_t)T * 4 + 15) & ~(size_t)15);   // fc1 fragments + step flags of the x-reusing variants (pipelined: 4; else one per step)
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
   bool half = false;
