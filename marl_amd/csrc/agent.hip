@@ -481,8 +481,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 // with the input tile and the fc1 output double-buffered in LDS (which is why it needs RT <= 3-4).
 // Results are bit-identical to agent_fwd_kernel (same MFMA sequences per output element).
 // XS (as in agent_fwd_kernel): the input-side work of steps 0..T-2 is read from what an earlier unroll stored (gi_in); fc1 runs
-// only for the last step and for the steps flagged through xneed (a row with ep_len - 1 == t), known two steps ahead because
-// team 1 computes fc1 a step early.  Team 0 alone walks the row tiles then (static order, so the sums can be prefetched).
+// only for the last step and for the steps flagged in xmask (a row with ep_len - 1 == t; the table is built at the start - team 1
+// computes fc1 a step early); observation loads and input-tile refills run for those steps alone.  Team 0 alone walks the row tiles then (static order, so the sums can be prefetched).
 template <int AC, bool SAVE, bool XS = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   static_assert(!XS || !SAVE, "XS: no saving");
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   int* rowlen = rown + rows;
   int* rowrho = rowlen + rows;
   int* tilecnt = rowrho + rows;                       // [2][4]: next GRU tile of each hidden-unit slice, by step parity
-  int* xneed = tilecnt + 8;                           // [4] (XS): some row of this workgroup has ep_len - 1 == t, by t & 3
+  int* xmask = tilecnt + 8;                           // [T] (XS): step t is computed in full - the last step, or some row of this workgroup has ep_len - 1 == t
 
   const long row0 = (long)blockIdx.x * rows;
   for (int r = tid; r < rows; r += FNT) {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     rowrho[r] = (int)rho;
   }
   if (tid < 8) tilecnt[tid] = 0;
-  if (XS && tid >= 8 && tid < 12) xneed[tid - 8] = 0;
+  if (XS) for (int e = tid; e < a.T; e += FNT) xmask[e] = e == a.T - 1 ? 1 : 0;
   __syncthreads();
   for (int e = tid; e < rows * H; e += FNT) {
     int r = e / H, k = e % H;
@@ -592,8 +592,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   const int mylen = tid < rows ? rowlen[tid] : 0x7fffffff;
   if (XS) {
     if (team == 0) gissue(Tm1 < 1 ? Tm1 : 1, 0);
-    if (mylen - 1 == 0) xneed[0] = 1;
-    if (mylen - 1 == 1) xneed[1] = 1;
+    if (mylen >= 1 && mylen - 1 < a.T) xmask[mylen - 1] = 1;      // published by the barrier below (staged weights)
   }
 
   f32x4 wih[3][4], whh[3][4], w2[AC][4];
@@ -700,7 +699,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
 
   // prologue: x(0) by both teams (tiles alternate between them); XS: only when step 0 is computed in full
   // (the barrier above - staged weights - also published the step flags)
-  if (!XS || Tm1 == 0 || xneed[0]) fc1(In0, Xt0, 0, team, 2);
+  if (!XS || xmask[0]) fc1(In0, Xt0, 0, team, 2);
   WG_BARRIER();
 
   float* Hp = Ha;
@@ -712,15 +711,11 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     const long svt = SAVE ? (long)t * NTILES + (long)blockIdx.x * a.RT : 0;      // (step, first row tile of this workgroup)
     float* Xc = Xt0 + par * rows * HS;                 // x(t), written in the previous step
     float* Inn = In0 + (par ^ 1) * rows * KS;           // input of step t+1 (committed during step t-1)
-    const bool xread = XS && t < Tm1 && xneed[t & 3] == 0;         // this step's input-side work is read, not computed
+    const bool xread = XS && xmask[t] == 0;            // this step's input-side work is read, not computed
     if (team == 1) {
-      if (t + 1 < a.T && (!XS || t + 1 == Tm1 || xneed[(t + 1) & 3])) fc1(Inn, Xt0 + (par ^ 1) * rows * HS, t + 1, 0, 1);
+      if (t + 1 < a.T && (!XS || xmask[t + 1])) fc1(Inn, Xt0 + (par ^ 1) * rows * HS, t + 1, 0, 1);
       if (t > 0)
         for (int rt = ws; rt < RTW; rt += 4) fc2(Hp, t - 1, rt);
-    }
-    if (XS) {                                            // flag of step t+2 (its slot was cleared a step ago); clear t+3's slot
-      if (mylen - 1 == t + 2) xneed[(t + 2) & 3] = 1;
-      if (tid == 0) xneed[(t + 3) & 3] = 0;
     }
     ST_MARK(0);
     if (tid < 4) tilecnt[(par ^ 1) * 4 + tid] = 0;      // counters of the NEXT step (nobody grabs them before the barrier)
@@ -805,9 +800,13 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     }
     ST_MARK(1);
     // input tile of step t+2 -> the buffer fc1 finished with in the previous step; start the loads of step t+3
-    if (par) commit(In0 + rows * KS, pu_lds1);
-    else commit(In0, pu_lds0);
-    issue(t + 3 < a.T ? t + 3 : Tm1);
+    // (XS: only the steps computed in full read an input tile - refill and observation loads run for those alone)
+    if (!XS || (t + 2 < a.T && xmask[t + 2])) {
+      if (par) commit(In0 + rows * KS, pu_lds1);
+      else commit(In0, pu_lds0);
+    }
+    if (!XS) issue(t + 3 < a.T ? t + 3 : Tm1);
+    else if (t + 3 < a.T && xmask[t + 3]) issue(t + 3);
     ST_MARK(2);
     WG_BARRIER();
     ST_MARK(3);
