@@ -189,6 +189,18 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NL; ++i)
       *reinterpret_cast<f32x4*>(In + loff[i] + (h ? hoff : 0)) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (XS && n4 > NL * FNT) {
+      // the reuse variant refills the input tile for the few steps it computes in full only, so it is not held to the rows
+      // the prefetch registers cover: the rest of a larger tile (wide observations) is fetched here, synchronously
+      const long toff = (long)(pt + a.obs_t0) * a.N * O;
+      for (int e = NL * FNT + tid; e < n4; e += FNT) {
+        const int r = (int)(((float)e + 0.5f) * invO4);
+        const int k4 = e - r * O4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pt < rowlen[r]) v = *reinterpret_cast<const f32x4*>(a.obs + rowobs[r] + 4 * k4 + toff);
+        *reinterpret_cast<f32x4*>(In + r * KS + 4 * k4) = v;
+      }
+    }
     if (h) return;
     if (a.has_act && tid < rows) {
       const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
@@ -1680,9 +1692,8 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap,
 }  // namespace
 
 // 1 when a T-step unroll of these dimensions over cu_budget CUs runs a kernel that stores (gi_out) / reads (gi_in) the
-// input-side gate sums: the multi-tile unroll with the plain observation prefetch, or the software-pipelined kernel (one row
-// tile per workgroup, T >= 4); not the half-tile prefetch variant of wide observations.  (Alignment of the actual pointers is
-// checked at launch; a launch that cannot reuse computes.)
+// input-side gate sums: the multi-tile unroll or the software-pipelined kernel (one row tile per workgroup, T >= 4).
+// (Alignment of the actual pointers is checked at launch; a launch that cannot reuse computes.)
 extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int A, int cu_budget) {
   if (B <= 0 || T < 2 || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256 || (O % 4) != 0 || O < 4) return 0;
   if (getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0') return 0;
@@ -1690,13 +1701,9 @@ extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int
   const long tiles = ((long)B * N + 15) / 16;
   const int want = (int)((tiles + cu_budget - 1) / cu_budget);
   const int cap2 = (NLDW * FNT) / (16 * (O / 4));
-  if (cap2 < 1 || (cap2 < want && cap2 < 8)) return 0;          // half-tile prefetch variant (or no vector path): no reuse
-  int rt = want < 1 ? 1 : want;
-  if (rt > 8) rt = 8;
-  if (rt > cap2) rt = cap2;
-  if (rt > marl_fwd_pipe_max_rt) return 1;
-  // the pipelined kernel: needs T >= 4 and its double-buffered tiles in LDS (otherwise the launch falls back to the multi-tile
-  // kernel, which has the variant as well)
+  (void)want;
+  if (cap2 < 1) return 0;                                        // no vector path
+  // (wide observations too: the reading launch is not held to the rows its prefetch registers cover, see commit())
   return 1;
 }
 
@@ -1723,7 +1730,9 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
   bool half = false;
-  if (a.vload) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW * 512 registers
+  static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
+  const bool xs_req = a.vload && gi_in && !saved && T >= 2 && !xs_off;      // the launch reads stored input-side sums
+  if (a.vload && !xs_req) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW * 512 registers
     int cap2 = (NLDW * FNT) / (16 * (O / 4));
     const long tiles = (a.R + 15) / 16;
     const int cus = T > 1 ? cu_budget : 256;
@@ -1749,7 +1758,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
   hipError_t e;
   // few row tiles per workgroup and a long unroll: the software-pipelined variant (one barrier per step)
-  if (a.vload && a.RT <= marl_fwd_pipe_max_rt && T >= 4) {
+  if (a.vload && a.RT <= marl_fwd_pipe_max_rt && T >= 4 && (long)a.RT * 16 * (O / 4) <= (long)NLDW * FNT) {
     const size_t per_row_p = (size_t)(2 * KS + 4 * HS) * 4 + 32;
     const size_t lds_p = fixed + per_row_p * a.RT * 16 + 64;
     if (lds_p <= 160 * 1024) {
@@ -1770,8 +1779,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const void* fn;
 #define FWD_PICK(AC_, SV_, VL_) (const void*)agent_fwd_kernel<AC_, SV_, VL_>
   const bool sv = saved != nullptr, vl = a.vload != 0;
-  static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
-  if (vl && !half && !sv && gi_in && T >= 2 && !xs_off) {
+  if (xs_req) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, true>;
   } else if (vl && half) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, false, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, false, true>;

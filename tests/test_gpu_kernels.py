@@ -394,13 +394,16 @@ def test_agent_unroll_shifted_storage(dev):
 
 
 @pytest.mark.parametrize("shape,B,T,cus", [("2s3z", 37, 5, 4), ("2s3z", 700, 6, 48), ("3s5z", 40, 4, 8), ("2s3z", 9, 2, 2),
-                                            ("2s3z", 37, 5, 16), ("2s3z", 300, 7, 256), ("3s5z", 21, 4, 64)])
+                                            ("2s3z", 37, 5, 16), ("2s3z", 300, 7, 256), ("3s5z", 21, 4, 64),
+                                            ("MMM2", 60, 4, 16), ("MMM2", 1000, 3, 256), ("MMM2", 30, 5, 128)])
 def test_double_q_unroll_reuses_input_side_work_bitwise(dev, shape, B, T, cus):
     """gi_out / gi_in (include/marl_hip.h): an unroll over steps 1..T of (T+1)-slot storage that READS the input-side gate sums
     an unroll over steps 0..T-1 stored == the same unroll computing everything, bit for bit - with ragged episode lengths
     (steps ep_len - 1 and T - 1 are computed in full), an episode map, a carried hidden state and a partial last row tile.
-    A small CU budget gives several row tiles per workgroup at test sizes (the multi-tile kernel); the last three cases run one
-    tile per workgroup (the software-pipelined kernel)."""
+    A small CU budget gives several row tiles per workgroup at test sizes (the multi-tile kernel); the last three 2s3z / 3s5z
+    cases run one tile per workgroup (the software-pipelined kernel).  MMM2 (176-wide observations, 18 actions): three row
+    tiles per workgroup are more rows than the prefetch registers of the reading launch cover (it fetches the rest when it
+    refills the tile), and the launch it is compared with is the half-tile prefetch kernel."""
     from marl_amd import ops
     args, p_np, _, _, _ = _agent_case(shape, B, T, dev)
     N, O, A = args.n_agents, args.obs_shape, args.n_actions
