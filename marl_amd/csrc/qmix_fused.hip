@@ -559,6 +559,7 @@ extern "C" int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl
                                         void* stream) {
   if (rows <= 0) return 0;
   if (!supported(N, S, Eq) || !q_tot_tgt || !r || !term || !padded || !loss2) return (int)hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(q_tot) & 15) return (int)hipErrorInvalidValue;       // written 16 bytes per lane
   if (ws_bytes < marl_qmix_fused_workspace(rows, N, S)) return (int)hipErrorInvalidValue;
   QmixArgs a;
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
