@@ -35,6 +35,7 @@ d=json.loads(sys.stdin.read()); print('envs_per_gpu=%d : ms_per_step %.3f env-st
 ( [ -x tools/probe/bw_probe ] && timeout 120 tools/probe/bw_probe ) > $OUT/${TAG}_bw_probe.txt 2>&1
 ( [ -x tools/probe/coissue_probe ] && timeout 120 tools/probe/coissue_probe ) > $OUT/${TAG}_coissue_probe.txt 2>&1
 ( [ -x tools/probe/mfma_peak_probe ] && timeout 120 tools/probe/mfma_peak_probe ) > $OUT/${TAG}_mfma_peak_probe.txt 2>&1
+( [ -x tools/probe/bf16x3_probe ] && timeout 120 tools/probe/bf16x3_probe ) > $OUT/${TAG}_bf16x3_probe.txt 2>&1
 # device idle gaps of the default bench step
 bash tools/prof_gaps.sh > $OUT/${TAG}_gaps.txt 2>&1
 cat $OUT/${TAG}_learner_rates.txt $OUT/${TAG}_shard_steps.txt

@@ -94,7 +94,7 @@ for sub, dst in (("_qtran", "_qtran_kernel_stats.csv"), ("_mmm2_fp32", "_mmm2_fp
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, tag + dst))
 for name in ("_bench_mmm2_fp32_line.json", "_bench_mmm2_bf16_line.json", "_learner_rates.txt", "_shard_steps.txt",
-             "_bw_probe.txt", "_coissue_probe.txt", "_mfma_peak_probe.txt", "_gaps.txt"):
+             "_bw_probe.txt", "_coissue_probe.txt", "_mfma_peak_probe.txt", "_bf16x3_probe.txt", "_gaps.txt"):
     src = os.path.join(G, tag + name)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(P, tag + name))
