@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
       for (int c = 0; c < TPW; ++c) acc[c] = mfma16x4(a4, wq[c][kc], acc[c]);
     }
     ST_MARK(2);
+    __builtin_amdgcn_sched_barrier(0);             // the MFMA run first, the epilogue after it (no fine interleaving)
     // ---- a_e = b1_e + sum_n q_n |w1[n,e]| for rows 4q..4q+3: the lane's groups, then the groups of the row
     f32x4 qv[TPW];                                 // q of the lane's agent (1 for b1, 0 for w2 / h / absent agents)
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
         }
       }
       ST_MARK(5);
+      __builtin_amdgcn_sched_barrier(0);
       // ---- dW += d(out)^T [s | 1]
       const float* sd = &Ss[buf][(4 * q4) * SS + m];
 #pragma unroll
