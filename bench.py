@@ -68,6 +68,201 @@ def learner_flops_per_transition(a, alg):
     raise ValueError(alg)
 
 
+class KernelTimers:
+    """HIP-event timing of the C-ABI calls of the hot path inside the timed region, on the stream each one is launched
+    on (events are recorded on torch's CURRENT stream at the call, which is the side stream for the forked launches).
+    Every timed call carries the FLOP it EXECUTES (2 x multiply-adds of the products the launch really computes, tile
+    padding not counted) and its algorithmic HBM bytes; `rocname` is the prefix of the kernel's name in a rocprofv3
+    kernel trace, so the line can be recomputed from profiles/*_kernel_stats.csv."""
+
+    def __init__(self, ops, args, E):
+        self.ops, self.on, self.rec, self._orig = ops, False, {}, {}
+        a = args
+        N, O, S, A, H, Em = a.n_agents, a.obs_shape, a.state_shape, a.n_actions, a.rnn_hidden_dim, a.qmix_hidden_dim
+        I = O + A + N
+        Fa = agent_flops(a)
+        fa_in = 2 * I * H + 6 * H * H                 # fc1 + x W_ih: what a reuse launch loads instead of computing
+
+        def fwd(ar, kw):
+            B, T, N_, A_ = ar[12], ar[13], ar[14], ar[16]
+            if T <= 1:
+                return None
+            rows = B * N_ * T
+            if kw.get("gi_in") is not None:
+                return ("agent_fwd_kernel[reuse: double-Q unroll reading the eval unroll's input-side gate sums]", "agent_fwd",
+                        Fa * rows - fa_in * B * N_ * (T - 1), Fa * rows, 4.0 * rows * (3 * H + A_))
+            if ar[11] is not None:
+                return ("agent_fwd_kernel[save: eval unroll storing 6 activation planes%s]" % (" + gate sums" if kw.get("gi_out") is not None else ""),
+                        "agent_fwd", Fa * rows, Fa * rows, 4.0 * rows * (O + A_ + 6 * H + (3 * H if kw.get("gi_out") is not None else 0)))
+            return ("agent_fwd_kernel[plain: target unroll]", "agent_fwd", Fa * rows, Fa * rows, 4.0 * rows * (O + A_))
+
+        def bwd(ar, kw):
+            B, T, N_, A_ = ar[8], ar[9], ar[10], ar[11]
+            rows = B * T * N_
+            f = (8 * 3 * H * H + 4 * A_ * H) * rows   # dx, dh_prev, dW_ih, dW_hh (2*192*64 each) + dq->dh and dW_2 (2*A*64 each)
+            return ("agent_bwd_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2)", "agent_bwd", f, f, 4.0 * rows * (10 * H + H))
+
+        def wgrad(ar, kw):
+            M, Nn, K = ar[4], ar[5], ar[6]
+            f = 2.0 * M * Nn * (K + 1)
+            return ("linear_wgrad (fc1 gradient: wgrad_tall_kernel at N=64)" if Nn == H and M >= 4096 else "linear_wgrad (generic)",
+                    "wgrad_", f, f, 4.0 * M * (Nn + K))
+
+        def lin(ar, kw):
+            M, Nn, K = ar[4], ar[5], ar[6]
+            f = 2.0 * M * Nn * K
+            return ("linear (generic GEMM)", "linear_kernel", f, f, 4.0 * M * (Nn + K))
+
+        def qmix(mult, label, roc):
+            def m(ar, kw):
+                rows, N_, S_, E_ = ar[-4], ar[-3], ar[-2], ar[-1]
+                f = 2.0 * rows * S_ * (N_ * E_ + 3 * E_) * mult
+                return (label, roc, f, f, 4.0 * rows * (S_ + N_ + 1))
+            return m
+
+        def qmix_kw(mult, label, roc, rows_at):
+            def m(ar, kw):
+                rows, N_, S_, E_ = ar[rows_at:rows_at + 4]
+                f = 2.0 * rows * S_ * (N_ * E_ + 3 * E_) * mult
+                return (label, roc, f, f, 4.0 * rows * (S_ + N_ + 1))
+            return m
+
+        def mlp3(back):
+            def m(ar, kw):
+                if back:
+                    w, x, dY, grads, M, K1, N3, g = ar[:8]
+                else:
+                    w, x, Y, M, K1, N3, g = ar[:7]
+                three = bool(w.w2)
+                h2 = 64 * 64 if three else 0
+                ffw = 2.0 * M * g * (K1 * 64 + h2 + 64 * N3)
+                f = 2.0 * M * g * (2 * K1 * 64 + 3 * h2 + 2 * 64 * N3) if back else ffw
+                return ("mlp3_%s_kernel (fused 64-wide heads, %d heads, K1=%d)" % ("bwd" if back else "fwd", g, K1),
+                        "mlp3_bwd" if back else "mlp3_fwd", f, ffw * (3 if back else 1), 4.0 * M * (K1 + g * N3))
+            return m
+
+        def roll(ar, kw):
+            E_, T_, N_ = ar[9], ar[10], ar[11]
+            f = float(Fa) * E_ * T_ * N_
+            return ("synth_rollout_kernel (whole rollout, T lock-steps)", "synth_rollout", f, f, 4.0 * E_ * (T_ + 1) * (N_ * O + S + N_ * A))
+
+        self.models = {"agent_unroll_fwd": fwd, "agent_unroll_bwd": bwd, "linear_wgrad": wgrad, "linear": lin,
+                       "qmix_fused_fwd": qmix(1, "qmix_fused_kernel forward (target mixer)", "qmix_fused_kernel<false"),
+                       "qmix_fused_bwd": qmix(2, "qmix_fused_kernel backward", "qmix_fused_kernel<true"),
+                       "qmix_fused_loss_bwd": qmix(2, "qmix_fused_kernel forward + TD loss + backward", "qmix_fused_kernel<true"),
+                       "qmix_wide_fwd": qmix_kw(1, "qmix_wide_kernel forward", "qmix_wide_kernel<false", 4),
+                       "qmix_wide_bwd": qmix_kw(2, "qmix_wide backward (recompute + d(out)) + weight-gradient GEMM", "qmix_wide", 6),
+                       "qmix_wide_loss_bwd": qmix_kw(2, "qmix_wide forward + TD loss + backward + weight-gradient GEMM", "qmix_wide", 12),
+                       "mlp3_fwd": mlp3(False), "mlp3_bwd": mlp3(True), "synth_rollout": roll}
+        for name, model in self.models.items():
+            self._wrap(name, model)
+
+    def close(self):
+        """restore the unwrapped entry points"""
+        for name, orig in self._orig.items():
+            setattr(self.ops, name, orig)
+        self._orig = {}
+
+    def _wrap(self, name, model):
+        orig = getattr(self.ops, name)
+        self._orig[name] = orig
+
+        def timed(*a, **k):
+            m = model(a, k) if self.on else None
+            if m is None:
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.rec.setdefault(m[0], {"roc": m[1], "ev": [], "exec": m[2], "alg": m[3], "bytes": m[4], "call": name})["ev"].append((e0, e1))
+            return r
+        setattr(self.ops, name, timed)
+
+    def table(self, pmc=None):
+        """per timed kernel: launches, mean ms (HIP events), executed FLOP per launch, fraction of the fp32 MFMA peak,
+        HBM bytes per launch from the committed PMC passes (when the workload is the one they were taken on)"""
+        rows = []
+        for label, r in self.rec.items():
+            ms = [a.elapsed_time(b) for a, b in r["ev"]]
+            avg = float(np.mean(ms))
+            tf = r["exec"] / (avg * 1e-3) / 1e12
+            e = {"name": label, "rocprof_name": r["roc"], "launches_timed": len(ms), "ms": avg, "total_ms": float(np.sum(ms)),
+                 "executed_flop": r["exec"], "algorithmic_flop": r["alg"], "tflops": tf, "frac": tf / PEAK_F32_TFLOPS,
+                 "algorithmic_bytes": r["bytes"], "hbm_gb": None, "hbm_frac": None}
+            rows.append(e)
+        rows.sort(key=lambda e: -e["total_ms"])
+        return rows
+
+
+# BASELINE.json configs[1..4] at their per-GPU shard sizes (SURVEY 8 config table): (label, alg, shape, envs per GPU, mixer dtype)
+OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp32"),
+                 ("cfg3 QPLEX 2s3z 512 envs (shard of 4096 / 8 GPUs)", "qplex", "2s3z", 512, "fp32"),
+                 ("cfg4 QTRAN-base 3s5z 512 envs (shard of 2048 / 4 GPUs)", "qtran_base", "3s5z", 512, "fp32"),
+                 ("cfg5 QMIX MMM2 1024 envs (shard of 8192 / 8 GPUs), bf16 mixer", "qmix", "MMM2", 1024, "bf16")]
+
+
+def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
+    """One learner-update leg of another BASELINE configuration at its per-GPU shard size (after the contract's timed
+    region; record already in HBM): updates/s, transitions/s, the whole-update fraction of the fp32 MFMA peak (SURVEY 8d
+    FLOP per transition) and the executed-FLOP roofline of the kernel the update spends the most time in."""
+    from marl_amd import ops
+    from marl_amd.controller.share_params import SharedMAC
+    from marl_amd.algorithm.q_learner import QLearner
+    from marl_amd.algorithm.qtran_learner import QTRANLearner
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    args = make_args(alg, shape, 0)
+    args.mixer_dtype = mixer_dtype
+    T = args.episode_limit
+    torch.manual_seed(0)
+    mac = SharedMAC(args)
+    learner = QTRANLearner(mac, args) if alg.startswith("qtran") else QLearner(mac, args)
+    env = SyntheticSMACEnv(envs, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, T, seed=1, fixed_length=True)
+    worker = RolloutWorker(env, mac, args)
+    timers = KernelTimers(ops, args, envs)
+    try:
+        ep = worker.generate_episodes(envs)[0]
+        for i in range(warmup):
+            learner.train(ep, i)
+        torch.cuda.synchronize()
+        timers.on = True
+        t0 = time.perf_counter()
+        for i in range(updates):
+            learner.train(ep, warmup + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / updates
+        timers.on = False
+        r0 = time.perf_counter()
+        steps = worker.generate_episodes(envs)[3]
+        torch.cuda.synchronize()
+        t_roll = time.perf_counter() - r0
+        kern = timers.table()
+    finally:
+        timers.close()
+    fpt = learner_flops_per_transition(args, alg)
+    upd_tf = fpt * envs * T / dt / 1e12
+    out = {"workload": "%s_%s_T%d_envs%d" % (alg, shape, T, envs), "what": label, "mixer_dtype": mixer_dtype,
+           "learner_updates_per_sec": 1.0 / dt, "learner_transitions_per_sec": envs * T / dt,
+           "rollout_env_steps_per_sec": steps / t_roll,
+           "roofline_update": {"bound": "mfma", "flop_per_transition": fpt, "achieved": upd_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": upd_tf / PEAK_F32_TFLOPS},
+           "kernels": [{k: e[k] for k in ("name", "launches_timed", "ms", "executed_flop", "frac")} for e in kern[:5]]}
+    if kern:
+        d = kern[0]
+        out["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": d["tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": d["frac"], "avg_launch_ms": d["ms"], "traffic": None}
+    mx = [e for e in kern if e["rocprof_name"] == "qmix_wide_kernel<false"]
+    if mx and mixer_dtype == "bf16":      # config 5's named roofline: the bf16 hypernet GEMM against the HBM read of the states
+        m = mx[0]
+        gbs = m["algorithmic_bytes"] / (m["ms"] * 1e-3) / 1e9
+        out["roofline_mixer"] = {"bound": "hbm", "kernel": m["name"] + " (bf16 operands)", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": m["ms"], "bytes_per_launch": m["algorithmic_bytes"], "traffic": None}
+    del learner, worker, env, mac, ep
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -78,21 +273,58 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(alg, shape, T, envs, budget_s):
-    """The CPU oracle (port of the reference path, pinned by the golden vectors) on a bounded sample
-    of the same workload, timed on this box's host cores: 2 warm-up + 5 timed train() calls."""
+def cpu_probe(alg, shape, T, envs, threads):
+    """updates/s of the CPU oracle's learner at a given torch thread count (one untimed + two timed updates)"""
     from oracle import seeded, learners, rollout as orl
-    host_cores = os.cpu_count() or 1
-    cores = min(host_cores, 16)     # torch-CPU oversubscribes beyond ~16 threads on these small ops (stated below)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     args = seeded.make_args(shape, alg, episode_limit=T)
     agent = seeded.seeded_state(seeded.agent_param_shapes(args), seed=11)
     mshapes = seeded.mixer_param_shapes(args)
     mixer = seeded.seeded_state(mshapes, seed=12) if mshapes else {}
+    sy = orl.SynthSMAC(args.n_agents, args.obs_shape, args.state_shape, args.n_actions, T, seed=1)
+    sy.length = lambda env, ep: np.full(len(np.atleast_1d(env)), T, dtype=np.int64)
+    ep, _, _, _, _ = orl.batched_rollout(agent, args, sy, envs, 0.5, rseed=0)
     st = learners.LearnerState(args, agent, mixer)
+    learners.train(st, ep, 0)
+    t0 = time.time()
+    for i in range(2):
+        learners.train(st, ep, 1 + i)
+    return 2.0 / (time.time() - t0)
+
+
+def cpu_baseline(alg, shape, T, envs, budget_s, threads=0):
+    """The CPU oracle (port of the reference path, pinned by the golden vectors) on a bounded sample
+    of the same workload, timed on this box's host cores (torch threads = os.cpu_count()).
+    threads = 0: a short sweep over 16 / 64 / all host CPUs picks the fastest thread count for the learner update
+    (1 warm-up + 2 timed train() calls each; the sweep is part of the object), then 2 warm-up + >= 5 timed calls there."""
+    from oracle import seeded, learners, rollout as orl
+    host_cores = os.cpu_count() or 1
+    args = seeded.make_args(shape, alg, episode_limit=T)
+    agent = seeded.seeded_state(seeded.agent_param_shapes(args), seed=11)
+    mshapes = seeded.mixer_param_shapes(args)
+    mixer = seeded.seeded_state(mshapes, seed=12) if mshapes else {}
     N, O, S, A = args.n_agents, args.obs_shape, args.state_shape, args.n_actions
     sy = orl.SynthSMAC(N, O, S, A, T, seed=1)
     sy.length = lambda env, ep: np.full(len(np.atleast_1d(env)), T, dtype=np.int64)
+    torch.set_num_threads(min(host_cores, 16))
+    ep, _, _, steps, _ = orl.batched_rollout(agent, args, sy, envs, 0.5, rseed=0)
+    sweep = {}
+    if threads > 0:
+        cores = threads
+    else:
+        # each candidate in a CHILD process under a time limit (ONE untimed + two timed updates): torch's thread pool can be
+        # pathologically slow when oversubscribed, and a running update cannot be interrupted from inside
+        import subprocess
+        for c in sorted({min(host_cores, x) for x in (16, 64, host_cores)}):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(c), "--cpu-envs", str(envs), "--alg", alg,
+                                    "--shape", shape, "--T", str(T)], capture_output=True, text=True, timeout=60)
+                sweep[c] = float(r.stdout.strip().splitlines()[-1])
+            except (subprocess.TimeoutExpired, ValueError, IndexError):
+                sweep[c] = 0.0          # did not finish three updates in 60 s
+        cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    st = learners.LearnerState(args, agent, mixer)
     t0 = time.time()
     ep, _, _, steps, _ = orl.batched_rollout(agent, args, sy, envs, 0.5, rseed=0)
     t_roll = time.time() - t0
@@ -110,8 +342,9 @@ def cpu_baseline(alg, shape, T, envs, budget_s):
     t_serial = time.time() - t0
     return {"value": steps / (t_roll + t_train), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "host_cpu_count": host_cores, "cpu_model": cpu_model(), "torch_threads": cores,
+            "thread_sweep_updates_per_sec": {str(k): v for k, v in sorted(sweep.items())},
             "sample": "%s %s: %d envs x T=%d batched CPU rollout + 2 warm-up and %d timed oracle train() calls on %d "
-                      "torch threads (of %d host CPUs); serial reference-style rollout of 8 episodes"
+                      "torch threads (of %d host CPUs; the fastest of the swept thread counts); serial reference-style rollout of 8 episodes"
                       % (alg, shape, envs, T, reps, cores, host_cores),
             "learner_updates_per_sec": 1.0 / t_train, "learner_transitions_per_sec": envs * T / t_train,
             "batched_rollout_env_steps_per_sec": steps / t_roll, "serial_rollout_env_steps_per_sec": ssteps / t_serial}
@@ -132,7 +365,11 @@ def main():
                          "and read at the end of the timed region - same device work, no host stall between steps)")
     ap.add_argument("--hip-graph", action="store_true", help="replay the learner's forward/backward schedule as one hipGraph (opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the learner legs of the other BASELINE configurations (configs[1..4] at "
+                    "their per-GPU shard sizes) that the default single-GPU run appends to the line as `configs`")
     ap.add_argument("--cpu-envs", type=int, default=256)
+    ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)     # child mode of the CPU thread sweep
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0: sweep 16 / 64 / all host CPUs, keep the fastest)")
     ap.add_argument("--leg-iters", type=int, default=5, help="iterations of the separately timed learner / rollout legs")
     ap.add_argument("--roofline-kernel", default="unroll", choices=["unroll", "mixer"],
                     help="kernel the roofline object describes: the agent unroll (fp32 MFMA bound; headline) or the fused "
@@ -140,6 +377,9 @@ def main():
     ap.add_argument("--dry", action="store_true", help="multi-GPU pre-flight only: init RCCL, one all-reduce of the real "
                     "gradient-buffer size, print the result and exit")
     o = ap.parse_args()
+    if o.cpu_probe:
+        print(cpu_probe(o.alg, o.shape, o.T or SHAPES[o.shape][4], o.cpu_envs, o.cpu_probe))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -211,34 +451,9 @@ def main():
     worker.record_sink = buf          # training rollouts are played straight into the replay ring
     np.random.seed(1 + rank)
 
-    # HIP-event timing of the dominant kernel (the persistent agent unroll, 3 launches per update)
-    ev_pairs, xs_pairs = [], []      # launches doing the full algorithmic work / the double-Q launch that reuses fc1 outputs
-    orig_fwd = ops.agent_unroll_fwd
-    timing = {"on": False}
-
-    def timed_fwd(*a, **k):
-        if timing["on"] and a[13] > 1:       # T > 1: learner unrolls only
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig_fwd(*a, **k)
-            e1.record()
-            (xs_pairs if k.get("gi_in") is not None else ev_pairs).append((e0, e1))
-        else:
-            orig_fwd(*a, **k)
-    ops.agent_unroll_fwd = timed_fwd
-    mix_pairs = []
-    orig_wide = ops.qmix_wide_fwd
-
-    def timed_wide(*a, **k):
-        if timing["on"]:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig_wide(*a, **k)
-            e1.record()
-            mix_pairs.append((e0, e1))
-        else:
-            orig_wide(*a, **k)
-    ops.qmix_wide_fwd = timed_wide
+    # HIP-event timing of every heavy C-ABI call inside the timed region (on the stream it is launched on)
+    timers = KernelTimers(ops, args, E)
+    timing = timers
 
     train_steps = [0]
 
@@ -272,7 +487,7 @@ def main():
     gc.collect()
     gc.disable()
     barrier()
-    timing["on"] = True
+    timers.on = True
     t0 = time.perf_counter()
     env_steps = 0
     for _ in range(o.steps):
@@ -287,7 +502,7 @@ def main():
                   ms["segment.all.current"], ms["reserved_bytes.all.current"] / 2**30, ms["allocation.all.allocated"]), file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
-    timing["on"] = False
+    timers.on = False
     env_steps += sum(st.steps() for st in lazy_stats[o.warmup:o.warmup + o.steps])
     tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -296,9 +511,6 @@ def main():
         tsum = tt.clone()
         torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
         dt, env_steps = float(tmax[0]), float(tsum[1])
-    kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
-    xs_ms = [a.elapsed_time(b) for a, b in xs_pairs]
-
     # separately timed legs (after the contract's timed region): learner-only and rollout-only
     batch = buf.sample(E)
     barrier(); t1 = time.perf_counter()
@@ -313,55 +525,72 @@ def main():
     gc.enable()
 
     if rank == 0:
-        fl = agent_flops(args) * E * N * T                 # algorithmic FLOP of one unroll launch
-        traffic = None                                     # HBM bytes/launch from the committed PMC passes (same workload only)
-        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), "")
-        if pmc and (o.alg, o.shape, o.envs, world, T) == ("qmix", "2s3z", 4096, 1, 120):
-            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if k.startswith("agent_fwd_kernel")]
-            n = sum(v["launches"] for v in ks)
-            if n and all("hbm_bytes_per_launch" in v for v in ks):
-                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / n
-        # (with --hip-graph the unrolls are launched from inside the replayed graph: no per-launch events, fields null)
-        # `achieved` follows the contract: ALGORITHMIC FLOP per launch (B*N*T*F_a) over the mean duration of the
-        # learner's unroll launches in the timed region (three per update).  One of the three - the double-Q unroll - reads
-        # the input-side work (fc1, x W_ih) the eval unroll stored instead of repeating it, and the eval unroll pays for
-        # those stores; `executed` says what the matrix pipe really did over the same launches, `by_launch` times each kind.
-        all_ms = kernel_ms + xs_ms
-        avg_ms = float(np.mean(all_ms)) if all_ms else None
-        ach = fl / (avg_ms * 1e-3) / 1e12 if avg_ms else None
         fpt = learner_flops_per_transition(args, o.alg)
         upd_tflops = fpt * (o.envs * T / t_learn) / 1e12
-        roof = {"bound": "mfma", "kernel": "agent_fwd_kernel (persistent GRU unroll, fp32 MFMA 16x16x4)",
-                "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS if ach else None,
-                "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and avg_ms) else None,
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                "separate passes; %s)" % (os.path.relpath(pmc, ROOT) if pmc else "no PMC file for this workload"),
-                "avg_launch_ms": avg_ms, "launches_timed": len(all_ms), "flop_per_launch": fl}
-        if all_ms:
-            I_ = args.obs_shape + args.n_actions + N
-            # fc1 and the input-side gate products (x W_ih) of all steps but the last are read, not computed, in a reuse launch
-            fl_x = fl - (2 * I_ * args.rnn_hidden_dim + 6 * args.rnn_hidden_dim ** 2) * E * N * (T - 1)
-            ex = (fl * len(kernel_ms) + fl_x * len(xs_ms)) / (sum(all_ms) * 1e-3) / 1e12
-            roof["executed"] = {"achieved": ex, "frac": ex / PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                                "what": "FLOP the launches executed (reuse launches: fc1 and x W_ih of all steps but the last are loaded)"}
-            roof["by_launch"] = {"full": {"avg_launch_ms": float(np.mean(kernel_ms)) if kernel_ms else None, "launches_timed": len(kernel_ms),
-                                          "flop_executed": fl, "what": "eval current-Q (saving activations + gate sums) and target next-Q"},
-                                 "reuse": {"avg_launch_ms": float(np.mean(xs_ms)) if xs_ms else None, "launches_timed": len(xs_ms),
-                                           "flop_executed": fl_x, "what": "double-Q unroll reading the eval unroll's input-side gate sums"}}
+        # HBM bytes per launch from the committed PMC passes (only when this run IS the workload they were taken on)
+        pmc_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc.json", "r02_pmc.json")) if os.path.exists(p)), "")
+        pmc = {}
+        if pmc_path and (o.alg, o.shape, o.envs, world, T, o.mixer_dtype) == ("qmix", "2s3z", 4096, 1, 120, "fp32"):
+            pmc = json.load(open(pmc_path))["kernels"]
+        kern = timers.table()
+        # (with --hip-graph the learner's kernels are launched from inside the replayed graph: no per-launch events)
+        for e in kern:
+            hit = [v for k, v in pmc.items() if k.startswith(e["rocprof_name"]) and "hbm_bytes_per_launch" in v]
+            if e["rocprof_name"] == "agent_fwd" and hit:
+                # three instantiations share the prefix: match by what the launch does (save: most written; reuse: <.., true, false>)
+                by = sorted(hit, key=lambda v: v.get("WRITE_SIZE", 0))
+                tag = e["name"].split("[")[1][:4]
+                hit = [by[-1]] if tag == "save" else ([v for v in by[:-1] if v.get("SQ_INSTS_MFMA", 0) == min(x.get("SQ_INSTS_MFMA", 0) for x in by[:-1])]
+                                                       if tag == "reus" else [v for v in by[:-1] if v.get("SQ_INSTS_MFMA", 0) == max(x.get("SQ_INSTS_MFMA", 0) for x in by[:-1])])
+            if len(hit) == 1:
+                e["hbm_gb"] = hit[0]["hbm_bytes_per_launch"] / 1e9
+                e["hbm_frac"] = hit[0]["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+                if "SQ_INSTS_MFMA" in hit[0]:
+                    e["mfma_flop_pmc"] = hit[0]["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
+        roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+        if kern:
+            # the roofline object describes the kernel the timed region spent the most time in; `achieved` = FLOP that kernel
+            # EXECUTES per launch / its mean launch duration (HIP events inside the timed region).  Work that is avoided
+            # (the double-Q unroll reading the eval unroll's input-side sums) is a throughput gain and is NOT credited here:
+            # it shows up in `algorithmic_rate` (SURVEY 8d FLOP / time) and in the end-to-end `roofline_update`.
+            d = kern[0]
+            roof.update(kernel=d["name"], rocprof_name=d["rocprof_name"], achieved=d["tflops"], frac=d["frac"],
+                        avg_launch_ms=d["ms"], launches_timed=d["launches_timed"], flop_per_launch=d["executed_flop"],
+                        traffic=(d["hbm_gb"] * 1e9 if d["hbm_gb"] else None), hbm_frac=d["hbm_frac"],
+                        traffic_unit="HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)"
+                                     % (os.path.relpath(pmc_path, ROOT) if pmc else "no PMC file for this workload"),
+                        what="executed FLOP (tile padding excluded) of the kernel with the largest total time in the timed region")
+            roof["kernels"] = [{k: e[k] for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "hbm_gb", "hbm_frac")}
+                               for e in kern[:6]]
+            un = [e for e in kern if e["rocprof_name"] == "agent_fwd"]
+            if un:
+                t_un = sum(e["total_ms"] for e in un)
+                roof["algorithmic_rate"] = {
+                    "what": "the learner's unroll launches (three per update): SURVEY 8d FLOP (B N T F_a per launch, whether computed or "
+                            "reused) / their mean duration - a throughput figure, not a pipe utilisation",
+                    "tflops": sum(e["algorithmic_flop"] * e["launches_timed"] for e in un) / (t_un * 1e-3) / 1e12,
+                    "executed_tflops": sum(e["executed_flop"] * e["launches_timed"] for e in un) / (t_un * 1e-3) / 1e12,
+                    "avg_launch_ms": t_un / sum(e["launches_timed"] for e in un)}
+            tot_exec = sum(e["executed_flop"] * e["launches_timed"] for e in kern)
+            tot_ms = sum(e["total_ms"] for e in kern)
+            roof["all_timed_kernels"] = {"executed_tflops": tot_exec / (tot_ms * 1e-3) / 1e12, "frac": tot_exec / (tot_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                                         "ms_per_step": tot_ms / o.steps}
         if o.roofline_kernel == "mixer":
             # fused wide-state QMIX forward: one launch reads every state row once (4 S bytes), the chosen Qs (4 N) and
             # writes q_tot (4): algorithmic bytes = rows * (4 S + 4 N + 4), rows = envs per GPU * T (with bf16
             # operands the hypernet GEMM sits below the bf16 ridge, i.e. it is bound by this read)
-            mix_ms = [a_.elapsed_time(b_) for a_, b_ in mix_pairs]
-            rows_l = E * T
-            byts = rows_l * (4 * args.state_shape + 4 * N + 4)
-            m_ms = float(np.mean(mix_ms)) if mix_ms else None
-            gbs = byts / (m_ms * 1e-3) / 1e9 if m_ms else None
-            flm = 2 * args.state_shape * (N * args.qmix_hidden_dim + 3 * args.qmix_hidden_dim) * rows_l
-            roof = {"bound": "hbm", "kernel": "qmix_wide_kernel forward (hypernet GEMM + mixing, %s operands)" % o.mixer_dtype,
-                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS if gbs else None,
-                    "traffic": None, "avg_launch_ms": m_ms, "launches_timed": len(mix_ms), "bytes_per_launch": byts,
-                    "flop_per_launch": flm, "tflops": flm / (m_ms * 1e-3) / 1e12 if m_ms else None}
+            mx = [e for e in kern if e["rocprof_name"] == "qmix_wide_kernel<false"]
+            if mx:
+                m = mx[0]
+                gbs = m["algorithmic_bytes"] / (m["ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": "qmix_wide_kernel forward (hypernet GEMM + mixing, %s operands)" % o.mixer_dtype,
+                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "traffic": None, "avg_launch_ms": m["ms"], "launches_timed": m["launches_timed"], "bytes_per_launch": m["algorithmic_bytes"],
+                        "flop_per_launch": m["executed_flop"], "tflops": m["tflops"], "kernels": roof.get("kernels")}
+        rccl = {"backend": "none (single process)", "world_seen": 1}
+        if world > 1:
+            rccl = {"backend": torch.distributed.get_backend(), "world_seen": torch.distributed.get_world_size(),
+                    "preflight": "all_reduce(sum) / all_reduce(max) / broadcast verified on every rank before the run"}
         out = {
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
@@ -376,13 +605,19 @@ def main():
             "learner_transitions_per_sec": o.envs * T / t_learn,
             "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
             "last_loss": float(loss), "loss_readback": "blocking" if o.blocking_loss else "deferred",
-            "roofline": roof,
+            "roofline": roof, "rccl": rccl,
             "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included)",
                                 "flop_per_transition": fpt, "achieved": upd_tflops, "peak": PEAK_F32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": upd_tflops / PEAK_F32_TFLOPS},
         }
+        if not o.no_configs and world == 1 and (o.alg, o.shape, o.envs) == ("qmix", "2s3z", 4096):
+            # the other BASELINE configurations, each at its per-GPU shard size, on this one GPU (legs after the timed region)
+            timers.close()
+            del learner, worker, buf, batch, env, mac
+            torch.cuda.empty_cache()
+            out["configs"] = [config_leg(*c) for c in OTHER_CONFIGS]
         if not o.no_cpu_baseline and world == 1:      # a reported baseline of the N=1 line only
-            out["cpu_baseline"] = cpu_baseline(o.alg, o.shape, T, o.cpu_envs, budget_s=20)
+            out["cpu_baseline"] = cpu_baseline(o.alg, o.shape, T, o.cpu_envs, budget_s=20, threads=o.cpu_threads)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

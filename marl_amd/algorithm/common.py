@@ -378,10 +378,12 @@ class GraphedUpdate:
             e = None
         dev = ring.obs.device
         if e is None:
-            idx = index.to(device=dev, dtype=torch.long)
+            # ONE persistent index tensor: the batch keeps a reference to it (the lazy `avail` gather of QPLEX reads the
+            # ring through it), so refreshing it below is what every later warm-up, capture and replay sees
+            idx = index.to(device=dev, dtype=torch.long).clone()
             small = ring.select_small(idx)
             db = DeviceBatch.from_record(ring, args, T=min(ring.T, args.episode_limit), index=idx, small=small)
-            e = self.entries[key] = dict(ring=weakref.ref(ring), idx=idx.clone(), small=small, db=db, calls=0, graph=None,
+            e = self.entries[key] = dict(ring=weakref.ref(ring), idx=idx, small=small, db=db, calls=0, graph=None,
                                          avail_next=db.avail_next.clone(), u_act=db.u_act.clone())
             db.avail_next, db.u_act = e["avail_next"], e["u_act"]
             e["T"] = db.T

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int H = 64;
-constexpr int HS = H + 4;      // LDS row stride of 64-wide tiles (floats); +4 spreads banks
+constexpr int HS = H + MARL_PAD_H;      // LDS row stride of 64-wide tiles (floats); +4 spreads banks
 constexpr int NT = 320;        // threads per workgroup
 
 struct FwdArgs {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const long NTILES = (a.R + 15) >> 4;               // global 16-row tiles (saved-activation layout)
   const int RTW = (int)((NTILES - (long)blockIdx.x * a.RT) < a.RT ? (NTILES - (long)blockIdx.x * a.RT) : a.RT);   // REAL row tiles of this workgroup: the last one may hold fewer (whole tiles past the batch are not processed)
   const int rows = a.RT * 16;
-  const int KP = a.KC * 16, KS = KP + 4;
+  const int KP = a.KC * 16, KS = KP + MARL_PAD_K;
   // LDS carve (all offsets multiples of 4 floats)
   float* W1s = smem;                                  // [4][KC][64] f32x4
   float* In = W1s + 4 * a.KC * 64 * 4;                // [rows][KS]
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   const long NTILES = (a.R + 15) >> 4;               // global 16-row tiles (saved-activation layout)
   const int RTW = (int)((NTILES - (long)blockIdx.x * a.RT) < a.RT ? (NTILES - (long)blockIdx.x * a.RT) : a.RT);   // REAL row tiles of this workgroup: the last one may hold fewer (whole tiles past the batch are not processed)
   const int rows = a.RT * 16;
-  const int KP = a.KC * 16, KS = KP + 4;
+  const int KP = a.KC * 16, KS = KP + MARL_PAD_K;
   float* W1s = smem;                                  // [4][KC][64] f32x4
   float* In0 = W1s + 4 * a.KC * 64 * 4;               // [2][rows][KS]
   float* Xt0 = In0 + 2 * rows * KS;                   // [2][rows][HS]
@@ -853,7 +853,7 @@ struct BwdArgs {
   long R;
 };
 
-constexpr int DGS = 256 + 4;
+constexpr int DGS = 256 + MARL_PAD_G;
 constexpr int BNT = 512;      // 8 waves: two per SIMD
 constexpr int NQ = 4;         // dq prefetch registers per thread
 
@@ -1724,7 +1724,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   a.KC = (a.I + 15) / 16;
   a.R = (long)B * N;
-  const int KS = a.KC * 16 + 4;
+  const int KS = a.KC * 16 + MARL_PAD_K;
   const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;   // + row tables: 2 long + 4 int
   const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16 + (((size_t)T * 4 + 15) & ~(size_t)15);   // fc1 fragments + step flags of the x-reusing variants (pipelined: 4; else one per step)
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;

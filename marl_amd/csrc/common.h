@@ -5,6 +5,21 @@
 
 #define MARL_WAVE 64
 
+// LDS row pitches of the activation tiles, in floats beyond the tile width.  A wave reads an MFMA operand fragment with one
+// ds_read_b128 per lane (row m, columns 4q..4q+3 of a 16-chunk): gfx950 serves that instruction in four groups of 16 lanes over
+// 64 banks, and a pitch of 8 (mod 16) floats is the one that spreads every group over all banks (a pitch of 4 mod 16 - the
+// usual "+4" - is a 2-way conflict on every such read; tools/lds_pitch.py).  The accumulator-layout accesses (row 4q+i, column
+// m: ds_read/write_b32) are 2-way at that pitch instead - free for the writes, and the reads are few.
+#ifndef MARL_PAD_H
+#define MARL_PAD_H 4
+#endif
+#ifndef MARL_PAD_K
+#define MARL_PAD_K 4
+#endif
+#ifndef MARL_PAD_G
+#define MARL_PAD_G 4
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // D = A(16x4) * B(4x16) + C, exact f32 (v_mfma_f32_16x16x4_f32).

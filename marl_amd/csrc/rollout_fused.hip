@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int H = 64;
-constexpr int HS = H + 4;
+constexpr int HS = H + MARL_PAD_H;
 constexpr int RNT = 512;
 
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
   const int team = wave >> 2, ws = wave & 3;
   const int q = lane >> 4, m = lane & 15;
   const int rows = a.RT * 16;
-  const int KP = a.KC * 16, KS = KP + 4;
+  const int KP = a.KC * 16, KS = KP + MARL_PAD_K;
   const int AS = a.A + 1;
   float* W1s = smem;                                  // [4][KC][64] f32x4
   float* In = W1s + 4 * a.KC * 64 * 4;                // [rows][KS]
@@ -509,7 +509,7 @@ ST_DEFINE_SETTER(marl_debug_stamps_rollout)
 // a workgroup holds whole environments (EPW*N rows padded to 16*RT, RT <= 8); the fc1 slice + the row state
 // must fit the 160 KB LDS (widest input assumed: last action and agent id appended)
 static int max_rt(int I, int A) {
-  const int KC = (I + 15) / 16, KS = KC * 16 + 4;
+  const int KC = (I + 15) / 16, KS = KC * 16 + MARL_PAD_K;
   const size_t fixed = (size_t)4 * KC * 64 * 16 + 16;
   const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12 + 32 + 8;
   int rt = 0;
@@ -518,7 +518,7 @@ static int max_rt(int I, int A) {
 }
 
 extern "C" int marl_synth_rollout_supported(int N, int O, int A) {
-  if (A > 32 || A < 1 || N < 1) return 0;
+  if (A > 32 || A < 1 || N < 1 || N > 64) return 0;      // the env step keeps an environment's agents in ONE wave
   return 16 * max_rt(O + A + N, A) >= N ? 1 : 0;
 }
 
@@ -528,7 +528,7 @@ extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, 
                                   float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N,
                                   int O, int S, int A, int last_action, int reuse_network, void* stream) {
   if (E <= 0 || T <= 0) return 0;
-  if (w->H != H || A > 32 || A < 1 || state_ld < S) return (int)hipErrorInvalidValue;
+  if (w->H != H || A > 32 || A < 1 || N < 1 || N > 64 || state_ld < S) return (int)hipErrorInvalidValue;
   RollArgs a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
   a.W2 = w->fc2_w; a.b2 = w->fc2_b;
@@ -540,7 +540,7 @@ extern "C" int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, 
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   a.KC = (a.I + 15) / 16;
   a.R = (long)E * N;
-  const int KS = a.KC * 16 + 4;
+  const int KS = a.KC * 16 + MARL_PAD_K;
   const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16;
   const size_t per_row = (size_t)(KS + 3 * HS + (A + 1) + 2 * A) * 4 + 16 + 12 + 32 + 8;
   // environments per workgroup: one workgroup per CU when the batch allows it (a lock-step is latency

@@ -71,15 +71,17 @@ class Runner:
             flatten_module(self._mac_roll.agent, self.learner.device)
             self._mac_roll._dev = self.learner.device
         cur = torch.cuda.current_stream()
+        # the snapshot is taken ON THE MAIN STREAM: it is ordered after every update enqueued so far and before the
+        # optimizer kernel of the next one (a copy on the side stream would only be ordered against the past)
+        self._mac_roll.agent._flat.flat.copy_(self.mac.agent._flat.flat)
         if self.overlap is True:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=cur.device)
-            self._side.wait_stream(cur)         # the snapshot reads what the main stream has written so far
+            self._side.wait_stream(cur)         # the rollout reads the snapshot (and the ring) as of this point
             ctx = torch.cuda.stream(self._side)
         else:
             ctx = torch.cuda.stream(cur)
         with ctx:
-            self._mac_roll.agent._flat.flat.copy_(self.mac.agent._flat.flat)
             pending = self.rolloutWorker.launch_episodes(mac=self._mac_roll)
         slot = getattr(pending[0], "sink_slot", None)
         return pending, (None if slot is None else (slot, pending[0].E))

@@ -94,9 +94,12 @@ def test_first_terminated_len_kernel_matches_reference_rule():
     assert DeviceBatch.first_terminated_len(none, 9) == 9
 
 
-def test_hip_graph_replay_equals_eager():
+@pytest.mark.parametrize("alg", ["qmix", "qplex"])
+def test_hip_graph_replay_equals_eager(alg):
     """Opt-in hipGraph replay of the learner's forward/backward (args.hip_graph): same ring, same sampled episodes ->
-    bitwise the same losses and parameters as eager launches, across the capture (update 3) and replays."""
+    bitwise the same losses and parameters as eager launches, across the capture (update 3) and replays.  QPLEX reads
+    the current-step availability of the SAMPLED episodes through the batch's index tensor (a different sample per
+    update: the replayed gather must follow it)."""
     import bench
     from marl_amd.controller.share_params import SharedMAC
     from marl_amd.algorithm.q_learner import QLearner
@@ -105,7 +108,7 @@ def test_hip_graph_replay_equals_eager():
     from marl_amd.common.replaybuffer import ReplayBuffer
     out = {}
     for mode in (False, True):
-        args = bench.make_args("qmix", "2s3z", 12)
+        args = bench.make_args(alg, "2s3z", 12)
         E = 96
         args.buffer_size, args.batch_size, args.hip_graph = 2 * E, E, mode
         torch.manual_seed(0)

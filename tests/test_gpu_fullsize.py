@@ -231,3 +231,66 @@ def test_config5_qmix_mmm2_shard_fullsize():
     assert Tm == T5
     _linearity(learner, rec, Tm, E5, 2, "full:cfg5_qmix_MMM2_1024x120")
     _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 511, 512, 700, 1023], Tm, "full:cfg5_qmix_MMM2_1024x120")
+
+
+def _full_batch_samples_vs_oracle(case, args, dbg, rec, idx, Tm, name, tol=1e-4):
+    """Forward tensors the FULL-batch launch produced (whatever schedule and kernel variants its size selected) for the
+    sampled episodes vs the CPU oracle run on those episodes alone (rows are independent)."""
+    import parity
+    from marl_amd.rollout import EpisodeBatch
+    from golden_cases import case_states
+    _, agent, mixer, v, extra = case_states(case)
+    st = learners.LearnerState(args, agent, mixer, v, extra)
+    sub = EpisodeBatch(rec.index_select(torch.as_tensor(idx, device=rec.obs.device))).numpy()
+    _, inter = learners.q_forward(st, sub, T=Tm)
+    E_ = rec.E
+    parity.close(name, "full-batch q_evals", dbg["q_evals"][idx], inter["q_evals"].detach().numpy(), tol=tol)
+    qt_o = inter["q_targets"].detach().numpy()              # the oracle's copy carries the -9999999 availability mask
+    ok = qt_o > -1e6
+    parity.close(name, "full-batch q_targets", dbg["q_targets"][idx][ok], qt_o[ok], tol=tol)
+    live = sub["padded"][:, :Tm, 0] == 0
+    for k in ("q_tot", "q_tot_target"):
+        a_ = dbg[k].reshape(E_, Tm)[idx]
+        b_ = inter[k].detach().numpy().reshape(len(idx), Tm)
+        parity.close(name, "full-batch " + k, a_[live], b_[live], tol=tol)
+
+
+def _chain_schedule_case(alg, envs, name):
+    """A shard whose size selects PairedUnroll.run_chain (eval current-Q -> double-Q continuation on 160 CUs, target
+    unroll beside it on 96 CUs of a side stream; reference q_learner.py:96-117, quirk Q1: the continuation starts from the
+    eval pass's final hidden state and here also READS its input-side gate sums across the stream fork)."""
+    from marl_amd.hostutil import DeviceBatch
+    T2 = 120
+    case, args, learner, rec = _shard_world("2s3z", alg, envs, T2, seed=31)
+    assert int(rec.padded.sum().item()) > 0, "ragged episodes wanted"
+    Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
+    assert Tm == T2
+    split = learner.pair.chain_split(envs * args.n_agents, Tm, args.obs_shape)
+    assert split is not None and split[0] + split[1] == 256, split
+    # (a) the chain schedule vs the plain schedule (pair, then the continuation over the whole chip) on the same record:
+    # rows are independent and every kernel variant accumulates a row's products in the same order -> bitwise equal
+    g_chain, dbg_chain = _grads(learner, rec, Tm)
+    learner.pair.chain = False
+    assert learner.pair.chain_split(envs * args.n_agents, Tm, args.obs_shape) is None
+    g_plain, dbg_plain = _grads(learner, rec, Tm)
+    learner.pair.chain = True
+    for k in ("q_evals", "q_targets", "q_tot", "q_tot_target"):
+        np.testing.assert_array_equal(dbg_chain[k], dbg_plain[k], err_msg=name + " chain vs plain " + k)
+    np.testing.assert_array_equal(g_chain, g_plain, err_msg=name + " chain vs plain gradx")
+    # (b) what the chain launches produced for sampled episodes vs the CPU oracle
+    idx = [0, 1, envs // 2 - 1, envs // 2, envs - 200, envs - 1]
+    _full_batch_samples_vs_oracle(case, args, dbg_chain, rec, idx, Tm, name)
+    # (c) shard linearity (the full shard runs the chain schedule; its halves whatever their size selects) and the sampled
+    # sub-batch incl. every gradient
+    _linearity(learner, rec, Tm, envs, 2, name)
+    _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name)
+
+
+def test_config2_qmix_2s3z_1024_chain_schedule():
+    """BASELINE config 2 (QMIX, 2s3z, 1024 envs x T = 120 on one MI355X): its size selects the chain schedule."""
+    _chain_schedule_case("qmix", 1024, "full:cfg2_qmix_2s3z_1024x120")
+
+
+def test_config3_qplex_2s3z_512_shard_chain_schedule():
+    """BASELINE config 3 at its per-GPU shard (QPLEX, 2s3z, 4096 envs / 8 GPUs = 512 envs x T = 120)."""
+    _chain_schedule_case("qplex", 512, "full:cfg3_qplex_2s3z_512x120")
