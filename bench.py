@@ -100,18 +100,19 @@ class KernelTimers:
             B, T, N_, A_ = ar[8], ar[9], ar[10], ar[11]
             rows = B * T * N_
             f = (8 * 3 * H * H + 4 * A_ * H) * rows   # dx, dh_prev, dW_ih, dW_hh (2*192*64 each) + dq->dh and dW_2 (2*A*64 each)
-            return ("agent_bwd_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2)", "agent_bwd", f, f, 4.0 * rows * (10 * H + H))
+            return ("agent_bwd_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2)", "agent_bwd_kernel", f, f, 4.0 * rows * (10 * H + H))
 
         def wgrad(ar, kw):
             M, Nn, K = ar[4], ar[5], ar[6]
             f = 2.0 * M * Nn * (K + 1)
-            return ("linear_wgrad (fc1 gradient: wgrad_tall_kernel at N=64)" if Nn == H and M >= 4096 else "linear_wgrad (generic)",
-                    "wgrad_", f, f, 4.0 * M * (Nn + K))
+            tall = Nn == H and M >= 4096 and K >= O
+            return ("linear_wgrad M=%d N=%d K=%d%s" % (M, Nn, K, " (fc1 gradient: wgrad_tall_kernel)" if tall else ""),
+                    "wgrad_tall_kernel" if tall else "wgrad_", f, f, 4.0 * M * (Nn + K))
 
         def lin(ar, kw):
             M, Nn, K = ar[4], ar[5], ar[6]
             f = 2.0 * M * Nn * K
-            return ("linear (generic GEMM)", "linear_kernel", f, f, 4.0 * M * (Nn + K))
+            return ("linear M=%d N=%d K=%d (generic GEMM)" % (M, Nn, K), "linear_kernel", f, f, 4.0 * M * (Nn + K))
 
         def qmix(mult, label, roc):
             def m(ar, kw):

@@ -175,23 +175,28 @@ __device__ __forceinline__ void fwd1(const f32x4 (&xv)[KC], const float* W1s, co
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = b1v[t];
-  // weight fragments one chunk ahead; the scheduling barrier keeps the compiler from hoisting every LDS read of
-  // the layer to the top (that cost > 256 registers and spilled)
-  f32x4 wn[4];
+  // weight fragments one chunk ahead in two named sets that alternate (no set-to-set copies: 16 moves per chunk on a SIMD
+  // where every vector instruction is matrix time lost); the scheduling barrier keeps the compiler from hoisting every
+  // LDS read of the layer to the top (that cost > 256 registers and spilled)
+  f32x4 wA[4], wB[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W1s + ((t * KC) * 64 + lane) * 4);
+  for (int t = 0; t < 4; ++t) wA[t] = *reinterpret_cast<const f32x4*>(W1s + ((t * KC) * 64 + lane) * 4);
 #pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    f32x4 wc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wc[t] = wn[t];
+  for (int c = 0; c < KC; c += 2) {
     if (c + 1 < KC) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W1s + ((t * KC + c + 1) * 64 + lane) * 4);
+      for (int t = 0; t < 4; ++t) wB[t] = *reinterpret_cast<const f32x4*>(W1s + ((t * KC + c + 1) * 64 + lane) * 4);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = mfma16x4(wc[t], xv[c], acc[t]);
+    mfma16x4_il4(wA[0], xv[c], acc[0], wA[1], xv[c], acc[1], wA[2], xv[c], acc[2], wA[3], xv[c], acc[3]);
     __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < KC) {
+      if (c + 2 < KC) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wA[t] = *reinterpret_cast<const f32x4*>(W1s + ((t * KC + c + 2) * 64 + lane) * 4);
+      }
+      mfma16x4_il4(wB[0], xv[c + 1], acc[0], wB[1], xv[c + 1], acc[1], wB[2], xv[c + 1], acc[2], wB[3], xv[c + 1], acc[3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) h1[t] = relu4(acc[t]);
@@ -201,20 +206,20 @@ __device__ __forceinline__ void fwd2(const f32x4 (&h1)[4], const float* W2s, con
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = b2v[t];
-  f32x4 wn[4];
+  f32x4 wA[4], wB[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W2s + ((t * 4) * 64 + lane) * 4);
+  for (int t = 0; t < 4; ++t) wA[t] = *reinterpret_cast<const f32x4*>(W2s + ((t * 4) * 64 + lane) * 4);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    f32x4 wc[4];
+  for (int c = 0; c < 4; c += 2) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wc[t] = wn[t];
-    if (c + 1 < 4) {
+    for (int t = 0; t < 4; ++t) wB[t] = *reinterpret_cast<const f32x4*>(W2s + ((t * 4 + c + 1) * 64 + lane) * 4);
+    mfma16x4_il4(wA[0], h1[c], acc[0], wA[1], h1[c], acc[1], wA[2], h1[c], acc[2], wA[3], h1[c], acc[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < 4) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W2s + ((t * 4 + c + 1) * 64 + lane) * 4);
+      for (int t = 0; t < 4; ++t) wA[t] = *reinterpret_cast<const f32x4*>(W2s + ((t * 4 + c + 2) * 64 + lane) * 4);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = mfma16x4(wc[t], h1[c], acc[t]);
+    mfma16x4_il4(wB[0], h1[c + 1], acc[0], wB[1], h1[c + 1], acc[1], wB[2], h1[c + 1], acc[2], wB[3], h1[c + 1], acc[3]);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     xr = x_row(a.x, (i_begin * BNW + wave) * 16 + m, a.M);
     x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
   }
+  ST_DECL(12);
   for (long it = i_begin; it < i_end; ++it) {
     // ---------------- phase A: this wave's 16-row tile, all in registers
     x_finish<KC>(xv, xr, tab, a.CF, lane);
@@ -382,6 +388,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) xT[(16 * c + 4 * q + i) * RS + 16 * wave + m] = xv[c][i];
     f32x4 h1[4], h2[4], dh2[4], dh1[4];
+    ST_MARK(0);
     fwd1<KC>(xv, W1s, b1v, h1, lane);
     // x is consumed: start the loads of the next iteration's tile (unconditional; the last one re-reads its own)
     {
@@ -389,50 +396,73 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
       xr = x_row(a.x, (ni * BNW + wave) * 16 + m, a.M);
       x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
     }
+    ST_MARK(1);
     if (THREE) fwd2(h1, W2s, b2v, h2, lane);
     else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) h2[t] = h1[t];
     }
+    ST_MARK(2);
+    {
+      f32x4 acc[4];                      // the four feature tiles round robin (independent accumulators, see common.h)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (4 * j < a.N3) acc = mfma16(W3Ts[(t * 4 + j) * 64 + lane], dy[j], acc);      // heads n3 = 4j + q
+        if (4 * j < a.N3) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dh2[t][i] = h2[t][i] > 0.f ? acc[i] : 0.f;
-    }
-    if (THREE) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(W2Ts + ((t * 4 + c) * 64 + lane) * 4);
-          acc = mfma16x4(w, dh2[c], acc);
+          for (int t = 0; t < 4; ++t) acc[t] = mfma16(W3Ts[(t * 4 + j) * 64 + lane], dy[j], acc[t]);      // heads n3 = 4j + q
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dh1[t][i] = h1[t][i] > 0.f ? acc[i] : 0.f;
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh2[t][i] = h2[t][i] > 0.f ? acc[t][i] : 0.f;
+    }
+    ST_MARK(3);
+    if (THREE) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const f32x4*>(W2Ts + ((t * 4 + c) * 64 + lane) * 4);
+        mfma16x4_il4(w[0], dh2[c], acc[0], w[1], dh2[c], acc[1], w[2], dh2[c], acc[2], w[3], dh2[c], acc[3]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh1[t][i] = h1[t][i] > 0.f ? acc[t][i] : 0.f;
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) dh1[t] = dh2[t];
     }
     stash4(dh1T, dh1, wave, q, m);
+    ST_MARK(4);
     WG_BARRIER();
+    ST_MARK(5);
     // ---------------- phase B1: dW1 rows [16w, 16w+16) over the 64 rows of the iteration
 #pragma unroll
     for (int rt = 0; rt < BNW; ++rt) {
       const f32x4 af = *reinterpret_cast<const f32x4*>(dh1T + (16 * wave + m) * RS + 16 * rt + 4 * q);
       bs1 += (af[0] + af[1]) + (af[2] + af[3]);
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(xT + (16 * c + m) * RS + 16 * rt + 4 * q);
-        dW1[c] = mfma16x4(af, bf, dW1[c]);
+      for (int c = 0; c < KC; c += 4) {        // up to four k tiles round robin (independent accumulators)
+        f32x4 bf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c + u < KC) bf[u] = *reinterpret_cast<const f32x4*>(xT + (16 * (c + u) + m) * RS + 16 * rt + 4 * q);
+        if (c + 3 < KC) mfma16x4_il4(af, bf[0], dW1[c], af, bf[1], dW1[c + 1], af, bf[2], dW1[c + 2], af, bf[3], dW1[c + 3]);
+        else if (c + 2 < KC) mfma16x4_il3(af, bf[0], dW1[c], af, bf[1], dW1[c + 1], af, bf[2], dW1[c + 2]);
+        else if (c + 1 < KC) mfma16x4_il2(af, bf[0], dW1[c], af, bf[1], dW1[c + 1]);
+        else dW1[c] = mfma16x4(af, bf[0], dW1[c]);
       }
     }
+    ST_MARK(6);
     WG_BARRIER();
+    ST_MARK(7);
     // ---------------- stage 2 operands
     if (THREE) {
       stash4(h1T, h1, wave, q, m);
@@ -441,26 +471,30 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     stash4(h2T, h2, wave, q, m);
 #pragma unroll
     for (int j = 0; j < 4; ++j) dYT[(4 * j + q) * RS + 16 * wave + m] = dy[j];
+    ST_MARK(8);
     WG_BARRIER();
+    ST_MARK(9);
     // ---------------- phase B2: dW2 rows [16w, 16w+16), dW3 columns [16w, 16w+16)
 #pragma unroll
     for (int rt = 0; rt < BNW; ++rt) {
       if (THREE) {
         const f32x4 af = *reinterpret_cast<const f32x4*>(dh2T + (16 * wave + m) * RS + 16 * rt + 4 * q);
         bs2 += (af[0] + af[1]) + (af[2] + af[3]);
+        f32x4 bf[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 bf = *reinterpret_cast<const f32x4*>(h1T + (16 * c + m) * RS + 16 * rt + 4 * q);
-          dW2[c] = mfma16x4(af, bf, dW2[c]);
-        }
+        for (int c = 0; c < 4; ++c) bf[c] = *reinterpret_cast<const f32x4*>(h1T + (16 * c + m) * RS + 16 * rt + 4 * q);
+        mfma16x4_il4(af, bf[0], dW2[0], af, bf[1], dW2[1], af, bf[2], dW2[2], af, bf[3], dW2[3]);
       }
       const f32x4 ay = *reinterpret_cast<const f32x4*>(dYT + m * RS + 16 * rt + 4 * q);
       const f32x4 bh = *reinterpret_cast<const f32x4*>(h2T + (16 * wave + m) * RS + 16 * rt + 4 * q);
       bs3 += (ay[0] + ay[1]) + (ay[2] + ay[3]);
       dW3 = mfma16x4(ay, bh, dW3);
     }
+    ST_MARK(10);
     WG_BARRIER();
+    ST_MARK(11);
   }
+  if (KC == 8 && THREE) { ST_DUMP(12); }      // (diagnostic build: the key / agents extractor launches)
 
   // ---------------- slab: [dW1 64 x (K1+1) | dW2 64 x 65 | dW3 16 x 65], bias gradient in the last column
   bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
@@ -577,6 +611,8 @@ bool fill_args(Mlp3Args& a, const marl_mlp3_weights_t* w, const marl_src_t* x, l
 }
 
 }  // namespace
+
+ST_DEFINE_SETTER(marl_debug_stamps_mlp3)
 
 extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups) {
   if (H1 != HD || (H2 != HD && H2 != 0) || N3 < 1 || N3 > 16 || groups < 1 || K1 < 1) return 0;

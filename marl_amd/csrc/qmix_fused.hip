@@ -265,8 +265,11 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
 #pragma unroll
     for (int kc = 0; kc < KCQ; ++kc) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(sr + 16 * kc);
+      // round robin over the wave's column tiles: back-to-back MFMAs on ONE accumulator run at 80 % of the pipe (common.h)
 #pragma unroll
-      for (int c = 0; c < TPW; ++c) acc[c] = mfma16x4(a4, wq[c][kc], acc[c]);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) acc[c] = mfma16(a4[i], wq[c][kc][i], acc[c]);
     }
     ST_MARK(2);
     __builtin_amdgcn_sched_barrier(0);             // the MFMA run first, the epilogue after it (no fine interleaving)
@@ -375,7 +378,9 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sD[i] = sd[i * SS + 16 * kc];
 #pragma unroll
-        for (int c = 0; c < TPW; ++c) accW[c][kc] = mfma16x4(dhy[c], sD, accW[c][kc]);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < TPW; ++c) accW[c][kc] = mfma16(dhy[c][i], sD[i], accW[c][kc]);
       }
       prow0 = row0;
     }

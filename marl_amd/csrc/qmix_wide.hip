@@ -200,9 +200,15 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
       const float bv = ct < NCT ? a.Bc[16 * ct + m] : 0.f;
       acc[ct] = (f32x4){bv, bv, bv, bv};
     }
-    f32x4 aA[2], aB[2];
+    // state fragments travel FOUR chunks ahead of their use in four named register sets (a chunk of a 128-row block is
+    // ~1 us of work for the workgroup, an HBM miss under load takes two or more: one chunk ahead - the first version -
+    // left every chunk waiting for its own loads, the kernel ran at 0.2 of the HBM rate with both pipes idle)
+    f32x4 a0[2], a1[2], a2[2], a3[2];
+    const int KCm = KC - 1;
     wfetch(0);
-    aload(aA, 0);
+    aload(a0, 0);
+    aload(a1, 1 < KCm ? 1 : KCm);
+    aload(a2, 2 < KCm ? 2 : KCm);
     wstash(0);
     if (KC > 1) wfetch(1);
     auto mac = [&](const f32x4 (&av)[2], int b) __attribute__((always_inline)) {
@@ -227,21 +233,23 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_kernel(WideArgs a) {
           }
       }
     };
-    // chunk loop: buffer kc & 1 holds chunk kc; chunk kc + 1 is in wpf and goes to the other buffer after the barrier
-    for (int kc = 0; kc < KC; kc += 2) {
-      WG_BARRIER();                                 // chunk kc is in Wl[0]; everybody is done with Wl[1]
-      if (kc + 1 < KC) wstash(1);
-      if (kc + 2 < KC) wfetch(kc + 2);
-      aload(aB, kc + 1 < KC ? kc + 1 : kc);
-      mac(aA, 0);
-      if (kc + 1 < KC) {
-        WG_BARRIER();                               // chunk kc + 1 is in Wl[1]; everybody is done with Wl[0]
-        if (kc + 2 < KC) wstash(0);
-        if (kc + 3 < KC) wfetch(kc + 3);
-        aload(aA, kc + 2 < KC ? kc + 2 : kc + 1);
-        mac(aB, 1);
-      }
+    // chunk loop: buffer c & 1 holds the weights of chunk c; chunk c + 1 is in wpf and goes to the other buffer after the
+    // barrier.  One step: barrier, stash + fetch weights, issue the state loads of chunk c + 3, multiply chunk c.
+#define WIDE_STEP(CUR, NXT3, c_)                                                    \
+    if ((c_) < KC) {                                                                \
+      WG_BARRIER();          /* chunk c is in Wl[c & 1]; everybody is done with the other buffer */ \
+      if ((c_) + 1 < KC) wstash(((c_) + 1) & 1);                                    \
+      if ((c_) + 2 < KC) wfetch((c_) + 2);                                          \
+      aload(NXT3, (c_) + 3 < KCm ? (c_) + 3 : KCm);                                 \
+      mac(CUR, (c_) & 1);                                                           \
     }
+    for (int kc = 0; kc < KC; kc += 4) {
+      WIDE_STEP(a0, a3, kc)
+      WIDE_STEP(a1, a0, kc + 1)
+      WIDE_STEP(a2, a1, kc + 2)
+      WIDE_STEP(a3, a2, kc + 3)
+    }
+#undef WIDE_STEP
     // ---- mixing, wave local.  acc[ct][i]: row 16 wave + 4 q + i, column 16 ct + m; column tile ct -> agent ct / 2, e-half
     // ct & 1 for the w1 tiles; then b1 (2N, 2N+1), w2 (2N+2, 2N+3), h (2N+4, 2N+5)
     const float* qrow = Qs + (16 * wave + 4 * q4) * 16;

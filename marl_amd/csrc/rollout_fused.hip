@@ -265,6 +265,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
     bias_z = a.bih[H + j] + a.bhh[H + j];
     bias_in = a.bih[2 * H + j];
     bias_hn = a.bhh[2 * H + j];
+    gru_prescale(wih, whh, bias_r, bias_z, bias_in, bias_hn);      // accumulators arrive as the exponents (common.h)
   }
   WG_BARRIER();
 
@@ -299,12 +300,12 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
         const bool odd = c + 1 < a.KC;
         const int cB = odd ? c + 1 : c, cA = c + 2 < a.KC ? c + 2 : c;
         FC1_LD(bB, aB, a1B, cB)
-        acc0 = mfma16x4(aA, bA, acc0);
-        if (two) acc1 = mfma16x4(a1A, bA, acc1);
+        if (two) mfma16x4_il2(aA, bA, acc0, a1A, bA, acc1);
+        else acc0 = mfma16x4(aA, bA, acc0);
         FC1_LD(bA, aA, a1A, cA)
         if (odd) {
-          acc0 = mfma16x4(aB, bB, acc0);
-          if (two) acc1 = mfma16x4(a1B, bB, acc1);
+          if (two) mfma16x4_il2(aB, bB, acc0, a1B, bB, acc1);
+          else acc0 = mfma16x4(aB, bB, acc0);
         }
       }
 #undef FC1_LD
@@ -351,25 +352,20 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_kernel(RollArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-        ar = mfma16x4(ax, wih[0][c], ar);
-        az = mfma16x4(ax, wih[1][c], az);
-        ain = mfma16x4(ax, wih[2][c], ain);
+        mfma16x4_il3(ax, wih[0][c], ar, ax, wih[1][c], az, ax, wih[2][c], ain);
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-        ahn = mfma16x4(ah, whh[2][c], ahn);
-        ar = mfma16x4(ah, whh[0][c], ar);
-        az = mfma16x4(ah, whh[1][c], az);
+        mfma16x4_il3(ah, whh[2][c], ahn, ah, whh[0][c], ar, ah, whh[1][c], az);
       }
       const int r0 = rt * 16 + 4 * q;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float hp = Hp[(r0 + i) * HS + j];
-        const float rg = sigmoidf_(ar[i]);
-        const float zg = sigmoidf_(az[i]);
-        const float ng = tanhf_(ain[i] + rg * ahn[i]);
-        Hn[(r0 + i) * HS + j] = (1.f - zg) * ng + zg * hp;
+        float rg, zg, ng, hv;
+        gru_point(ar[i], az[i], ain[i], ahn[i], hp, rg, zg, ng, hv);
+        Hn[(r0 + i) * HS + j] = hv;
       }
     }
     ST_MARK(3);

@@ -54,6 +54,8 @@ def test_bench_runs_under_torchrun_two_ranks():
               "--T", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--leg-iters", "1"],
              {"MARL_BENCH_BACKEND": "gloo", "MARL_BENCH_ONE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 32 and d["value"] > 0
-    # (at full size the double-Q unroll reuses the eval unroll's input-side work and is listed beside the other two)
-    assert d["scaling"] == "strong" and d["roofline"]["launches_timed"] == 6
-    assert d["roofline"]["by_launch"]["reuse"]["launches_timed"] == 2     # the double-Q unroll of each update (pipelined kernel here)
+    # the roofline object describes the kernel with the largest total time; every timed kernel is listed with its launches
+    assert d["scaling"] == "strong" and d["roofline"]["frac"] > 0 and d["roofline"]["launches_timed"] >= 2
+    names = {k["name"].split("[")[0].split(" ")[0]: k["launches_timed"] for k in d["roofline"]["kernels"]}
+    assert names.get("agent_fwd_kernel") == 2 and names.get("agent_bwd_kernel") == 2, names      # (one entry per unroll kind, 2 steps)
+    assert d["rccl"] == {"backend": "gloo", "world_seen": 2, "preflight": d["rccl"]["preflight"]}

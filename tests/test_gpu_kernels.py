@@ -434,6 +434,56 @@ def test_double_q_unroll_reuses_input_side_work_bitwise(dev, shape, B, T, cus):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("shape,B,T,cus", [("2s3z", 37, 5, 4), ("2s3z", 300, 7, 16), ("3s5z", 40, 4, 8), ("MMM2", 60, 4, 16),
+                                            ("MMM2", 1024, 3, 256), ("MMM2", 30, 5, 128)])
+def test_saving_unroll_lds_dma_equals_register_prefetch_bitwise(dev, shape, B, T, cus):
+    """The activation-saving unroll with its observation tile (and the fed-back actions) filled by LDS-DMA
+    (MARL_FWD_DMA=1; the default for wide observations - MMM2 - where the prefetch registers would cap the workgroup at
+    two row tiles) == the same unroll through prefetch registers (MARL_FWD_DMA=0), bit for bit: q, the final hidden state,
+    all six saved planes and the input-side gate sums; ragged episode lengths (rows past their end feed zeros), an
+    episode map, (T+1)-slot storage with the shifted last action, a partial last row tile."""
+    import os
+    from marl_amd import ops
+    args, p_np, _, _, _ = _agent_case(shape, B, T, dev)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    rng = np.random.default_rng(B + T)
+    E = B + 2
+    store = cu(rng.standard_normal((E, T + 1, N, O)).astype(np.float32), dev)
+    u = cu(rng.integers(-1, A, size=(B, T, N)), dev, torch.int32)
+    emap = cu(rng.permutation(E)[:B], dev, torch.int32)
+    lens = rng.integers(1, T + 1, size=B)
+    lens[0], lens[-1] = T, 1
+    ep_len = cu(lens, dev, torch.int32)
+    h0 = cu(rng.standard_normal((B * N, 64)).astype(np.float32) * 0.3, dev)
+    w = ops.agent_weights({k: cu(v, dev) for k, v in p_np.items()})
+    outs = {}
+    old = os.environ.get("MARL_FWD_DMA")
+    try:
+        for mode in ("0", "1"):
+            os.environ["MARL_FWD_DMA"] = mode
+            for t0, ut0 in ((0, -1), (1, 0)):
+                saved = torch.zeros(ops.saved_shape(T, B, N), device=dev)
+                gi = torch.zeros(ops.saved_shape(T, B, N, planes=3), device=dev)
+                q, hl = torch.empty(B, T, N, A, device=dev), torch.empty(B * N, 64, device=dev)
+                ops.agent_unroll_fwd(w, store, (T + 1) * N, t0, u, T * N, ut0, h0, q, None, hl, saved, B, T, N, O, A,
+                                     ep_len=ep_len, ep_map=emap, cu_budget=cus, gi_out=gi)
+                rows = B * N
+                planes = [ops.saved_plane(saved, k, rows).cpu() for k in range(6)] + [ops.saved_plane(gi, k, rows).cpu() for k in range(3)]
+                outs[(mode, t0)] = (q.cpu(), hl.cpu(), planes)
+    finally:
+        if old is None:
+            os.environ.pop("MARL_FWD_DMA", None)
+        else:
+            os.environ["MARL_FWD_DMA"] = old
+    for t0 in (0, 1):
+        a, b = outs[("0", t0)], outs[("1", t0)]
+        assert torch.isfinite(a[0]).all()
+        assert torch.equal(a[0], b[0]), "q (t0=%d)" % t0
+        assert torch.equal(a[1], b[1]), "h_last"
+        for k, (x, y) in enumerate(zip(a[2], b[2])):
+            assert torch.equal(x, y), "plane %d (t0=%d)" % (k, t0)
+
+
 @pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
 def test_agent_unroll_bwd(dev, shape, B, T):
     """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll.  Up to four row tiles per workgroup a

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+( timeout 100 python tools/stamps_fwd_save.py 2s3z 4096; timeout 100 python tools/stamps_fwd_save.py MMM2 1024 ) 2>&1 | grep -v amdgpu > gpurun_out/r03_stamps_dma2.txt; cat gpurun_out/r03_stamps_dma2.txt
+( for D in 0 1; do MARL_FWD_DMA=$D timeout 200 python tools/ktime.py --tag dma$D --rollouts 0 2>&1 | grep -v amdgpu.ids | head -4; done
+  for D in 0 -1; do MARL_FWD_DMA=$D timeout 200 python tools/ktime.py --tag dma$D --shape MMM2 --envs 1024 --rollouts 0 2>&1 | grep -v amdgpu.ids | head -4; done ) > gpurun_out/r03_ab5.txt 2>&1
+cat gpurun_out/r03_ab5.txt

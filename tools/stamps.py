@@ -17,6 +17,7 @@ SEGS = {
     "wgrad": ["barrier", "work"],
     "bwd_pipe": ["product", "gates/dxp", "accum", "barrier"],
     "bwd": ["phaseB", "bar1", "phaseC", "dqwrite", "bar2"],
+    "mlp3": ["xfin+stx", "fwd1", "fwd2", "dh2", "dh1+st", "bar1", "B1:dW1", "bar2", "stash2", "bar3", "B2:dW2,3", "bar4"],
 }
 
 
@@ -33,7 +34,7 @@ def main():
     from marl_amd.algorithm.q_learner import QLearner
     from marl_amd.rollout import RolloutWorker
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
-    args = bench.make_args("qmix", "2s3z", 0)
+    args = bench.make_args("qplex" if which == "mlp3" else "qmix", "2s3z", 0)
     mac = SharedMAC(args)
     env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, args.episode_limit, seed=1, fixed_length=True)
     w = RolloutWorker(env, mac, args)
