@@ -101,7 +101,11 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
 // them (s_waitcnt vmcnt(0)) before the barrier that ends the gate phase: that team has the fewer row tiles (or as many), so
 // the wait - which also covers its activation stores - falls into its slack.  hipcc inserts no waits of its own around an LDS-DMA
 // (checked in the ISA); the two explicit ones below are what orders it.
-template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false, bool HALF = false, bool DMA = false>
+// W2L: the fc2 fragments live in LDS instead of 16 * AC registers (read once per row tile in the short fc2 phase).  The
+// registers pay for a wider observation prefetch (NL = 6): the activation-saving unroll of wide observations with two action
+// tiles (MMM2: O = 176, A = 18) was held to two row tiles per workgroup by its four prefetch registers - 640 row tiles ran as
+// 320 workgroups, two rounds on 256 CUs; with three tiles per workgroup it is 214 workgroups, one round.
+template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false, bool HALF = false, bool DMA = false, bool W2L = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   static_assert(!XS || (VL && !SAVE && NL == NLDW && !HALF), "XS: vector path, no saving");
   static_assert(!HALF || VL, "HALF: vector path");
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   int* rowrho = rowlen + rows;                               // [rows]: b*N + n
   int* xmask = rowrho + rows;                                // [T] (XS): step t is computed in full - the last step, or some row of this workgroup has ep_len - 1 == t
   int* ulds = xmask + ((a.T + 3) & ~3);                      // [2][rows] (DMA): actions fed at a step, by step parity
+  float* W2s = reinterpret_cast<float*>(ulds + 2 * rows);    // [AC][4][64] f32x4 (W2L): fc2 fragments
 
   // Rows past the end of the batch (last workgroup only) are CLAMPED to the last valid row: they load
   // the same inputs, compute the same values and store them to the same addresses, so no per-lane
@@ -343,8 +348,11 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     for (int ac = 0; ac < AC; ++ac) {
       int arow = 16 * ac + m; if (arow >= a.A) arow = a.A - 1;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        w2[ac][c] = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
+        if (W2L) { if (wave == 0) *reinterpret_cast<f32x4*>(W2s + ((ac * 4 + c) * 64 + lane) * 4) = wv; }
+        else w2[ac][c] = wv;
+      }
       bias2[ac] = a.b2[arow];
     }
     bias1 = a.b1[j];
@@ -537,7 +545,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       for (int c = 0; c < 4; ++c) {
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
 #pragma unroll
-        for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
+        for (int ac = 0; ac < AC; ++ac)
+          acc[ac] = mfma16x4(ah, W2L ? *reinterpret_cast<const f32x4*>(W2s + ((ac * 4 + c) * 64 + lane) * 4) : w2[ac][c], acc[ac]);
       }
       const i32x4 ri = *reinterpret_cast<const i32x4*>(rowidx + rt * 16 + 4 * q);
       const unsigned A4 = (unsigned)a.A * 4u;
@@ -1796,7 +1805,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16 + (((size_t)T * 4 + 15) & ~(size_t)15);   // fc1 fragments + step flags of the x-reusing variants (pipelined: 4; else one per step)
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
-  bool half = false, dma = false;
+  bool half = false, dma = false, w2l = false;
   static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
   // MARL_FWD_DMA=1 (read per call): the activation-saving unroll fills its observation tile by LDS-DMA (DMA kernels).  OFF by
   // default - measured slower (2s3z / 4096 envs 1.75 vs 1.62 ms; MMM2 / 1024 envs 2.98 ms at three row tiles per workgroup vs
@@ -1812,6 +1821,13 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
     // activation-saving unroll of wide observations: the observation tile goes through LDS-DMA, the workgroup is not held
     // to the rows its prefetch registers would cover (DMA kernels)
     if (saved && T > 1 && dma_mode == 1) { dma = true; cap2 = 8; }
+    // activation-saving unroll, wide observations, two action tiles: six prefetch registers, fc2 fragments in LDS (W2L kernels)
+    const bool w2l_off = getenv("MARL_FWD_W2L") && getenv("MARL_FWD_W2L")[0] == '0';      // A/B switch (read per call)
+    // (only where it makes the launch a single round of workgroups: beside the target unroll under the pair schedule -
+    // cu_budget 128 - three tiles per workgroup were SLOWER than two, 2.57 vs 2.24 ms at MMM2 / 1024 envs; alone on the chip
+    // 1.25 vs 1.75 ms, profiles/r03_mmm2_schedules.txt)
+    const int cap6 = (6 * FNT) / (16 * (O / 4));
+    if (saved && !dma && T > 1 && A > 16 && cap2 < want && cap2 < 8 && want <= cap6 && !w2l_off) { w2l = true; cap2 = cap6; }
     if (cap2 < want && cap2 < 8 && T > 1 && O % 8 == 0 && !saved) {  // wide observations: the registers hold one column
       half = true;                                                   // half of the tile at a time (HALF kernels).  Not the
       cap2 = (NLDW * FNT) / (16 * (O / 8));                          // activation-saving variant: hipcc cannot count its
@@ -1823,8 +1839,9 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   // a single step (rollout) is latency-bound: many small workgroups overlap their prologues better than
   // 256 big ones; a long unroll amortises the prologue and wants one workgroup per CU
   if (T == 1 && rt_cap > marl_fwd_rt_single) rt_cap = marl_fwd_rt_single;
-  a.RT = pick_rt(a.R, per_row, fixed, rt_cap, T > 1 ? cu_budget : 256);
-  const size_t lds = fixed + per_row * a.RT * 16;
+  const size_t fixed_k = fixed + (w2l ? (size_t)2 * 4 * 64 * 16 : 0);
+  a.RT = pick_rt(a.R, per_row, fixed_k, rt_cap, T > 1 ? cu_budget : 256);
+  const size_t lds = fixed_k + per_row * a.RT * 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const long rows = a.RT * 16;
   dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(FNT);
@@ -1833,7 +1850,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
   hipError_t e;
   // few row tiles per workgroup and a long unroll: the software-pipelined variant (one barrier per step)
-  if (a.vload && !dma && a.RT <= marl_fwd_pipe_max_rt && T >= 4 && (long)a.RT * 16 * (O / 4) <= (long)NLDW * FNT) {
+  if (a.vload && !dma && !w2l && a.RT <= marl_fwd_pipe_max_rt && T >= 4 && (long)a.RT * 16 * (O / 4) <= (long)NLDW * FNT) {
     const size_t per_row_p = (size_t)(2 * KS + 4 * HS) * 4 + 32;
     const size_t lds_p = fixed + per_row_p * a.RT * 16 + 64;
     if (lds_p <= 160 * 1024) {
@@ -1856,6 +1873,8 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const bool sv = saved != nullptr, vl = a.vload != 0;
   if (xs_req) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, true>;
+  } else if (w2l) {
+    fn = (const void*)agent_fwd_kernel<2, true, true, 6, false, false, false, true>;
   } else if (dma) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, true, true, NLDW, false, false, true> : (const void*)agent_fwd_kernel<2, true, true, NLDW, false, false, true>;
   } else if (vl && half) {

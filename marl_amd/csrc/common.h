@@ -9,15 +9,17 @@
 // ds_read_b128 per lane (row m, columns 4q..4q+3 of a 16-chunk): gfx950 serves that instruction in four groups of 16 lanes over
 // 64 banks, and a pitch of 8 (mod 16) floats is the one that spreads every group over all banks (a pitch of 4 mod 16 - the
 // usual "+4" - is a 2-way conflict on every such read; tools/lds_pitch.py).  The accumulator-layout accesses (row 4q+i, column
-// m: ds_read/write_b32) are 2-way at that pitch instead - free for the writes, and the reads are few.
+// m: ds_read/write_b32) are 2-way at that pitch instead - free for the writes, and the reads are few.  Time-neutral at the
+// headline shape (LDS is ~15 % busy there; A/B within the +-1.5 % run-to-run spread, profiles/r03_ab_variants.txt), it removes
+// the conflict cycles the counters show.
 #ifndef MARL_PAD_H
-#define MARL_PAD_H 4
+#define MARL_PAD_H 8
 #endif
 #ifndef MARL_PAD_K
-#define MARL_PAD_K 4
+#define MARL_PAD_K 8
 #endif
 #ifndef MARL_PAD_G
-#define MARL_PAD_G 4
+#define MARL_PAD_G 8
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

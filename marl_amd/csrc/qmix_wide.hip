@@ -17,6 +17,7 @@
 // as bf16) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation - "bf16 mixer with MFMA"; then the kernel is bound by
 // reading the states from HBM.  Everything else (mixing, gradients, the weight-gradient GEMM) stays fp32.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/marl_hip.h"
 
 namespace {
@@ -100,6 +101,18 @@ __global__ __launch_bounds__(256) void qmix_pack_kernel(PackArgs a) {
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 __device__ __forceinline__ float sum16(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+// sum over each aligned group of 16 lanes with DPP moves (no LDS crossbar round trips); every lane gets the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror: the other quad of each 8 lanes
+  v += dpp_f<0x140>(v);     // row_mirror: the other half of the row
   return v;
 }
 __device__ __forceinline__ float sum32(float v) { v = sum16(v); v += __shfl_xor(v, 16, 64); return v; }
@@ -558,6 +571,129 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward with bf16 operands and the weights RESIDENT in LDS (BASELINE config 5: "bf16 mixer with MFMA" - the kernel SURVEY 8d
+// prices against the HBM read of the states).  The streaming kernel above re-stages all 26 column tiles per 128-row block
+// (one barrier and one L2 round trip per k-chunk) and, at 216 registers, runs ONE workgroup per CU: every chunk waited for
+// its own loads - 88 us = 0.22 of the HBM rate with the matrix pipe 17 % busy.  Here the column tiles are split by
+// embedding half (e < 16 / e >= 16): a workgroup keeps the N + 3 tiles of ITS half - w1[n, half], b1, w2, h - for the whole
+// k range in LDS (13 tiles x 11 chunks x 1 KB = 143 KB at MMM2), loaded once, and then only streams states: no barrier in the
+// row loop, one load stream per wave, so the state fragments of the NEXT row tile (the whole k range: 22 x 16 B per lane)
+// are in flight while the current one is multiplied - each register pair is re-issued as soon as its chunk is consumed.
+// The mixing math of a half is wave local as before; a row's q_tot is the sum of its two halves, formed by one float atomic
+// each on a zeroed output (two addends: the result does not depend on their order).  The two workgroups of a row group sit
+// on the same XCD (blockIdx % 8), so the second read of a state row is an L2 hit.
+#ifndef RES_SB
+#define RES_SB 1
+#endif
+template <int NH, int KCT>
+__global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res_fwd_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int N = NH - 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q4 = lane >> 4, m = lane & 15;
+  const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3, h = rr & 1;
+  const int grp = (rr >> 1) * 8 + xcd, ngrp = (int)(gridDim.x >> 1);
+  float* Wl = smem;                                   // [NH][KCT][64] 8 x bf16
+  float* Qw = smem + NH * KCT * 256 + wave * 256;     // this wave's [16][16] q tile
+  float* Bl = smem + NH * KCT * 256 + NW * 256;       // [NH][16] biases of this half's columns
+  const f32x4* Wp4 = reinterpret_cast<const f32x4*>(a.Wp);
+  auto ct_of = [&](int j) { return j < N ? 2 * j + h : 2 * N + 2 * (j - N) + h; };      // w1[n, half] | b1 | w2 | h tiles of this half
+  for (int e = tid; e < NH * KCT * 64; e += 64 * NW) {
+    const int j = e / (KCT * 64), rem = e - j * (KCT * 64);
+    *reinterpret_cast<f32x4*>(Wl + (long)e * 4) = Wp4[(long)ct_of(j) * (KCT * 64) + rem];
+  }
+  if (tid < NH * 16) Bl[tid] = a.Bc[16 * ct_of(tid >> 4) + (tid & 15)];
+  const float wb2 = a.wb2[16 * h + m];
+  const float bb2 = h == 0 ? a.bb2[0] : 0.f;          // added once per row (by the first half)
+  __syncthreads();
+
+  const long tiles = (a.rows + 15) >> 4;
+  const long per = (tiles + ngrp - 1) / ngrp;
+  const long t_begin = (long)grp * per;
+  const long t_end = t_begin + per < tiles ? t_begin + per : tiles;
+  long tile = t_begin + wave;
+  if (tile >= t_end) return;
+  const int S4x4 = ((a.S + 3) >> 2) * 4;              // readable floats of a state row
+  // fragment loads: chunk kc, half hf = 4 floats at column 32 kc + 8 q + 4 hf - an immediate offset from (row + 8 q); only
+  // the LAST chunk can run past the row: its two offsets are clamped into it (the weights of columns >= S are zero)
+  const int kl0 = (32 * (KCT - 1) + 8 * q4 < S4x4 ? 32 * (KCT - 1) + 8 * q4 : S4x4 - 4) - 8 * q4;
+  const int kl1 = (32 * (KCT - 1) + 8 * q4 + 4 < S4x4 ? 32 * (KCT - 1) + 8 * q4 + 4 : S4x4 - 4) - 8 * q4;
+  auto kof = [&](int kc, int hf) { return kc < KCT - 1 ? 32 * kc + 4 * hf : (hf ? kl1 : kl0); };
+  auto srow_of = [&](long tl) -> const float* {
+    long row = tl * 16 + m;
+    if (row > a.rows - 1) row = a.rows - 1;
+    const ConcatRow cr = concat_row(a.s, row);
+    return a.s.p0 + cr.r0 * a.s.ld0 + 8 * q4;
+  };
+  f32x4 st[KCT][2];
+  const float* srow = srow_of(tile);
+#pragma unroll
+  for (int kc = 0; kc < KCT; ++kc) {
+    st[kc][0] = *reinterpret_cast<const f32x4*>(srow + kof(kc, 0));
+    st[kc][1] = *reinterpret_cast<const f32x4*>(srow + kof(kc, 1));
+  }
+  // the row address of the tile after next is resolved a tile ahead of the loads that use it (episode map: a dependent load)
+  const float* srow_n = srow_of(tile + NW < t_end ? tile + NW : tile);
+  for (; tile < t_end; tile += NW) {
+    const long t2 = tile + 2 * NW < t_end ? tile + 2 * NW : (tile + NW < t_end ? tile + NW : tile);
+    const float* srow_n2 = srow_of(t2);
+    // q of this wave's 16 rows (issued first: consumed in the epilogue, when it is the oldest load in flight)
+    float qv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int e = lane + 64 * i; if (e > 16 * N - 1) e = 16 * N - 1;
+      long row = tile * 16 + e / N; if (row > a.rows - 1) row = a.rows - 1;
+      qv[i] = a.q[row * N + e % N];
+    }
+    f32x4 acc[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) { const float b = Bl[16 * j + m]; acc[j] = (f32x4){b, b, b, b}; }
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc) {
+      bf16x8_t a8;
+      const bf16x4_t lo = __builtin_convertvector(st[kc][0], bf16x4_t), hi = __builtin_convertvector(st[kc][1], bf16x4_t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a8[i] = lo[i]; a8[4 + i] = hi[i]; }
+      // this chunk's registers are free: the same chunk of the next row tile goes into them (unconditional, clamped)
+      st[kc][0] = *reinterpret_cast<const f32x4*>(srow_n + kof(kc, 0));
+      st[kc][1] = *reinterpret_cast<const f32x4*>(srow_n + kof(kc, 1));
+      const float* wl = Wl + (kc * 64 + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        const bf16x8_t w8 = *reinterpret_cast<const bf16x8_t*>(wl + j * (KCT * 256));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, w8, acc[j], 0, 0, 0);
+      }
+      if (RES_SB) __builtin_amdgcn_sched_barrier(0);      // (keeps the chunk order: loads of the next tile issued chunk by chunk)
+    }
+    // ---- mixing of this half, wave local: acc[j][i] = row 4 q + i, embedding unit 16 h + m
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = lane + 64 * i;
+      if (e < 16 * N) Qw[(e / N) * 16 + e % N] = qv[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes (no other wave touches Qw)
+    const float* qrow = Qw + 4 * q4 * 16;
+    const long rbase = tile * 16 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // the row's q values: three 16-byte LDS reads (same address in all 16 lanes of the row group: a broadcast)
+      f32x4 qa[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qrow + i * 16 + 4 * u);
+      float pa = 0.f;
+#pragma unroll
+      for (int n = 0; n < N; ++n) pa += qa[n >> 2][n & 3] * fabsf(acc[n][i]);
+      const float ae = pa + acc[N][i];
+      const float ex = __expf(ae);
+      const float hid = ae > 0.f ? ae : ex - 1.f;                         // elu, alpha = 1
+      const float t = row_sum16(hid * fabsf(acc[N + 1][i]) + fmaxf(acc[N + 2][i], 0.f) * wb2);
+      if (m == 0 && rbase + i < a.rows) atomicAdd(a.q_tot + rbase + i, t + bb2);
+    }
+    srow_n = srow_n2;
+  }
+}
+
 struct WideRedArgs {
   const float* ws; const float* slab2; int nslab, nwg, N, S, C, KT;
   float *dW[4], *dB[4], *dwb2, *dbb2;
@@ -681,6 +817,20 @@ extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t
   if (rc) return rc;
   a.s = state_src(s); a.q = q; a.q_tot = q_tot; a.rows = rows;
   const unsigned grid = grid_for(rows);
+  // bf16, 10 agents, <= 11 k-chunks (MMM2) and enough row tiles for 128 row groups: the resident-weights kernel
+  const bool res_off = getenv("MARL_WIDE_RES") && getenv("MARL_WIDE_RES")[0] == '0';      // A/B switch (read per call)
+  if (bf && N == 10 && a.KC == 11 && rows >= 128L * 16 * 16 && !res_off) {
+    const size_t lds = (size_t)(13 * 11 * 256 + NW * 256 + 13 * 16) * 4;
+    hipError_t e = hipMemsetAsync(q_tot, 0, (size_t)rows * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)qmix_wide_res_fwd_kernel<13, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    void* kargs[] = {(void*)&a};
+    e = hipLaunchKernel((const void*)qmix_wide_res_fwd_kernel<13, 11>, dim3(256), dim3(64 * NW), kargs, lds, st);
+    if (e != hipSuccess) return (int)e;
+    MARL_CHECK_LAUNCH();
+    return 0;
+  }
   if (a.NCT == NCTM) return bf ? launch_main(qmix_wide_kernel<false, true, NCTM>, a, grid, true, st)
                                : launch_main(qmix_wide_kernel<false, false, NCTM>, a, grid, false, st);
   return bf ? launch_main(qmix_wide_kernel<false, true, 0>, a, grid, true, st)

@@ -436,12 +436,13 @@ def test_double_q_unroll_reuses_input_side_work_bitwise(dev, shape, B, T, cus):
 
 @pytest.mark.parametrize("shape,B,T,cus", [("2s3z", 37, 5, 4), ("2s3z", 300, 7, 16), ("3s5z", 40, 4, 8), ("MMM2", 60, 4, 16),
                                             ("MMM2", 1024, 3, 256), ("MMM2", 30, 5, 128)])
-def test_saving_unroll_lds_dma_equals_register_prefetch_bitwise(dev, shape, B, T, cus):
-    """The activation-saving unroll with its observation tile (and the fed-back actions) filled by LDS-DMA
-    (MARL_FWD_DMA=1; the default for wide observations - MMM2 - where the prefetch registers would cap the workgroup at
-    two row tiles) == the same unroll through prefetch registers (MARL_FWD_DMA=0), bit for bit: q, the final hidden state,
-    all six saved planes and the input-side gate sums; ragged episode lengths (rows past their end feed zeros), an
-    episode map, (T+1)-slot storage with the shifted last action, a partial last row tile."""
+def test_saving_unroll_variants_equal_register_prefetch_bitwise(dev, shape, B, T, cus):
+    """Variants of the activation-saving unroll == the plain four-register prefetch kernel, bit for bit (q, the final hidden
+    state, all six saved planes and the input-side gate sums; ragged episode lengths - rows past their end feed zeros -, an
+    episode map, (T+1)-slot storage with the shifted last action, a partial last row tile):
+      * MARL_FWD_DMA=1: observation tile and fed-back actions filled by LDS-DMA (opt-in experiment);
+      * the default for wide observations with two action tiles (MMM2 at >= 3 row tiles per workgroup: six prefetch
+        registers, fc2 fragments in LDS) against MARL_FWD_W2L=0."""
     import os
     from marl_amd import ops
     args, p_np, _, _, _ = _agent_case(shape, B, T, dev)
@@ -459,8 +460,9 @@ def test_saving_unroll_lds_dma_equals_register_prefetch_bitwise(dev, shape, B, T
     outs = {}
     old = os.environ.get("MARL_FWD_DMA")
     try:
-        for mode in ("0", "1"):
-            os.environ["MARL_FWD_DMA"] = mode
+        for mode in ("0", "1", "w2l"):
+            os.environ["MARL_FWD_DMA"] = "0" if mode == "w2l" else mode
+            os.environ["MARL_FWD_W2L"] = "1" if mode == "w2l" else "0"
             for t0, ut0 in ((0, -1), (1, 0)):
                 saved = torch.zeros(ops.saved_shape(T, B, N), device=dev)
                 gi = torch.zeros(ops.saved_shape(T, B, N, planes=3), device=dev)
@@ -471,17 +473,19 @@ def test_saving_unroll_lds_dma_equals_register_prefetch_bitwise(dev, shape, B, T
                 planes = [ops.saved_plane(saved, k, rows).cpu() for k in range(6)] + [ops.saved_plane(gi, k, rows).cpu() for k in range(3)]
                 outs[(mode, t0)] = (q.cpu(), hl.cpu(), planes)
     finally:
+        os.environ.pop("MARL_FWD_W2L", None)
         if old is None:
             os.environ.pop("MARL_FWD_DMA", None)
         else:
             os.environ["MARL_FWD_DMA"] = old
     for t0 in (0, 1):
-        a, b = outs[("0", t0)], outs[("1", t0)]
-        assert torch.isfinite(a[0]).all()
-        assert torch.equal(a[0], b[0]), "q (t0=%d)" % t0
-        assert torch.equal(a[1], b[1]), "h_last"
-        for k, (x, y) in enumerate(zip(a[2], b[2])):
-            assert torch.equal(x, y), "plane %d (t0=%d)" % (k, t0)
+        for other in ("1", "w2l"):
+            a, b = outs[("0", t0)], outs[(other, t0)]
+            assert torch.isfinite(a[0]).all()
+            assert torch.equal(a[0], b[0]), "%s: q (t0=%d)" % (other, t0)
+            assert torch.equal(a[1], b[1]), "%s: h_last" % other
+            for k, (x, y) in enumerate(zip(a[2], b[2])):
+                assert torch.equal(x, y), "%s: plane %d (t0=%d)" % (other, k, t0)
 
 
 @pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
@@ -905,6 +909,49 @@ def _qmix_reference(P, s, q, gq, N, E, bf16):
     qt = (hid * lin("w2").abs()).sum(1) + F.linear(torch.relu(lin("h")), P["b2_w"], P["b2_b"]).squeeze(1)
     (qt * gq).sum().backward()
     return qt
+
+
+@pytest.mark.parametrize("R", [40007, 32768])
+def test_qmix_wide_resident_forward(dev, R):
+    """bf16 forward with the weights resident in LDS (qmix_wide_res_fwd_kernel: MMM2 shape, >= 32 768 rows; each row's q_tot is
+    the sum of two embedding halves computed by two workgroups) vs torch-CPU with the hypernet operands rounded to bf16,
+    and vs the streaming kernel (MARL_WIDE_RES=0) - the two differ only in the order of the final sums."""
+    import os
+    from marl_amd import ops
+    N, S, E = 10, 322, 32
+    g = torch.Generator().manual_seed(R)
+    outs = {"w1": N * E, "b1": E, "w2": E, "h": E}
+    P = {}
+    for k in outs:
+        P[k] = torch.randn(outs[k], S, generator=g) * 0.2
+        P[k + "_b"] = torch.randn(outs[k], generator=g) * 0.2
+    P["b2_w"] = torch.randn(1, E, generator=g)
+    P["b2_b"] = torch.randn(1, generator=g)
+    s = torch.randn(R, S, generator=g)
+    q = torch.randn(R, N, generator=g)
+    with torch.no_grad():
+        rnd = lambda t: t.bfloat16().float()
+        hy = {k: F.linear(rnd(s), rnd(P[k]), P[k + "_b"]) for k in outs}
+        hid = F.elu(torch.bmm(q.view(R, 1, N), hy["w1"].abs().view(R, N, E)).view(R, E) + hy["b1"])
+        qt = (hid * hy["w2"].abs()).sum(1) + F.linear(F.relu(hy["h"]), P["b2_w"], P["b2_b"]).view(R)
+    Wd = {k: cu(v, dev) for k, v in P.items()}
+    ld = (S + 3) // 4 * 4
+    sd = torch.zeros(R, ld, device=dev)
+    sd[:, :S] = cu(s, dev)
+    xs = ops.src(sd[:, :S])
+    qd = cu(q, dev)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["MARL_WIDE_RES"] = mode
+            out = torch.full((R,), 9.0, device=dev)
+            ops.qmix_wide_fwd(ops.qmix_weights(Wd), xs, qd, out, R, N, S, E, bf16=True)
+            res[mode] = out.cpu()
+    finally:
+        os.environ.pop("MARL_WIDE_RES", None)
+    scale = max(1.0, float(qt.abs().max()))
+    close(res["1"], qt, 1e-4 * scale, 1e-4, msg="q_tot (resident weights)")
+    close(res["1"], res["0"], 2e-6 * scale, 1e-5, msg="resident vs streaming kernel")
 
 
 @pytest.mark.parametrize("R,N,S,bf16", [(333, 10, 322, False), (64, 10, 322, False), (5000, 10, 322, False), (100, 3, 50, False),

@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qtran -o p -
 # config 5: QMIX, MMM2, 1024 envs (8192 / 8 GPUs), fp32 and bf16 mixer: kernel stats + the bench lines (HBM-bound roofline of the mixer)
 for DT in fp32 bf16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_mmm2_$DT -o p -- python3 tools/prof_learner.py --alg qmix --shape MMM2 --envs 1024 --warmup 3 --updates 10 --mixer-dtype $DT > $OUT/${TAG}_mmm2_$DT.log 2>&1
-  python3 bench.py --shape MMM2 --envs 1024 --mixer-dtype $DT --roofline-kernel mixer --no-cpu-baseline --steps 10 --warmup 3 > $OUT/${TAG}_bench_mmm2_$DT.log 2>&1
+  python3 bench.py --shape MMM2 --envs 1024 --mixer-dtype $DT --roofline-kernel mixer --no-cpu-baseline --no-configs --steps 10 --warmup 3 > $OUT/${TAG}_bench_mmm2_$DT.log 2>&1
   grep '^{"metric"' $OUT/${TAG}_bench_mmm2_$DT.log | tail -1 > $OUT/${TAG}_bench_mmm2_${DT}_line.json
 done
 # HBM traffic of the wide-state QMIX kernels (separate PMC passes, --kernel-trace only)
@@ -27,7 +27,7 @@ done
   echo -n "qmix MMM2 envs=1024 mixer bf16 : "; python3 tools/prof_learner.py --alg qmix --shape MMM2 --envs 1024 --warmup 5 --updates 20 --mixer-dtype bf16 2>/dev/null | grep updates ) > $OUT/${TAG}_learner_rates.txt
 # single-GPU step times at the shard sizes of the 2 / 4 / 8-GPU strong-scaling runs
 ( for E in 512 1024 2048 4096; do
-    python3 bench.py --envs $E --steps 20 --warmup 6 --no-cpu-baseline $SHARD_FLAGS 2>/dev/null | grep '^{"metric"' | python3 -c "
+    python3 bench.py --envs $E --steps 20 --warmup 6 --no-cpu-baseline --no-configs $SHARD_FLAGS 2>/dev/null | grep '^{"metric"' | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('envs_per_gpu=%d : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['global_envs'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"
   done ) > $OUT/${TAG}_shard_steps.txt
