@@ -523,6 +523,22 @@ def main():
     for i in range(o.leg_iters):
         rs += worker.generate_episodes(E)[3]
     barrier(); t_roll = (time.perf_counter() - t1) / o.leg_iters
+    # the same pipeline step with the REFERENCE's host semantics: every rollout's statistics and every update's loss are read
+    # back at once (runner.py:85-98 uses both immediately); same device work, the host waits for it twice per step
+    t_block = None
+    if not o.blocking_loss:
+        args.lazy_loss = False
+        learner.loss_readback.lazy = False
+        blk_steps = 0
+        barrier(); t1 = time.perf_counter()
+        for i in range(o.leg_iters):
+            episodes, _, _, st_ = worker.generate_episodes(E)
+            buf.store_episode(episodes)
+            loss_b = float(learner.train(buf.sample(min(buf.current_size, args.batch_size)), train_steps[0]))
+            train_steps[0] += 1
+            blk_steps += st_
+        barrier(); t_block = (time.perf_counter() - t1) / o.leg_iters
+        blk_rate = blk_steps / (t_block * o.leg_iters)
     gc.enable()
 
     if rank == 0:
@@ -606,6 +622,10 @@ def main():
             "learner_transitions_per_sec": o.envs * T / t_learn,
             "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
             "last_loss": float(loss), "loss_readback": "blocking" if o.blocking_loss else "deferred",
+            "blocking_readbacks": None if t_block is None else {
+                "what": "the same step with the reference's host semantics (loss and rollout statistics read back every step); "
+                        "per-rank figure of rank 0, after the timed region", "ms_per_step": t_block * 1e3,
+                "env_steps_per_sec_per_gpu": blk_rate},
             "roofline": roof, "rccl": rccl,
             "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included)",
                                 "flop_per_transition": fpt, "achieved": upd_tflops, "peak": PEAK_F32_TFLOPS,

@@ -375,6 +375,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const unsigned jb = (unsigned)j * 4u;
   float* Hp = Ha;
   float* Hn = Hb;
+#ifdef MARL_PRIO_YOUNG
+  if (wave >= 4) __builtin_amdgcn_s_setprio(MARL_PRIO_YOUNG);      // A/B: static priority for the younger half of the workgroup
+#endif
   ST_DECL(6);
   for (int t = 0; t < a.T; ++t) {
     const unsigned trow = (unsigned)t * (unsigned)a.N;
@@ -1227,6 +1230,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 
   int par = 0;
   bool c0A_carry = true;             // where a team WITHOUT phase-B tiles finds phase-C tile 0 of the coming step
+#ifdef MARL_PRIO_YOUNG
+  if (wave >= 4) __builtin_amdgcn_s_setprio(MARL_PRIO_YOUNG);      // A/B: static priority for the younger half of the workgroup
+#endif
   ST_DECL(5);
   for (int t = a.T - 1; t >= 0; --t, par ^= 1) {
     float* DQ = par ? DQ1 : DQ0;
