@@ -594,14 +594,27 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res_fwd_kernel(WideArgs 
   const int q4 = lane >> 4, m = lane & 15;
   const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3, h = rr & 1;
   const int grp = (rr >> 1) * 8 + xcd, ngrp = (int)(gridDim.x >> 1);
+  ST_DECL(5);
   float* Wl = smem;                                   // [NH][KCT][64] 8 x bf16
   float* Qw = smem + NH * KCT * 256 + wave * 256;     // this wave's [16][16] q tile
   float* Bl = smem + NH * KCT * 256 + NW * 256;       // [NH][16] biases of this half's columns
   const f32x4* Wp4 = reinterpret_cast<const f32x4*>(a.Wp);
   auto ct_of = [&](int j) { return j < N ? 2 * j + h : 2 * N + 2 * (j - N) + h; };      // w1[n, half] | b1 | w2 | h tiles of this half
-  for (int e = tid; e < NH * KCT * 64; e += 64 * NW) {
-    const int j = e / (KCT * 64), rem = e - j * (KCT * 64);
-    *reinterpret_cast<f32x4*>(Wl + (long)e * 4) = Wp4[(long)ct_of(j) * (KCT * 64) + rem];
+  {
+    // all of a thread's loads in flight before the first LDS store (a load - wait - store loop serialised 18 memory round trips)
+    constexpr int NIT = (NH * KCT * 64 + 64 * NW - 1) / (64 * NW);
+    f32x4 wv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int e = tid + 64 * NW * it; if (e > NH * KCT * 64 - 1) e = NH * KCT * 64 - 1;
+      const int j = e / (KCT * 64), rem = e - j * (KCT * 64);
+      wv[it] = Wp4[(long)ct_of(j) * (KCT * 64) + rem];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 64 * NW * it;
+      if (e < NH * KCT * 64) *reinterpret_cast<f32x4*>(Wl + (long)e * 4) = wv[it];
+    }
   }
   if (tid < NH * 16) Bl[tid] = a.Bc[16 * ct_of(tid >> 4) + (tid & 15)];
   const float wb2 = a.wb2[16 * h + m];
@@ -635,6 +648,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res_fwd_kernel(WideArgs 
   }
   // the row address of the tile after next is resolved a tile ahead of the loads that use it (episode map: a dependent load)
   const float* srow_n = srow_of(tile + NW < t_end ? tile + NW : tile);
+  ST_MARK(4);       // prologue (weights -> LDS, first loads)
   for (; tile < t_end; tile += NW) {
     const long t2 = tile + 2 * NW < t_end ? tile + 2 * NW : (tile + NW < t_end ? tile + NW : tile);
     const float* srow_n2 = srow_of(t2);
@@ -649,6 +663,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res_fwd_kernel(WideArgs 
     f32x4 acc[NH];
 #pragma unroll
     for (int j = 0; j < NH; ++j) { const float b = Bl[16 * j + m]; acc[j] = (f32x4){b, b, b, b}; }
+    ST_MARK(0);
 #pragma unroll
     for (int kc = 0; kc < KCT; ++kc) {
       bf16x8_t a8;
@@ -666,15 +681,18 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res_fwd_kernel(WideArgs 
       }
       if (RES_SB) __builtin_amdgcn_sched_barrier(0);      // (keeps the chunk order: loads of the next tile issued chunk by chunk)
     }
+    ST_MARK(1);
     // ---- mixing of this half, wave local: acc[j][i] = row 4 q + i, embedding unit 16 h + m
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int e = lane + 64 * i;
       if (e < 16 * N) Qw[(e / N) * 16 + e % N] = qv[i];
     }
+    ST_MARK(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes (no other wave touches Qw)
     const float* qrow = Qw + 4 * q4 * 16;
     const long rbase = tile * 16 + 4 * q4;
+    float tsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // the row's q values: three 16-byte LDS reads (same address in all 16 lanes of the row group: a broadcast)
@@ -687,11 +705,192 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res_fwd_kernel(WideArgs 
       const float ae = pa + acc[N][i];
       const float ex = __expf(ae);
       const float hid = ae > 0.f ? ae : ex - 1.f;                         // elu, alpha = 1
-      const float t = row_sum16(hid * fabsf(acc[N + 1][i]) + fmaxf(acc[N + 2][i], 0.f) * wb2);
-      if (m == 0 && rbase + i < a.rows) atomicAdd(a.q_tot + rbase + i, t + bb2);
+      tsum[i] = row_sum16(hid * fabsf(acc[N + 1][i]) + fmaxf(acc[N + 2][i], 0.f) * wb2) + bb2;
+    }
+    if (m == 0) {                                    // one divergent region for the four rows' atomics
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rbase + i < a.rows) atomicAdd(a.q_tot + rbase + i, tsum[i]);
     }
     srow_n = srow_n2;
+    ST_MARK(3);
   }
+  ST_DUMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same forward on 32-row tiles (v_mfma_f32_32x32x16_bf16) in TRANSPOSED form: out^T[column][row] = W[column][k] s^T[k][row].
+// Why: with 16-row tiles every 1 KB weight-fragment read from LDS feeds ONE MFMA, so the resident kernel above needs the LDS's full
+// 256 B/clk just to keep the bf16 pipe busy (stamps: 47 cycles per MFMA); a 32 x 32 x 16 MFMA does twice the multiplies per
+// fragment byte.  Transposed, because the 32 x 32 accumulator has its COLUMN index on the lane and its row index in the 16
+// registers: with the batch row on the lane, everything a row's mixing needs - the 32 hypernet columns of a tile - sits in
+// that lane's registers (two lanes per row: l and l + 32 hold eight embedding units each), so the sums over agents and
+// embedding units are plain register arithmetic and one cross-lane add; q is loaded straight into registers, no LDS tile.
+// Column tiles of an embedding half (16 units): five tiles [agent 2t | agent 2t+1], one [b1 | w2], one [h | 0] - 7 x 21
+// k-chunks x 1 KB = 147 KB of bf16 fragments, written by the workgroup itself from the fp32 parameters (no pack launch).
+struct Wide32Args {
+  const float* W[4]; const float* Bv[4];      // w1 (N*E, S) | b1 (E, S) | w2 (E, S) | h (E, S) and their biases
+  float* Wp;                                  // packed bf16 fragments [2 halves][7][KCT][64] x 16 B (pack kernel -> main kernel)
+  const float *wb2, *bb2;
+  ConcatSrc s;
+  const float* q;
+  float* q_tot;
+  long rows;
+  int S;
+};
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// column i of tile t of embedding half eh -> (segment, row of the segment), or none
+__device__ __forceinline__ void wide32_col(int eh, int t, int i, int& seg, int& row) {
+  const int g = i >> 4, e = 16 * eh + (i & 15);
+  if (t < 5) { seg = 0; row = (2 * t + g) * E + e; }
+  else if (t == 5) { seg = g ? 2 : 1; row = e; }
+  else { seg = g ? -1 : 3; row = e; }
+}
+// fp32 parameters -> bf16 A fragments of the 32 x 32 x 16 MFMA: item (half, tile, chunk, lane l) = W[column l & 31][16 kc + 8 (l >> 5) + 0..7]
+__global__ __launch_bounds__(256) void qmix_pack32_kernel(Wide32Args a, int KCT) {
+  const long total = 2L * 7 * KCT * 64;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int l = (int)(e & 63);
+    const long tc = e >> 6;
+    const int kc = (int)(tc % KCT), t = (int)((tc / KCT) % 7), eh = (int)(tc / (7L * KCT));
+    int seg, row;
+    wide32_col(eh, t, l & 31, seg, row);
+    const int k0 = 16 * kc + 8 * (l >> 5);
+    bf16x8_t v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (__bf16)((seg >= 0 && k0 + u < a.S) ? a.W[seg][(long)row * a.S + k0 + u] : 0.f);
+    *reinterpret_cast<bf16x8_t*>(a.Wp + e * 4) = v;
+  }
+}
+
+template <int KCT /* 16-wide k chunks */, int PF /* chunks of state prefetch in flight; KCT % PF == 0 */>
+__global__ __launch_bounds__(64 * NW, 2) void qmix_wide_res32_fwd_kernel(Wide32Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int N = 10, NT = 7;
+  static_assert(KCT % PF == 0, "the prefetch slots rotate with the chunk index");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hk = lane >> 5;
+  const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3, eh = rr & 1;          // eh: embedding half of this workgroup
+  const int grp = (rr >> 1) * 8 + xcd, ngrp = (int)(gridDim.x >> 1);
+  ST_DECL(5);
+  float* Wl = smem;                                   // [NT][KCT][64] 8 x bf16 (A fragments: lane l = column l & 31, k = 8 (l >> 5) ..)
+  float* Bl = smem + NT * KCT * 256;                  // [NT][2][16]: bias of the column a lane half holds in register r
+  {
+    // this half's fragment image (written by qmix_pack32_kernel): all of a thread's loads in flight before the first LDS store
+    constexpr int NIT = (NT * KCT * 64 + 64 * NW - 1) / (64 * NW);
+    const f32x4* Wp4 = reinterpret_cast<const f32x4*>(a.Wp) + (long)eh * (NT * KCT * 64);
+    f32x4 wv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int e = tid + 64 * NW * it; if (e > NT * KCT * 64 - 1) e = NT * KCT * 64 - 1;
+      wv[it] = Wp4[e];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 64 * NW * it;
+      if (e < NT * KCT * 64) *reinterpret_cast<f32x4*>(Wl + (long)e * 4) = wv[it];
+    }
+  }
+  if (tid < NT * 32) {
+    const int t = tid >> 5, h2 = (tid >> 4) & 1, r = tid & 15;
+    int seg, row;
+    wide32_col(eh, t, (r & 3) + 8 * (r >> 2) + 4 * h2, seg, row);
+    Bl[tid] = seg >= 0 ? a.Bv[seg][row] : 0.f;
+  }
+  // hyper_b2.2 weights of the eight embedding units of this lane half: unit u -> e = 16 eh + (u & 3) + 8 (u >> 2) + 4 hk
+  float wb2v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) wb2v[u] = a.wb2[16 * eh + (u & 3) + 8 * (u >> 2) + 4 * hk];
+  const float bb2 = eh == 0 ? a.bb2[0] : 0.f;
+  __syncthreads();
+
+  const long tiles = (a.rows + 31) >> 5;
+  const long per = (tiles + ngrp - 1) / ngrp;
+  const long t_begin = (long)grp * per;
+  const long t_end = t_begin + per < tiles ? t_begin + per : tiles;
+  long tile = t_begin + wave;
+  if (tile >= t_end) return;
+  const int S4x4 = ((a.S + 3) >> 2) * 4;
+  // B fragment of chunk kc: 8 floats at column 16 kc + 8 hk of the lane's row - two 16-byte loads at immediate offsets from
+  // (row + 8 hk); only the last chunk can run past the row: clamped into it (the weights of columns >= S are zero)
+  const int kb = 16 * (KCT - 1) + 8 * hk;
+  const int kl0 = (kb < S4x4 ? kb : S4x4 - 4) - 8 * hk, kl1 = (kb + 4 < S4x4 ? kb + 4 : S4x4 - 4) - 8 * hk;
+  auto kof = [&](int kc, int hf) { return kc < KCT - 1 ? 16 * kc + 4 * hf : (hf ? kl1 : kl0); };
+  auto rowc_of = [&](long tl) { long row = tl * 32 + j; return row > a.rows - 1 ? a.rows - 1 : row; };
+  auto srow_of = [&](long tl) -> const float* {
+    const ConcatRow cr = concat_row(a.s, rowc_of(tl));
+    return a.s.p0 + cr.r0 * a.s.ld0 + 8 * hk;
+  };
+  f32x4 st[PF][2];
+  const float* srow = srow_of(tile);
+#pragma unroll
+  for (int kc = 0; kc < PF; ++kc) {
+    st[kc][0] = *reinterpret_cast<const f32x4*>(srow + kof(kc, 0));
+    st[kc][1] = *reinterpret_cast<const f32x4*>(srow + kof(kc, 1));
+  }
+  const float* srow_n = srow_of(tile + NW < t_end ? tile + NW : tile);
+  ST_MARK(4);       // prologue (weights -> LDS, first loads)
+  for (; tile < t_end; tile += NW) {
+    const long t2 = tile + 2 * NW < t_end ? tile + 2 * NW : (tile + NW < t_end ? tile + NW : tile);
+    const float* srow_n2 = srow_of(t2);            // (episode map: a dependent load - resolved a tile ahead of its use)
+    const long rowc = rowc_of(tile);
+    // q of this lane's row: floats 0-3 | 4-7 | 6-9 (three in-row 16-byte loads), consumed in the epilogue
+    const float* qp = a.q + rowc * N;
+    const f32x4 qA = *reinterpret_cast<const f32x4*>(qp), qB = *reinterpret_cast<const f32x4*>(qp + 4);
+    const f32x4 qC = *reinterpret_cast<const f32x4*>(qp + 6);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(Bl + (t * 2 + hk) * 16 + 4 * r4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][4 * r4 + i] = b[i];
+      }
+    }
+    ST_MARK(0);
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc) {
+      bf16x8_t b8;
+      const bf16x4_t lo = __builtin_convertvector(st[kc % PF][0], bf16x4_t), hi = __builtin_convertvector(st[kc % PF][1], bf16x4_t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { b8[i] = lo[i]; b8[4 + i] = hi[i]; }
+      // the slot is free: chunk kc + PF goes into it - of this tile, or of the next one (unconditional, clamped)
+      const float* nsrc = kc + PF < KCT ? srow : srow_n;
+      const int nkc = kc + PF < KCT ? kc + PF : kc + PF - KCT;
+      st[kc % PF][0] = *reinterpret_cast<const f32x4*>(nsrc + kof(nkc, 0));
+      st[kc % PF][1] = *reinterpret_cast<const f32x4*>(nsrc + kof(nkc, 1));
+      const float* wl = Wl + (kc * 64 + lane) * 4;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(wl + t * (KCT * 256));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ST_MARK(1);
+    // ---- mixing, in registers: register u (first 16 columns of a tile) / 8 + u (second 16) = embedding unit u of this lane half
+    float tot = 0.f;
+    const float qv[N] = {qA[0], qA[1], qA[2], qA[3], qB[0], qB[1], qB[2], qB[3], qC[2], qC[3]};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float pa = 0.f;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) pa += qv[2 * t] * fabsf(acc[t][u]) + qv[2 * t + 1] * fabsf(acc[t][8 + u]);
+      const float ae = pa + acc[5][u];
+      const float ex = __expf(ae);
+      const float hid = ae > 0.f ? ae : ex - 1.f;                         // elu, alpha = 1
+      tot += hid * fabsf(acc[5][8 + u]) + fmaxf(acc[6][u], 0.f) * wb2v[u];
+    }
+    ST_MARK(2);
+    tot += __shfl_xor(tot, 32, 64);                                       // the row's other eight units of this half
+    if (hk == 0 && tile * 32 + j < a.rows) atomicAdd(a.q_tot + tile * 32 + j, tot + bb2);
+    srow = srow_n;
+    srow_n = srow_n2;
+    ST_MARK(3);
+  }
+  ST_DUMP(5);
 }
 
 struct WideRedArgs {
@@ -793,6 +992,8 @@ int launch_main(K fn, const WideArgs& a, unsigned grid, bool bf, hipStream_t st)
 
 }  // namespace
 
+ST_DEFINE_SETTER(marl_debug_stamps_wide)
+
 extern "C" int marl_qmix_wide_supported(int N, int S, int Eq) { return supported(N, S, Eq) ? 1 : 0; }
 
 extern "C" size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward) {
@@ -812,13 +1013,34 @@ extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t
   if (ws_bytes < marl_qmix_wide_workspace(rows, N, S, 0) || (reinterpret_cast<uintptr_t>(ws) & 15)) return (int)hipErrorInvalidValue;
   const bool bf = (flags & 1) != 0;
   hipStream_t st = (hipStream_t)stream;
+  // bf16, 10 agents, 21 / 11 k-chunks (MMM2) and enough row tiles for 128 row groups: the resident-weights kernels
+  const bool res_off = getenv("MARL_WIDE_RES") && getenv("MARL_WIDE_RES")[0] == '0';      // A/B switches (read per call)
+  // (the 32-row-tile variant is opt-in: measured 65 us against 60 us for the 16-row one - both run their chunk loops with the
+  // bf16 pipe ~75 % busy, the 32 x 32 tiles pay 8 % padding and a longer dependent chain per tile)
+  const bool res32_on = getenv("MARL_WIDE_RES32") && getenv("MARL_WIDE_RES32")[0] == '1';
+  if (bf && N == 10 && (S + 15) / 16 == 21 && rows >= 128L * 16 * 16 && !res_off && res32_on) {
+    Wide32Args b = {};
+    b.W[0] = w->w1; b.Bv[0] = w->w1_b; b.W[1] = w->b1; b.Bv[1] = w->b1_b; b.W[2] = w->w2; b.Bv[2] = w->w2_b; b.W[3] = w->h; b.Bv[3] = w->h_b;
+    b.wb2 = w->b2_w; b.bb2 = w->b2_b; b.s = state_src(s); b.q = q; b.q_tot = q_tot; b.rows = rows; b.S = S;
+    b.Wp = ws;                                   // 2 x 7 x 21 KB = 294 KB of the workspace (packed_floats covers 26 x 21 KB)
+    const size_t lds = (size_t)(7 * 21 * 256 + 7 * 32) * 4;
+    hipLaunchKernelGGL(qmix_pack32_kernel, dim3(74), dim3(256), 0, st, b, 21);
+    MARL_CHECK_LAUNCH();
+    hipError_t e = hipMemsetAsync(q_tot, 0, (size_t)rows * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)qmix_wide_res32_fwd_kernel<21, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    void* kargs[] = {(void*)&b};
+    e = hipLaunchKernel((const void*)qmix_wide_res32_fwd_kernel<21, 7>, dim3(256), dim3(64 * NW), kargs, lds, st);
+    if (e != hipSuccess) return (int)e;
+    MARL_CHECK_LAUNCH();
+    return 0;
+  }
   WideArgs a = {};
   int rc = pack(w, N, S, bf, ws, st, a);
   if (rc) return rc;
   a.s = state_src(s); a.q = q; a.q_tot = q_tot; a.rows = rows;
   const unsigned grid = grid_for(rows);
-  // bf16, 10 agents, <= 11 k-chunks (MMM2) and enough row tiles for 128 row groups: the resident-weights kernel
-  const bool res_off = getenv("MARL_WIDE_RES") && getenv("MARL_WIDE_RES")[0] == '0';      // A/B switch (read per call)
   if (bf && N == 10 && a.KC == 11 && rows >= 128L * 16 * 16 && !res_off) {
     const size_t lds = (size_t)(13 * 11 * 256 + NW * 256 + 13 * 16) * 4;
     hipError_t e = hipMemsetAsync(q_tot, 0, (size_t)rows * sizeof(float), st);

@@ -942,16 +942,21 @@ def test_qmix_wide_resident_forward(dev, R):
     qd = cu(q, dev)
     res = {}
     try:
-        for mode in ("1", "0"):
-            os.environ["MARL_WIDE_RES"] = mode
+        # res16: 16-row tiles (the default); res32: 32-row tiles, transposed product, mixing in registers (opt-in); stream: the streaming kernel
+        for mode, env in (("res32", {"MARL_WIDE_RES32": "1"}), ("res16", {}), ("stream", {"MARL_WIDE_RES": "0"})):
+            for k in ("MARL_WIDE_RES", "MARL_WIDE_RES32"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
             out = torch.full((R,), 9.0, device=dev)
             ops.qmix_wide_fwd(ops.qmix_weights(Wd), xs, qd, out, R, N, S, E, bf16=True)
             res[mode] = out.cpu()
     finally:
-        os.environ.pop("MARL_WIDE_RES", None)
+        for k in ("MARL_WIDE_RES", "MARL_WIDE_RES32"):
+            os.environ.pop(k, None)
     scale = max(1.0, float(qt.abs().max()))
-    close(res["1"], qt, 1e-4 * scale, 1e-4, msg="q_tot (resident weights)")
-    close(res["1"], res["0"], 2e-6 * scale, 1e-5, msg="resident vs streaming kernel")
+    for mode in ("res32", "res16"):
+        close(res[mode], qt, 1e-4 * scale, 1e-4, msg="q_tot (%s)" % mode)
+        close(res[mode], res["stream"], 2e-6 * scale, 1e-5, msg="%s vs streaming kernel" % mode)
 
 
 @pytest.mark.parametrize("R,N,S,bf16", [(333, 10, 322, False), (64, 10, 322, False), (5000, 10, 322, False), (100, 3, 50, False),
