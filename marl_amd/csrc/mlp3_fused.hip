@@ -82,24 +82,47 @@ __device__ __forceinline__ void build_tab(int* tab, const ConcatSrc& x, int K1, 
 }
 
 // weight fragments (A operands), fragment-major: [(t * KCn + c) * 64 + lane] f32x4 = W[16t + m][16c + 4q + 0..3]
-__device__ __forceinline__ void stage_w(float* dst, const float* W, int ldw, int rows_valid, int K, int KCn, int NT_, int nthreads) {
-  for (int e = threadIdx.x; e < NT_ * KCn * 64; e += nthreads) {
+// (all of a thread's loads are issued - unconditionally, indices clamped - before its first LDS store: a load - mask - store
+// loop serialises one memory round trip per item, which at the small shards is a visible part of the launch)
+template <int NITEMS, int NTHR>
+__device__ __forceinline__ void stage_w(float* dst, const float* W, int ldw, int rows_valid, int K, int KCn) {
+  constexpr int NIT = (NITEMS + NTHR - 1) / NTHR;
+  f32x4 v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int e = threadIdx.x + NTHR * it; if (e > NITEMS - 1) e = NITEMS - 1;
+    const int l = e & 63, tc = e >> 6, t = tc / KCn, c = tc - t * KCn;
+    int n = 16 * t + (l & 15); if (n > rows_valid - 1) n = rows_valid - 1;
+    const int k0 = 16 * c + 4 * (l >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[it][i] = W[(long)n * ldw + (k0 + i < K ? k0 + i : K - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = threadIdx.x + NTHR * it;
     const int l = e & 63, tc = e >> 6, t = tc / KCn, c = tc - t * KCn;
     const int n = 16 * t + (l & 15), k0 = 16 * c + 4 * (l >> 4);
-    f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (n < rows_valid && k0 + i < K) ? W[(long)n * ldw + k0 + i] : 0.f;
-    *reinterpret_cast<f32x4*>(dst + (long)e * 4) = v;
+    for (int i = 0; i < 4; ++i) v[it][i] = (n < rows_valid && k0 + i < K) ? v[it][i] : 0.f;
+    if (e < NITEMS) *reinterpret_cast<f32x4*>(dst + (long)e * 4) = v[it];
   }
 }
 // transposed fragments: [(t * 4 + c) * 64 + lane] f32x4 = W[16c + 4q + i][16t + m]   (A operand of dX^T = W^T dY^T)
-__device__ __forceinline__ void stage_wT(float* dst, const float* W, int ldw, int nthreads) {
-  for (int e = threadIdx.x; e < 16 * 64; e += nthreads) {
-    const int l = e & 63, tc = e >> 6, t = tc >> 2, c = tc & 3;
-    f32x4 v;
+template <int NTHR>
+__device__ __forceinline__ void stage_wT(float* dst, const float* W, int ldw) {
+  constexpr int NIT = (16 * 64 + NTHR - 1) / NTHR;
+  f32x4 v[NIT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = W[(long)(16 * c + 4 * (l >> 4) + i) * ldw + 16 * t + (l & 15)];
-    *reinterpret_cast<f32x4*>(dst + (long)e * 4) = v;
+  for (int it = 0; it < NIT; ++it) {
+    int e = threadIdx.x + NTHR * it; if (e > 16 * 64 - 1) e = 16 * 64 - 1;
+    const int l = e & 63, tc = e >> 6, t = tc >> 2, c = tc & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[it][i] = W[(long)(16 * c + 4 * (l >> 4) + i) * ldw + 16 * t + (l & 15)];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = threadIdx.x + NTHR * it;
+    if (e < 16 * 64) *reinterpret_cast<f32x4*>(dst + (long)e * 4) = v[it];
   }
 }
 
@@ -242,9 +265,9 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
   const float* W1 = a.W1 + g * a.gs_w1;
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
-  stage_w(W1s, W1, a.K1, HD, a.K1, KC, 4, 64 * FNW);
-  if (THREE) stage_w(W2s, W2, HD, HD, HD, 4, 4, 64 * FNW);
-  stage_w(W3s, W3, HD, a.N3, HD, 4, 1, 64 * FNW);
+  stage_w<4 * KC * 64, 64 * FNW>(W1s, W1, a.K1, HD, a.K1, KC);
+  if (THREE) stage_w<16 * 64, 64 * FNW>(W2s, W2, HD, HD, HD, 4);
+  stage_w<4 * 64, 64 * FNW>(W3s, W3, HD, a.N3, HD, 4);
   build_tab(tab, a.x, a.K1, a.CF, KC, 64 * FNW);
   f32x4 b1v[4], b2v[4], b3v;
 #pragma unroll
@@ -326,10 +349,10 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   const float* W1 = a.W1 + g * a.gs_w1;
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
-  stage_w(W1s, W1, a.K1, HD, a.K1, KC, 4, 64 * BNW);
+  stage_w<4 * KC * 64, 64 * BNW>(W1s, W1, a.K1, HD, a.K1, KC);
   if (THREE) {
-    stage_w(W2s, W2, HD, HD, HD, 4, 4, 64 * BNW);
-    stage_wT(W2Ts, W2, HD, 64 * BNW);
+    stage_w<16 * 64, 64 * BNW>(W2s, W2, HD, HD, HD, 4);
+    stage_wT<64 * BNW>(W2Ts, W2, HD);
   }
   for (int e = tid; e < 16 * 64; e += 64 * BNW) {
     const int l = e & 63, tj = e >> 6, t = tj >> 2, j = tj & 3;
