@@ -140,8 +140,12 @@ __device__ __forceinline__ XRow x_row(const ConcatSrc& x, long row, long M) {
 }
 
 // issue the loads of one 16-row x tile (raw bits; nothing here consumes a loaded value)
-template <int KC>
-__device__ __forceinline__ void x_issue(f32x4 (&xv)[KC], const ConcatSrc& x, const XRow& r, const int* tab, int CF, int lane) {
+// CFT >= 0: the number of leading 16-byte-loadable chunks is a compile-time constant (QPLEX on 2s3z: 7 = a 120-wide state):
+// with a runtime CF every chunk of the unrolled loops carried a branch, the table reads of the generic path and their waits -
+// ~250 vector instructions per 16-row tile around 208 MFMAs (PMC: 1.04 non-MFMA vector instructions per MFMA in the forward)
+template <int KC, int CFT>
+__device__ __forceinline__ void x_issue(f32x4 (&xv)[KC], const ConcatSrc& x, const XRow& r, const int* tab, int CFr, int lane) {
+  const int CF = CFT >= 0 ? CFT : CFr;
   const int q = lane >> 4;
   const char* d0 = reinterpret_cast<const char*>(x.p0 + r.r0c * x.ld0);
   const char* d1 = x.p1 ? reinterpret_cast<const char*>(x.p1 + r.rowc * x.ld1) : d0;
@@ -163,8 +167,9 @@ __device__ __forceinline__ void x_issue(f32x4 (&xv)[KC], const ConcatSrc& x, con
   }
 }
 // raw -> values of the virtual concat (selects only)
-template <int KC>
-__device__ __forceinline__ void x_finish(f32x4 (&xv)[KC], const XRow& r, const int* tab, int CF, int lane) {
+template <int KC, int CFT>
+__device__ __forceinline__ void x_finish(f32x4 (&xv)[KC], const XRow& r, const int* tab, int CFr, int lane) {
+  const int CF = CFT >= 0 ? CFT : CFr;
   const bool ok0 = (r.flags & 2) != 0, oki = (r.flags & 4) != 0;
   // rows that read as zero (remap before the first slot) are rare: one wave-uniform test instead of 4 selects per chunk
   const bool any_bad0 = __builtin_amdgcn_ballot_w64(!ok0) != 0;
@@ -251,7 +256,7 @@ __device__ __forceinline__ void fwd2(const f32x4 (&h1)[4], const float* W2s, con
 
 // ------------------------------------------------------------------------------------------------- forward
 // THREE = false: two-layer heads  y = W3 relu(W1 x + b1) + b3  (W2 == NULL; QPLEX transformation nets)
-template <int KC, bool THREE>
+template <int KC, bool THREE, int CFT = -1>
 __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
@@ -292,9 +297,9 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
   long tile = t_begin + wave;
   if (tile >= t_end) return;
   XRow xr = x_row(a.x, tile * 16 + m, a.M);
-  x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
+  x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
   for (; tile < t_end; tile += FNW) {
-    x_finish<KC>(xv, xr, tab, a.CF, lane);
+    x_finish<KC, CFT>(xv, xr, tab, a.CF, lane);
     const bool live = (xr.flags & 1) != 0;
     float* y = Y + xr.rowc * a.ldy + 4 * q;
     f32x4 h1[4], h2[4];
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
     {
       const long nt = tile + FNW < t_end ? tile + FNW : tile;
       xr = x_row(a.x, nt * 16 + m, a.M);
-      x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
+      x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
     }
     if (THREE) fwd2(h1, W2s, b2v, h2, lane);
     else {
@@ -332,7 +337,7 @@ __device__ __forceinline__ void stash4(float* st, const f32x4 (&v)[4], int wave,
     for (int i = 0; i < 4; ++i) st[(16 * t + 4 * q + i) * RS + 16 * wave + m] = v[t][i];
 }
 
-template <int KC, bool THREE>
+template <int KC, bool THREE, int CFT = -1>
 __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
@@ -392,12 +397,12 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   XRow xr;
   if (i_begin < i_end) {
     xr = x_row(a.x, (i_begin * BNW + wave) * 16 + m, a.M);
-    x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
+    x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
   }
   ST_DECL(12);
   for (long it = i_begin; it < i_end; ++it) {
     // ---------------- phase A: this wave's 16-row tile, all in registers
-    x_finish<KC>(xv, xr, tab, a.CF, lane);
+    x_finish<KC, CFT>(xv, xr, tab, a.CF, lane);
     const bool live = (xr.flags & 1) != 0;
     const long rowc = xr.rowc;
     float dy[4];                                   // dY[row m][4j + q]
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     {
       const long ni = it + 1 < i_end ? it + 1 : it;
       xr = x_row(a.x, (ni * BNW + wave) * 16 + m, a.M);
-      x_issue<KC>(xv, a.x, xr, tab, a.CF, lane);
+      x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
     }
     ST_MARK(1);
     if (THREE) fwd2(h1, W2s, b2v, h2, lane);
@@ -663,7 +668,9 @@ extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = fwd_lds(KC, a.CF);
-#define MLP3_PICK(K, T3) (KC == 4 ? (const void*)K<4, T3> : KC == 8 ? (const void*)K<8, T3> : KC == 11 ? (const void*)K<11, T3> : (const void*)K<12, T3>)
+// (seven leading full chunks = a 120-wide dense segment 0: the QPLEX heads on 2s3z-sized maps get the compile-time variants)
+#define MLP3_PICK(K, T3) (KC == 4 ? (const void*)K<4, T3> : KC == 8 ? (a.CF == 7 ? (const void*)K<8, T3, 7> : (const void*)K<8, T3>) \
+                          : KC == 11 ? (a.CF == 7 ? (const void*)K<11, T3, 7> : (const void*)K<11, T3>) : (const void*)K<12, T3>)
   const void* fn = three ? MLP3_PICK(mlp3_fwd_kernel, true) : MLP3_PICK(mlp3_fwd_kernel, false);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
