@@ -253,6 +253,12 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
         d = kern[0]
         out["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": d["tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                            "frac": d["frac"], "avg_launch_ms": d["ms"], "traffic": None}
+        busy = sum(e["total_ms"] for e in kern) / updates
+        if busy > 1.05 * dt * 1e3:
+            # small shards: the unrolls run side by side on two streams over parts of the chip (pair / chain schedule), so a
+            # kernel's time is not exclusive and its fraction of the WHOLE chip's peak understates it
+            out["roofline"]["note"] = ("kernels overlap on two streams at this size (%.2f ms of kernel time per %.2f ms update): "
+                                       "per-kernel fractions are against the whole chip's peak" % (busy, dt * 1e3))
     mx = [e for e in kern if e["rocprof_name"] == "qmix_wide_kernel<false"]
     if mx and mixer_dtype == "bf16":      # config 5's named roofline: the bf16 hypernet GEMM against the HBM read of the states
         m = mx[0]
