@@ -911,8 +911,8 @@ def _qmix_reference(P, s, q, gq, N, E, bf16):
     return qt
 
 
-@pytest.mark.parametrize("R", [40007, 32768])
-def test_qmix_wide_resident_forward(dev, R):
+@pytest.mark.parametrize("R,remap", [(40007, False), (32768, False), (36000, True)])
+def test_qmix_wide_resident_forward(dev, R, remap):
     """bf16 forward with the weights resident in LDS (qmix_wide_res_fwd_kernel: MMM2 shape, >= 32 768 rows; each row's q_tot is
     the sum of two embedding halves computed by two workgroups) vs torch-CPU with the hypernet operands rounded to bf16,
     and vs the streaming kernel (MARL_WIDE_RES=0) - the two differ only in the order of the final sums."""
@@ -936,9 +936,21 @@ def test_qmix_wide_resident_forward(dev, R):
         qt = (hid * hy["w2"].abs()).sum(1) + F.linear(F.relu(hy["h"]), P["b2_w"], P["b2_b"]).view(R)
     Wd = {k: cu(v, dev) for k, v in P.items()}
     ld = (S + 3) // 4 * 4
-    sd = torch.zeros(R, ld, device=dev)
-    sd[:, :S] = cu(s, dev)
-    xs = ops.src(sd[:, :S])
+    if remap:
+        # the learner's view of a replay sample: (T+1)-slot storage of more episodes than the batch, read in place through
+        # an episode map and a slot offset (ops.Rows: row r -> storage row emap[r / T] * (T + 1) + r % T + 1)
+        T = 120
+        Eb, Es = R // T, R // T + 7
+        perm = torch.randperm(Es, generator=g)[:Eb]
+        store = torch.zeros(Es, T + 1, ld)
+        store[:, :, :S] = torch.randn(Es, T + 1, S, generator=g)          # other slots / episodes hold different data
+        store[perm, 1:, :S] = s.view(Eb, T, S)
+        sd = cu(store.view(Es * (T + 1), ld), dev)
+        xs = ops.src(ops.Rows(sd[:, :S], (T, T + 1, 1), cu(perm, dev, torch.int32)))
+    else:
+        sd = torch.zeros(R, ld, device=dev)
+        sd[:, :S] = cu(s, dev)
+        xs = ops.src(sd[:, :S])
     qd = cu(q, dev)
     res = {}
     try:
