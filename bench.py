@@ -135,11 +135,13 @@ class KernelTimers:
                 else:
                     w, x, Y, M, K1, N3, g = ar[:7]
                 three = bool(w.w2)
+                kept = kw.get("hsave") is not None      # h1 / h2 travel forward -> backward instead of being recomputed
                 h2 = 64 * 64 if three else 0
                 ffw = 2.0 * M * g * (K1 * 64 + h2 + 64 * N3)
-                f = 2.0 * M * g * (2 * K1 * 64 + 3 * h2 + 2 * 64 * N3) if back else ffw
-                return ("mlp3_%s_kernel (fused 64-wide heads, %d heads, K1=%d)" % ("bwd" if back else "fwd", g, K1),
-                        "mlp3_bwd" if back else "mlp3_fwd", f, ffw * (3 if back else 1), 4.0 * M * (K1 + g * N3))
+                f = 2.0 * M * g * ((1 if kept else 2) * K1 * 64 + (2 if kept else 3) * h2 + 2 * 64 * N3) if back else ffw
+                return ("mlp3_%s_kernel (fused 64-wide heads, %d heads, K1=%d%s)" % ("bwd" if back else "fwd", g, K1, ", hidden activations kept" if kept else ""),
+                        "mlp3_bwd" if back else "mlp3_fwd", f, ffw * (3 if back else 1),
+                        4.0 * M * (K1 + g * N3) + (4.0 * M * g * (128 if three else 64) if kept else 0.0))
             return m
 
         def roll(ar, kw):

@@ -242,6 +242,17 @@ size_t marl_mlp3_bwd_workspace(long M, int K1, int N3, int groups);
 int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
                   const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, long M, int K1, int N3,
                   int groups, void* stream);
+/* The same pair with the hidden activations KEPT between forward and backward instead of recomputed (what autograd
+ * does for these heads in the reference, network/mixer.py:149-171): the forward writes relu(h1) [and relu(h2)] of
+ * every 16-row tile as the MFMA fragments the backward wants (`hsave`: marl_mlp3_save_floats(M, three, groups)
+ * floats, layout private to the pair), the backward reads them back with 16-byte coalesced loads and skips layers
+ * 1-2.  Bit-identical to the recomputing pair.  hsave == NULL: exactly marl_mlp3_fwd / marl_mlp3_bwd. */
+size_t marl_mlp3_save_floats(long M, int three, int groups);
+int marl_mlp3_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
+                       float* hsave, size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
+int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
+                        const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, const float* hsave,
+                        size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
 
 /* ---- fused QTRAN-base heads (qtran_fused.hip) ------------------------------------------------
  * QtranQBase.forward (network/mixer.py:378-388, A = n_actions > 0, AE = 64 + A) and QtranV.forward (:411-418, A = 0,

@@ -99,6 +99,9 @@ SIGNATURES = {
     "marl_mlp3_fwd": (I, [M3, SRC, P, L, L, L, I, I, I, P]),
     "marl_mlp3_bwd_workspace": (SZ, [L, I, I, I]),
     "marl_mlp3_bwd": (I, [M3, SRC, P, L, L, M3, P, SZ, L, I, I, I, P]),
+    "marl_mlp3_save_floats": (SZ, [L, I, I]),
+    "marl_mlp3_fwd_save": (I, [M3, SRC, P, L, L, P, SZ, L, I, I, I, P]),
+    "marl_mlp3_bwd_saved": (I, [M3, SRC, P, L, L, M3, P, SZ, P, SZ, L, I, I, I, P]),
     "marl_qtran_supported": (I, [I, I, I]),
     "marl_qtran_head_fwd": (I, [QT, P, P, P, P, P, P, P, P, L, I, I, I, P]),
     "marl_qtran_bwd_workspace": (SZ, [L, I]),

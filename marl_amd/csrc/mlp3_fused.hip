@@ -37,6 +37,7 @@ struct Mlp3Args {
   long gs_w1, gs_b1, gs_w2, gs_b2, gs_w3, gs_b3;     // element strides between heads
   float* Y; long ldy, gs_y;                          // forward: outputs; backward: dY (read only)
   float* ws;                                         // backward: [slab][group][slab_floats]
+  float* hs;                                         // kept hidden activations [group][16-row tile][plane][64 lanes] f32x4, or NULL
   long M;
   int K1, N3, groups, nst, CF;                       // nst stripes per group; CF leading 16-byte-loadable chunks
 };
@@ -314,6 +315,18 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) h2[t] = h1[t];
     }
+    if (a.hs) {
+      // kept for the backward as the fragments it consumes (1 KB per store instruction; streaming - x lives in this XCD's L2 for
+      // the other heads of the stripe and these 8 KB per tile and head must not push it out)
+      constexpr int NP = THREE ? 8 : 4;
+      f32x4* hp = reinterpret_cast<f32x4*>(a.hs) + (((long)g * tiles + tile) * NP) * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(h1[c], hp + c * 64);
+      if (THREE) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(h2[c], hp + (4 + c) * 64);
+      }
+    }
     f32x4 acc = b3v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -337,7 +350,8 @@ __device__ __forceinline__ void stash4(float* st, const f32x4 (&v)[4], int wave,
     for (int i = 0; i < 4; ++i) st[(16 * t + 4 * q + i) * RS + 16 * wave + m] = v[t][i];
 }
 
-template <int KC, bool THREE, int CFT = -1>
+// LOAD: h1 / h2 come from the forward's `hs` planes (one iteration ahead in a second register set) instead of being recomputed
+template <int KC, bool THREE, int CFT = -1, bool LOAD = false>
 __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
@@ -395,9 +409,30 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 
   f32x4 xv[KC];
   XRow xr;
+  f32x4 hn1[4], hn2[4];                  // LOAD: the next iteration's kept activations and dY elements
+  float dyn[4];
+  const long tiles = (a.M + 15) / 16;
+  constexpr int NP = THREE ? 8 : 4;
+  auto issue_kept = [&](long it_) __attribute__((always_inline)) {
+    const bool lv = (xr.flags & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n3 = 4 * j + q;
+      dyn[j] = (lv && n3 < a.N3) ? dY[xr.rowc * a.ldy + n3] : 0.f;
+    }
+    long tl = it_ * BNW + wave; if (tl > tiles - 1) tl = tiles - 1;      // (a tile past the end multiplies zero gradients)
+    const f32x4* hp = reinterpret_cast<const f32x4*>(a.hs) + (((long)g * tiles + tl) * NP) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hn1[c] = __builtin_nontemporal_load(hp + c * 64);
+    if (THREE) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hn2[c] = __builtin_nontemporal_load(hp + (4 + c) * 64);
+    }
+  };
   if (i_begin < i_end) {
     xr = x_row(a.x, (i_begin * BNW + wave) * 16 + m, a.M);
     x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
+    if (LOAD) issue_kept(i_begin);
   }
   ST_DECL(12);
   for (long it = i_begin; it < i_end; ++it) {
@@ -409,7 +444,8 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n3 = 4 * j + q;
-      dy[j] = (live && n3 < a.N3) ? dY[rowc * a.ldy + n3] : 0.f;
+      if (LOAD) dy[j] = dyn[j];
+      else dy[j] = (live && n3 < a.N3) ? dY[rowc * a.ldy + n3] : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
@@ -417,18 +453,26 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
       for (int i = 0; i < 4; ++i) xT[(16 * c + 4 * q + i) * RS + 16 * wave + m] = xv[c][i];
     f32x4 h1[4], h2[4], dh2[4], dh1[4];
     ST_MARK(0);
-    fwd1<KC>(xv, W1s, b1v, h1, lane);
+    if (LOAD) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { h1[t] = hn1[t]; h2[t] = THREE ? hn2[t] : hn1[t]; }
+    } else {
+      fwd1<KC>(xv, W1s, b1v, h1, lane);
+    }
     // x is consumed: start the loads of the next iteration's tile (unconditional; the last one re-reads its own)
     {
       const long ni = it + 1 < i_end ? it + 1 : it;
       xr = x_row(a.x, (ni * BNW + wave) * 16 + m, a.M);
       x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
+      if (LOAD) issue_kept(ni);
     }
     ST_MARK(1);
-    if (THREE) fwd2(h1, W2s, b2v, h2, lane);
-    else {
+    if (!LOAD) {
+      if (THREE) fwd2(h1, W2s, b2v, h2, lane);
+      else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) h2[t] = h1[t];
+        for (int t = 0; t < 4; ++t) h2[t] = h1[t];
+      }
     }
     ST_MARK(2);
     {
@@ -607,6 +651,8 @@ inline ConcatSrc to_src3(const marl_src_t* s) {
   return c;
 }
 
+#define MLP3_CF7_(T3, CF, ...) T3, 7, ##__VA_ARGS__
+#define MLP3_CF7(...) MLP3_CF7_(__VA_ARGS__)
 // instantiated chunk counts: 4, 8, 11 (QPLEX [state 120 | one-hot 55] exactly), 12
 inline int kc_bucket(int K1) { const int kc = (K1 + 15) / 16; return kc == 11 ? 11 : (kc + 3) / 4 * 4; }
 inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 512 * 4; }
@@ -654,24 +700,29 @@ extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, 
   return bwd_lds(KC, CF) <= 160 * 1024 && fwd_lds(KC, CF) <= 160 * 1024;
 }
 
-extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
-                             long M, int K1, int N3, int groups, void* stream) {
+extern "C" size_t marl_mlp3_save_floats(long M, int three, int groups) {
+  return M <= 0 ? 0 : (size_t)groups * (size_t)((M + 15) / 16) * (three ? 8 : 4) * 256;
+}
+
+extern "C" int marl_mlp3_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
+                                  float* hsave, size_t hsave_floats, long M, int K1, int N3, int groups, void* stream) {
   if (M <= 0) return 0;
   const bool three = w->w2 != nullptr;
+  if (hsave && (hsave_floats < marl_mlp3_save_floats(M, three, groups) || !aligned16(hsave))) return (int)hipErrorInvalidValue;
   if (!marl_mlp3_supported(x, K1, HD, three ? HD : 0, N3, groups)) return (int)hipErrorInvalidValue;
   // bias rows are read with 16-byte loads
   if (!aligned16(w->b1) || w->gs_b1 % 4 || (three && (!aligned16(w->b2) || w->gs_b2 % 4))) return (int)hipErrorInvalidValue;
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
-  a.Y = Y; a.ldy = ldy; a.gs_y = gs_y; a.ws = nullptr;
+  a.Y = Y; a.ldy = ldy; a.gs_y = gs_y; a.ws = nullptr; a.hs = hsave;
   const long tiles = (M + 15) / 16;
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = fwd_lds(KC, a.CF);
 // (seven leading full chunks = a 120-wide dense segment 0: the QPLEX heads on 2s3z-sized maps get the compile-time variants)
-#define MLP3_PICK(K, T3) (KC == 4 ? (const void*)K<4, T3> : KC == 8 ? (a.CF == 7 ? (const void*)K<8, T3, 7> : (const void*)K<8, T3>) \
-                          : KC == 11 ? (a.CF == 7 ? (const void*)K<11, T3, 7> : (const void*)K<11, T3>) : (const void*)K<12, T3>)
-  const void* fn = three ? MLP3_PICK(mlp3_fwd_kernel, true) : MLP3_PICK(mlp3_fwd_kernel, false);
+#define MLP3_PICK(K, ...) (KC == 4 ? (const void*)K<4, __VA_ARGS__> : KC == 8 ? (a.CF == 7 ? (const void*)K<8, MLP3_CF7(__VA_ARGS__)> : (const void*)K<8, __VA_ARGS__>) \
+                           : KC == 11 ? (a.CF == 7 ? (const void*)K<11, MLP3_CF7(__VA_ARGS__)> : (const void*)K<11, __VA_ARGS__>) : (const void*)K<12, __VA_ARGS__>)
+  const void* fn = three ? MLP3_PICK(mlp3_fwd_kernel, true, -1) : MLP3_PICK(mlp3_fwd_kernel, false, -1);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * FNW);
@@ -682,28 +733,35 @@ extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   return 0;
 }
 
+extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
+                             long M, int K1, int N3, int groups, void* stream) {
+  return marl_mlp3_fwd_save(w, x, Y, ldy, gs_y, nullptr, 0, M, K1, N3, groups, stream);
+}
+
 extern "C" size_t marl_mlp3_bwd_workspace(long M, int K1, int N3, int groups) {
   (void)N3;
   const int nst = stripes((M + 63) / 64, groups);
   return (size_t)nst * groups * mlp3_slab_floats(K1) * sizeof(float);
 }
 
-extern "C" int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
-                             const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, long M, int K1, int N3,
-                             int groups, void* stream) {
+extern "C" int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
+                                   const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, const float* hsave,
+                                   size_t hsave_floats, long M, int K1, int N3, int groups, void* stream) {
   if (M <= 0) return 0;
   const bool three = w->w2 != nullptr;
+  if (hsave && (hsave_floats < marl_mlp3_save_floats(M, three, groups) || !aligned16(hsave))) return (int)hipErrorInvalidValue;
   if (!marl_mlp3_supported(x, K1, HD, three ? HD : 0, N3, groups)) return (int)hipErrorInvalidValue;
   if (!aligned16(w->b1) || w->gs_b1 % 4 || (three && (!aligned16(w->b2) || w->gs_b2 % 4))) return (int)hipErrorInvalidValue;
   if (three != (grads->w2 != nullptr)) return (int)hipErrorInvalidValue;
   if (ws_bytes < marl_mlp3_bwd_workspace(M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
-  a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws;
+  a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws; a.hs = const_cast<float*>(hsave);
   a.nst = stripes((M + 63) / 64, groups);
   const int KC = kc_bucket(K1);
   const size_t lds = bwd_lds(KC, a.CF);
-  const void* fn = three ? MLP3_PICK(mlp3_bwd_kernel, true) : MLP3_PICK(mlp3_bwd_kernel, false);
+  const void* fn = hsave ? (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK(mlp3_bwd_kernel, false, -1, true))
+                         : (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, false) : MLP3_PICK(mlp3_bwd_kernel, false, -1, false));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * BNW);
@@ -723,4 +781,10 @@ extern "C" int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
   hipLaunchKernelGGL(mlp3_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r);
   MARL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
+                             const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, long M, int K1, int N3,
+                             int groups, void* stream) {
+  return marl_mlp3_bwd_saved(w, x, dY, lddy, gs_dy, grads, ws, ws_bytes, nullptr, 0, M, K1, N3, groups, stream);
 }

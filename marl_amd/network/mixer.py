@@ -7,6 +7,8 @@ forward with saved activations, then an explicit backward that accumulates into 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -360,6 +362,12 @@ class DMAQer(_Precision, nn.Module):
             return None
         return ops.mlp3_weights(heads, grad=grad)
 
+    def _kept(self, name, rows, three, groups, dev):
+        """buffer for the hidden activations a fused family keeps for its backward (MARL_MLP3_KEEP=0: recompute)."""
+        if os.environ.get("MARL_MLP3_KEEP", "1") == "0":
+            return None
+        return self._s.get(name + "_hs", (ops.mlp3_save_floats(rows, three, groups),), dev)
+
     def _fused_transform(self, xs, grad=False):
         """hyper_w_final and V (Linear-ReLU-Linear, same shapes) as two heads of the fused kernel, or None."""
         if self._bf16() or getattr(self, "no_fused", False):
@@ -383,10 +391,14 @@ class DMAQer(_Precision, nn.Module):
             outs[name] = out
             fw = self._fused_family(mods, x_in, nout)
             if fw is not None:
-                # one kernel per family: the 10 heads' hidden activations never leave the CU
-                ops.mlp3_fwd(fw, x_in, out, rows, ops.src_width(x_in), nout, K)
+                # one kernel per family: the 10 heads' hidden activations never travel between layers.  When a backward
+                # follows they are kept as the backward's MFMA fragments (streamed out once, read once) - recomputing
+                # layers 1-2 there was a third of its time
+                hs = self._kept(name, rows, True, K, dev) if keep is not None else None
+                ops.mlp3_fwd(fw, x_in, out, rows, ops.src_width(x_in), nout, K, hsave=hs)
                 if keep is not None:
                     keep[name + "_h"] = None
+                    keep[name + "_hs"] = hs
                 continue
             nl = len(_linears(mods[0]))
             hs = []
@@ -415,7 +427,10 @@ class DMAQer(_Precision, nn.Module):
         if tw is not None:
             # hyper_w_final and V as ONE two-head launch of the fused kernel; wv[0] = w_raw, wv[1] = v
             wv = self._s.get("wv" + tag, (2, rows, N), dev)
-            ops.mlp3_fwd(tw, xs, wv, rows, self.state_dim, N, 2)
+            wv_hs = self._kept("wv", rows, False, 2, dev) if ctx is not None else None
+            ops.mlp3_fwd(tw, xs, wv, rows, self.state_dim, N, 2, hsave=wv_hs)
+            if ctx is not None:
+                ctx["wv_hs"] = wv_hs
             w_raw, v = wv[0], wv[1]
         else:
             hw = self._s.get("hw" + tag, (rows, HE), dev)
@@ -456,7 +471,8 @@ class DMAQer(_Precision, nn.Module):
         xs = ops.src(s)
         # transformation nets
         if ctx["hw"] is None:
-            ops.mlp3_bwd(self._fused_transform(xs), xs, dwv, self._fused_transform(xs, grad=True), rows, self.state_dim, N, 2)
+            ops.mlp3_bwd(self._fused_transform(xs), xs, dwv, self._fused_transform(xs, grad=True), rows, self.state_dim, N, 2,
+                         hsave=ctx.get("wv_hs"))
         else:
             for seq, hbuf, dout in ((self.hyper_w_final, ctx["hw"], dw_raw), (self.V, ctx["hv"], dv)):
                 l0, l2 = _linears(seq)
@@ -471,7 +487,8 @@ class DMAQer(_Precision, nn.Module):
             hs = ctx[name + "_h"]
             if hs is None:      # fused forward: the backward recomputes the hidden activations on chip
                 ops.mlp3_bwd(self._fused_family(mods, x_in, nout), x_in, douts[name],
-                             self._fused_family(mods, x_in, nout, grad=True), rows, ops.src_width(x_in), nout, K)
+                             self._fused_family(mods, x_in, nout, grad=True), rows, ops.src_width(x_in), nout, K,
+                             hsave=ctx.get(name + "_hs"))
                 continue
             nl = len(_linears(mods[0]))
             dcur, dcur_gs, gate = douts[name], nout, None

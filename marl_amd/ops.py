@@ -503,20 +503,28 @@ def _head_layout(Y, M, N3, groups):
     return Y.stride(0), N3
 
 
-def mlp3_fwd(w, x, Y, M, K1, N3, groups):
+def mlp3_save_floats(M, three, groups):
+    """floats of the kept-activation buffer of one fused head family (layout private to the kernel pair)."""
+    return int(_lib.load().marl_mlp3_save_floats(M, 1 if three else 0, groups))
+
+
+def mlp3_fwd(w, x, Y, M, K1, N3, groups, hsave=None):
+    """hsave (float32, >= mlp3_save_floats): keep the hidden activations for mlp3_bwd instead of recomputing them."""
     ld, gs = _head_layout(Y, M, N3, groups)
     assert src_width(x) == K1
-    check(_lib.load().marl_mlp3_fwd(C.byref(w), C.byref(x), _p(_f32(Y)), ld, gs, M, K1, N3, groups, _stream()),
+    hp, hn = (_p(_f32(hsave)), hsave.numel()) if hsave is not None else (None, 0)
+    check(_lib.load().marl_mlp3_fwd_save(C.byref(w), C.byref(x), _p(_f32(Y)), ld, gs, hp, hn, M, K1, N3, groups, _stream()),
           "marl_mlp3_fwd")
 
 
-def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups):
+def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups, hsave=None):
     lib = _lib.load()
     ld, gs = _head_layout(dY, M, N3, groups)
     assert src_width(x) == K1
     ws = WS.get("mlp3", lib.marl_mlp3_bwd_workspace(M, K1, N3, groups), dY.device)
-    check(lib.marl_mlp3_bwd(C.byref(w), C.byref(x), _p(_f32(dY)), ld, gs, C.byref(grads), _p(ws), ws.numel() * 4,
-                            M, K1, N3, groups, _stream()), "marl_mlp3_bwd")
+    hp, hn = (_p(_f32(hsave)), hsave.numel()) if hsave is not None else (None, 0)
+    check(lib.marl_mlp3_bwd_saved(C.byref(w), C.byref(x), _p(_f32(dY)), ld, gs, C.byref(grads), _p(ws), ws.numel() * 4,
+                                  hp, hn, M, K1, N3, groups, _stream()), "marl_mlp3_bwd")
 
 
 # ---- fused QTRAN-base heads (csrc/qtran_fused.hip)

@@ -282,6 +282,17 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
         for name, pr, gv in zip(("W1", "b1", "W2", "b2", "W3", "b3") if nl == 3 else ("W1", "b1", "W3", "b3"), ps, views(gd, k)):
             scale = max(1.0, float(pr.grad.abs().max()))
             close(gv / scale, 2.0 * pr.grad / scale, 3e-4, 1e-4, msg="head %d d%s" % (k, name))
+    # the pair that KEEPS h1 / h2 between forward and backward (marl_mlp3_fwd_save / marl_mlp3_bwd_saved) is bit-identical to the
+    # recomputing pair: same outputs, same gradients
+    hs = torch.full((ops.mlp3_save_floats(rows, nl == 3, G),), float("nan"), device=dev)
+    Y2, gd_rec = torch.full((rows, G * N3), 7.0, device=dev), gd.clone()
+    ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y2, rows, K1, N3, G, hsave=hs)
+    assert torch.equal(Y2, Y)
+    gd.zero_()
+    for rep in range(2):
+        ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G, hsave=hs)
+    assert torch.equal(gd, gd_rec)
+    assert not torch.isnan(gd).any()
 
 
 @pytest.mark.parametrize("B,O", [(6, 24), (30, 24), (20, 80), (17, 116), (21, 64), (19, 52), (18, 128), (17, 176), (17, 148)])

@@ -35,8 +35,12 @@ for name, K1, N3, x in (("key", S, 1, ops.src(s)), ("agents", S, N, ops.src(s)),
     dY = torch.randn(rows, G * N3, device=dev)
     w, gw = ops.mlp3_weights(heads), ops.mlp3_weights(heads, grad=True)
     fl = 2.0 * rows * G * (K1 * 64 + 64 * 64 + 64 * N3)
+    hs = torch.empty(ops.mlp3_save_floats(rows, True, G), device=dev)
+    bm = 3.0 - (K1 * 64) / (K1 * 64 + 64 * 64 + 64 * N3)
     for what, fn, mult in (("fwd", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G), 1.0),
-                           ("bwd", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G), 3.0 - (K1 * 64) / (K1 * 64 + 64 * 64 + 64 * N3))):
+                           ("bwd", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G), bm),
+                           ("fwd keeping h1,h2", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G, hsave=hs), 1.0),
+                           ("bwd from kept h1,h2", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G, hsave=hs), bm)):
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,4 +49,4 @@ for name, K1, N3, x in (("key", S, 1, ops.src(s)), ("agents", S, N, ops.src(s)),
             fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        print("%-7s %s  K1=%3d N3=%d  %.3f ms  %.1f TFLOP/s (algorithmic %.1f GFLOP)" % (name, what, K1, N3, ms, fl * mult / ms / 1e9, fl * mult / 1e9))
+        print("%-7s %-19s  K1=%3d N3=%d  %.3f ms  %.1f TFLOP/s (algorithmic %.1f GFLOP)" % (name, what, K1, N3, ms, fl * mult / ms / 1e9, fl * mult / 1e9))
