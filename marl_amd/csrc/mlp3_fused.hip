@@ -40,7 +40,13 @@ struct Mlp3Args {
   float* hs;                                         // kept hidden activations [group][16-row tile][plane][64 lanes] f32x4, or NULL
   long M;
   int K1, N3, groups, nst, CF;                       // nst stripes per group; CF leading 16-byte-loadable chunks
+  int kpad, KV;                                      // virtual K axis: kpad zero columns after dense0 (so that k0 + kpad is a multiple of 4), KV = K1 + kpad
 };
+
+// virtual column (K axis of the kernels) -> column of W1 / dW1, or -1 for a pad column.  A lane's four consecutive columns must
+// come from ONE segment of the concat; a dense0 width that is not a multiple of 4 (MMM2: 322 state columns) is padded in the
+// kernels' own K axis instead of asking the caller for another weight layout.
+__host__ __device__ inline int vcol(int k, int k0, int kpad) { return k < k0 ? k : (k < k0 + kpad ? -1 : k - kpad); }
 
 __host__ __device__ inline long mlp3_slab_floats(int K1) { return (long)HD * (K1 + 1) + (long)HD * (HD + 1) + 16L * (HD + 1); }
 
@@ -53,23 +59,26 @@ __device__ __forceinline__ bool wg_map(int groups, int nst, int& stripe, int& g)
   return stripe < nst;
 }
 
-// Table of the generic chunks (those not wholly inside the 16-byte aligned part of dense0), two int4 per (chunk, lane):
+// Table of the generic chunks (those not wholly inside the 16-byte aligned part of dense0), two int4 per (chunk, q = lane / 16) -
+// a lane's columns 16c + 4q + i do not depend on its row, and the 16 lanes of a q read one address (LDS broadcast):
 //   [0] byte offsets of the lane's four elements from the base of its group's source row
 //   [1] {cmp0 | cmp1 << 16, cmp2 | cmp3 << 16, kind, -}   kind: 0 zero, 1 dense0, 2 one-hot index, 3 dense1
-// Segment widths are multiples of 4 (checked on the host), so the four elements k = 16c+4q+0..3 of a lane come from
-// ONE source: a lane selects one row base per chunk and the element loads are base + offset - no per-element branching.
-__device__ __forceinline__ void build_tab(int* tab, const ConcatSrc& x, int K1, int CF, int KC, int nthreads) {
-  for (int e = threadIdx.x; e < (KC - CF) * 64; e += nthreads) {
-    const int gc = e >> 6, l = e & 63;
-    const int kb = 16 * (CF + gc) + 4 * (l >> 4);
+// Segment starts are multiples of 4 on the kernels' K axis (dense0 padded by `kpad` zero columns, dense1 checked on the host), so
+// the four elements k = 16c+4q+0..3 of a lane come from ONE source: a lane selects one row base per chunk and the element loads
+// are base + offset - no per-element branching.
+__device__ __forceinline__ void build_tab(int* tab, const ConcatSrc& x, int KV, int kpad, int CF, int KC, int nthreads) {
+  for (int e = threadIdx.x; e < (KC - CF) * 4; e += nthreads) {
+    const int gc = e >> 2, qq = e & 3;
+    const int kb = 16 * (CF + gc) + 4 * qq;
     int off[4], cmp[4], kind = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int k = kb + i;
       off[i] = 0; cmp[i] = 0xffff;
-      if (k >= K1) continue;
+      if (k >= KV) continue;
       if (k < x.k0) { kind = 1; off[i] = 4 * k; }
-      else if (k - x.k0 < x.k1) { kind = 3; off[i] = 4 * (k - x.k0); }
+      else if (k < x.k0 + kpad) { kind = 1; continue; }      // pad column: reads column 0 (finite), meets a zero weight
+      else if ((k -= kpad) - x.k0 < x.k1) { kind = 3; off[i] = 4 * (k - x.k0); }
       else {
         k -= x.k0 + x.k1;
         const int j = k / x.hot_w;
@@ -86,7 +95,7 @@ __device__ __forceinline__ void build_tab(int* tab, const ConcatSrc& x, int K1, 
 // (all of a thread's loads are issued - unconditionally, indices clamped - before its first LDS store: a load - mask - store
 // loop serialises one memory round trip per item, which at the small shards is a visible part of the launch)
 template <int NITEMS, int NTHR>
-__device__ __forceinline__ void stage_w(float* dst, const float* W, int ldw, int rows_valid, int K, int KCn) {
+__device__ __forceinline__ void stage_w(float* dst, const float* W, int ldw, int rows_valid, int K, int KCn, int k0 = 1 << 30, int kpad = 0) {
   constexpr int NIT = (NITEMS + NTHR - 1) / NTHR;
   f32x4 v[NIT];
 #pragma unroll
@@ -94,17 +103,24 @@ __device__ __forceinline__ void stage_w(float* dst, const float* W, int ldw, int
     int e = threadIdx.x + NTHR * it; if (e > NITEMS - 1) e = NITEMS - 1;
     const int l = e & 63, tc = e >> 6, t = tc / KCn, c = tc - t * KCn;
     int n = 16 * t + (l & 15); if (n > rows_valid - 1) n = rows_valid - 1;
-    const int k0 = 16 * c + 4 * (l >> 4);
+    const int kq = 16 * c + 4 * (l >> 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[it][i] = W[(long)n * ldw + (k0 + i < K ? k0 + i : K - 1)];
+    for (int i = 0; i < 4; ++i) {
+      int kr = vcol(kq + i, k0, kpad);
+      kr = kr < 0 ? 0 : (kr < K ? kr : K - 1);
+      v[it][i] = W[(long)n * ldw + kr];
+    }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = threadIdx.x + NTHR * it;
     const int l = e & 63, tc = e >> 6, t = tc / KCn, c = tc - t * KCn;
-    const int n = 16 * t + (l & 15), k0 = 16 * c + 4 * (l >> 4);
+    const int n = 16 * t + (l & 15), kq = 16 * c + 4 * (l >> 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[it][i] = (n < rows_valid && k0 + i < K) ? v[it][i] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int kr = vcol(kq + i, k0, kpad);
+      v[it][i] = (n < rows_valid && kr >= 0 && kr < K) ? v[it][i] : 0.f;
+    }
     if (e < NITEMS) *reinterpret_cast<f32x4*>(dst + (long)e * 4) = v[it];
   }
 }
@@ -156,7 +172,7 @@ __device__ __forceinline__ void x_issue(f32x4 (&xv)[KC], const ConcatSrc& x, con
     if (c < CF) {
       xv[c] = *reinterpret_cast<const f32x4*>(d0 + 64 * c + 16 * q);
     } else {
-      const int* t = tab + ((c - CF) * 64 + lane) * 8;
+      const int* t = tab + ((c - CF) * 4 + q) * 8;
       const uint4 off = *reinterpret_cast<const uint4*>(t);            // unsigned: no sign extension per address
       const int kind = t[6];
       const char* base = kind == 2 ? di : (kind == 3 ? d1 : d0);      // one row base per lane and chunk
@@ -179,7 +195,7 @@ __device__ __forceinline__ void x_finish(f32x4 (&xv)[KC], const XRow& r, const i
     if (c < CF) {
       if (any_bad0 && !ok0) xv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
-      const int4 t1 = *reinterpret_cast<const int4*>(tab + ((c - CF) * 64 + lane) * 8 + 4);
+      const int4 t1 = *reinterpret_cast<const int4*>(tab + ((c - CF) * 4 + (lane >> 4)) * 8 + 4);
       const int kind = t1.z;
       const bool dense = (kind == 1 && ok0) || kind == 3;
       const bool hot = kind == 2 && oki;
@@ -257,8 +273,9 @@ __device__ __forceinline__ void fwd2(const f32x4 (&h1)[4], const float* W2s, con
 
 // ------------------------------------------------------------------------------------------------- forward
 // THREE = false: two-layer heads  y = W3 relu(W1 x + b1) + b3  (W2 == NULL; QPLEX transformation nets)
+// KC > 12 (K1 up to 512: QPLEX on MMM2-sized maps): x of a tile is 64-128 registers and W1 64-128 KB of LDS - one workgroup per CU
 template <int KC, bool THREE, int CFT = -1>
-__global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
+__global__ __launch_bounds__(64 * FNW, KC > 12 ? 1 : 2) void mlp3_fwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
   if (!wg_map(a.groups, a.nst, stripe, g)) return;
@@ -271,10 +288,10 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3_fwd_kernel(Mlp3Args a) {
   const float* W1 = a.W1 + g * a.gs_w1;
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
-  stage_w<4 * KC * 64, 64 * FNW>(W1s, W1, a.K1, HD, a.K1, KC);
+  stage_w<4 * KC * 64, 64 * FNW>(W1s, W1, a.K1, HD, a.K1, KC, a.x.k0, a.kpad);
   if (THREE) stage_w<16 * 64, 64 * FNW>(W2s, W2, HD, HD, HD, 4);
   stage_w<4 * 64, 64 * FNW>(W3s, W3, HD, a.N3, HD, 4);
-  build_tab(tab, a.x, a.K1, a.CF, KC, 64 * FNW);
+  build_tab(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * FNW);
   f32x4 b1v[4], b2v[4], b3v;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -358,19 +375,22 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   if (!wg_map(a.groups, a.nst, stripe, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
-  constexpr int SF = (16 * KC + HD) > 208 ? (16 * KC + HD) : 208;    // stage features: max(x + dh1, h1 + dh2 + h2 + dY)
-  float* W1s = smem;                              // [4][KC][64] f32x4
-  float* W2s = W1s + 4 * KC * 256;                // [4][4][64] f32x4
-  float* W2Ts = W2s + 16 * 256;                   // [4][4][64] f32x4
+  // x^T is staged KH chunks at a time (KC > 24: two passes of 16 - 32 chunks of 64 rows are 139 KB on their own)
+  constexpr int KH = KC > 24 ? 16 : KC, NH = KC / KH;
+  static_assert(KC % KH == 0 && (LOAD || KC <= 12), "K1 > 192 only with kept activations (W1 does not fit beside the stage)");
+  constexpr int SF = (16 * KH + HD) > 208 ? (16 * KH + HD) : 208;    // stage features: max(x + dh1, h1 + dh2 + h2 + dY)
+  float* W1s = smem;                              // [4][KC][64] f32x4      (recomputing variant only)
+  float* W2s = W1s + (LOAD ? 0 : 4 * KC * 256);   // [4][4][64] f32x4       (recomputing variant only)
+  float* W2Ts = W2s + (LOAD ? 0 : 16 * 256);      // [4][4][64] f32x4
   float* W3Ts = W2Ts + 16 * 256;                  // [4 t][4 j][64]: W3[4j + q][16t + m]
   float* stage = W3Ts + 16 * 64;                  // [SF][RS]
   int* tab = reinterpret_cast<int*>(stage + SF * RS);
   const float* W1 = a.W1 + g * a.gs_w1;
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
-  stage_w<4 * KC * 64, 64 * BNW>(W1s, W1, a.K1, HD, a.K1, KC);
+  if (!LOAD) stage_w<4 * KC * 64, 64 * BNW>(W1s, W1, a.K1, HD, a.K1, KC, a.x.k0, a.kpad);
   if (THREE) {
-    stage_w<16 * 64, 64 * BNW>(W2s, W2, HD, HD, HD, 4);
+    if (!LOAD) stage_w<16 * 64, 64 * BNW>(W2s, W2, HD, HD, HD, 4);
     stage_wT<64 * BNW>(W2Ts, W2, HD);
   }
   for (int e = tid; e < 16 * 64; e += 64 * BNW) {
@@ -378,12 +398,14 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     const int n3 = 4 * j + (l >> 4);
     W3Ts[e] = n3 < a.N3 ? W3[(long)n3 * HD + 16 * t + (l & 15)] : 0.f;
   }
-  build_tab(tab, a.x, a.K1, a.CF, KC, 64 * BNW);
+  build_tab(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * BNW);
   f32x4 b1v[4], b2v[4];
+  if (!LOAD) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    b1v[t] = *reinterpret_cast<const f32x4*>(a.b1 + g * a.gs_b1 + 16 * t + 4 * q);
-    if (THREE) b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
+    for (int t = 0; t < 4; ++t) {
+      b1v[t] = *reinterpret_cast<const f32x4*>(a.b1 + g * a.gs_b1 + 16 * t + 4 * q);
+      if (THREE) b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
+    }
   }
   __syncthreads();
 
@@ -400,8 +422,8 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) dW2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float* xT = stage;                     // stage 1: [16*KC][RS] x^T, then [64][RS] dh1^T
-  float* dh1T = stage + 16 * KC * RS;
+  float* xT = stage;                     // stage 1: [16*KH][RS] x^T (KH chunks at a time), then [64][RS] dh1^T
+  float* dh1T = stage + 16 * KH * RS;
   float* h1T = stage;                    // stage 2: h1^T, dh2^T, h2^T [64][RS] each, dY^T [16][RS]
   float* dh2T = stage + 64 * RS;
   float* h2T = stage + 128 * RS;
@@ -413,12 +435,12 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   float dyn[4];
   const long tiles = (a.M + 15) / 16;
   constexpr int NP = THREE ? 8 : 4;
-  auto issue_kept = [&](long it_) __attribute__((always_inline)) {
-    const bool lv = (xr.flags & 1) != 0;
+  auto issue_kept = [&](long it_, const XRow& xk) __attribute__((always_inline)) {
+    const bool lv = (xk.flags & 1) != 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n3 = 4 * j + q;
-      dyn[j] = (lv && n3 < a.N3) ? dY[xr.rowc * a.ldy + n3] : 0.f;
+      dyn[j] = (lv && n3 < a.N3) ? dY[xk.rowc * a.ldy + n3] : 0.f;
     }
     long tl = it_ * BNW + wave; if (tl > tiles - 1) tl = tiles - 1;      // (a tile past the end multiplies zero gradients)
     const f32x4* hp = reinterpret_cast<const f32x4*>(a.hs) + (((long)g * tiles + tl) * NP) * 64 + lane;
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   if (i_begin < i_end) {
     xr = x_row(a.x, (i_begin * BNW + wave) * 16 + m, a.M);
     x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
-    if (LOAD) issue_kept(i_begin);
+    if (LOAD) issue_kept(i_begin, xr);
   }
   ST_DECL(12);
   for (long it = i_begin; it < i_end; ++it) {
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
       else dy[j] = (live && n3 < a.N3) ? dY[rowc * a.ldy + n3] : 0.f;
     }
 #pragma unroll
-    for (int c = 0; c < KC; ++c)
+    for (int c = 0; c < KH; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) xT[(16 * c + 4 * q + i) * RS + 16 * wave + m] = xv[c][i];
     f32x4 h1[4], h2[4], dh2[4], dh1[4];
@@ -459,12 +481,12 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     } else {
       fwd1<KC>(xv, W1s, b1v, h1, lane);
     }
-    // x is consumed: start the loads of the next iteration's tile (unconditional; the last one re-reads its own)
+    // x is consumed (NH == 1): start the loads of the next iteration's tile (unconditional; the last one re-reads its own)
     {
       const long ni = it + 1 < i_end ? it + 1 : it;
       xr = x_row(a.x, (ni * BNW + wave) * 16 + m, a.M);
-      x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
-      if (LOAD) issue_kept(ni);
+      if (NH == 1) x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
+      if (LOAD) issue_kept(ni, xr);
     }
     ST_MARK(1);
     if (!LOAD) {
@@ -517,19 +539,32 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     ST_MARK(5);
     // ---------------- phase B1: dW1 rows [16w, 16w+16) over the 64 rows of the iteration
 #pragma unroll
-    for (int rt = 0; rt < BNW; ++rt) {
-      const f32x4 af = *reinterpret_cast<const f32x4*>(dh1T + (16 * wave + m) * RS + 16 * rt + 4 * q);
-      bs1 += (af[0] + af[1]) + (af[2] + af[3]);
+    for (int hf = 0; hf < NH; ++hf) {
+      if (hf > 0) {          // next KH chunks of x^T into the same stage rows (dh1^T stays where it is)
+        WG_BARRIER();
 #pragma unroll
-      for (int c = 0; c < KC; c += 4) {        // up to four k tiles round robin (independent accumulators)
-        f32x4 bf[4];
+        for (int c = 0; c < KH; ++c)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (c + u < KC) bf[u] = *reinterpret_cast<const f32x4*>(xT + (16 * (c + u) + m) * RS + 16 * rt + 4 * q);
-        if (c + 3 < KC) mfma16x4_il4(af, bf[0], dW1[c], af, bf[1], dW1[c + 1], af, bf[2], dW1[c + 2], af, bf[3], dW1[c + 3]);
-        else if (c + 2 < KC) mfma16x4_il3(af, bf[0], dW1[c], af, bf[1], dW1[c + 1], af, bf[2], dW1[c + 2]);
-        else if (c + 1 < KC) mfma16x4_il2(af, bf[0], dW1[c], af, bf[1], dW1[c + 1]);
-        else dW1[c] = mfma16x4(af, bf[0], dW1[c]);
+          for (int i = 0; i < 4; ++i) xT[(16 * c + 4 * q + i) * RS + 16 * wave + m] = xv[hf * KH + c][i];
+        if (hf == NH - 1) x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);      // x is consumed: the next iteration's tile
+        WG_BARRIER();
+      }
+#pragma unroll
+      for (int rt = 0; rt < BNW; ++rt) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(dh1T + (16 * wave + m) * RS + 16 * rt + 4 * q);
+        if (hf == 0) bs1 += (af[0] + af[1]) + (af[2] + af[3]);
+#pragma unroll
+        for (int c = 0; c < KH; c += 4) {        // up to four k tiles round robin (independent accumulators)
+          const int cg = hf * KH + c;
+          f32x4 bf[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (c + u < KH) bf[u] = *reinterpret_cast<const f32x4*>(xT + (16 * (c + u) + m) * RS + 16 * rt + 4 * q);
+          if (c + 3 < KH) mfma16x4_il4(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1], af, bf[2], dW1[cg + 2], af, bf[3], dW1[cg + 3]);
+          else if (c + 2 < KH) mfma16x4_il3(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1], af, bf[2], dW1[cg + 2]);
+          else if (c + 1 < KH) mfma16x4_il2(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1]);
+          else dW1[cg] = mfma16x4(af, bf[0], dW1[cg]);
+        }
       }
     }
     ST_MARK(6);
@@ -580,8 +615,8 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   for (int c = 0; c < KC; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = 16 * wave + 4 * q + i, k = 16 * c + m;
-      if (k < a.K1) s1[(long)n * K1x + k] = dW1[c][i];
+      const int n = 16 * wave + 4 * q + i, k = vcol(16 * c + m, a.x.k0, a.kpad);      // pad columns of the K axis hold nothing
+      if (k >= 0 && k < a.K1) s1[(long)n * K1x + k] = dW1[c][i];
     }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -653,12 +688,18 @@ inline ConcatSrc to_src3(const marl_src_t* s) {
 
 #define MLP3_CF7_(T3, CF, ...) T3, 7, ##__VA_ARGS__
 #define MLP3_CF7(...) MLP3_CF7_(__VA_ARGS__)
-// instantiated chunk counts: 4, 8, 11 (QPLEX [state 120 | one-hot 55] exactly), 12
-inline int kc_bucket(int K1) { const int kc = (K1 + 15) / 16; return kc == 11 ? 11 : (kc + 3) / 4 * 4; }
-inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 512 * 4; }
-inline size_t bwd_lds(int KC, int CF) {
-  const int SF = (16 * KC + HD) > 208 ? (16 * KC + HD) : 208;
-  return (size_t)(4 * KC * 256 + 2 * 16 * 256 + 16 * 64 + SF * RS) * 4 + (size_t)(KC - CF) * 512 * 4;
+// instantiated chunk counts: 4, 8, 11 (QPLEX [state 120 | one-hot 55] exactly), 12; 16, 24, 32 (K1 up to 512: the backward of
+// these exists only for kept activations)
+inline int kc_bucket(int KV) {
+  const int kc = (KV + 15) / 16;
+  return kc == 11 ? 11 : kc <= 12 ? (kc + 3) / 4 * 4 : kc <= 16 ? 16 : (kc + 7) / 8 * 8;
+}
+inline int kpad_of(const marl_src_t* x) { return (4 - x->k0 % 4) % 4; }
+inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 32 * 4; }
+inline size_t bwd_lds(int KC, int CF, bool kept) {
+  const int KH = KC > 24 ? 16 : KC;
+  const int SF = (16 * KH + HD) > 208 ? (16 * KH + HD) : 208;
+  return (size_t)((kept ? 0 : 4 * KC * 256 + 16 * 256) + 16 * 256 + 16 * 64 + SF * RS) * 4 + (size_t)(KC - CF) * 32 * 4;
 }
 inline int lead_chunks(const marl_src_t* x) {
   const bool al = x->p0 && (x->ld0 % 4 == 0) && aligned16(x->p0);
@@ -680,6 +721,7 @@ bool fill_args(Mlp3Args& a, const marl_mlp3_weights_t* w, const marl_src_t* x, l
   a.W1 = w->w1; a.b1 = w->b1; a.W2 = w->w2; a.b2 = w->b2; a.W3 = w->w3; a.b3 = w->b3;
   a.gs_w1 = w->gs_w1; a.gs_b1 = w->gs_b1; a.gs_w2 = w->gs_w2; a.gs_b2 = w->gs_b2; a.gs_w3 = w->gs_w3; a.gs_b3 = w->gs_b3;
   a.M = M; a.K1 = K1; a.N3 = N3; a.groups = groups;
+  a.kpad = kpad_of(x); a.KV = K1 + a.kpad;
   a.CF = lead_chunks(x);
   return true;
 }
@@ -693,12 +735,14 @@ extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, 
   if (!x->p0 || x->k0 < 4 || x->m0 || x->nid) return 0;
   if (x->nhot && (x->hot_w < 1 || x->hot_w >= 16384 || x->nhot >= 8192)) return 0;
   if (x->k0 >= 16384 || x->k1 >= 16384) return 0;
-  if (x->k0 % 4 || x->k1 % 4) return 0;               // a lane's four consecutive columns come from one segment
-  const int KC = kc_bucket(K1);
-  if (KC > 12) return 0;
+  if (x->k1 % 4) return 0;               // a lane's four consecutive columns come from one segment (dense0 is padded by the kernels)
+  const int KC = kc_bucket(K1 + kpad_of(x));
+  if (KC > 32) return 0;
   const int CF = lead_chunks(x);
-  return bwd_lds(KC, CF) <= 160 * 1024 && fwd_lds(KC, CF) <= 160 * 1024;
+  return bwd_lds(KC, CF, KC > 12) <= 160 * 1024 && fwd_lds(KC, CF) <= 160 * 1024;
 }
+
+extern "C" int marl_mlp3_needs_kept(const marl_src_t* x, int K1) { return kc_bucket(K1 + kpad_of(x)) > 12; }
 
 extern "C" size_t marl_mlp3_save_floats(long M, int three, int groups) {
   return M <= 0 ? 0 : (size_t)groups * (size_t)((M + 15) / 16) * (three ? 8 : 4) * 256;
@@ -717,12 +761,14 @@ extern "C" int marl_mlp3_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t
   a.Y = Y; a.ldy = ldy; a.gs_y = gs_y; a.ws = nullptr; a.hs = hsave;
   const long tiles = (M + 15) / 16;
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
-  const int KC = kc_bucket(K1);
+  const int KC = kc_bucket(a.KV);
   const size_t lds = fwd_lds(KC, a.CF);
 // (seven leading full chunks = a 120-wide dense segment 0: the QPLEX heads on 2s3z-sized maps get the compile-time variants)
 #define MLP3_PICK(K, ...) (KC == 4 ? (const void*)K<4, __VA_ARGS__> : KC == 8 ? (a.CF == 7 ? (const void*)K<8, MLP3_CF7(__VA_ARGS__)> : (const void*)K<8, __VA_ARGS__>) \
                            : KC == 11 ? (a.CF == 7 ? (const void*)K<11, MLP3_CF7(__VA_ARGS__)> : (const void*)K<11, __VA_ARGS__>) : (const void*)K<12, __VA_ARGS__>)
-  const void* fn = three ? MLP3_PICK(mlp3_fwd_kernel, true, -1) : MLP3_PICK(mlp3_fwd_kernel, false, -1);
+#define MLP3_PICK_BIG(K, ...) (KC == 16 ? (const void*)K<16, __VA_ARGS__> : KC == 24 ? (const void*)K<24, __VA_ARGS__> : (const void*)K<32, __VA_ARGS__>)
+  const void* fn = KC > 12 ? (three ? MLP3_PICK_BIG(mlp3_fwd_kernel, true, -1) : MLP3_PICK_BIG(mlp3_fwd_kernel, false, -1))
+                           : (three ? MLP3_PICK(mlp3_fwd_kernel, true, -1) : MLP3_PICK(mlp3_fwd_kernel, false, -1));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * FNW);
@@ -758,10 +804,12 @@ extern "C" int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws; a.hs = const_cast<float*>(hsave);
   a.nst = stripes((M + 63) / 64, groups);
-  const int KC = kc_bucket(K1);
-  const size_t lds = bwd_lds(KC, a.CF);
-  const void* fn = hsave ? (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK(mlp3_bwd_kernel, false, -1, true))
-                         : (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, false) : MLP3_PICK(mlp3_bwd_kernel, false, -1, false));
+  const int KC = kc_bucket(a.KV);
+  if (KC > 12 && !hsave) return (int)hipErrorInvalidValue;      // marl_mlp3_needs_kept(): no recomputing backward for K1 > 192
+  const size_t lds = bwd_lds(KC, a.CF, hsave != nullptr);
+  const void* fn = KC > 12 ? (three ? MLP3_PICK_BIG(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK_BIG(mlp3_bwd_kernel, false, -1, true))
+                   : hsave ? (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK(mlp3_bwd_kernel, false, -1, true))
+                           : (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, false) : MLP3_PICK(mlp3_bwd_kernel, false, -1, false));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * BNW);

@@ -303,6 +303,11 @@ class DMAQ_SI_Weight(nn.Module):
         raise RuntimeError("DMAQ_SI_Weight is evaluated inside DMAQer.hip_forward (fused lambda-net path)")
 
 
+def _keep_hidden():
+    """the fused head families keep their hidden activations for the backward (MARL_MLP3_KEEP=0: recompute them there)"""
+    return os.environ.get("MARL_MLP3_KEEP", "1") != "0"
+
+
 def _head_stride(mods, attr):
     """element stride between consecutive heads' tensors if uniform (flat parameter buffer), else None."""
     ts = [getattr(m, attr) for m in mods]
@@ -360,11 +365,13 @@ class DMAQer(_Precision, nn.Module):
         l0, l1, l2 = heads[0]
         if not ops.mlp3_supported(x_in, l0.in_features, l0.out_features, l1.out_features, nout, len(heads)):
             return None
+        if ops.mlp3_needs_kept(x_in, l0.in_features) and not _keep_hidden():
+            return None
         return ops.mlp3_weights(heads, grad=grad)
 
     def _kept(self, name, rows, three, groups, dev):
         """buffer for the hidden activations a fused family keeps for its backward (MARL_MLP3_KEEP=0: recompute)."""
-        if os.environ.get("MARL_MLP3_KEEP", "1") == "0":
+        if not _keep_hidden():
             return None
         return self._s.get(name + "_hs", (ops.mlp3_save_floats(rows, three, groups),), dev)
 
@@ -374,6 +381,8 @@ class DMAQer(_Precision, nn.Module):
             return None
         heads = [_linears(self.hyper_w_final), _linears(self.V)]
         if len(heads[0]) != 2 or not ops.mlp3_supported(xs, self.state_dim, heads[0][0].out_features, 0, self.n_agents, 2):
+            return None
+        if ops.mlp3_needs_kept(xs, self.state_dim) and not _keep_hidden():
             return None
         return ops.mlp3_weights(heads, grad=grad)
 

@@ -493,6 +493,11 @@ def mlp3_supported(x, K1, H1, H2, N3, groups):
     return bool(_lib.load().marl_mlp3_supported(C.byref(x), K1, H1, H2, N3, groups))
 
 
+def mlp3_needs_kept(x, K1):
+    """True when the fused backward of this input shape exists only for kept activations (K1 > 192)."""
+    return bool(_lib.load().marl_mlp3_needs_kept(C.byref(x), K1))
+
+
 def _head_layout(Y, M, N3, groups):
     """(ld, group stride) of the head outputs: (M, groups*N3) with head g in columns [g*N3, (g+1)*N3), or
     (groups, M, N3) with one contiguous (M, N3) block per head."""

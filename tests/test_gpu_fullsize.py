@@ -294,3 +294,27 @@ def test_config2_qmix_2s3z_1024_chain_schedule():
 def test_config3_qplex_2s3z_512_shard_chain_schedule():
     """BASELINE config 3 at its per-GPU shard (QPLEX, 2s3z, 4096 envs / 8 GPUs = 512 envs x T = 120)."""
     _chain_schedule_case("qplex", 512, "full:cfg3_qplex_2s3z_512x120")
+
+
+def test_qplex_mmm2_heads_run_fused_and_match_oracle():
+    """QPLEX on an MMM2-sized map (off the five BASELINE configurations): state 322 (not a multiple of 4) and
+    [state | 10 x 18 one-hot actions] = 502 input columns - the lambda-net families (mixer.py:117-145) and the transformation
+    pair take the fused head kernels' K1 > 192 variants (kept activations, x^T staged in two passes), not the marl_linear
+    composition.  Shard linearity + every gradient vs the CPU oracle on sampled episodes."""
+    from marl_amd import ops
+    from marl_amd.hostutil import DeviceBatch
+    Eq, Tq = 96, 40
+    case, args, learner, rec = _shard_world("MMM2", "qplex", Eq, Tq, seed=37)
+    Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
+    assert Tm == Tq
+    mx = learner.mixer
+    rows = Eq * Tm
+    s = DeviceBatch.from_record(rec, args, T=Tm).s               # what the learner hands the mixer (rows of the (T+1)-slot storage)
+    xs = ops.src(s)
+    xsa = ops.src(s, idx=torch.zeros(rows, args.n_agents, dtype=torch.int32, device=rec.obs.device), nhot=args.n_agents,
+                  hot_w=args.n_actions)
+    assert mx._fused_transform(xs) is not None and ops.mlp3_needs_kept(xs, args.state_shape)
+    for fname, mods, nout in mx.si_weight.families():
+        assert mx._fused_family(mods, xsa if fname == "ac" else xs, nout) is not None, fname
+    _linearity(learner, rec, Tm, Eq, 2, "full:qplex_MMM2_96x40")
+    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 47, 95], Tm, "full:qplex_MMM2_96x40")

@@ -212,7 +212,13 @@ def test_wgrad_full_width(dev, M, N, K0, HW, gate):
                                                         (70, 24, 2, 3, 2, 3, False, 3), (4100, 120, 5, 11, 5, 4, True, 3),
                                                         (129, 72, 0, 0, 16, 2, False, 3), (50, 36, 4, 9, 3, 1, False, 3),
                                                         (777, 120, 0, 0, 5, 2, False, 2), (4100, 120, 0, 0, 5, 2, True, 2),
-                                                        (65, 28, 1, 4, 7, 3, False, 2)])
+                                                        (65, 28, 1, 4, 7, 3, False, 2),
+                                                        # K1 > 192 (kept activations only) and state widths that are not multiples of 4:
+                                                        # QPLEX on MMM2 (state 322, 10 x 18 actions), on 3s5z (216 + 8 x 14), odd small shapes
+                                                        (700, 322, 10, 18, 10, 3, False, 3), (333, 322, 0, 0, 1, 4, False, 3),
+                                                        (500, 322, 0, 0, 10, 2, False, 2), (129, 30, 2, 5, 3, 2, False, 3),
+                                                        (1230, 216, 8, 14, 8, 2, True, 3), (90, 250, 0, 0, 4, 1, False, 3),
+                                                        (77, 322, 10, 18, 10, 2, False, 3), (60, 203, 1, 7, 2, 2, False, 2)])
 def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     """Fused three-layer heads (QPLEX lambda-net families, mixer.py:117-145) vs torch-CPU autograd: outputs and all six
     parameter gradients of every head; x = [state | one-hot actions] with ragged sizes, 'no action' indices and
@@ -231,7 +237,13 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     else:
         x0 = torch.randn(rows, S, generator=g)
         # S = 36 / 72: rows at an odd stride - no 16-byte loads, every chunk takes the element path
-        x0_src = cu(x0, dev) if S % 8 == 0 else cu(torch.cat([x0, x0[:, :1]], 1), dev)[:, :S]
+        # S = 322 with rows = 700 / 333 / 500: rows padded to 16 bytes (how the replay stores MMM2 states) - 20 vector chunks
+        if S % 8 == 0:
+            x0_src = cu(x0, dev)
+        elif S == 322 and rows > 100:
+            x0_src = cu(torch.cat([x0, torch.full((rows, 2), float("nan"))], 1), dev)[:, :S]
+        else:
+            x0_src = cu(torch.cat([x0, x0[:, :1]], 1), dev)[:, :S]
     parts = [x0]
     idx = None
     if NH:
@@ -267,10 +279,17 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     xs = ops.src(x0_src, idx=cu(idx, dev, torch.int32) if NH else None, nhot=NH, hot_w=HW)
     assert ops.mlp3_supported(xs, K1, 64, 64 if nl == 3 else 0, N3, G)
     Y = torch.full((rows, G * N3), 7.0, device=dev)
-    ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G)
+    kept_only = ops.mlp3_needs_kept(xs, K1)      # K1 > 192: no recomputing backward
+    assert kept_only == ((K1 + (-S) % 4 + 15) // 16 > 12)
+    hs = torch.full((ops.mlp3_save_floats(rows, nl == 3, G),), float("nan"), device=dev)
+    ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G, hsave=hs if kept_only else None)
     dY = torch.randn(rows, G * N3, generator=g)
+    if kept_only:
+        with pytest.raises(Exception):
+            ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G)
     for rep in range(2):      # gradients ACCUMULATE: the second call doubles them
-        ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G)
+        ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G,
+                     hsave=hs if kept_only else None)
     for k in range(G):
         ps = [v.clone().requires_grad_(True) for v in views(flat, k)]
         h = torch.relu(F.linear(X, ps[0], ps[1]))
@@ -282,9 +301,11 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
         for name, pr, gv in zip(("W1", "b1", "W2", "b2", "W3", "b3") if nl == 3 else ("W1", "b1", "W3", "b3"), ps, views(gd, k)):
             scale = max(1.0, float(pr.grad.abs().max()))
             close(gv / scale, 2.0 * pr.grad / scale, 3e-4, 1e-4, msg="head %d d%s" % (k, name))
+    assert not torch.isnan(gd).any()
+    if kept_only:
+        return
     # the pair that KEEPS h1 / h2 between forward and backward (marl_mlp3_fwd_save / marl_mlp3_bwd_saved) is bit-identical to the
     # recomputing pair: same outputs, same gradients
-    hs = torch.full((ops.mlp3_save_floats(rows, nl == 3, G),), float("nan"), device=dev)
     Y2, gd_rec = torch.full((rows, G * N3), 7.0, device=dev), gd.clone()
     ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y2, rows, K1, N3, G, hsave=hs)
     assert torch.equal(Y2, Y)

@@ -8,9 +8,11 @@ from marl_amd import ops
 import torch.nn as nn
 
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-rows, S, N, A, G = envs * 120, 120, 5, 11, 10
+shape = sys.argv[2] if len(sys.argv) > 2 else "2s3z"          # MMM2: K1 = 322 / 502 (kept activations only)
+S, N, A = {"2s3z": (120, 5, 11), "3s5z": (216, 8, 14), "MMM2": (322, 10, 18)}[shape]
+rows, G = envs * 120, 10
 dev = torch.device("cuda:0")
-s = torch.randn(rows, S, device=dev)
+s = torch.randn(rows, (S + 3) // 4 * 4, device=dev)[:, :S]      # rows padded to 16 bytes, as the episode record stores them
 u = torch.randint(0, A, (rows, N), device=dev, dtype=torch.int32)
 for name, K1, N3, x in (("key", S, 1, ops.src(s)), ("agents", S, N, ops.src(s)),
                         ("action", S + N * A, N, ops.src(s, idx=u, nhot=N, hot_w=A))):
@@ -37,10 +39,13 @@ for name, K1, N3, x in (("key", S, 1, ops.src(s)), ("agents", S, N, ops.src(s)),
     fl = 2.0 * rows * G * (K1 * 64 + 64 * 64 + 64 * N3)
     hs = torch.empty(ops.mlp3_save_floats(rows, True, G), device=dev)
     bm = 3.0 - (K1 * 64) / (K1 * 64 + 64 * 64 + 64 * N3)
-    for what, fn, mult in (("fwd", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G), 1.0),
-                           ("bwd", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G), bm),
-                           ("fwd keeping h1,h2", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G, hsave=hs), 1.0),
-                           ("bwd from kept h1,h2", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G, hsave=hs), bm)):
+    legs = [("fwd", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G), 1.0),
+            ("bwd", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G), bm),
+            ("fwd keeping h1,h2", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G, hsave=hs), 1.0),
+            ("bwd from kept h1,h2", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G, hsave=hs), bm)]
+    if ops.mlp3_needs_kept(x, K1):
+        del legs[1]
+    for what, fn, mult in legs:
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
