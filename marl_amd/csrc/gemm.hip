@@ -1025,6 +1025,61 @@ inline int try_wgrad_tall(WgradArgs& a, size_t ws_bytes, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One-output layers (the last layer of QTRAN's joint-Q / V heads, network/mixer.py:384-388 / :410-414, and of QMIX's hyper_b2,
+// mixer.py:44-46): dW[k] = sum_m g[m] x[m][k] is a weighted column sum - HBM bound on reading x once.  The MFMA kernels above spend
+// a 64-column output block on it (M = 76 800, K = 64: 49 us for 20 MB).  Here thread (rl, cg) walks rows rl, rl + RL, ... of its
+// slab with one 16-byte load per row, four rows in flight; the RL partial sums of a column are added in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
+  __shared__ float part[256 * 4 + 256];
+  const int tid = threadIdx.x;
+  const int KG = (a.K + 3) >> 2, RL = 256 / KG;
+  const int cg = tid % KG, rl = tid / KG;
+  const long per = ((long)a.M + gridDim.x - 1) / gridDim.x;
+  const long r_begin = (long)blockIdx.x * per;
+  long r_end = r_begin + per; if (r_end > a.M) r_end = a.M;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float gs = 0.f;
+  if (rl < RL) {
+    const float* xp = a.x.p0 + 4 * cg;
+    long r = r_begin + rl;
+    for (; r + 3L * RL < r_end; r += 4L * RL) {
+      float g[4]; f32x4 xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { g[u] = a.G[(r + (long)u * RL) * a.ldg]; xv[u] = *reinterpret_cast<const f32x4*>(xp + (r + (long)u * RL) * a.x.ld0); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc += g[u] * xv[u]; gs += g[u]; }
+    }
+    for (; r < r_end; r += RL) {
+      const float g = a.G[r * a.ldg];
+      acc += g * *reinterpret_cast<const f32x4*>(xp + r * a.x.ld0);
+      gs += g;
+    }
+  }
+  *reinterpret_cast<f32x4*>(part + tid * 4) = acc;          // [rl][cg][4] = [rl][column]
+  if (cg == 0 && rl < RL) part[1024 + rl] = gs;
+  __syncthreads();
+  float* slab = a.ws + (long)blockIdx.x * (a.K + 1);
+  if (tid < a.K) {
+    float t = 0.f;
+    for (int j = 0; j < RL; ++j) t += part[(j * KG) * 4 + tid];
+    slab[tid] = t;
+  } else if (tid == a.K) {
+    float t = 0.f;
+    for (int j = 0; j < RL; ++j) t += part[1024 + j];
+    slab[a.K] = t;
+  }
+}
+
+// returns -1 when the shape is not covered
+inline int try_wgrad_thin(WgradArgs& a, hipStream_t s) {
+  if (a.N != 1 || a.groups != 1 || a.Yact || !a.xvec || a.M < 4096 || a.K > 252 || (a.x.ld0 & 3)) return -1;
+  if (!a.x.p0 || a.x.k0 != a.K || a.x.k1 || a.x.nhot || a.x.nid || a.x.m0 || a.x.rpe0 || a.x.emap0) return -1;
+  if (a.x.ld0 < (a.K + 3) / 4 * 4) return -1;                // the last 16-byte load of a row stays inside its pitch
+  hipLaunchKernelGGL(wgrad_thin_kernel, dim3(a.slabs), dim3(256), 0, s, a);
+  return 0;
+}
+
 struct WredArgs {
   const float* ws; float* dW; long lddw; float* db;
   int N, K, slabs, groups; long gs_dw, gs_db;
@@ -1211,7 +1266,8 @@ extern "C" int marl_linear_wgrad(const float* G, long ldg, const float* Yact, lo
       return 0;
     }
   }
-  int done = bf ? -1 : try_wgrad_direct(a, s);
+  int done = try_wgrad_thin(a, s);            // fp32 either way: one output column is not matrix work
+  if (done != 0) done = bf ? -1 : try_wgrad_direct(a, s);
   bool one_base = a.x.p0 && !a.x.m0 && !a.x.nid && a.x.k0 < 16384 && a.x.k1 < 16384 && a.x.nhot < 16384 && a.x.hot_w < 0xfff0;
   for (int c4 = 0; one_base && c4 < K; c4 += 4) {       // segment of the first and the last real column of each item
     auto seg = [&](int k) { return k < a.x.k0 ? 0 : (k - a.x.k0 < a.x.k1 ? 1 : 2); };

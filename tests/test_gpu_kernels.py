@@ -208,6 +208,24 @@ def test_wgrad_full_width(dev, M, N, K0, HW, gate):
     close(db - 0.25, Gm.sum(0), 2e-3, 1e-3)
 
 
+@pytest.mark.parametrize("M,K", [(76800, 64), (9001, 32), (4100, 30), (5000, 252), (4096, 4)])
+def test_wgrad_one_output_column(dev, M, K):
+    """N = 1 layers (last layer of QtranQBase.q / QtranV.v, mixer.py:384-388 / :410-414; hyper_b2[2], mixer.py:44-46):
+    the weighted column sum kernel; gradients accumulate."""
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    X, dY = torch.randn(M, K, generator=g), torch.randn(M, 1, generator=g)
+    ld = (K + 3) // 4 * 4
+    Xd = cu(torch.cat([X, torch.full((M, ld - K), float("nan"))], 1), dev)[:, :K] if ld != K else cu(X, dev)
+    dW, db = torch.full((1, K), 0.5, device=dev), torch.full((1,), 0.25, device=dev)
+    for rep in range(2):
+        ops.linear_wgrad(cu(dY, dev), ops.src(Xd), dW, db, M, 1, K)
+    ref = (dY.double().t() @ X.double()).float()
+    scale = max(1.0, float(ref.abs().max()))
+    close((dW - 0.5) / scale, 2.0 * ref / scale, 1e-4, 1e-4)
+    close(db - 0.25, 2.0 * dY.sum(0), 1e-3, 1e-4)
+
+
 @pytest.mark.parametrize("rows,S,NH,HW,N3,G,remap,nl", [(333, 120, 0, 0, 1, 10, False, 3), (1000, 120, 5, 11, 5, 10, False, 3),
                                                         (70, 24, 2, 3, 2, 3, False, 3), (4100, 120, 5, 11, 5, 4, True, 3),
                                                         (129, 72, 0, 0, 16, 2, False, 3), (50, 36, 4, 9, 3, 1, False, 3),
