@@ -248,10 +248,13 @@ int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float
  * floats, layout private to the pair), the backward reads them back with 16-byte coalesced loads and skips layers
  * 1-2.  Bit-identical to the recomputing pair.  hsave == NULL: exactly marl_mlp3_fwd / marl_mlp3_bwd. */
 size_t marl_mlp3_save_floats(long M, int three, int groups);
-/* 1 when the backward of this input shape exists only as marl_mlp3_bwd_saved with hsave != NULL (K1 > 192, e.g. the heads of
+/* Wide outputs: two-layer heads (w2 == NULL) take 16 < N3 <= 160 outputs, N3 a multiple of 4 (hyper_w1 / hyper_w2 of QMixMixer
+ * with two_hyper_layers, network/mixer.py:36-43: state -> 64 -> n_agents * embed); a wider head is evaluated as `groups` column
+ * blocks that share layer 1 (gs_w1 = gs_b1 = 0: those gradients are then summed over the groups).
+ * 1 when the backward of this shape exists only as marl_mlp3_bwd_saved with hsave != NULL (N3 > 16, or K1 > 192, e.g. the heads of
  * DMAQ_SI_Weight on MMM2: state 322 [+ 10 x 18 one-hot actions], network/mixer.py:117-145): W1 no longer fits in LDS beside the
  * operand exchange, so layer 1 is not recomputed. */
-int marl_mlp3_needs_kept(const marl_src_t* x, int K1);
+int marl_mlp3_needs_kept(const marl_src_t* x, int K1, int N3);
 int marl_mlp3_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
                        float* hsave, size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
 int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,

@@ -100,7 +100,7 @@ SIGNATURES = {
     "marl_mlp3_bwd_workspace": (SZ, [L, I, I, I]),
     "marl_mlp3_bwd": (I, [M3, SRC, P, L, L, M3, P, SZ, L, I, I, I, P]),
     "marl_mlp3_save_floats": (SZ, [L, I, I]),
-    "marl_mlp3_needs_kept": (I, [SRC, I]),
+    "marl_mlp3_needs_kept": (I, [SRC, I, I]),
     "marl_mlp3_fwd_save": (I, [M3, SRC, P, L, L, P, SZ, L, I, I, I, P]),
     "marl_mlp3_bwd_saved": (I, [M3, SRC, P, L, L, M3, P, SZ, P, SZ, L, I, I, I, P]),
     "marl_qtran_supported": (I, [I, I, I]),

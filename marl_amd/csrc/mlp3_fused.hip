@@ -41,14 +41,19 @@ struct Mlp3Args {
   long M;
   int K1, N3, groups, nst, CF;                       // nst stripes per group; CF leading 16-byte-loadable chunks
   int kpad, KV;                                      // virtual K axis: kpad zero columns after dense0 (so that k0 + kpad is a multiple of 4), KV = K1 + kpad
+  int n3t, yvec;                                     // WIDE kernels: output tiles of 16 (N3 up to 160); Y rows take 16-byte accesses
 };
+constexpr int NTW = 10;           // output tiles of the WIDE variants (hypernet heads of QMIX with two_hyper_layers: N*E = 160 columns)
 
 // virtual column (K axis of the kernels) -> column of W1 / dW1, or -1 for a pad column.  A lane's four consecutive columns must
 // come from ONE segment of the concat; a dense0 width that is not a multiple of 4 (MMM2: 322 state columns) is padded in the
 // kernels' own K axis instead of asking the caller for another weight layout.
 __host__ __device__ inline int vcol(int k, int k0, int kpad) { return k < k0 ? k : (k < k0 + kpad ? -1 : k - kpad); }
 
-__host__ __device__ inline long mlp3_slab_floats(int K1) { return (long)HD * (K1 + 1) + (long)HD * (HD + 1) + 16L * (HD + 1); }
+__host__ __device__ inline long mlp3_slab_floats(int K1, int N3) {
+  const long n3p = N3 <= 16 ? 16 : (N3 + 15) / 16 * 16;
+  return (long)HD * (K1 + 1) + (long)HD * (HD + 1) + n3p * (HD + 1);
+}
 
 // workgroup -> (stripe, head): the `groups` heads of one stripe of rows run on the SAME XCD (blockIdx % 8) next to
 // each other in time, so the stripe's x rows are fetched from HBM once and hit that XCD's L2 for the other heads
@@ -274,8 +279,9 @@ __device__ __forceinline__ void fwd2(const f32x4 (&h1)[4], const float* W2s, con
 // ------------------------------------------------------------------------------------------------- forward
 // THREE = false: two-layer heads  y = W3 relu(W1 x + b1) + b3  (W2 == NULL; QPLEX transformation nets)
 // KC > 12 (K1 up to 512: QPLEX on MMM2-sized maps): x of a tile is 64-128 registers and W1 64-128 KB of LDS - one workgroup per CU
-template <int KC, bool THREE, int CFT = -1>
-__global__ __launch_bounds__(64 * FNW, KC > 12 ? 1 : 2) void mlp3_fwd_kernel(Mlp3Args a) {
+// WIDE: N3 up to 160 outputs in tiles of 16 (two-layer hypernet heads S -> 64 -> N*E of QMixMixer, mixer.py:36-43)
+template <int KC, bool THREE, int CFT = -1, bool WIDE = false>
+__global__ __launch_bounds__(64 * FNW, (KC > 12 || WIDE) ? 1 : 2) void mlp3_fwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
   if (!wg_map(a.groups, a.nst, stripe, g)) return;
@@ -283,14 +289,17 @@ __global__ __launch_bounds__(64 * FNW, KC > 12 ? 1 : 2) void mlp3_fwd_kernel(Mlp
   const int q = lane >> 4, m = lane & 15;
   float* W1s = smem;                              // [4][KC][64] f32x4
   float* W2s = W1s + 4 * KC * 256;                // [4][4][64] f32x4
-  float* W3s = W2s + 16 * 256;                    // [4][64] f32x4 (rows >= N3 zero)
-  int* tab = reinterpret_cast<int*>(W3s + 4 * 256);
+  float* W3s = W2s + 16 * 256;                    // [NT][4][64] f32x4 (rows >= N3 zero)
+  float* b3s = W3s + (WIDE ? NTW : 1) * 4 * 256;  // WIDE: [16 * NTW] output biases
+  int* tab = reinterpret_cast<int*>(b3s + (WIDE ? 16 * NTW : 0));
   const float* W1 = a.W1 + g * a.gs_w1;
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
   stage_w<4 * KC * 64, 64 * FNW>(W1s, W1, a.K1, HD, a.K1, KC, a.x.k0, a.kpad);
   if (THREE) stage_w<16 * 64, 64 * FNW>(W2s, W2, HD, HD, HD, 4);
-  stage_w<4 * 64, 64 * FNW>(W3s, W3, HD, a.N3, HD, 4);
+  stage_w<(WIDE ? NTW : 1) * 4 * 64, 64 * FNW>(W3s, W3, HD, a.N3, HD, 4);
+  if (WIDE)
+    for (int e = tid; e < 16 * NTW; e += 64 * FNW) b3s[e] = e < a.N3 ? a.b3[g * a.gs_b3 + e] : 0.f;
   build_tab(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * FNW);
   f32x4 b1v[4], b2v[4], b3v;
 #pragma unroll
@@ -344,16 +353,44 @@ __global__ __launch_bounds__(64 * FNW, KC > 12 ? 1 : 2) void mlp3_fwd_kernel(Mlp
         for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(h2[c], hp + (4 + c) * 64);
       }
     }
-    f32x4 acc = b3v;
+    if (WIDE) {
+      // output tiles two at a time (independent accumulators); a tile's four outputs of a row are one 16-byte store
+      for (int nt = 0; nt < a.n3t; nt += 2) {
+        const bool two = nt + 1 < a.n3t;
+        const int n1 = two ? nt + 1 : nt;
+        f32x4 acc0 = *reinterpret_cast<const f32x4*>(b3s + 16 * nt + 4 * q);
+        f32x4 acc1 = *reinterpret_cast<const f32x4*>(b3s + 16 * n1 + 4 * q);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W3s + (c * 64 + lane) * 4);
-      acc = mfma16x4(w, h2[c], acc);
-    }
-    if (live) {
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(W3s + ((nt * 4 + c) * 64 + lane) * 4);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(W3s + ((n1 * 4 + c) * 64 + lane) * 4);
+          mfma16x4_il2(w0, h2[c], acc0, w1, h2[c], acc1);
+        }
+        if (live) {
+          if (a.yvec) {
+            if (16 * nt + 4 * q < a.N3) *reinterpret_cast<f32x4*>(y + 16 * nt) = acc0;
+            if (two && 16 * n1 + 4 * q < a.N3) *reinterpret_cast<f32x4*>(y + 16 * n1) = acc1;
+          } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (4 * q + i < a.N3) y[i] = acc[i];
+            for (int i = 0; i < 4; ++i) {
+              if (16 * nt + 4 * q + i < a.N3) y[16 * nt + i] = acc0[i];
+              if (two && 16 * n1 + 4 * q + i < a.N3) y[16 * n1 + i] = acc1[i];
+            }
+          }
+        }
+      }
+    } else {
+      f32x4 acc = b3v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W3s + (c * 64 + lane) * 4);
+        acc = mfma16x4(w, h2[c], acc);
+      }
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < a.N3) y[i] = acc[i];
+      }
     }
   }
 }
@@ -368,7 +405,8 @@ __device__ __forceinline__ void stash4(float* st, const f32x4 (&v)[4], int wave,
 }
 
 // LOAD: h1 / h2 come from the forward's `hs` planes (one iteration ahead in a second register set) instead of being recomputed
-template <int KC, bool THREE, int CFT = -1, bool LOAD = false>
+// WIDE: N3 up to 160 (kept activations only); dY / dW3 in tiles of 16 outputs
+template <int KC, bool THREE, int CFT = -1, bool LOAD = false, bool WIDE = false>
 __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
@@ -378,12 +416,16 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   // x^T is staged KH chunks at a time (KC > 24: two passes of 16 - 32 chunks of 64 rows are 139 KB on their own)
   constexpr int KH = KC > 24 ? 16 : KC, NH = KC / KH;
   static_assert(KC % KH == 0 && (LOAD || KC <= 12), "K1 > 192 only with kept activations (W1 does not fit beside the stage)");
-  constexpr int SF = (16 * KH + HD) > 208 ? (16 * KH + HD) : 208;    // stage features: max(x + dh1, h1 + dh2 + h2 + dY)
+  static_assert(!WIDE || LOAD, "wide outputs only with kept activations");
+  constexpr int NT = WIDE ? NTW : 1;
+  constexpr int S2H = THREE ? 192 : 64;                               // stage 2: [h1 | dh2 |] h2, then dY^T
+  constexpr int SF2 = S2H + 16 * NT;
+  constexpr int SF = (16 * KH + HD) > SF2 ? (16 * KH + HD) : SF2;    // stage features: max(x + dh1, h1 + dh2 + h2 + dY)
   float* W1s = smem;                              // [4][KC][64] f32x4      (recomputing variant only)
   float* W2s = W1s + (LOAD ? 0 : 4 * KC * 256);   // [4][4][64] f32x4       (recomputing variant only)
   float* W2Ts = W2s + (LOAD ? 0 : 16 * 256);      // [4][4][64] f32x4
-  float* W3Ts = W2Ts + 16 * 256;                  // [4 t][4 j][64]: W3[4j + q][16t + m]
-  float* stage = W3Ts + 16 * 64;                  // [SF][RS]
+  float* W3Ts = W2Ts + (THREE || !WIDE ? 16 * 256 : 0);   // [4 t][4 j][64]: W3[4j + q][16t + m]; WIDE: [NT][4 t][64] f32x4 = W3[16nt + 4q + i][16t + m]
+  float* stage = W3Ts + (WIDE ? NT * 4 * 256 : 16 * 64);  // [SF][RS]
   int* tab = reinterpret_cast<int*>(stage + SF * RS);
   const float* W1 = a.W1 + g * a.gs_w1;
   const float* W2 = a.W2 + g * a.gs_w2;
@@ -393,10 +435,23 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     if (!LOAD) stage_w<16 * 64, 64 * BNW>(W2s, W2, HD, HD, HD, 4);
     stage_wT<64 * BNW>(W2Ts, W2, HD);
   }
-  for (int e = tid; e < 16 * 64; e += 64 * BNW) {
-    const int l = e & 63, tj = e >> 6, t = tj >> 2, j = tj & 3;
-    const int n3 = 4 * j + (l >> 4);
-    W3Ts[e] = n3 < a.N3 ? W3[(long)n3 * HD + 16 * t + (l & 15)] : 0.f;
+  if (WIDE) {
+    for (int e = tid; e < a.n3t * 4 * 64; e += 64 * BNW) {
+      const int l = e & 63, t = (e >> 6) & 3, nt = e >> 8;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n3 = 16 * nt + 4 * (l >> 4) + i;
+        v[i] = n3 < a.N3 ? W3[(long)n3 * HD + 16 * t + (l & 15)] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(W3Ts + (long)e * 4) = v;
+    }
+  } else {
+    for (int e = tid; e < 16 * 64; e += 64 * BNW) {
+      const int l = e & 63, tj = e >> 6, t = tj >> 2, j = tj & 3;
+      const int n3 = 4 * j + (l >> 4);
+      W3Ts[e] = n3 < a.N3 ? W3[(long)n3 * HD + 16 * t + (l & 15)] : 0.f;
+    }
   }
   build_tab(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * BNW);
   f32x4 b1v[4], b2v[4];
@@ -417,6 +472,10 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 
   f32x4 dW1[KC], dW2[4], dW3 = {0.f, 0.f, 0.f, 0.f};
   float bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+  f32x4 dW3w[NT];                        // WIDE: [16 outputs of tile nt] x [features 16w .. 16w+15]
+  float bs3w[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { dW3w[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; bs3w[nt] = 0.f; }
 #pragma unroll
   for (int c = 0; c < KC; ++c) dW1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -426,21 +485,30 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   float* dh1T = stage + 16 * KH * RS;
   float* h1T = stage;                    // stage 2: h1^T, dh2^T, h2^T [64][RS] each, dY^T [16][RS]
   float* dh2T = stage + 64 * RS;
-  float* h2T = stage + 128 * RS;
-  float* dYT = stage + 192 * RS;
+  float* h2T = stage + (S2H - 64) * RS;
+  float* dYT = stage + S2H * RS;
 
   f32x4 xv[KC];
   XRow xr;
   f32x4 hn1[4], hn2[4];                  // LOAD: the next iteration's kept activations and dY elements
   float dyn[4];
+  f32x4 dynw[NT];                        // WIDE: dY[row m][16nt + 4q .. +3]
   const long tiles = (a.M + 15) / 16;
   constexpr int NP = THREE ? 8 : 4;
   auto issue_kept = [&](long it_, const XRow& xk) __attribute__((always_inline)) {
     const bool lv = (xk.flags & 1) != 0;
+    if (WIDE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n3 = 4 * j + q;
-      dyn[j] = (lv && n3 < a.N3) ? dY[xk.rowc * a.ldy + n3] : 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        dynw[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (nt < a.n3t && lv && 16 * nt + 4 * q < a.N3) dynw[nt] = *reinterpret_cast<const f32x4*>(dY + xk.rowc * a.ldy + 16 * nt + 4 * q);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n3 = 4 * j + q;
+        dyn[j] = (lv && n3 < a.N3) ? dY[xk.rowc * a.ldy + n3] : 0.f;
+      }
     }
     long tl = it_ * BNW + wave; if (tl > tiles - 1) tl = tiles - 1;      // (a tile past the end multiplies zero gradients)
     const f32x4* hp = reinterpret_cast<const f32x4*>(a.hs) + (((long)g * tiles + tl) * NP) * 64 + lane;
@@ -463,11 +531,17 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     const bool live = (xr.flags & 1) != 0;
     const long rowc = xr.rowc;
     float dy[4];                                   // dY[row m][4j + q]
+    f32x4 dyw[NT];
+    if (WIDE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n3 = 4 * j + q;
-      if (LOAD) dy[j] = dyn[j];
-      else dy[j] = (live && n3 < a.N3) ? dY[rowc * a.ldy + n3] : 0.f;
+      for (int nt = 0; nt < NT; ++nt) dyw[nt] = dynw[nt];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n3 = 4 * j + q;
+        if (LOAD) dy[j] = dyn[j];
+        else dy[j] = (live && n3 < a.N3) ? dY[rowc * a.ldy + n3] : 0.f;
+      }
     }
 #pragma unroll
     for (int c = 0; c < KH; ++c)
@@ -501,12 +575,24 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
       f32x4 acc[4];                      // the four feature tiles round robin (independent accumulators, see common.h)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (WIDE) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * j < a.N3) {
+        for (int nt = 0; nt < NT; ++nt)
+          if (nt < a.n3t) {
+            f32x4 w[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = mfma16(W3Ts[(t * 4 + j) * 64 + lane], dy[j], acc[t]);      // heads n3 = 4j + q
-        }
+            for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const f32x4*>(W3Ts + ((nt * 4 + t) * 64 + lane) * 4);
+            mfma16x4_il4(w[0], dyw[nt], acc[0], w[1], dyw[nt], acc[1], w[2], dyw[nt], acc[2], w[3], dyw[nt], acc[3]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * j < a.N3) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma16(W3Ts[(t * 4 + j) * 64 + lane], dy[j], acc[t]);      // heads n3 = 4j + q
+          }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -576,8 +662,17 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
       stash4(dh2T, dh2, wave, q, m);
     }
     stash4(h2T, h2, wave, q, m);
+    if (WIDE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dYT[(4 * j + q) * RS + 16 * wave + m] = dy[j];
+      for (int nt = 0; nt < NT; ++nt)
+        if (nt < a.n3t) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dYT[(16 * nt + 4 * q + i) * RS + 16 * wave + m] = dyw[nt][i];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dYT[(4 * j + q) * RS + 16 * wave + m] = dy[j];
+    }
     ST_MARK(8);
     WG_BARRIER();
     ST_MARK(9);
@@ -592,10 +687,31 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
         for (int c = 0; c < 4; ++c) bf[c] = *reinterpret_cast<const f32x4*>(h1T + (16 * c + m) * RS + 16 * rt + 4 * q);
         mfma16x4_il4(af, bf[0], dW2[0], af, bf[1], dW2[1], af, bf[2], dW2[2], af, bf[3], dW2[3]);
       }
-      const f32x4 ay = *reinterpret_cast<const f32x4*>(dYT + m * RS + 16 * rt + 4 * q);
       const f32x4 bh = *reinterpret_cast<const f32x4*>(h2T + (16 * wave + m) * RS + 16 * rt + 4 * q);
-      bs3 += (ay[0] + ay[1]) + (ay[2] + ay[3]);
-      dW3 = mfma16x4(ay, bh, dW3);
+      if (WIDE) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt += 2)
+          if (nt < a.n3t) {
+            const int n1 = nt + 1 < a.n3t ? nt + 1 : nt;
+            const f32x4 ay0 = *reinterpret_cast<const f32x4*>(dYT + (16 * nt + m) * RS + 16 * rt + 4 * q);
+            const f32x4 ay1 = *reinterpret_cast<const f32x4*>(dYT + (16 * n1 + m) * RS + 16 * rt + 4 * q);
+            bs3w[nt] += (ay0[0] + ay0[1]) + (ay0[2] + ay0[3]);
+            if (nt + 1 < NT) {
+              if (nt + 1 < a.n3t) {
+                bs3w[nt + 1] += (ay1[0] + ay1[1]) + (ay1[2] + ay1[3]);
+                mfma16x4_il2(ay0, bh, dW3w[nt], ay1, bh, dW3w[nt + 1]);
+              } else {
+                dW3w[nt] = mfma16x4(ay0, bh, dW3w[nt]);
+              }
+            } else {
+              dW3w[nt] = mfma16x4(ay0, bh, dW3w[nt]);
+            }
+          }
+      } else {
+        const f32x4 ay = *reinterpret_cast<const f32x4*>(dYT + m * RS + 16 * rt + 4 * q);
+        bs3 += (ay[0] + ay[1]) + (ay[2] + ay[3]);
+        dW3 = mfma16x4(ay, bh, dW3);
+      }
     }
     ST_MARK(10);
     WG_BARRIER();
@@ -608,7 +724,7 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   bs2 += __shfl_xor(bs2, 16, 64); bs2 += __shfl_xor(bs2, 32, 64);
   bs3 += __shfl_xor(bs3, 16, 64); bs3 += __shfl_xor(bs3, 32, 64);
   const int K1x = a.K1 + 1;
-  float* s1 = a.ws + ((long)stripe * a.groups + g) * mlp3_slab_floats(a.K1);
+  float* s1 = a.ws + ((long)stripe * a.groups + g) * mlp3_slab_floats(a.K1, a.N3);
   float* s2 = s1 + (long)HD * K1x;
   float* s3 = s2 + (long)HD * (HD + 1);
 #pragma unroll
@@ -622,12 +738,24 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) s2[(16 * wave + 4 * q + i) * (HD + 1) + 16 * c + m] = dW2[c][i];
+  if (WIDE) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s3[(4 * q + i) * (HD + 1) + 16 * wave + m] = dW3[i];
+    for (int nt = 0; nt < NT; ++nt)
+      if (nt < a.n3t) {
+        float b = bs3w[nt];
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s3[(16 * nt + 4 * q + i) * (HD + 1) + 16 * wave + m] = dW3w[nt][i];
+        if (q == 0 && wave == 0) s3[(16 * nt + m) * (HD + 1) + HD] = b;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s3[(4 * q + i) * (HD + 1) + 16 * wave + m] = dW3[i];
+  }
   if (q == 0) {
     s1[(long)(16 * wave + m) * K1x + a.K1] = bs1;
     s2[(16 * wave + m) * (HD + 1) + HD] = bs2;
-    if (wave == 0) s3[m * (HD + 1) + HD] = bs3;
+    if (wave == 0 && !WIDE) s3[m * (HD + 1) + HD] = bs3;
   }
 }
 
@@ -638,24 +766,30 @@ struct Mlp3RedArgs {
   int K1, N3, groups, nst;
 };
 
-// grads += sum over the stripes' slabs, in stripe order (deterministic)
+// grads += sum over the stripes' slabs, in stripe order (deterministic).  Heads that SHARE their first layer(s) (element stride 0
+// between groups: one wide head evaluated as column blocks of 160 outputs) have those gradients summed over the groups by
+// the thread of group 0, in group order.
 __global__ __launch_bounds__(256) void mlp3_reduce_kernel(Mlp3RedArgs a) {
-  const long SZ = mlp3_slab_floats(a.K1);
+  const long SZ = mlp3_slab_floats(a.K1, a.N3);
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= SZ * a.groups) return;
   const int g = (int)(e / SZ);
   long r = e - (long)g * SZ;
-  float s = 0.f;
-  for (int sl = 0; sl < a.nst; ++sl) s += a.ws[((long)sl * a.groups + g) * SZ + r];
   const int K1x = a.K1 + 1;
-  if (r < (long)HD * K1x) {
+  const bool first = r < (long)HD * K1x, second = !first && r < (long)HD * K1x + HD * (HD + 1);
+  const bool shared = a.groups > 1 && ((first && a.gs_w1 == 0 && a.gs_b1 == 0) || (second && a.gs_w2 == 0 && a.gs_b2 == 0));
+  if (shared && g != 0) return;
+  float s = 0.f;
+  for (int gg = g; gg < (shared ? a.groups : g + 1); ++gg)
+    for (int sl = 0; sl < a.nst; ++sl) s += a.ws[((long)sl * a.groups + gg) * SZ + r];
+  if (first) {
     const int n = (int)(r / K1x), k = (int)(r - (long)n * K1x);
     if (k < a.K1) a.dW1[g * a.gs_w1 + (long)n * a.K1 + k] += s;
     else a.db1[g * a.gs_b1 + n] += s;
     return;
   }
   r -= (long)HD * K1x;
-  if (r < HD * (HD + 1)) {
+  if (second) {
     const int n = (int)(r / (HD + 1)), k = (int)(r - n * (HD + 1));
     if (!a.dW2) return;                       // two-layer head
     if (k < HD) a.dW2[g * a.gs_w2 + n * HD + k] += s;
@@ -695,11 +829,15 @@ inline int kc_bucket(int KV) {
   return kc == 11 ? 11 : kc <= 12 ? (kc + 3) / 4 * 4 : kc <= 16 ? 16 : (kc + 7) / 8 * 8;
 }
 inline int kpad_of(const marl_src_t* x) { return (4 - x->k0 % 4) % 4; }
-inline size_t fwd_lds(int KC, int CF) { return (size_t)(4 * KC * 256 + 16 * 256 + 4 * 256) * 4 + (size_t)(KC - CF) * 32 * 4; }
-inline size_t bwd_lds(int KC, int CF, bool kept) {
+inline size_t fwd_lds(int KC, int CF, bool wide) {
+  return (size_t)(4 * KC * 256 + 16 * 256 + (wide ? NTW : 1) * 4 * 256 + (wide ? 16 * NTW : 0)) * 4 + (size_t)(KC - CF) * 32 * 4;
+}
+inline size_t bwd_lds(int KC, int CF, bool kept, bool wide, bool three) {
   const int KH = KC > 24 ? 16 : KC;
-  const int SF = (16 * KH + HD) > 208 ? (16 * KH + HD) : 208;
-  return (size_t)((kept ? 0 : 4 * KC * 256 + 16 * 256) + 16 * 256 + 16 * 64 + SF * RS) * 4 + (size_t)(KC - CF) * 32 * 4;
+  const int SF2 = (three ? 192 : 64) + 16 * (wide ? NTW : 1);
+  const int SF = (16 * KH + HD) > SF2 ? (16 * KH + HD) : SF2;
+  return (size_t)((kept ? 0 : 4 * KC * 256 + 16 * 256) + (three || !wide ? 16 * 256 : 0) + (wide ? NTW * 4 * 256 : 16 * 64) + SF * RS) * 4 +
+         (size_t)(KC - CF) * 32 * 4;
 }
 inline int lead_chunks(const marl_src_t* x) {
   const bool al = x->p0 && (x->ld0 % 4 == 0) && aligned16(x->p0);
@@ -723,6 +861,7 @@ bool fill_args(Mlp3Args& a, const marl_mlp3_weights_t* w, const marl_src_t* x, l
   a.M = M; a.K1 = K1; a.N3 = N3; a.groups = groups;
   a.kpad = kpad_of(x); a.KV = K1 + a.kpad;
   a.CF = lead_chunks(x);
+  a.n3t = (N3 + 15) / 16; a.yvec = 0;
   return true;
 }
 
@@ -731,18 +870,21 @@ bool fill_args(Mlp3Args& a, const marl_mlp3_weights_t* w, const marl_src_t* x, l
 ST_DEFINE_SETTER(marl_debug_stamps_mlp3)
 
 extern "C" int marl_mlp3_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups) {
-  if (H1 != HD || (H2 != HD && H2 != 0) || N3 < 1 || N3 > 16 || groups < 1 || K1 < 1) return 0;
+  if (H1 != HD || (H2 != HD && H2 != 0) || N3 < 1 || N3 > 16 * NTW || groups < 1 || K1 < 1) return 0;
+  const bool wide = N3 > 16;              // two-layer heads with up to 160 outputs in tiles of 16 (kept activations only)
+  if (wide && (H2 != 0 || N3 % 4)) return 0;
   if (!x->p0 || x->k0 < 4 || x->m0 || x->nid) return 0;
   if (x->nhot && (x->hot_w < 1 || x->hot_w >= 16384 || x->nhot >= 8192)) return 0;
   if (x->k0 >= 16384 || x->k1 >= 16384) return 0;
   if (x->k1 % 4) return 0;               // a lane's four consecutive columns come from one segment (dense0 is padded by the kernels)
   const int KC = kc_bucket(K1 + kpad_of(x));
   if (KC > 32) return 0;
+  if (wide && KC != 8 && KC != 16 && KC != 24) return 0;      // instantiated: state widths of 2s3z / 3s5z / MMM2-sized maps
   const int CF = lead_chunks(x);
-  return bwd_lds(KC, CF, KC > 12) <= 160 * 1024 && fwd_lds(KC, CF) <= 160 * 1024;
+  return bwd_lds(KC, CF, KC > 12 || wide, wide, H2 != 0) <= 160 * 1024 && fwd_lds(KC, CF, wide) <= 160 * 1024;
 }
 
-extern "C" int marl_mlp3_needs_kept(const marl_src_t* x, int K1) { return kc_bucket(K1 + kpad_of(x)) > 12; }
+extern "C" int marl_mlp3_needs_kept(const marl_src_t* x, int K1, int N3) { return kc_bucket(K1 + kpad_of(x)) > 12 || N3 > 16; }
 
 extern "C" size_t marl_mlp3_save_floats(long M, int three, int groups) {
   return M <= 0 ? 0 : (size_t)groups * (size_t)((M + 15) / 16) * (three ? 8 : 4) * 256;
@@ -762,13 +904,17 @@ extern "C" int marl_mlp3_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t
   const long tiles = (M + 15) / 16;
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
   const int KC = kc_bucket(a.KV);
-  const size_t lds = fwd_lds(KC, a.CF);
+  const bool wide = N3 > 16;
+  a.yvec = (ldy % 4 == 0) && (gs_y % 4 == 0) && aligned16(Y) && (N3 % 4 == 0);
+  const size_t lds = fwd_lds(KC, a.CF, wide);
 // (seven leading full chunks = a 120-wide dense segment 0: the QPLEX heads on 2s3z-sized maps get the compile-time variants)
 #define MLP3_PICK(K, ...) (KC == 4 ? (const void*)K<4, __VA_ARGS__> : KC == 8 ? (a.CF == 7 ? (const void*)K<8, MLP3_CF7(__VA_ARGS__)> : (const void*)K<8, __VA_ARGS__>) \
                            : KC == 11 ? (a.CF == 7 ? (const void*)K<11, MLP3_CF7(__VA_ARGS__)> : (const void*)K<11, __VA_ARGS__>) : (const void*)K<12, __VA_ARGS__>)
 #define MLP3_PICK_BIG(K, ...) (KC == 16 ? (const void*)K<16, __VA_ARGS__> : KC == 24 ? (const void*)K<24, __VA_ARGS__> : (const void*)K<32, __VA_ARGS__>)
-  const void* fn = KC > 12 ? (three ? MLP3_PICK_BIG(mlp3_fwd_kernel, true, -1) : MLP3_PICK_BIG(mlp3_fwd_kernel, false, -1))
-                           : (three ? MLP3_PICK(mlp3_fwd_kernel, true, -1) : MLP3_PICK(mlp3_fwd_kernel, false, -1));
+#define MLP3_PICK_WIDE(K, ...) (KC == 8 ? (const void*)K<8, __VA_ARGS__> : KC == 16 ? (const void*)K<16, __VA_ARGS__> : (const void*)K<24, __VA_ARGS__>)
+  const void* fn = wide ? MLP3_PICK_WIDE(mlp3_fwd_kernel, false, -1, true)
+                   : KC > 12 ? (three ? MLP3_PICK_BIG(mlp3_fwd_kernel, true, -1) : MLP3_PICK_BIG(mlp3_fwd_kernel, false, -1))
+                             : (three ? MLP3_PICK(mlp3_fwd_kernel, true, -1) : MLP3_PICK(mlp3_fwd_kernel, false, -1));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * FNW);
@@ -785,9 +931,8 @@ extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
 }
 
 extern "C" size_t marl_mlp3_bwd_workspace(long M, int K1, int N3, int groups) {
-  (void)N3;
   const int nst = stripes((M + 63) / 64, groups);
-  return (size_t)nst * groups * mlp3_slab_floats(K1) * sizeof(float);
+  return (size_t)nst * groups * mlp3_slab_floats(K1, N3) * sizeof(float);
 }
 
 extern "C" int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
@@ -805,9 +950,11 @@ extern "C" int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_
   a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws; a.hs = const_cast<float*>(hsave);
   a.nst = stripes((M + 63) / 64, groups);
   const int KC = kc_bucket(a.KV);
-  if (KC > 12 && !hsave) return (int)hipErrorInvalidValue;      // marl_mlp3_needs_kept(): no recomputing backward for K1 > 192
-  const size_t lds = bwd_lds(KC, a.CF, hsave != nullptr);
-  const void* fn = KC > 12 ? (three ? MLP3_PICK_BIG(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK_BIG(mlp3_bwd_kernel, false, -1, true))
+  const bool wide = N3 > 16;
+  if ((KC > 12 || wide) && !hsave) return (int)hipErrorInvalidValue;      // marl_mlp3_needs_kept(): no recomputing backward for these
+  if (wide && (lddy % 4 || gs_dy % 4 || !aligned16(dY))) return (int)hipErrorInvalidValue;      // dY tiles are 16-byte loads
+  const size_t lds = bwd_lds(KC, a.CF, hsave != nullptr, wide, three);
+  const void* fn = wide ? MLP3_PICK_WIDE(mlp3_bwd_kernel, false, -1, true, true) : KC > 12 ? (three ? MLP3_PICK_BIG(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK_BIG(mlp3_bwd_kernel, false, -1, true))
                    : hsave ? (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, true) : MLP3_PICK(mlp3_bwd_kernel, false, -1, true))
                            : (three ? MLP3_PICK(mlp3_bwd_kernel, true, -1, false) : MLP3_PICK(mlp3_bwd_kernel, false, -1, false));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -825,7 +972,7 @@ extern "C" int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_
   r.gs_w1 = grads->gs_w1; r.gs_b1 = grads->gs_b1; r.gs_w2 = grads->gs_w2; r.gs_b2 = grads->gs_b2;
   r.gs_w3 = grads->gs_w3; r.gs_b3 = grads->gs_b3;
   r.K1 = K1; r.N3 = N3; r.groups = groups; r.nst = a.nst;
-  const long total = mlp3_slab_floats(K1) * groups;
+  const long total = mlp3_slab_floats(K1, N3) * groups;
   hipLaunchKernelGGL(mlp3_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r);
   MARL_CHECK_LAUNCH();
   return 0;

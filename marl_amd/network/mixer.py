@@ -123,6 +123,17 @@ class QMixMixer(_Precision, nn.Module):
                 and xs.ld0 % 4 == 0 and xs.ld0 >= (S + 3) // 4 * 4 and (xs.p0 or 0) % 16 == 0
                 and not (xs.k1 or xs.nhot or xs.nid or xs.m0))
 
+    def _fused_hyper(self, seq, xs, grad=False):
+        """hyper_w1 / hyper_w2 of the two_hyper_layers mixer (state -> hyper_hidden_dim -> N*E | E, mixer.py:36-43) on the fused
+        head kernels (csrc/mlp3_fused.hip, wide outputs): (weights, groups, outputs per group) or None."""
+        if self._bf16() or getattr(self, "no_fused", False) or not _keep_hidden():
+            return None
+        l0, l2 = _linears(seq)
+        wh = ops.mlp3_wide_head(l0, l2, grad=grad)
+        if wh is None or not ops.mlp3_supported(xs, l0.in_features, l0.out_features, 0, wh[2], wh[1]):
+            return None
+        return wh
+
     def _fused_tensors(self, grad=False):
         b20, b22 = _linears(self.hyper_b2)
         pick = (lambda p: p.grad) if grad else (lambda p: p.data)
@@ -177,14 +188,22 @@ class QMixMixer(_Precision, nn.Module):
         qtot = self._s.get("qtot" + tag, (rows,), dev)
         hw1 = hw2 = None
         if a.two_hyper_layers:
-            hw1 = self._s.get("hw1" + tag, (rows, HH), dev)
-            hw2 = self._s.get("hw2" + tag, (rows, HH), dev)
-            l10, l12 = _linears(self.hyper_w1)
-            l20, l22 = _linears(self.hyper_w2)
-            self._lin(l10).fwd(xs, hw1, rows, act=1)
-            self._lin(l12).fwd(ops.src(hw1), hy[:, :N * E], rows)
-            self._lin(l20).fwd(xs, hw2, rows, act=1)
-            self._lin(l22).fwd(ops.src(hw2), hy[:, N * E + E:N * E + 2 * E], rows)
+            kept, hid = {}, {}
+            for name, seq, cols in (("w1", self.hyper_w1, slice(0, N * E)), ("w2", self.hyper_w2, slice(N * E + E, N * E + 2 * E))):
+                wh = self._fused_hyper(seq, xs)
+                if wh is not None:
+                    # both layers in one launch; the hidden activations go to HBM only as the backward's fragments
+                    w, G, n3g = wh
+                    hs = None
+                    if ctx is not None:
+                        hs = kept[name] = self._s.get("hs_" + name, (ops.mlp3_save_floats(rows, False, G),), dev)
+                    ops.mlp3_fwd(w, xs, hy[:, cols], rows, a.state_shape, n3g, G, hsave=hs)
+                    continue
+                l0, l2 = _linears(seq)
+                hbuf = hid[name] = self._s.get("h" + name + tag, (rows, HH), dev)
+                self._lin(l0).fwd(xs, hbuf, rows, act=1)
+                self._lin(l2).fwd(ops.src(hbuf), hy[:, cols], rows)
+            hw1, hw2 = hid.get("w1"), hid.get("w2")
         else:
             self._lin(self.hyper_w1).fwd(xs, hy[:, :N * E], rows)
             self._lin(self.hyper_w2).fwd(xs, hy[:, N * E + E:N * E + 2 * E], rows)
@@ -194,7 +213,7 @@ class QMixMixer(_Precision, nn.Module):
         self._lin(b22).fwd(ops.src(hy[:, N * E + 2 * E:]), b2, rows)
         ops.qmix_mix_fwd(hy, b2, q, qtot, rows, N, E)
         if ctx is not None:
-            ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2)
+            ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2, kept=kept if a.two_hyper_layers else {})
         return qtot
 
     def loss_backward_fused(self, s):
@@ -248,8 +267,13 @@ class QMixMixer(_Precision, nn.Module):
         self._lin(b20).wgrad(dhb, xs, rows, Yact=hb)
         self._lin(self.hyper_b1).wgrad(dhy[:, N * E:N * E + E], xs, rows)
         if a.two_hyper_layers:
-            for seq, hbuf, cols in ((self.hyper_w1, ctx["hw1"], slice(0, N * E)),
-                                    (self.hyper_w2, ctx["hw2"], slice(N * E + E, N * E + 2 * E))):
+            for name, seq, hbuf, cols in (("w1", self.hyper_w1, ctx["hw1"], slice(0, N * E)),
+                                          ("w2", self.hyper_w2, ctx["hw2"], slice(N * E + E, N * E + 2 * E))):
+                hs = ctx["kept"].get(name)
+                if hs is not None:
+                    w, G, n3g = self._fused_hyper(seq, xs)
+                    ops.mlp3_bwd(w, xs, dhy[:, cols], self._fused_hyper(seq, xs, grad=True)[0], rows, a.state_shape, n3g, G, hsave=hs)
+                    continue
                 l0, l2 = _linears(seq)
                 self._lin(l2).wgrad(dhy[:, cols], ops.src(hbuf), rows)
                 dh = self._s.get("dhw", (rows, HH), dev)

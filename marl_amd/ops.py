@@ -489,13 +489,32 @@ def mlp3_weights(heads, grad=False):
     return w
 
 
+def mlp3_wide_head(l0, l2, grad=False):
+    """A two-layer head Linear(K1, 64) - ReLU - Linear(64, N3) with more outputs than one launch group holds (160), as
+    ``groups`` column blocks that share layer 1: returns (marl_mlp3_weights_t, groups, outputs per group) or None."""
+    pick = (lambda p: p.grad) if grad else (lambda p: p.data)
+    ts = [pick(l0.weight), pick(l0.bias), pick(l2.weight), pick(l2.bias)]
+    if any(t is None or not t.is_contiguous() or t.dtype != torch.float32 or not t.is_cuda or t.data_ptr() % 16 for t in ts):
+        return None
+    N3 = l2.out_features
+    G = (N3 + 159) // 160
+    if N3 % (4 * G) or l0.out_features != 64 or l2.in_features != 64:
+        return None
+    w = MarlMlp3Weights()
+    w.w1, w.b1, w.w3, w.b3 = (t.data_ptr() for t in ts)
+    w.gs_w1 = w.gs_b1 = 0
+    w.gs_w3, w.gs_b3 = (N3 // G) * 64, N3 // G
+    w._keep = ts
+    return w, G, N3 // G
+
+
 def mlp3_supported(x, K1, H1, H2, N3, groups):
     return bool(_lib.load().marl_mlp3_supported(C.byref(x), K1, H1, H2, N3, groups))
 
 
-def mlp3_needs_kept(x, K1):
-    """True when the fused backward of this input shape exists only for kept activations (K1 > 192)."""
-    return bool(_lib.load().marl_mlp3_needs_kept(C.byref(x), K1))
+def mlp3_needs_kept(x, K1, N3=1):
+    """True when the fused backward of this shape exists only for kept activations (K1 > 192 or more than 16 outputs)."""
+    return bool(_lib.load().marl_mlp3_needs_kept(C.byref(x), K1, N3))
 
 
 def _head_layout(Y, M, N3, groups):

@@ -236,7 +236,11 @@ def test_wgrad_one_output_column(dev, M, K):
                                                         (700, 322, 10, 18, 10, 3, False, 3), (333, 322, 0, 0, 1, 4, False, 3),
                                                         (500, 322, 0, 0, 10, 2, False, 2), (129, 30, 2, 5, 3, 2, False, 3),
                                                         (1230, 216, 8, 14, 8, 2, True, 3), (90, 250, 0, 0, 4, 1, False, 3),
-                                                        (77, 322, 10, 18, 10, 2, False, 3), (60, 203, 1, 7, 2, 2, False, 2)])
+                                                        (77, 322, 10, 18, 10, 2, False, 3), (60, 203, 1, 7, 2, 2, False, 2),
+                                                        # wide outputs (two-layer hypernet heads of QMIX with two_hyper_layers, mixer.py:36-43)
+                                                        (777, 120, 0, 0, 160, 1, False, 2), (500, 120, 0, 0, 32, 1, False, 2),
+                                                        (300, 322, 0, 0, 160, 2, False, 2), (260, 216, 0, 0, 128, 2, False, 2),
+                                                        (100, 120, 0, 0, 20, 3, False, 2), (4100, 120, 0, 0, 160, 1, True, 2)])
 def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     """Fused three-layer heads (QPLEX lambda-net families, mixer.py:117-145) vs torch-CPU autograd: outputs and all six
     parameter gradients of every head; x = [state | one-hot actions] with ragged sizes, 'no action' indices and
@@ -297,8 +301,8 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     xs = ops.src(x0_src, idx=cu(idx, dev, torch.int32) if NH else None, nhot=NH, hot_w=HW)
     assert ops.mlp3_supported(xs, K1, 64, 64 if nl == 3 else 0, N3, G)
     Y = torch.full((rows, G * N3), 7.0, device=dev)
-    kept_only = ops.mlp3_needs_kept(xs, K1)      # K1 > 192: no recomputing backward
-    assert kept_only == ((K1 + (-S) % 4 + 15) // 16 > 12)
+    kept_only = ops.mlp3_needs_kept(xs, K1, N3)      # K1 > 192 or wide outputs: no recomputing backward
+    assert kept_only == ((K1 + (-S) % 4 + 15) // 16 > 12 or N3 > 16)
     hs = torch.full((ops.mlp3_save_floats(rows, nl == 3, G),), float("nan"), device=dev)
     ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G, hsave=hs if kept_only else None)
     dY = torch.randn(rows, G * N3, generator=g)
@@ -1076,3 +1080,42 @@ def test_qmix_wide(dev, R, N, S, bf16):
         sc = max(1.0, float(want.abs().max()))
         tol = (2e-2 if bf16 and k in outs else 1e-4) * sc
         close(got, want, tol, 1e-4 if not bf16 else 2e-2, msg=k)
+
+
+@pytest.mark.parametrize("rows,S,N3", [(600, 322, 320), (300, 216, 256), (200, 120, 160)])
+def test_mlp3_wide_head_in_column_blocks(dev, rows, S, N3):
+    """hyper_w1 of QMixMixer(two_hyper_layers) on MMM2 / 3s5z-sized maps: state -> 64 -> n_agents * 32 outputs evaluated as
+    column blocks of <= 160 that SHARE layer 1 (element stride 0 between the groups): outputs and the three gradients vs torch."""
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(rows + N3)
+    ld = (S + 3) // 4 * 4
+    x = torch.randn(rows, S, generator=g)
+    xd = cu(torch.cat([x, torch.zeros(rows, ld - S)], 1), dev)[:, :S]
+    l0, l2 = torch.nn.Linear(S, 64), torch.nn.Linear(64, N3)
+    with torch.no_grad():
+        for p in list(l0.parameters()) + list(l2.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    d0, d2 = torch.nn.Linear(S, 64).to(dev), torch.nn.Linear(64, N3).to(dev)
+    d0.load_state_dict(l0.state_dict()); d2.load_state_dict(l2.state_dict())
+    for p in list(d0.parameters()) + list(d2.parameters()):
+        p.requires_grad_(False)
+        p.grad = torch.zeros_like(p)
+    xs = ops.src(xd)
+    w, G, n3g = ops.mlp3_wide_head(d0, d2)
+    assert G == (N3 + 159) // 160 and G * n3g == N3 and ops.mlp3_supported(xs, S, 64, 0, n3g, G)
+    wid = N3 + 96
+    hy = torch.full((rows, wid), 7.0, device=dev)
+    hs = torch.empty(ops.mlp3_save_floats(rows, False, G), device=dev)
+    ops.mlp3_fwd(w, xs, hy[:, 32:32 + N3], rows, S, n3g, G, hsave=hs)
+    assert bool((hy[:, :32] == 7).all()) and bool((hy[:, 32 + N3:] == 7).all())
+    y = l2(torch.relu(l0(x)))
+    close(hy[:, 32:32 + N3], y, 2e-4)
+    dY = torch.randn(rows, N3, generator=g)
+    dhy = torch.zeros(rows, wid, device=dev)
+    dhy[:, 32:32 + N3] = cu(dY, dev)
+    ops.mlp3_bwd(w, xs, dhy[:, 32:32 + N3], ops.mlp3_wide_head(d0, d2, grad=True)[0], rows, S, n3g, G, hsave=hs)
+    y.backward(dY)
+    for name, got, ref in (("W1", d0.weight.grad, l0.weight.grad), ("b1", d0.bias.grad, l0.bias.grad),
+                           ("W3", d2.weight.grad, l2.weight.grad), ("b3", d2.bias.grad, l2.bias.grad)):
+        scale = max(1.0, float(ref.abs().max()))
+        close(got / scale, ref / scale, 3e-4, 1e-4, msg=name)
