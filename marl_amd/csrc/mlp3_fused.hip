@@ -29,6 +29,14 @@ constexpr int RS = 68;            // row stride (floats) of the [feature][64 row
 constexpr int FNW = 8;            // forward: waves per workgroup
 constexpr int BNW = 4;            // backward: waves per workgroup (= 16-row tiles per iteration)
 
+// kept activations stream through HBM once each way (A/B: -DMARL_KEEP_TEMPORAL uses ordinary accesses)
+#ifdef MARL_KEEP_TEMPORAL
+#define KEEP_ST(v, p) (*(p) = (v))
+#define KEEP_LD(p) (*(p))
+#else
+#define KEEP_ST(v, p) __builtin_nontemporal_store((v), (p))
+#define KEEP_LD(p) __builtin_nontemporal_load(p)
+#endif
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 struct Mlp3Args {
@@ -347,10 +355,10 @@ __global__ __launch_bounds__(64 * FNW, (KC > 12 || WIDE) ? 1 : 2) void mlp3_fwd_
       constexpr int NP = THREE ? 8 : 4;
       f32x4* hp = reinterpret_cast<f32x4*>(a.hs) + (((long)g * tiles + tile) * NP) * 64 + lane;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(h1[c], hp + c * 64);
+      for (int c = 0; c < 4; ++c) KEEP_ST(h1[c], hp + c * 64);
       if (THREE) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(h2[c], hp + (4 + c) * 64);
+        for (int c = 0; c < 4; ++c) KEEP_ST(h2[c], hp + (4 + c) * 64);
       }
     }
     if (WIDE) {
@@ -513,10 +521,10 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
     long tl = it_ * BNW + wave; if (tl > tiles - 1) tl = tiles - 1;      // (a tile past the end multiplies zero gradients)
     const f32x4* hp = reinterpret_cast<const f32x4*>(a.hs) + (((long)g * tiles + tl) * NP) * 64 + lane;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) hn1[c] = __builtin_nontemporal_load(hp + c * 64);
+    for (int c = 0; c < 4; ++c) hn1[c] = KEEP_LD(hp + c * 64);
     if (THREE) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) hn2[c] = __builtin_nontemporal_load(hp + (4 + c) * 64);
+      for (int c = 0; c < 4; ++c) hn2[c] = KEEP_LD(hp + (4 + c) * 64);
     }
   };
   if (i_begin < i_end) {
