@@ -246,7 +246,8 @@ int marl_mlp3_bwd(const marl_mlp3_weights_t* w, const marl_src_t* x, const float
  * does for these heads in the reference, network/mixer.py:149-171): the forward writes relu(h1) [and relu(h2)] of
  * every 16-row tile as the MFMA fragments the backward wants (`hsave`: marl_mlp3_save_floats(M, three, groups)
  * floats, layout private to the pair), the backward reads them back with 16-byte coalesced loads and skips layers
- * 1-2.  Bit-identical to the recomputing pair.  hsave == NULL: exactly marl_mlp3_fwd / marl_mlp3_bwd. */
+ * 1-2.  Same values as the recomputing pair (outputs bit-identical; the gradients are sums over another number of row
+ * stripes).  hsave == NULL: exactly marl_mlp3_fwd / marl_mlp3_bwd. */
 size_t marl_mlp3_save_floats(long M, int three, int groups);
 /* Wide outputs: two-layer heads (w2 == NULL) take 16 < N3 <= 160 outputs, N3 a multiple of 4 (hyper_w1 / hyper_w2 of QMixMixer
  * with two_hyper_layers, network/mixer.py:36-43: state -> 64 -> n_agents * embed); a wider head is evaluated as `groups` column

@@ -51,6 +51,13 @@ struct Mlp3Args {
   int kpad, KV;                                      // virtual K axis: kpad zero columns after dense0 (so that k0 + kpad is a multiple of 4), KV = K1 + kpad
   int n3t, yvec;                                     // WIDE kernels: output tiles of 16 (N3 up to 160); Y rows take 16-byte accesses
 };
+// The kept-activation backward runs TWO workgroups per CU up to this chunk count (256 registers per wave, <= 80 KB of LDS each:
+// more than 8 chunks of x^T go through the stage 6 at a time): four barriers per 64 rows with one wave per SIMD left the
+// matrix pipe idle 43 % of the time; two independent workgroups fill each other's exchange phases (key / agents / action head
+// backward 2.06 / 2.15 / 2.63 -> 1.71 / 1.74 / 2.21 ms; -DMLP3_BWD2_KC=0 is the one-workgroup form).
+#ifndef MLP3_BWD2_KC
+#define MLP3_BWD2_KC 11
+#endif
 constexpr int NTW = 10;           // output tiles of the WIDE variants (hypernet heads of QMIX with two_hyper_layers: N*E = 160 columns)
 
 // virtual column (K axis of the kernels) -> column of W1 / dW1, or -1 for a pad column.  A lane's four consecutive columns must
@@ -415,15 +422,17 @@ __device__ __forceinline__ void stash4(float* st, const f32x4 (&v)[4], int wave,
 // LOAD: h1 / h2 come from the forward's `hs` planes (one iteration ahead in a second register set) instead of being recomputed
 // WIDE: N3 up to 160 (kept activations only); dY / dW3 in tiles of 16 outputs
 template <int KC, bool THREE, int CFT = -1, bool LOAD = false, bool WIDE = false>
-__global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
+__global__ __launch_bounds__(64 * BNW, (LOAD && !WIDE && KC <= MLP3_BWD2_KC) ? 2 : 1) void mlp3_bwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int stripe, g;
   if (!wg_map(a.groups, a.nst, stripe, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
   // x^T is staged KH chunks at a time (KC > 24: two passes of 16 - 32 chunks of 64 rows are 139 KB on their own)
-  constexpr int KH = KC > 24 ? 16 : KC, NH = KC / KH;
-  static_assert(KC % KH == 0 && (LOAD || KC <= 12), "K1 > 192 only with kept activations (W1 does not fit beside the stage)");
+  // (two workgroups per CU: 80 KB each - more than 8 chunks go through the stage 6 at a time)
+  constexpr bool TWO = LOAD && !WIDE && KC <= MLP3_BWD2_KC;
+  constexpr int KH = KC > 24 ? 16 : (TWO && KC > 8) ? 6 : KC, NH = (KC + KH - 1) / KH;
+  static_assert(LOAD || KC <= 12, "K1 > 192 only with kept activations (W1 does not fit beside the stage)");
   static_assert(!WIDE || LOAD, "wide outputs only with kept activations");
   constexpr int NT = WIDE ? NTW : 1;
   constexpr int S2H = THREE ? 192 : 64;                               // stage 2: [h1 | dh2 |] h2, then dY^T
@@ -638,8 +647,10 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
         WG_BARRIER();
 #pragma unroll
         for (int c = 0; c < KH; ++c)
+          if (hf * KH + c < KC) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) xT[(16 * c + 4 * q + i) * RS + 16 * wave + m] = xv[hf * KH + c][i];
+            for (int i = 0; i < 4; ++i) xT[(16 * c + 4 * q + i) * RS + 16 * wave + m] = xv[hf * KH + c][i];
+          }
         if (hf == NH - 1) x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);      // x is consumed: the next iteration's tile
         WG_BARRIER();
       }
@@ -650,13 +661,16 @@ __global__ __launch_bounds__(64 * BNW, 1) void mlp3_bwd_kernel(Mlp3Args a) {
 #pragma unroll
         for (int c = 0; c < KH; c += 4) {        // up to four k tiles round robin (independent accumulators)
           const int cg = hf * KH + c;
+          constexpr int KE = KH;
+          const int lim = (KC - hf * KH) < KE ? (KC - hf * KH) : KE;      // chunks of this pass (compile time after unrolling)
+          if (c >= lim) continue;
           f32x4 bf[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (c + u < KH) bf[u] = *reinterpret_cast<const f32x4*>(xT + (16 * (c + u) + m) * RS + 16 * rt + 4 * q);
-          if (c + 3 < KH) mfma16x4_il4(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1], af, bf[2], dW1[cg + 2], af, bf[3], dW1[cg + 3]);
-          else if (c + 2 < KH) mfma16x4_il3(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1], af, bf[2], dW1[cg + 2]);
-          else if (c + 1 < KH) mfma16x4_il2(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1]);
+            if (c + u < lim) bf[u] = *reinterpret_cast<const f32x4*>(xT + (16 * (c + u) + m) * RS + 16 * rt + 4 * q);
+          if (c + 3 < lim) mfma16x4_il4(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1], af, bf[2], dW1[cg + 2], af, bf[3], dW1[cg + 3]);
+          else if (c + 2 < lim) mfma16x4_il3(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1], af, bf[2], dW1[cg + 2]);
+          else if (c + 1 < lim) mfma16x4_il2(af, bf[0], dW1[cg], af, bf[1], dW1[cg + 1]);
           else dW1[cg] = mfma16x4(af, bf[0], dW1[cg]);
         }
       }
@@ -841,7 +855,8 @@ inline size_t fwd_lds(int KC, int CF, bool wide) {
   return (size_t)(4 * KC * 256 + 16 * 256 + (wide ? NTW : 1) * 4 * 256 + (wide ? 16 * NTW : 0)) * 4 + (size_t)(KC - CF) * 32 * 4;
 }
 inline size_t bwd_lds(int KC, int CF, bool kept, bool wide, bool three) {
-  const int KH = KC > 24 ? 16 : KC;
+  const bool two = kept && !wide && KC <= MLP3_BWD2_KC;
+  const int KH = KC > 24 ? 16 : (two && KC > 8) ? 6 : KC;
   const int SF2 = (three ? 192 : 64) + 16 * (wide ? NTW : 1);
   const int SF = (16 * KH + HD) > SF2 ? (16 * KH + HD) : SF2;
   return (size_t)((kept ? 0 : 4 * KC * 256 + 16 * 256) + (three || !wide ? 16 * 256 : 0) + (wide ? NTW * 4 * 256 : 16 * 64) + SF * RS) * 4 +
@@ -854,8 +869,8 @@ inline int lead_chunks(const marl_src_t* x) {
 // stripes per group: a multiple of 8 (one per XCD and round, see wg_map) with stripes * groups <= 256 workgroups, so
 // that every XCD gets the same number of workgroups and all of them are resident at once (one per CU): 26 stripes
 // x 10 heads = 260 workgroups ran as two rounds and took twice as long as 24 x 10
-inline int stripes(long units, int groups) {
-  long n = 256 / groups / 8 * 8;
+inline int stripes(long units, int groups, int wgs = 256) {
+  long n = wgs / groups / 8 * 8;
   if (n < 8) n = 8;
   if (n > units) n = units;
   return (int)(n < 1 ? 1 : n);
@@ -939,7 +954,7 @@ extern "C" int marl_mlp3_fwd(const marl_mlp3_weights_t* w, const marl_src_t* x, 
 }
 
 extern "C" size_t marl_mlp3_bwd_workspace(long M, int K1, int N3, int groups) {
-  const int nst = stripes((M + 63) / 64, groups);
+  const int nst = stripes((M + 63) / 64, groups, 512);      // (the variants with two workgroups per CU write twice the slabs)
   return (size_t)nst * groups * mlp3_slab_floats(K1, N3) * sizeof(float);
 }
 
@@ -956,9 +971,9 @@ extern "C" int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws; a.hs = const_cast<float*>(hsave);
-  a.nst = stripes((M + 63) / 64, groups);
   const int KC = kc_bucket(a.KV);
   const bool wide = N3 > 16;
+  a.nst = stripes((M + 63) / 64, groups, (hsave && !wide && KC <= MLP3_BWD2_KC) ? 512 : 256);
   if ((KC > 12 || wide) && !hsave) return (int)hipErrorInvalidValue;      // marl_mlp3_needs_kept(): no recomputing backward for these
   if (wide && (lddy % 4 || gs_dy % 4 || !aligned16(dY))) return (int)hipErrorInvalidValue;      // dY tiles are 16-byte loads
   const size_t lds = bwd_lds(KC, a.CF, hsave != nullptr, wide, three);

@@ -326,16 +326,23 @@ def test_mlp3_fused(dev, rows, S, NH, HW, N3, G, remap, nl):
     assert not torch.isnan(gd).any()
     if kept_only:
         return
-    # the pair that KEEPS h1 / h2 between forward and backward (marl_mlp3_fwd_save / marl_mlp3_bwd_saved) is bit-identical to the
-    # recomputing pair: same outputs, same gradients
+    # the pair that KEEPS h1 / h2 between forward and backward (marl_mlp3_fwd_save / marl_mlp3_bwd_saved): the kept values are the
+    # values the backward would recompute - outputs bit-identical; the gradients are the same per-stripe sums added over another
+    # number of stripes (the kept backward runs two workgroups per CU)
     Y2, gd_rec = torch.full((rows, G * N3), 7.0, device=dev), gd.clone()
     ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y2, rows, K1, N3, G, hsave=hs)
     assert torch.equal(Y2, Y)
     gd.zero_()
     for rep in range(2):
         ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G, hsave=hs)
-    assert torch.equal(gd, gd_rec)
+    scale = float(gd_rec.abs().max())
+    close(gd / scale, gd_rec / scale, 2e-6, 1e-5)
     assert not torch.isnan(gd).any()
+    gd2 = gd.clone()
+    gd.zero_()
+    for rep in range(2):      # run to run: bitwise
+        ops.mlp3_bwd(ops.mlp3_weights(heads), xs, cu(dY, dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G, hsave=hs)
+    assert torch.equal(gd, gd2)
 
 
 @pytest.mark.parametrize("B,O", [(6, 24), (30, 24), (20, 80), (17, 116), (21, 64), (19, 52), (18, 128), (17, 176), (17, 148)])
