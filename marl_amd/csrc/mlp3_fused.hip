@@ -661,8 +661,7 @@ __global__ __launch_bounds__(64 * BNW, (LOAD && !WIDE && KC <= MLP3_BWD2_KC) ? 2
 #pragma unroll
         for (int c = 0; c < KH; c += 4) {        // up to four k tiles round robin (independent accumulators)
           const int cg = hf * KH + c;
-          constexpr int KE = KH;
-          const int lim = (KC - hf * KH) < KE ? (KC - hf * KH) : KE;      // chunks of this pass (compile time after unrolling)
+          const int lim = KC - hf * KH < KH ? KC - hf * KH : KH;           // chunks of this pass (a constant once unrolled)
           if (c >= lim) continue;
           f32x4 bf[4];
 #pragma unroll
