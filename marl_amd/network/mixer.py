@@ -31,6 +31,17 @@ class _Scratch:
             self.d[key] = t
         return t
 
+    def get_flat(self, name, n, device):
+        """>= n floats, grow-only and keyed by NAME alone: the kept-activation buffers of the fused head families are gigabytes
+        at the large batches, and max_episode_len - hence `rows` - may differ from update to update (one buffer per distinct
+        shape would pile them up)."""
+        key = (name, "flat")
+        t = self.d.get(key)
+        if t is None or t.device != device or t.numel() < n:
+            t = torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+            self.d[key] = t
+        return t
+
     def get_rows(self, name, rows, width, device):
         """(rows, width) fp32 view whose row stride is rounded up to 4 floats: every row starts on a 16-byte boundary,
         so the GEMM kernels take their vector-load paths (QTRAN's 78-wide intermediates)."""
@@ -196,7 +207,7 @@ class QMixMixer(_Precision, nn.Module):
                     w, G, n3g = wh
                     hs = None
                     if ctx is not None:
-                        hs = kept[name] = self._s.get("hs_" + name, (ops.mlp3_save_floats(rows, False, G),), dev)
+                        hs = kept[name] = self._s.get_flat("hs_" + name, ops.mlp3_save_floats(rows, False, G), dev)
                     ops.mlp3_fwd(w, xs, hy[:, cols], rows, a.state_shape, n3g, G, hsave=hs)
                     continue
                 l0, l2 = _linears(seq)
@@ -397,7 +408,7 @@ class DMAQer(_Precision, nn.Module):
         """buffer for the hidden activations a fused family keeps for its backward (MARL_MLP3_KEEP=0: recompute)."""
         if not _keep_hidden():
             return None
-        return self._s.get(name + "_hs", (ops.mlp3_save_floats(rows, three, groups),), dev)
+        return self._s.get_flat(name + "_hs", ops.mlp3_save_floats(rows, three, groups), dev)
 
     def _fused_transform(self, xs, grad=False):
         """hyper_w_final and V (Linear-ReLU-Linear, same shapes) as two heads of the fused kernel, or None."""
