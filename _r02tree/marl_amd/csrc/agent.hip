@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int H = 64;
-constexpr int HS = H + MARL_PAD_H;      // LDS row stride of 64-wide tiles (floats); +4 spreads banks
+constexpr int HS = H + 4;      // LDS row stride of 64-wide tiles (floats); +4 spreads banks
 constexpr int NT = 320;        // threads per workgroup
 
 struct FwdArgs {
@@ -90,26 +90,10 @@ __device__ __forceinline__ void st32(float* base, unsigned byte_off, float v) {
 // half committed (and the next step's left half issued) at the end of the gate phase - both inside the window in which the
 // input tile may be rewritten, both with a gate phase or more between issue and use.  The same registers then cover twice
 // the rows (a six-register variant spilled).  Non-saving unrolls only.
-// DMA: the observation part of the input tile is filled by LDS-DMA (global_load_lds_dwordx4: global -> LDS with no register
-// destination) instead of through prefetch registers.  The register path keeps one step's observation tile of the WORKGROUP
-// in NL x 512 float4 registers, which caps the rows of a workgroup at 2048 * NL / O floats - for wide observations (MMM2:
-// O = 176) two row tiles, i.e. a 640-tile shard runs as 320 workgroups = two rounds on 256 CUs.  With DMA a workgroup takes
-// as many row tiles as its LDS holds (MMM2: three -> 214 workgroups, one round).  One wave-instruction writes 64 consecutive
-// 16-byte slots of the tile image (M0 base + lane * 16) from per-lane source addresses: lane -> (row, column group) of the
-// slot it covers, slots of the one-hot / agent-id / padding columns are masked off, rows past their episode end are zero-filled
-// with a plain LDS store.  The waves of team 1 issue the DMAs of step t+1 right after the barrier that ends fc1(t) and wait for
-// them (s_waitcnt vmcnt(0)) before the barrier that ends the gate phase: that team has the fewer row tiles (or as many), so
-// the wait - which also covers its activation stores - falls into its slack.  hipcc inserts no waits of its own around an LDS-DMA
-// (checked in the ISA); the two explicit ones below are what orders it.
-// W2L: the fc2 fragments live in LDS instead of 16 * AC registers (read once per row tile in the short fc2 phase).  The
-// registers pay for a wider observation prefetch (NL = 6): the activation-saving unroll of wide observations with two action
-// tiles (MMM2: O = 176, A = 18) was held to two row tiles per workgroup by its four prefetch registers - 640 row tiles ran as
-// 320 workgroups, two rounds on 256 CUs; with three tiles per workgroup it is 214 workgroups, one round.
-template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false, bool HALF = false, bool DMA = false, bool W2L = false>
+template <int AC, bool SAVE, bool VL, int NL = NLDW, bool XS = false, bool HALF = false>
 __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   static_assert(!XS || (VL && !SAVE && NL == NLDW && !HALF), "XS: vector path, no saving");
   static_assert(!HALF || VL, "HALF: vector path");
-  static_assert(!DMA || (VL && !XS && !HALF), "DMA: vector path, plain schedule");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int team = wave >> 2, ws = wave & 3;
@@ -117,11 +101,11 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const long NTILES = (a.R + 15) >> 4;               // global 16-row tiles (saved-activation layout)
   const int RTW = (int)((NTILES - (long)blockIdx.x * a.RT) < a.RT ? (NTILES - (long)blockIdx.x * a.RT) : a.RT);   // REAL row tiles of this workgroup: the last one may hold fewer (whole tiles past the batch are not processed)
   const int rows = a.RT * 16;
-  const int KP = a.KC * 16, KS = KP + MARL_PAD_K;
+  const int KP = a.KC * 16, KS = KP + 4;
   // LDS carve (all offsets multiples of 4 floats)
-  float* In = smem;                                   // [rows][KS]  (first: the LDS-DMA destinations stay below 64 KB)
-  float* W1s = In + rows * KS;                        // [4][KC][64] f32x4
-  float* Xt = W1s + 4 * a.KC * 64 * 4;                // [rows][HS]
+  float* W1s = smem;                                  // [4][KC][64] f32x4
+  float* In = W1s + 4 * a.KC * 64 * 4;                // [rows][KS]
+  float* Xt = In + rows * KS;                         // [rows][HS]
   float* Ha = Xt + rows * HS;                         // [rows][HS] x2
   float* Hb = Ha + rows * HS;
   long* rowobs = reinterpret_cast<long*>(Hb + rows * HS);    // [rows]: (b*obs_bs + n) * O
@@ -131,8 +115,6 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   int* rowlen = rown + rows;                                 // [rows]: episode length (INT_MAX if none)
   int* rowrho = rowlen + rows;                               // [rows]: b*N + n
   int* xmask = rowrho + rows;                                // [T] (XS): step t is computed in full - the last step, or some row of this workgroup has ep_len - 1 == t
-  int* ulds = xmask + ((a.T + 3) & ~3);                      // [2][rows] (DMA): actions fed at a step, by step parity
-  float* W2s = reinterpret_cast<float*>(ulds + 2 * rows);    // [AC][4][64] f32x4 (W2L): fc2 fragments
 
   // Rows past the end of the batch (last workgroup only) are CLAMPED to the last valid row: they load
   // the same inputs, compute the same values and store them to the same addresses, so no per-lane
@@ -166,53 +148,6 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   int pu = -1, pu_lds = -1;           // action fed at the step being prefetched / one-hot column currently set in LDS
   // the element -> (row, column group) map of the prefetch is the same every step: resolve it once
   long goff[NL]; int loff[NL], plen[NL];
-  // DMA: 16-byte slots per row of the tile image, wave-instructions (64 slots) that cover it
-  const int SPR = KS >> 2, nchunks = (rows * SPR + 63) >> 6;
-  const float invSPR = 1.0f / (float)SPR;
-  auto dma_fill = [&](int t, int k0, int kstep) {      // observations of step t -> In (k0, kstep: this wave's share of the chunks)
-    const long toff = (long)(t + a.obs_t0) * a.N * O;
-    for (int k = k0; k < nchunks; k += kstep) {
-      const int sl = k * 64 + lane;
-      const int r = (int)(((float)sl + 0.5f) * invSPR);
-      const int c4 = sl - r * SPR;
-      const bool act = r < rows && c4 < (O >> 2);
-      const int rc = act ? r : 0;
-      const float* src = a.obs + rowobs[rc] + 4 * c4 + toff;
-      if (act) {
-        if (t < rowlen[rc]) {
-          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(In + k * 256), 16, 0, 0);
-        } else {
-          *reinterpret_cast<f32x4*>(In + sl * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};      // steps past the episode end feed zeros
-        }
-      }
-    }
-  };
-  // ... and the actions fed back (one per row and step) travel the same way, as 4-byte DMAs into a table: the step loop of the
-  // DMA kernels then holds NO ordinary load, and hipcc - which cannot count vmcnt past an LDS-DMA and would wait vmcnt(0),
-  // i.e. for every store of the wave, where such a load's result is used - inserts no wait of its own
-  auto dma_u = [&](int t) {                            // actions fed at step t -> ulds[t & 1]  (waves of team 1)
-    int* dst = ulds + (t & 1) * rows;
-    const bool has = a.ufed && t + a.u_t0 >= 0;
-    for (int k = ws; k * 64 < rows; k += 4) {
-      const int r = k * 64 + lane;
-      if (r < rows) {
-        if (has) __builtin_amdgcn_global_load_lds(a.ufed + rowu[r] + (long)(t + a.u_t0) * a.N, (__attribute__((address_space(3))) void*)(dst + k * 64), 4, 0, 0);
-        else dst[r] = -1;
-      }
-    }
-  };
-  auto flip_u = [&](int t) {                           // one-hot(last action) column of the input tile -> step t's
-    if (a.has_act && tid < rows) {
-      const int u = ulds[(t & 1) * rows + tid];
-      const int pn = (u >= 0 && u < a.A) ? u : -1;
-      if (pn != pu_lds) {
-        if (pu_lds >= 0) In[tid * KS + O + pu_lds] = 0.f;
-        if (pn >= 0) In[tid * KS + O + pn] = 1.f;
-        pu_lds = pn;
-      }
-    }
-  };
-  if (!DMA)
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     // elements past the tile are clamped to its last one (same value, same address): branch-free step loop
@@ -239,12 +174,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   if (XS) for (int e = tid; e < a.T; e += FNT) xmask[e] = e == a.T - 1 ? 1 : 0;      // (before the barrier of the constant columns)
   auto issue = [&](int t, int h = 0) {   // start the loads of step t's observations (vector path; h: column half)
     const long toff = (long)(t + a.obs_t0) * a.N * O + (h ? hoff : 0);
-    if (!DMA) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        // always loaded (the record has every slot); steps past the episode end are zeroed at commit
-        pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
-      }
+    for (int i = 0; i < NL; ++i) {
+      // always loaded (the record has every slot); steps past the episode end are zeroed at commit
+      pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
     }
     pt = t;
     if (h) return;
@@ -253,11 +186,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     pu = u;
   };
   auto commit = [&](int h = 0) {      // registers -> LDS tile; the one-hot(last action) column is flipped in place
-    if (!DMA) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i)
-        *reinterpret_cast<f32x4*>(In + loff[i] + (h ? hoff : 0)) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < NL; ++i)
+      *reinterpret_cast<f32x4*>(In + loff[i] + (h ? hoff : 0)) = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (XS && n4 > NL * FNT) {
       // the reuse variant refills the input tile for the few steps it computes in full only, so it is not held to the rows
       // the prefetch registers cover: the rest of a larger tile (wide observations) is fetched here, synchronously
@@ -309,12 +240,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   // NOTE the prefetch is issued UNCONDITIONALLY every step (the step index is clamped): a conditional issue makes
   // the prefetch registers a phi of (loaded, old) and the compiler then drains vmcnt right after the loads to copy
   if (HALF) { issue(0, 0); commit(0); issue(0, 1); commit(1); issue(a.T > 1 ? 1 : 0, 0); }
-  else if (VL) {
-    if (DMA) {                                // (waited for below, in front of the barrier that publishes the staged weights)
-      dma_fill(0, wave, 8);
-      if (team == 1) { dma_u(0); dma_u(a.T > 1 ? 1 : 0); }
-    } else { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
-  }
+  else if (VL) { issue(0); commit(); issue(a.T > 1 ? 1 : 0); }
   else load_generic(0);
   if (XS) {
     if (team < RTW) gissue(1, team);
@@ -348,11 +274,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     for (int ac = 0; ac < AC; ++ac) {
       int arow = 16 * ac + m; if (arow >= a.A) arow = a.A - 1;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
-        if (W2L) { if (wave == 0) *reinterpret_cast<f32x4*>(W2s + ((ac * 4 + c) * 64 + lane) * 4) = wv; }
-        else w2[ac][c] = wv;
-      }
+      for (int c = 0; c < 4; ++c)
+        w2[ac][c] = *reinterpret_cast<const f32x4*>(a.W2 + (long)arow * H + 16 * c + 4 * q);
       bias2[ac] = a.b2[arow];
     }
     bias1 = a.b1[j];
@@ -360,11 +283,6 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     bias_z = a.bih[H + j] + a.bhh[H + j];
     bias_in = a.bih[2 * H + j];
     bias_hn = a.bhh[2 * H + j];
-  }
-  if (DMA) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed
-    WG_BARRIER();
-    flip_u(0);
   }
   WG_BARRIER();   // input tile of step 0 and the fc1 fragments are in LDS
 
@@ -374,9 +292,6 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
   const unsigned jb = (unsigned)j * 4u;
   float* Hp = Ha;
   float* Hn = Hb;
-#ifdef MARL_PRIO_YOUNG
-  if (wave >= 4) __builtin_amdgcn_s_setprio(MARL_PRIO_YOUNG);      // A/B: static priority for the younger half of the workgroup
-#endif
   ST_DECL(6);
   for (int t = 0; t < a.T; ++t) {
     const unsigned trow = (unsigned)t * (unsigned)a.N;
@@ -392,11 +307,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       for (int c = 0; c < a.KC; ++c) {
         f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
         f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
+        acc0 = mfma16x4(a0, bv, acc0);
         if (two) {
           f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
-          mfma16x4_il2(a0, bv, acc0, a1, bv, acc1);
-        } else {
-          acc0 = mfma16x4(a0, bv, acc0);
+          acc1 = mfma16x4(a1, bv, acc1);
         }
       }
       const int r0 = rt * 16 + 4 * q;
@@ -431,21 +345,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       commit(0);                                  // left half of step t+1's input; its right half travels during the gates
       issue(t + 1 < a.T ? t + 1 : a.T - 1, 1);
     } else if (VL) {
-      if (DMA) {
-        flip_u(t + 1 < a.T ? t + 1 : a.T - 1);
-        if (team == 1) {                          // observations of step t+1 and actions of step t+2, in flight during the gates
-          // waves 4-7 are the younger half of the workgroup and lose the issue arbitration against their SIMD partners'
-          // MFMA streams (profiles/r03_phase_probe.txt): without the priority the ~40 address instructions per DMA crawl
-          // through the partners' gate phase (stamps: 45 % of a step for nine DMAs)
-          __builtin_amdgcn_s_setprio(3);
-          dma_fill(t + 1 < a.T ? t + 1 : a.T - 1, ws, 4);
-          dma_u(t + 2 < a.T ? t + 2 : a.T - 1);
-          __builtin_amdgcn_s_setprio(0);
-        }
-      } else {
-        commit();                                 // (after the last step this writes a tile nobody reads)
-        issue(t + 2 < a.T ? t + 2 : a.T - 1);
-      }
+      commit();                                   // (after the last step this writes a tile nobody reads)
+      issue(t + 2 < a.T ? t + 2 : a.T - 1);
     } else if (t + 1 < a.T) {
       load_generic(t + 1);
     }
@@ -476,17 +377,27 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-          mfma16x4_il3(ax, wih[0][c], ar, ax, wih[1][c], az, ax, wih[2][c], ain);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
         }
       } else if (!xread) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
           f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-          mfma16x4_il4(ax, wih[0][c], ar, ax, wih[1][c], az, ax, wih[2][c], ain, ah, whh[2][c], ahn);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
+          ahn = mfma16x4(ah, whh[2][c], ahn);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+          ahn = mfma16x4(ah, whh[2][c], ahn);
         }
       }
-      // (XS, step read: the candidate's hidden-side product joins the other two below - three chains instead of one)
       if (SAVE && a.gi_out) {
         float* const gp = a.gi_out + sv_off(svt + rt, 3, 0, ws, lane);
         *reinterpret_cast<f32x4*>(gp) = ar;
@@ -496,24 +407,26 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-        if (xread || AC == 2) mfma16x4_il3(ah, whh[2][c], ahn, ah, whh[0][c], ar, ah, whh[1][c], az);
-        else mfma16x4_il2(ah, whh[0][c], ar, ah, whh[1][c], az);
+        if (!xread && AC == 2) ahn = mfma16x4(ah, whh[2][c], ahn);
+        ar = mfma16x4(ah, whh[0][c], ar);
+        az = mfma16x4(ah, whh[1][c], az);
       }
       f32x4 vhp, vr, vz, vn, vh;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         vhp[i] = Hp[(r0 + i) * HS + j];
-        float r_, z_, n_, h_;
-        gru_point_plain(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);      // (not the pre-scaled form: common.h)
-        vr[i] = r_; vz[i] = z_; vn[i] = n_; vh[i] = h_;
+        vr[i] = sigmoidf_(ar[i]);
+        vz[i] = sigmoidf_(az[i]);
+        vn[i] = tanhf_(ain[i] + vr[i] * ahn[i]);
+        vh[i] = (1.f - vz[i]) * vn[i] + vz[i] * vhp[i];
         Hn[(r0 + i) * HS + j] = vh[i];
       }
       if (a.hs) {
-        const i32x4 ri = *reinterpret_cast<const i32x4*>(rowidx + r0);
+        const int4 ri = *reinterpret_cast<const int4*>(rowidx + r0);
         st32(a.hs, ((unsigned)ri.x + trow) * 256u + jb, vh[0]); st32(a.hs, ((unsigned)ri.y + trow) * 256u + jb, vh[1]);
         st32(a.hs, ((unsigned)ri.z + trow) * 256u + jb, vh[2]); st32(a.hs, ((unsigned)ri.w + trow) * 256u + jb, vh[3]);
       }
-      const i32x4 rr = *reinterpret_cast<const i32x4*>(rowrho + r0);
+      const int4 rr = *reinterpret_cast<const int4*>(rowrho + r0);
       if (SAVE) {
         float* const sp = a.saved + sv_off(svt + rt, 6, 0, ws, lane);       // plane k at sp + 1024 k
         *reinterpret_cast<f32x4*>(sp) = vhp;
@@ -533,7 +446,6 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       commit(1);                                  // right half of step t+1's input
       issue(t + 2 < a.T ? t + 2 : a.T - 1, 0);
     }
-    if (DMA && team == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed (and its stores)
     ST_MARK(3);
     WG_BARRIER();
     ST_MARK(4);
@@ -547,10 +459,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       for (int c = 0; c < 4; ++c) {
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
 #pragma unroll
-        for (int ac = 0; ac < AC; ++ac)
-          acc[ac] = mfma16x4(ah, W2L ? *reinterpret_cast<const f32x4*>(W2s + ((ac * 4 + c) * 64 + lane) * 4) : w2[ac][c], acc[ac]);
+        for (int ac = 0; ac < AC; ++ac) acc[ac] = mfma16x4(ah, w2[ac][c], acc[ac]);
       }
-      const i32x4 ri = *reinterpret_cast<const i32x4*>(rowidx + rt * 16 + 4 * q);
+      const int4 ri = *reinterpret_cast<const int4*>(rowidx + rt * 16 + 4 * q);
       const unsigned A4 = (unsigned)a.A * 4u;
 #pragma unroll
       for (int ac = 0; ac < AC; ++ac) {
@@ -594,7 +505,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
   const long NTILES = (a.R + 15) >> 4;               // global 16-row tiles (saved-activation layout)
   const int RTW = (int)((NTILES - (long)blockIdx.x * a.RT) < a.RT ? (NTILES - (long)blockIdx.x * a.RT) : a.RT);   // REAL row tiles of this workgroup: the last one may hold fewer (whole tiles past the batch are not processed)
   const int rows = a.RT * 16;
-  const int KP = a.KC * 16, KS = KP + MARL_PAD_K;
+  const int KP = a.KC * 16, KS = KP + 4;
   float* W1s = smem;                                  // [4][KC][64] f32x4
   float* In0 = W1s + 4 * a.KC * 64 * 4;               // [2][rows][KS]
   float* Xt0 = In0 + 2 * rows * KS;                   // [2][rows][HS]
@@ -747,11 +658,10 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
       for (int c = 0; c < a.KC; ++c) {
         f32x4 bv = *reinterpret_cast<const f32x4*>(wf + c * 256);
         f32x4 a0 = *reinterpret_cast<const f32x4*>(in0 + 16 * c);
+        acc0 = mfma16x4(a0, bv, acc0);
         if (two) {
           f32x4 a1 = *reinterpret_cast<const f32x4*>(in1 + 16 * c);
-          mfma16x4_il2(a0, bv, acc0, a1, bv, acc1);
-        } else {
-          acc0 = mfma16x4(a0, bv, acc0);
+          acc1 = mfma16x4(a1, bv, acc1);
         }
       }
       const int r0 = rt * 16 + 4 * q;
@@ -850,7 +760,9 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           f32x4 ax = *reinterpret_cast<const f32x4*>(xr + 16 * c);
-          mfma16x4_il3(ax, wih[0][c], ar, ax, wih[1][c], az, ax, wih[2][c], ain);
+          ar = mfma16x4(ax, wih[0][c], ar);
+          az = mfma16x4(ax, wih[1][c], az);
+          ain = mfma16x4(ax, wih[2][c], ain);
         }
       }
       if (SAVE && a.gi_out) {
@@ -862,16 +774,19 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 ah = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-        mfma16x4_il3(ah, whh[2][c], ahn, ah, whh[0][c], ar, ah, whh[1][c], az);
+        ahn = mfma16x4(ah, whh[2][c], ahn);
+        ar = mfma16x4(ah, whh[0][c], ar);
+        az = mfma16x4(ah, whh[1][c], az);
       }
       const int r0 = rt * 16 + 4 * q;
       f32x4 vhp, vr, vz, vn, vh;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         vhp[i] = Hp[(r0 + i) * HS + j];
-        float r_, z_, n_, h_;
-        gru_point_plain(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);      // (not the pre-scaled form: common.h)
-        vr[i] = r_; vz[i] = z_; vn[i] = n_; vh[i] = h_;
+        vr[i] = sigmoidf_(ar[i]);
+        vz[i] = sigmoidf_(az[i]);
+        vn[i] = tanhf_(ain[i] + vr[i] * ahn[i]);
+        vh[i] = (1.f - vz[i]) * vn[i] + vz[i] * vhp[i];
         Hn[(r0 + i) * HS + j] = vh[i];
       }
       if (a.hs) {
@@ -938,7 +853,7 @@ struct BwdArgs {
   long R;
 };
 
-constexpr int DGS = 256 + MARL_PAD_G;
+constexpr int DGS = 256 + 4;
 constexpr int BNT = 512;      // 8 waves: two per SIMD
 constexpr int NQ = 4;         // dq prefetch registers per thread
 
@@ -1154,7 +1069,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(gr + 16 * c);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(gr + 64 + 16 * c);
       const f32x4 a2 = *reinterpret_cast<const f32x4*>(gr + c2off);
-      mfma16x4_il3(a0, wT[c], main, a1, wT[4 + c], m1, a2, wT[8 + c], m2);
+      main = mfma16x4(a0, wT[c], main);
+      m1 = mfma16x4(a1, wT[4 + c], m1);
+      m2 = mfma16x4(a2, wT[8 + c], m2);
     }
     main += m1 + m2;
     // gate-gradient tiles of this wave's 16 columns in accumulator layout (they ARE the A^T fragments)
@@ -1167,7 +1084,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      mfma16x4_il3(g0, P[c], accW[0][c], g1, P[c], accW[1][c], g2, P[c], accW[2][c]);
+      accW[0][c] = mfma16x4(g0, P[c], accW[0][c]);
+      accW[1][c] = mfma16x4(g1, P[c], accW[1][c]);
+      accW[2][c] = mfma16x4(g2, P[c], accW[2][c]);
     }
     if (team) {
 #pragma unroll
@@ -1228,9 +1147,6 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_kernel(BwdArgs a) {
 
   int par = 0;
   bool c0A_carry = true;             // where a team WITHOUT phase-B tiles finds phase-C tile 0 of the coming step
-#ifdef MARL_PRIO_YOUNG
-  if (wave >= 4) __builtin_amdgcn_s_setprio(MARL_PRIO_YOUNG);      // A/B: static priority for the younger half of the workgroup
-#endif
   ST_DECL(5);
   for (int t = a.T - 1; t >= 0; --t, par ^= 1) {
     float* DQ = par ? DQ1 : DQ0;
@@ -1538,7 +1454,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(gr + 16 * c);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(gr + 64 + 16 * c);
       const f32x4 a2 = *reinterpret_cast<const f32x4*>(gr + c2off);
-      mfma16x4_il3(a0, wT[c], main, a1, wT[4 + c], m1, a2, wT[8 + c], m2);
+      main = mfma16x4(a0, wT[c], main);
+      m1 = mfma16x4(a1, wT[4 + c], m1);
+      m2 = mfma16x4(a2, wT[8 + c], m2);
     }
     main += m1 + m2;
     return main;
@@ -1555,7 +1473,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_pipe_kernel(BwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      mfma16x4_il3(g0, P[c], accW[0][c], g1, P[c], accW[1][c], g2, P[c], accW[2][c]);
+      accW[0][c] = mfma16x4(g0, P[c], accW[0][c]);
+      accW[1][c] = mfma16x4(g1, P[c], accW[1][c]);
+      accW[2][c] = mfma16x4(g2, P[c], accW[2][c]);
     }
   };
   const bool full_wg = row0 + rows <= a.R;
@@ -1804,34 +1724,19 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   a.KC = (a.I + 15) / 16;
   a.R = (long)B * N;
-  const int KS = a.KC * 16 + MARL_PAD_K;
-  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32 + 8;   // + row tables: 2 long + 4 int, + 2 int of the DMA kernels' action table
+  const int KS = a.KC * 16 + 4;
+  const size_t per_row = (size_t)(KS + 3 * HS) * 4 + 32;   // + row tables: 2 long + 4 int
   const size_t fixed = (size_t)4 * a.KC * 64 * 16 + 16 + (((size_t)T * 4 + 15) & ~(size_t)15);   // fc1 fragments + step flags of the x-reusing variants (pipelined: 4; else one per step)
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
-  bool half = false, dma = false, w2l = false;
+  bool half = false;
   static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
-  // MARL_FWD_DMA=1 (read per call): the activation-saving unroll fills its observation tile by LDS-DMA (DMA kernels).  OFF by
-  // default - measured slower (2s3z / 4096 envs 1.75 vs 1.62 ms; MMM2 / 1024 envs 2.98 ms at three row tiles per workgroup vs
-  // 2.24 ms at two through registers): the issuing waves spend a third of every step in the nine to eleven DMA issues
-  // (profiles/r03_stamps_dma.txt), although a wave alone issues such a DMA every ~100 cycles (profiles/r03_dma_probe.txt)
-  const int dma_mode = getenv("MARL_FWD_DMA") ? atoi(getenv("MARL_FWD_DMA")) : 0;
   const bool xs_req = a.vload && gi_in && !saved && T >= 2 && !xs_off;      // the launch reads stored input-side sums
   if (a.vload && !xs_req) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW * 512 registers
     int cap2 = (NLDW * FNT) / (16 * (O / 4));
     const long tiles = (a.R + 15) / 16;
     const int cus = T > 1 ? cu_budget : 256;
     const int want = (int)((tiles + cus - 1) / cus);                 // row tiles per workgroup that fill the CUs in one round
-    // activation-saving unroll of wide observations: the observation tile goes through LDS-DMA, the workgroup is not held
-    // to the rows its prefetch registers would cover (DMA kernels)
-    if (saved && T > 1 && dma_mode == 1) { dma = true; cap2 = 8; }
-    // activation-saving unroll, wide observations, two action tiles: six prefetch registers, fc2 fragments in LDS (W2L kernels)
-    const bool w2l_off = getenv("MARL_FWD_W2L") && getenv("MARL_FWD_W2L")[0] == '0';      // A/B switch (read per call)
-    // (only where it makes the launch a single round of workgroups: beside the target unroll under the pair schedule -
-    // cu_budget 128 - three tiles per workgroup were SLOWER than two, 2.57 vs 2.24 ms at MMM2 / 1024 envs; alone on the chip
-    // 1.25 vs 1.75 ms, profiles/r03_mmm2_schedules.txt)
-    const int cap6 = (6 * FNT) / (16 * (O / 4));
-    if (saved && !dma && T > 1 && A > 16 && cap2 < want && cap2 < 8 && want <= cap6 && !w2l_off) { w2l = true; cap2 = cap6; }
     if (cap2 < want && cap2 < 8 && T > 1 && O % 8 == 0 && !saved) {  // wide observations: the registers hold one column
       half = true;                                                   // half of the tile at a time (HALF kernels).  Not the
       cap2 = (NLDW * FNT) / (16 * (O / 8));                          // activation-saving variant: hipcc cannot count its
@@ -1843,9 +1748,8 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   // a single step (rollout) is latency-bound: many small workgroups overlap their prologues better than
   // 256 big ones; a long unroll amortises the prologue and wants one workgroup per CU
   if (T == 1 && rt_cap > marl_fwd_rt_single) rt_cap = marl_fwd_rt_single;
-  const size_t fixed_k = fixed + (w2l ? (size_t)2 * 4 * 64 * 16 : 0);
-  a.RT = pick_rt(a.R, per_row, fixed_k, rt_cap, T > 1 ? cu_budget : 256);
-  const size_t lds = fixed_k + per_row * a.RT * 16;
+  a.RT = pick_rt(a.R, per_row, fixed, rt_cap, T > 1 ? cu_budget : 256);
+  const size_t lds = fixed + per_row * a.RT * 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const long rows = a.RT * 16;
   dim3 grid((unsigned)((a.R + rows - 1) / rows)), block(FNT);
@@ -1854,7 +1758,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
   hipError_t e;
   // few row tiles per workgroup and a long unroll: the software-pipelined variant (one barrier per step)
-  if (a.vload && !dma && !w2l && a.RT <= marl_fwd_pipe_max_rt && T >= 4 && (long)a.RT * 16 * (O / 4) <= (long)NLDW * FNT) {
+  if (a.vload && a.RT <= marl_fwd_pipe_max_rt && T >= 4 && (long)a.RT * 16 * (O / 4) <= (long)NLDW * FNT) {
     const size_t per_row_p = (size_t)(2 * KS + 4 * HS) * 4 + 32;
     const size_t lds_p = fixed + per_row_p * a.RT * 16 + 64;
     if (lds_p <= 160 * 1024) {
@@ -1877,10 +1781,6 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   const bool sv = saved != nullptr, vl = a.vload != 0;
   if (xs_req) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, true>;
-  } else if (w2l) {
-    fn = (const void*)agent_fwd_kernel<2, true, true, 6, false, false, false, true>;
-  } else if (dma) {
-    fn = A <= 16 ? (const void*)agent_fwd_kernel<1, true, true, NLDW, false, false, true> : (const void*)agent_fwd_kernel<2, true, true, NLDW, false, false, true>;
   } else if (vl && half) {
     fn = A <= 16 ? (const void*)agent_fwd_kernel<1, false, true, NLDW, false, true> : (const void*)agent_fwd_kernel<2, false, true, NLDW, false, true>;
   } else

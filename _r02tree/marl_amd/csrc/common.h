@@ -5,28 +5,7 @@
 
 #define MARL_WAVE 64
 
-// LDS row pitches of the activation tiles, in floats beyond the tile width.  A wave reads an MFMA operand fragment with one
-// ds_read_b128 per lane (row m, columns 4q..4q+3 of a 16-chunk): gfx950 serves that instruction in four groups of 16 lanes over
-// 64 banks, and a pitch of 8 (mod 16) floats is the one that spreads every group over all banks (a pitch of 4 mod 16 - the
-// usual "+4" - is a 2-way conflict on every such read; tools/lds_pitch.py).  The accumulator-layout accesses (row 4q+i, column
-// m: ds_read/write_b32) are 2-way at that pitch instead - free for the writes, and the reads are few.  Time-neutral at the
-// headline shape (LDS is ~15 % busy there; A/B within the +-1.5 % run-to-run spread, profiles/r03_ab_variants.txt), it removes
-// the conflict cycles the counters show.
-#ifndef MARL_PAD_H
-#define MARL_PAD_H 8
-#endif
-#ifndef MARL_PAD_K
-#define MARL_PAD_K 8
-#endif
-#ifndef MARL_PAD_G
-#define MARL_PAD_G 8
-#endif
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// 16-byte integer LDS reads use THIS type, not HIP's int4: int4 is a union-based struct, its loads carry "may alias anything"
-// type information, and hipcc then waits vmcnt(0) in front of every such LDS read while an LDS-DMA (global_load_lds) may be
-// pending - draining the DMA (and the wave's stores) right there.  Scalar int / ext-vector loads do not get that wait.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // D = A(16x4) * B(4x16) + C, exact f32 (v_mfma_f32_16x16x4_f32).
 // lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]; D reg r: D[row 4*(l>>4)+r][col l&15].
@@ -43,42 +22,6 @@ __device__ __forceinline__ f32x4 mfma16x4(const f32x4& a, const f32x4& b, f32x4 
   c = mfma16(a[3], b[3], c);
   return c;
 }
-
-// Interleaved forms for INDEPENDENT accumulators.  v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result can feed the
-// next MFMA only after 40: four back-to-back MFMAs on ONE accumulator (mfma16x4 above, which is how hipcc emits it - it keeps
-// the source order) run at 80 % of the pipe rate.  Round-robin over two to four accumulators keeps the pipe full; the order
-// of the four products inside each accumulator is unchanged, so results are bit-identical to the plain form.
-#ifdef MARL_NO_INTERLEAVE      // A/B builds (tools/build_variant.sh): the plain order
-__device__ __forceinline__ void mfma16x4_il2(const f32x4& a0, const f32x4& b0, f32x4& c0, const f32x4& a1, const f32x4& b1, f32x4& c1) {
-  c0 = mfma16x4(a0, b0, c0); c1 = mfma16x4(a1, b1, c1);
-}
-__device__ __forceinline__ void mfma16x4_il3(const f32x4& a0, const f32x4& b0, f32x4& c0, const f32x4& a1, const f32x4& b1, f32x4& c1,
-                                             const f32x4& a2, const f32x4& b2, f32x4& c2) {
-  c0 = mfma16x4(a0, b0, c0); c1 = mfma16x4(a1, b1, c1); c2 = mfma16x4(a2, b2, c2);
-}
-__device__ __forceinline__ void mfma16x4_il4(const f32x4& a0, const f32x4& b0, f32x4& c0, const f32x4& a1, const f32x4& b1, f32x4& c1,
-                                             const f32x4& a2, const f32x4& b2, f32x4& c2, const f32x4& a3, const f32x4& b3, f32x4& c3) {
-  c0 = mfma16x4(a0, b0, c0); c1 = mfma16x4(a1, b1, c1); c2 = mfma16x4(a2, b2, c2); c3 = mfma16x4(a3, b3, c3);
-}
-#else
-__device__ __forceinline__ void mfma16x4_il2(const f32x4& a0, const f32x4& b0, f32x4& c0, const f32x4& a1, const f32x4& b1, f32x4& c1) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { c0 = mfma16(a0[i], b0[i], c0); c1 = mfma16(a1[i], b1[i], c1); }
-}
-__device__ __forceinline__ void mfma16x4_il3(const f32x4& a0, const f32x4& b0, f32x4& c0, const f32x4& a1, const f32x4& b1, f32x4& c1,
-                                             const f32x4& a2, const f32x4& b2, f32x4& c2) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { c0 = mfma16(a0[i], b0[i], c0); c1 = mfma16(a1[i], b1[i], c1); c2 = mfma16(a2[i], b2[i], c2); }
-}
-__device__ __forceinline__ void mfma16x4_il4(const f32x4& a0, const f32x4& b0, f32x4& c0, const f32x4& a1, const f32x4& b1, f32x4& c1,
-                                             const f32x4& a2, const f32x4& b2, f32x4& c2, const f32x4& a3, const f32x4& b3, f32x4& c3) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    c0 = mfma16(a0[i], b0[i], c0); c1 = mfma16(a1[i], b1[i], c1); c2 = mfma16(a2[i], b2[i], c2); c3 = mfma16(a3[i], b3[i], c3);
-  }
-}
-
-#endif
 
 // bf16 operands, fp32 accumulate (v_mfma_f32_16x16x16_bf16): with the K-permutation above one instruction replaces
 // the four fp32 MFMAs of a 16-chunk.  Opt-in for the MIXER GEMMs only (BASELINE config 5, "bf16 mixer with MFMA").
@@ -102,47 +45,6 @@ __device__ __forceinline__ float tanhf_(float x) {
   float e = __expf(2.0f * x);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-
-// ---- GRU gate math on PRE-SCALED accumulators (every GRU forward kernel: unroll, pipelined unroll, rollout).
-// fp32 MFMAs and vector instructions share the SIMD's issue, so a vector instruction saved is matrix time
-// gained.  sigmoid(x) = 1 / (1 + 2^(-x log2 e)) and tanh(y) = 1 - 2 / (2^(2 y log2 e) + 1): the kernels multiply the r / z rows of
-// W_ih, W_hh and their biases by -log2(e) and the candidate rows by 2 log2(e) ONCE, when the fragments are loaded into
-// registers, so the accumulators arrive as the exponents and the per-element multiplies (5 of 17 vector instructions per
-// element) are gone.  Scaling a weight rounds it once more (relative 6e-8, the size of the products' own rounding).
-#define MARL_NLOG2E (-1.4426950408889634f)
-#define MARL_2LOG2E (2.8853900817779268f)
-// Measured (same box, alternating, profiles/r03_prescale_ab.txt): the rollout kernel gains 1.5 % from this, the learner's unroll kernels
-// LOSE 2 % (the saving unroll also has to un-scale the plane it stores for BPTT) - they use gru_point_plain().
-// -DMARL_NO_PRESCALE: plain form everywhere (A/B).
-__device__ __forceinline__ void gru_point_plain(float ar, float az, float ain, float ahn, float hp, float& r, float& z, float& n, float& h) {
-  r = sigmoidf_(ar); z = sigmoidf_(az);
-  n = tanhf_(ain + r * ahn);
-  h = (1.f - z) * n + z * hp;
-}
-#ifdef MARL_NO_PRESCALE
-__device__ __forceinline__ void gru_prescale(f32x4 (&)[3][4], f32x4 (&)[3][4], float&, float&, float&, float&) {}
-__device__ __forceinline__ void gru_point(float ar, float az, float ain, float ahn, float hp, float& r, float& z, float& n, float& h) {
-  gru_point_plain(ar, az, ain, ahn, hp, r, z, n, h);
-}
-#else
-__device__ __forceinline__ void gru_prescale(f32x4 (&wih)[3][4], f32x4 (&whh)[3][4], float& b_r, float& b_z, float& b_in, float& b_hn) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    wih[0][c] *= MARL_NLOG2E; whh[0][c] *= MARL_NLOG2E;
-    wih[1][c] *= MARL_NLOG2E; whh[1][c] *= MARL_NLOG2E;
-    wih[2][c] *= MARL_2LOG2E; whh[2][c] *= MARL_2LOG2E;
-  }
-  b_r *= MARL_NLOG2E; b_z *= MARL_NLOG2E; b_in *= MARL_2LOG2E; b_hn *= MARL_2LOG2E;
-}
-// ar, az: -log2(e) x (gate pre-activation);  ain, ahn: 2 log2(e) x (input-side / hidden-side part of the candidate's)
-__device__ __forceinline__ void gru_point(float ar, float az, float ain, float ahn, float hp, float& r, float& z, float& n, float& h) {
-  r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ar));
-  z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(az));
-  const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(r, ahn, ain));
-  n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-  h = __builtin_fmaf(z, hp - n, n);                       // (1 - z) n + z h_prev
-}
-#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

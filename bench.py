@@ -496,10 +496,13 @@ def main():
     gc.collect()
     gc.disable()
     barrier()
-    timers.on = True
+    # HIP-event timing of the kernels on every THIRD step of the timed region: the ~16 event records of a step cost it 0.1 ms (1 %;
+    # measured with MARL_BENCH_TIMER_STRIDE=1 / 0 on one box: 9.74 / 9.63 ms per step) - the value must not pay for its own roofline
+    stride = int(os.environ.get("MARL_BENCH_TIMER_STRIDE", "3" if o.steps >= 6 else "1"))
     t0 = time.perf_counter()
     env_steps = 0
-    for _ in range(o.steps):
+    for si in range(o.steps):
+        timers.on = stride > 0 and si % stride == 0
         ts = time.perf_counter()
         s, loss = one_step()
         env_steps += s
