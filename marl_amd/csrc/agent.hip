@@ -360,6 +360,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
     bias_z = a.bih[H + j] + a.bhh[H + j];
     bias_in = a.bih[2 * H + j];
     bias_hn = a.bhh[2 * H + j];
+    if (AC == 2) gru_prescale(wih, whh, bias_r, bias_z, bias_in, bias_hn);      // gate math on pre-scaled accumulators: see GRU_PRE in common.h
   }
   if (DMA) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
       for (int i = 0; i < 4; ++i) {
         vhp[i] = Hp[(r0 + i) * HS + j];
         float r_, z_, n_, h_;
-        gru_point_plain(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);      // (not the pre-scaled form: common.h)
+        if (AC == 2) gru_point(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);
+        else gru_point_plain(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);
         vr[i] = r_; vz[i] = z_; vn[i] = n_; vh[i] = h_;
         Hn[(r0 + i) * HS + j] = vh[i];
       }
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         *reinterpret_cast<f32x4*>(sp + 2 * 1024) = vr;
         *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
         *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
-        *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
+        *reinterpret_cast<f32x4*>(sp + 5 * 1024) = AC == 2 ? ahn * MARL_INV_2LOG2E : ahn;      // BPTT wants W_hn h + b_hn itself
         // the hidden state AFTER the last step, where the backward pass looks for h(t): plane 0 of step t+1
         if (t == a.T - 1) *reinterpret_cast<f32x4*>(sp + NTILES * (6 * 1024)) = vh;
       }
@@ -731,6 +733,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
     bias_z = a.bih[H + j] + a.bhh[H + j];
     bias_in = a.bih[2 * H + j];
     bias_hn = a.bhh[2 * H + j];
+    if (AC == 2) gru_prescale(wih, whh, bias_r, bias_z, bias_in, bias_hn);      // gate math on pre-scaled accumulators: see GRU_PRE in common.h
   }
   WG_BARRIER();
   const unsigned jb = (unsigned)j * 4u;
@@ -870,7 +873,8 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
       for (int i = 0; i < 4; ++i) {
         vhp[i] = Hp[(r0 + i) * HS + j];
         float r_, z_, n_, h_;
-        gru_point_plain(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);      // (not the pre-scaled form: common.h)
+        if (AC == 2) gru_point(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);
+        else gru_point_plain(ar[i], az[i], ain[i], ahn[i], vhp[i], r_, z_, n_, h_);
         vr[i] = r_; vz[i] = z_; vn[i] = n_; vh[i] = h_;
         Hn[(r0 + i) * HS + j] = vh[i];
       }
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_pipe_kernel(FwdArgs a) {
         *reinterpret_cast<f32x4*>(sp + 2 * 1024) = vr;
         *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
         *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
-        *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
+        *reinterpret_cast<f32x4*>(sp + 5 * 1024) = AC == 2 ? ahn * MARL_INV_2LOG2E : ahn;      // BPTT wants W_hn h + b_hn itself
         // the hidden state AFTER the last step, where the backward pass looks for h(t): plane 0 of step t+1
         if (t == a.T - 1) *reinterpret_cast<f32x4*>(sp + NTILES * (6 * 1024)) = vh;
       }

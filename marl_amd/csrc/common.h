@@ -111,8 +111,10 @@ __device__ __forceinline__ float tanhf_(float x) {
 // element) are gone.  Scaling a weight rounds it once more (relative 6e-8, the size of the products' own rounding).
 #define MARL_NLOG2E (-1.4426950408889634f)
 #define MARL_2LOG2E (2.8853900817779268f)
-// Measured (same box, alternating, profiles/r03_prescale_ab.txt): the rollout kernel gains 1.5 % from this, the learner's unroll kernels
-// LOSE 2 % (the saving unroll also has to un-scale the plane it stores for BPTT) - they use gru_point_plain().
+#define MARL_INV_2LOG2E (0.34657359027997264f)
+// Measured (same box, alternating, profiles/r03_prescale_ab.txt): the rollout kernel gains 1.5 % from this; of the learner's unroll
+// kernels the two-action-tile instantiations (AC = 2: MMM2, 18 actions) gain 10 % and the one-tile ones (2s3z, 3s5z) LOSE 2 % (the
+// saving unroll also has to un-scale the plane it stores for BPTT) - those use gru_point_plain().  GRU_PRE: agent.hip decides by AC.
 // -DMARL_NO_PRESCALE: plain form everywhere (A/B).
 __device__ __forceinline__ void gru_point_plain(float ar, float az, float ain, float ahn, float hp, float& r, float& z, float& n, float& h) {
   r = sigmoidf_(ar); z = sigmoidf_(az);
@@ -120,6 +122,8 @@ __device__ __forceinline__ void gru_point_plain(float ar, float az, float ain, f
   h = (1.f - z) * n + z * hp;
 }
 #ifdef MARL_NO_PRESCALE
+#undef MARL_INV_2LOG2E
+#define MARL_INV_2LOG2E (1.0f)
 __device__ __forceinline__ void gru_prescale(f32x4 (&)[3][4], f32x4 (&)[3][4], float&, float&, float&, float&) {}
 __device__ __forceinline__ void gru_point(float ar, float az, float ain, float ahn, float hp, float& r, float& z, float& n, float& h) {
   gru_point_plain(ar, az, ain, ahn, hp, r, z, n, h);
