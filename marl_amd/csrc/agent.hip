@@ -13,6 +13,14 @@
 //     recurrent critical path;
 //   * GRU pointwise math is done on the accumulator (D) layout in registers; activations that the
 //     backward pass needs are written once, coalesced per 16-lane group.
+// LDS tile pitches of THIS file: +4 floats.  The +8 of common.h halves the bank-conflict share of the b128 fragment reads
+// (tools/lds_pitch.py) but is time-neutral on 2s3z-sized tiles and COSTS the wide ones: QMIX on MMM2 / 1024 envs 159.6 -> 169.2
+// updates/s with +4 here, QTRAN-base 3s5z 282 -> 284, QMIX 2s3z within +-0.3 % (same box, alternating: profiles/r03_prescale_ab.txt, 8).
+#ifndef MARL_PAD_H
+#define MARL_PAD_H 4
+#define MARL_PAD_K 4
+#define MARL_PAD_G 4
+#endif
 #include "common.h"
 #include <cstdlib>
 #include "../../include/marl_hip.h"
