@@ -2,6 +2,7 @@
 tail, the fused clip+optimizer wrapper, the agent backward pass and data-parallel reduction."""
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -313,6 +314,9 @@ class PairedUnroll:
         whole chip) is at least as fast by the step-time model."""
         if not self.chain or not self.applies(rows, T):
             return None
+        forced = os.environ.get("MARL_CHAIN_SPLIT")                 # experiments: CUs of the chain side (the model's choice otherwise)
+        if forced:
+            return (int(forced), 256 - int(forced)) if int(forced) > 0 else None
         tiles = (rows + 15) // 16
         cap = max(1, min(8, 2048 // (4 * max(obs_dim, 4))))          # row tiles per workgroup the unroll kernel can hold
         ceil = lambda a, b: -(-a // b)
