@@ -49,6 +49,10 @@ CASES = [
     ("qplex_2s3z_nodq", "2s3z", "qplex", 3, 4, [4, 2, 3], {"double_q": False}),
     ("qtran_3s5z", "3s5z", "qtran_base", 4, 6, [6, 2, -1, 5], {}),
     ("qmix_MMM2", "MMM2", "qmix", 3, 5, [5, 3, 4], {}),
+    # round 3: the shapes that left the marl_linear composition (heads with 322 / 502 input columns, 320-wide hypernet heads)
+    ("qplex_MMM2", "MMM2", "qplex", 3, 4, [4, 2, 3], {}),
+    ("qmix_MMM2_hyper2", "MMM2", "qmix", 3, 5, [5, 2, 4], {"two_hyper_layers": True}),
+    ("qplex_3s5z", "3s5z", "qplex", 3, 4, [3, -1, 4], {}),
 ]
 TRAIN_STEPS = [0, 1, 200, 201]   # 200 crosses the target-sync boundary (quirk Q6)
 
@@ -234,8 +238,11 @@ def gen_matrix_table():
 
 
 if __name__ == "__main__":
+    only = os.environ.get("MARL_GOLDEN_ONLY", "")      # comma-separated case names: (re)generate just these learner cases
     for c in CASES:
-        gen_learner_case(c)
-    gen_rollout()
-    gen_replay()
-    gen_matrix_table()
+        if not only or c[0] in only.split(","):
+            gen_learner_case(c)
+    if not only:
+        gen_rollout()
+        gen_replay()
+        gen_matrix_table()

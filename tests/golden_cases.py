@@ -16,6 +16,10 @@ CASES = [
     ("qplex_2s3z_nodq", "2s3z", "qplex", 3, 4, [4, 2, 3], {"double_q": False}),
     ("qtran_3s5z", "3s5z", "qtran_base", 4, 6, [6, 2, -1, 5], {}),
     ("qmix_MMM2", "MMM2", "qmix", 3, 5, [5, 3, 4], {}),
+    # round 3: the shapes that left the marl_linear composition (heads with 322 / 502 input columns, 320-wide hypernet heads)
+    ("qplex_MMM2", "MMM2", "qplex", 3, 4, [4, 2, 3], {}),
+    ("qmix_MMM2_hyper2", "MMM2", "qmix", 3, 5, [5, 2, 4], {"two_hyper_layers": True}),
+    ("qplex_3s5z", "3s5z", "qplex", 3, 4, [3, -1, 4], {}),
 ]
 TRAIN_STEPS = [0, 1, 200, 201]
 
