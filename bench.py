@@ -367,6 +367,26 @@ def cpu_baseline(alg, shape, T, envs, budget_s, threads=0):
             "batched_rollout_env_steps_per_sec": steps / t_roll, "serial_rollout_env_steps_per_sec": ssteps / t_serial}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run this file under torch.distributed.run as a child process
+    (N ranks on 127.0.0.1, a free port), stdout / stderr inherited, and return the child's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()         # (counting devices does not initialise HIP in this process)
+    if have < n and os.environ.get("MARL_BENCH_ONE_DEVICE") != "1":
+        print("[bench] --gpus %d asked for, %d visible on this node" % (n, have), file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=dict(os.environ)).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,6 +417,12 @@ def main():
     if o.cpu_probe:
         print(cpu_probe(o.alg, o.shape, o.T or SHAPES[o.shape][4], o.cpu_envs, o.cpu_probe))
         return
+
+    if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: nothing in this process has touched the GPU yet (importing torch does not), so
+        # start the N ranks as a FRESH child - torch.distributed.run, one process per GPU - let it print rank 0's JSON line on
+        # our stdout and leave with its return code (a process that has initialised HIP must never be replaced by exec)
+        sys.exit(self_launch(o.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

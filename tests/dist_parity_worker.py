@@ -16,8 +16,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     alg, shape = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group(backend=os.environ.get("MARL_BENCH_BACKEND", "gloo"))
+    backend = os.environ.get("MARL_BENCH_BACKEND", "gloo")
+    if backend == "nccl":          # RCCL: one GPU per rank
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    else:                          # gloo moving CUDA tensors: every rank on GPU 0 (1-GPU box)
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend=backend)
     from oracle import seeded
     from test_gpu_learners import build_product
     B, T = 6, 6
