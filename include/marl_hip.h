@@ -262,6 +262,23 @@ int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const
                         const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, const float* hsave,
                         size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
 
+/* ---- the same heads with the multiplies as an fp32-accurate SPLIT on the bf16 matrix cores (mlp3_x6.hip) -------------
+ * Opt-in (args.gemm_mode = "bf16x6"; the default is the pair above on v_mfma_f32_16x16x4_f32).  Every fp32 operand is split
+ * exactly into three bf16 terms (hi + mid + lo) and a product is the six bf16 products hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid
+ * accumulated in fp32 by v_mfma_f32_16x16x32_bf16: the error against fp64 is that of the fp32 MFMA path (dropped terms <= 2^-24 of a
+ * product), at 0.4 of its matrix-pipe time.  Same math as marl_mlp3_fwd_save / marl_mlp3_bwd_saved (network/mixer.py:117-145,
+ * :149-171) for THREE-layer heads with N3 <= 16 outputs and up to 192 input columns whose width is not a multiple of 16 (the first
+ * free column carries the ones that produce the layer-1 bias gradient).  The kept activations are the split planes (768 bytes per
+ * row and head): `hsave` of marl_mlp3_x6_save_floats(M, groups) floats, layout private to this pair - not interchangeable with the fp32
+ * pair's.  hsave == NULL in the forward: nothing is kept (target mixer).  Workspace: marl_mlp3_bwd_workspace(). */
+int marl_mlp3_x6_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups);
+size_t marl_mlp3_x6_save_floats(long M, int groups);
+int marl_mlp3_x6_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
+                          float* hsave, size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
+int marl_mlp3_x6_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,
+                           const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, const float* hsave,
+                           size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
+
 /* ---- fused QTRAN-base heads (qtran_fused.hip) ------------------------------------------------
  * QtranQBase.forward (network/mixer.py:378-388, A = n_actions > 0, AE = 64 + A) and QtranV.forward (:411-418, A = 0,
  * AE = 64):  out[bt] = q( [s | sum_n enc([h_n | onehot(u_n)])] ).  The per-agent encoder activations never leave the

@@ -527,28 +527,40 @@ def _head_layout(Y, M, N3, groups):
     return Y.stride(0), N3
 
 
-def mlp3_save_floats(M, three, groups):
-    """floats of the kept-activation buffer of one fused head family (layout private to the kernel pair)."""
+def mlp3_x6_supported(x, K1, H1, H2, N3, groups):
+    """the bf16x6 split pair (csrc/mlp3_x6.hip) exists for this head shape"""
+    return bool(_lib.load().marl_mlp3_x6_supported(C.byref(x), K1, H1, H2, N3, groups))
+
+
+def mlp3_save_floats(M, three, groups, x6=False):
+    """floats of the kept-activation buffer of one fused head family (layout private to the kernel pair; x6: the
+    split planes of the bf16x6 pair, 1.5 x the fp32 pair's)."""
+    if x6:
+        assert three
+        return int(_lib.load().marl_mlp3_x6_save_floats(M, groups))
     return int(_lib.load().marl_mlp3_save_floats(M, 1 if three else 0, groups))
 
 
-def mlp3_fwd(w, x, Y, M, K1, N3, groups, hsave=None):
-    """hsave (float32, >= mlp3_save_floats): keep the hidden activations for mlp3_bwd instead of recomputing them."""
+def mlp3_fwd(w, x, Y, M, K1, N3, groups, hsave=None, x6=False):
+    """hsave (float32, >= mlp3_save_floats): keep the hidden activations for mlp3_bwd instead of recomputing them.
+    x6: the bf16x6 split kernels (fp32-accurate products on the bf16 matrix cores; opt-in args.gemm_mode = "bf16x6")."""
     ld, gs = _head_layout(Y, M, N3, groups)
     assert src_width(x) == K1
     hp, hn = (_p(_f32(hsave)), hsave.numel()) if hsave is not None else (None, 0)
-    check(_lib.load().marl_mlp3_fwd_save(C.byref(w), C.byref(x), _p(_f32(Y)), ld, gs, hp, hn, M, K1, N3, groups, _stream()),
-          "marl_mlp3_fwd")
+    fn = _lib.load().marl_mlp3_x6_fwd_save if x6 else _lib.load().marl_mlp3_fwd_save
+    check(fn(C.byref(w), C.byref(x), _p(_f32(Y)), ld, gs, hp, hn, M, K1, N3, groups, _stream()),
+          "marl_mlp3_x6_fwd" if x6 else "marl_mlp3_fwd")
 
 
-def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups, hsave=None):
+def mlp3_bwd(w, x, dY, grads, M, K1, N3, groups, hsave=None, x6=False):
     lib = _lib.load()
     ld, gs = _head_layout(dY, M, N3, groups)
     assert src_width(x) == K1
     ws = WS.get("mlp3", lib.marl_mlp3_bwd_workspace(M, K1, N3, groups), dY.device)
     hp, hn = (_p(_f32(hsave)), hsave.numel()) if hsave is not None else (None, 0)
-    check(lib.marl_mlp3_bwd_saved(C.byref(w), C.byref(x), _p(_f32(dY)), ld, gs, C.byref(grads), _p(ws), ws.numel() * 4,
-                                  hp, hn, M, K1, N3, groups, _stream()), "marl_mlp3_bwd")
+    fn = lib.marl_mlp3_x6_bwd_saved if x6 else lib.marl_mlp3_bwd_saved
+    check(fn(C.byref(w), C.byref(x), _p(_f32(dY)), ld, gs, C.byref(grads), _p(ws), ws.numel() * 4,
+             hp, hn, M, K1, N3, groups, _stream()), "marl_mlp3_x6_bwd" if x6 else "marl_mlp3_bwd")
 
 
 # ---- fused QTRAN-base heads (csrc/qtran_fused.hip)
