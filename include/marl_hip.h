@@ -268,11 +268,10 @@ int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const
  * accumulated in fp32 by v_mfma_f32_16x16x32_bf16: the error against fp64 is that of the fp32 MFMA path (dropped terms <= 2^-24 of a
  * product), at 0.4 of its matrix-pipe time.  Same math as marl_mlp3_fwd_save / marl_mlp3_bwd_saved (network/mixer.py:117-145,
  * :149-171) for THREE-layer heads with N3 <= 16 outputs and up to 192 input columns whose width is not a multiple of 16 (the first
- * free column carries the ones that produce the layer-1 bias gradient).  The kept activations are the split planes (768 bytes per
- * row and head): `hsave` of marl_mlp3_x6_save_floats(M, groups) floats, layout private to this pair - not interchangeable with the fp32
- * pair's.  hsave == NULL in the forward: nothing is kept (target mixer).  Workspace: marl_mlp3_bwd_workspace(). */
+ * free column carries the ones that produce the layer-1 bias gradient).  `hsave`: marl_mlp3_save_floats(M, 1, groups) floats in the
+ * layout of the fp32 pair (the kept fp32 activations; the backward splits them).  hsave == NULL in the forward: nothing is kept
+ * (target mixer).  Workspace: marl_mlp3_bwd_workspace(). */
 int marl_mlp3_x6_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups);
-size_t marl_mlp3_x6_save_floats(long M, int groups);
 int marl_mlp3_x6_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
                           float* hsave, size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
 int marl_mlp3_x6_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const float* dY, long lddy, long gs_dy,

@@ -104,7 +104,6 @@ SIGNATURES = {
     "marl_mlp3_fwd_save": (I, [M3, SRC, P, L, L, P, SZ, L, I, I, I, P]),
     "marl_mlp3_bwd_saved": (I, [M3, SRC, P, L, L, M3, P, SZ, P, SZ, L, I, I, I, P]),
     "marl_mlp3_x6_supported": (I, [SRC, I, I, I, I, I]),
-    "marl_mlp3_x6_save_floats": (SZ, [L, I]),
     "marl_mlp3_x6_fwd_save": (I, [M3, SRC, P, L, L, P, SZ, L, I, I, I, P]),
     "marl_mlp3_x6_bwd_saved": (I, [M3, SRC, P, L, L, M3, P, SZ, P, SZ, L, I, I, I, P]),
     "marl_qtran_supported": (I, [I, I, I]),

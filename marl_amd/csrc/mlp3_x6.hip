@@ -133,12 +133,9 @@ __device__ __forceinline__ f32x4 xv_or_zero(const f32x4 (&xv)[KC], int c) {     
   return c < KC ? xv[c < KC ? c : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-__host__ __device__ inline long x6_save_floats_per_tile(bool three) { return (three ? 2 : 1) * 2 * 3 * 256; }
-
 // ------------------------------------------------------------------------------------------------- forward
 // 8 waves, each walks its own 16-row tiles (x of the next tile in flight); hidden activations never leave the wave.  a.hs != NULL:
-// the split planes of relu(h1), relu(h2) - the B fragments this kernel forms anyway - are kept for the backward,
-// [head][tile][activation][chunk][plane][lane] 16 bytes (768 bytes per row and head).
+// relu(h1), relu(h2) are kept for the backward as fp32 accumulator fragments (the layout of the fp32 pair, 512 bytes per row and head).
 template <int KC, bool THREE, int CFT>
 __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -170,8 +167,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
   const long t_begin = (long)stripe * per;
   long t_end = t_begin + per; if (t_end > tiles) t_end = tiles;
   float* Y = a.Y + g * a.gs_y;
-  constexpr int NA = THREE ? 2 : 1;
-
+  
   f32x4 xv[KC];
   long tile = t_begin + wave;
   if (tile >= t_end) return;
@@ -198,16 +194,18 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
       xr = x_row(a.x, nt * 16 + m, a.M);
       x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
     }
-    F3 hb[2];
-    hb[0] = split8(relu4(acc[0]), relu4(acc[1]));
-    hb[1] = split8(relu4(acc[2]), relu4(acc[3]));
-    i32x4* hp = a.hs ? reinterpret_cast<i32x4*>(a.hs) + (((long)g * tiles + tile) * NA) * 384 + lane : nullptr;
+    // kept for the backward: relu(h1), relu(h2) as the fp32 accumulator fragments, in the layout of the fp32 pair
+    // ([head][tile][plane 0..7][lane] f32x4 - the two pairs' kept buffers are interchangeable)
+    f32x4* hp = a.hs ? reinterpret_cast<f32x4*>(a.hs) + (((long)g * tiles + tile) * (THREE ? 8 : 4)) * 64 + lane : nullptr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = relu4(acc[t]);
     if (hp) {
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
-        KEEP_ST(hb[c2].h, hp + c2 * 192); KEEP_ST(hb[c2].m, hp + c2 * 192 + 64); KEEP_ST(hb[c2].l, hp + c2 * 192 + 128);
-      }
+      for (int c = 0; c < 4; ++c) KEEP_ST(acc[c], hp + c * 64);
     }
+    F3 hb[2];
+    hb[0] = split8(acc[0], acc[1]);
+    hb[1] = split8(acc[2], acc[3]);
     if (THREE) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = b2v[t];
@@ -219,14 +217,14 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
         mm6x4(wa, hb[c2], acc);
         __builtin_amdgcn_sched_barrier(0);
       }
-      hb[0] = split8(relu4(acc[0]), relu4(acc[1]));
-      hb[1] = split8(relu4(acc[2]), relu4(acc[3]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = relu4(acc[t]);
       if (hp) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-          KEEP_ST(hb[c2].h, hp + 384 + c2 * 192); KEEP_ST(hb[c2].m, hp + 384 + c2 * 192 + 64); KEEP_ST(hb[c2].l, hp + 384 + c2 * 192 + 128);
-        }
+        for (int c = 0; c < 4; ++c) KEEP_ST(acc[c], hp + (4 + c) * 64);
       }
+      hb[0] = split8(acc[0], acc[1]);
+      hb[1] = split8(acc[2], acc[3]);
     }
     f32x4 o = b3v;
 #pragma unroll
@@ -240,56 +238,59 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------- backward (kept activations)
-// One workgroup of 8 waves per CU, 128 rows per iteration (wave w: the 16-row tile 8 it + w).
+// TWO workgroups of 4 waves per CU (<= 80 KB of LDS and 256 registers each), 64 rows per iteration (wave w: the 16-row tile 4 it + w):
+// the phases below alternate between matrix-pipe work and LDS / VALU work with a barrier after each - two independent workgroups are
+// never in the same phase for long (one workgroup of 8 waves over 128 rows per iteration: 1.69 ms where this form takes ...).
 //   phase A (registers, per wave): dh2^T = relu'(h2) (W3^T dy^T), dh1^T = relu'(h1) (W2^T dh2^T) - the transposed chain with
-//            pre-split W3^T / W2^T fragments from LDS; relu' from the sign of the kept hi plane; bias sums of layers 2, 3.
+//            pre-split W3^T / W2^T fragments from LDS; relu' from the kept fp32 activations; bias sums of layers 2, 3.
 //   phase B (weight gradients, reduce over the 128 rows): operands through the [plane][128 rows][256 B] image, two 64-column
 //            blocks per row:  [x columns 64 pt .. 64 pt + 63 | dh1]  (one pass per 64 columns of x: dW1; the bias gradient of layer 1
 //            comes out of the same products through a ones column placed at the first free virtual column of x),
-//            [h1 | dh2] (dW2), [h2 | dy] (dW3).  Wave w accumulates feature tile w & 3 x column tiles 2 (w >> 2), 2 (w >> 2) + 1.
-constexpr int XR = 128;                               // rows per iteration
-constexpr int XNW = 8;
-__device__ __forceinline__ int st_off(int pl, int row, int ch, int sub) {
-  return pl * (XR * 256) + row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + sub;
+//            [h1 | dh2] (dW2), [h2 | dy] (dW3).  Wave w accumulates feature tile w x the four column tiles of a block.
+// Image addressing: byte(plane, row, 16-byte chunk ch, sub) = plane * 32768 + row * 256 + 16 * (ch ^ swz(row)) + sub with
+// swz(row) = ((row & 3) << 2) | ((row >> 2) & 3).  A lane's row (writes) and its row mod 32 (transposed reads) never change, and
+// the chunk of a column tile is even, so every address is  (a per-lane constant) ^ (16 * chunk)  + plane / k-chunk offsets: the
+// per-lane parts are computed once, outside the row loop (computed per access they were most of the kernel's vector instructions).
+constexpr int XR = 64;                                // rows per iteration
+constexpr int XNW = 4;
+constexpr int PLS = XR * 256;                         // bytes per plane
+// a fragment's 8 slots of the lane's row -> columns cb + 4q + (0..3) and cb + 16 + 4q + (0..3)   (pb: the lane's put base)
+__device__ __forceinline__ void img_put8(char* st, int pb, const F3& f, int cb) {
+  const int a0 = pb ^ (16 * (cb >> 3)), a1 = pb ^ (16 * ((cb >> 3) + 2));
+  *reinterpret_cast<i32x2*>(st + a0) = (i32x2){f.h[0], f.h[1]};
+  *reinterpret_cast<i32x2*>(st + a1) = (i32x2){f.h[2], f.h[3]};
+  *reinterpret_cast<i32x2*>(st + a0 + PLS) = (i32x2){f.m[0], f.m[1]};
+  *reinterpret_cast<i32x2*>(st + a1 + PLS) = (i32x2){f.m[2], f.m[3]};
+  *reinterpret_cast<i32x2*>(st + a0 + 2 * PLS) = (i32x2){f.l[0], f.l[1]};
+  *reinterpret_cast<i32x2*>(st + a1 + 2 * PLS) = (i32x2){f.l[2], f.l[3]};
 }
-// a fragment's 8 slots of row `row` -> columns cb + 4q + (0..3) and cb + 16 + 4q + (0..3) of the image (cb a multiple of 32)
-__device__ __forceinline__ void img_put8(char* st, const F3& f, int row, int cb, int q) {
-  const int c0 = cb + 4 * q, c1 = c0 + 16, sub = 8 * (q & 1);
-  const i32x4 pl[3] = {f.h, f.m, f.l};
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    *reinterpret_cast<i32x2*>(st + st_off(p, row, c0 >> 3, sub)) = (i32x2){pl[p][0], pl[p][1]};
-    *reinterpret_cast<i32x2*>(st + st_off(p, row, c1 >> 3, sub)) = (i32x2){pl[p][2], pl[p][3]};
-  }
+__device__ __forceinline__ void img_put4(char* st, int pb, const F3h& f, int cb) {
+  const int a0 = pb ^ (16 * (cb >> 3));
+  *reinterpret_cast<i32x2*>(st + a0) = f.h;
+  *reinterpret_cast<i32x2*>(st + a0 + PLS) = f.m;
+  *reinterpret_cast<i32x2*>(st + a0 + 2 * PLS) = f.l;
 }
-__device__ __forceinline__ void img_put4(char* st, const F3h& f, int row, int cb, int q) {
-  const int c0 = cb + 4 * q, sub = 8 * (q & 1);
-  *reinterpret_cast<i32x2*>(st + st_off(0, row, c0 >> 3, sub)) = f.h;
-  *reinterpret_cast<i32x2*>(st + st_off(1, row, c0 >> 3, sub)) = f.m;
-  *reinterpret_cast<i32x2*>(st + st_off(2, row, c0 >> 3, sub)) = f.l;
-}
-// operand fragment of a product that sums over the image's rows rb + 8g + (0..7): lane (g, i) gets column c0 + i
-__device__ __forceinline__ i32x4 img_tr(const char* st, int pl, int rb, int c0, int lane) {
-  const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
-  const int r0 = rb + 8 * g + qq;
+// operand fragment of a product that sums over the image's rows 32 kc + 8g + (0..7): lane (g, i) gets column c0 + i.
+// t0 / t1: the lane's read bases of this column tile for rows 8g + (0..3) / 8g + (4..7)  (tr_base below)
+__device__ __forceinline__ i32x4 img_tr(const char* st, int t0, int t1, int off) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + st_off(pl, r0, (c0 >> 3) + (p >> 1), 8 * (p & 1))));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + st_off(pl, r0 + 4, (c0 >> 3) + (p >> 1), 8 * (p & 1))));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + t0 + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + t1 + off));
   return __builtin_bit_cast(i32x4, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-__device__ __forceinline__ F3 img_tr3(const char* st, int rb, int c0, int lane) {
+__device__ __forceinline__ F3 img_tr3(const char* st, int t0, int t1, int kc) {
   F3 f;
-  f.h = img_tr(st, 0, rb, c0, lane); f.m = img_tr(st, 1, rb, c0, lane); f.l = img_tr(st, 2, rb, c0, lane);
+  f.h = img_tr(st, t0, t1, kc * 8192); f.m = img_tr(st, t0, t1, kc * 8192 + PLS); f.l = img_tr(st, t0, t1, kc * 8192 + 2 * PLS);
   return f;
 }
-// relu'(h) from the kept hi plane: slot s of the fragment (bf16 in half s & 1 of dword s >> 1) is positive
-__device__ __forceinline__ bool slot_pos(const i32x4& hi, int s) {
-  const unsigned d = (unsigned)hi[s >> 1];
-  return (int)((s & 1) ? (d & 0xffff0000u) : (d << 16)) > 0;
+__device__ __forceinline__ int tr_base(int lane, int c0, int half) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
+  const int row = 8 * g + qq + 4 * half;
+  return row * 256 + 16 * (((c0 >> 3) + (p >> 1)) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (p & 1);
 }
 
 template <int KC, bool THREE, int CFT>
-__global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {
+__global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {      // (2 waves per SIMD = two workgroups per CU)
   static_assert(THREE, "three-layer heads only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NP = (KC + 3) / 4;                  // passes of 64 x columns
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {
   int* W2Ts = reinterpret_cast<int*>(smem);         // [4][2] items of 768 dwords: A[i = f1][slot <-> f2] = W2[f2][f1]
   int* W3Ts = W2Ts + 8 * 768;                       // [4 t][3 planes][64 lanes] 8 bytes: A[i = f2 = 16t + m][k = n3 = 4q + j] = W3[n3][f2]
   char* st = reinterpret_cast<char*>(W3Ts + 4 * 3 * 128);      // the image: 3 * 128 * 256 bytes
-  int* tab = reinterpret_cast<int*>(st + 3 * XR * 256);
+  int* tab = reinterpret_cast<int*>(st + 3 * PLS);
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
   stage6<true, 64 * XNW>(W2Ts, W2, HD, HD, HD, 4, 2, 1 << 30, 0);
@@ -325,44 +326,59 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {
   long i_end = i_begin + per; if (i_end > its) i_end = its;
   const float* dY = a.Y + g * a.gs_y;
   const long tiles = (a.M + 15) / 16;
-  const i32x4* hs = reinterpret_cast<const i32x4*>(a.hs);
+  const f32x4* hs = reinterpret_cast<const f32x4*>(a.hs);
 
-  const int tf = wave & 3, chh = wave >> 2;        // feature tile, column-tile pair of this wave's weight-gradient accumulators
-  f32x4 dW1[NP][2], dW2[2], dW3 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 bs2[4];
-  f32x4 bs3 = {0.f, 0.f, 0.f, 0.f};
+  const int tf = wave;                              // feature tile of this wave's weight-gradient accumulators
+  f32x4 dW1[NP][4], dW2[4], dW3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int p = 0; p < NP; ++p) { dW1[p][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dW1[p][1] = dW1[p][0]; }
-  dW2[0] = dW2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) bs2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 4; ++u) dW1[p][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dW2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // the ones column: first virtual column past the input (K1 + kpad), there is one because 16 KC > KV (marl_mlp3_x6_supported)
   const int kone = a.KV;
+  // per-lane address parts (see the note above)
+  const int row = 16 * wave + m;                   // this lane's row of the image
+  const int pb = row * 256 + 16 * ((q >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (q & 1);
+  const int tB0 = tr_base(lane, 0, 0), tB1 = tr_base(lane, 0, 1);      // column tile 0; tile ct: ^ (32 * ct)  (the chunk of a tile is even)
+  const int tA0 = tB0 ^ (32 * (4 + tf)), tA1 = tB1 ^ (32 * (4 + tf));  // dh1 / dh2: feature tile tf of the right block
+  const int tY0 = tB0 ^ (32 * 4), tY1 = tB1 ^ (32 * 4);                // dy
+  const int tH0 = tB0 ^ (32 * wave), tH1 = tB1 ^ (32 * wave);          // h2 column tile of this wave
+  const int one_off = (row * 256 + 16 * (((kone & 63) >> 3) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 2 * (kone & 7));
 
   f32x4 xv[KC];
   XRow xr;
-  i32x4 hi1[2], hi2[2];            // kept hi planes of this wave's tile (relu masks), loaded an iteration ahead
+  f32x4 h1f[4], h2f[4];            // kept relu(h1), relu(h2) of this wave's tile (accumulator layout), loaded an iteration ahead
   f32x4 dyn;                       // dY[row m][4q .. 4q + 3]
-  auto issue_next = [&](long it_) __attribute__((always_inline)) {
+  auto issue_x = [&](long it_) __attribute__((always_inline)) {
     xr = x_row(a.x, (it_ * XNW + wave) * 16 + m, a.M);
     x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
     const bool lv = (xr.flags & 1) != 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) dyn[j] = (lv && 4 * q + j < a.N3) ? dY[xr.rowc * a.ldy + 4 * q + j] : 0.f;
-    long tl = it_ * XNW + wave; if (tl > tiles - 1) tl = tiles - 1;
-    const i32x4* hp = hs + (((long)g * tiles + tl) * 2) * 384 + lane;
-    hi1[0] = KEEP_LD(hp); hi1[1] = KEEP_LD(hp + 192);
-    hi2[0] = KEEP_LD(hp + 384); hi2[1] = KEEP_LD(hp + 384 + 192);
   };
-  if (i_begin < i_end) issue_next(i_begin);
-  const int row = 16 * wave + m;                   // this lane's row of the image
+  auto issue_h = [&](long it_) __attribute__((always_inline)) {
+    long tl = it_ * XNW + wave; if (tl > tiles - 1) tl = tiles - 1;      // (a tile past the end multiplies zero gradients)
+    const f32x4* hp = hs + (((long)g * tiles + tl) * 8) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { h1f[c] = KEEP_LD(hp + c * 64); h2f[c] = KEEP_LD(hp + (4 + c) * 64); }
+  };
+  if (i_begin < i_end) { issue_x(i_begin); issue_h(i_begin); }
+  // bias gradients of layers 2 and 3 ride on the weight-gradient products: A fragment x a fragment of ones (bf16 1.0 in every slot:
+  // only the three products against its hi plane are non-zero) = the row sum of the A operand, in every column of the tile
+  const i32x4 ones = {0x3F803F80, 0x3F803F80, 0x3F803F80, 0x3F803F80};
+  f32x4 bs2 = {0.f, 0.f, 0.f, 0.f}, bs3 = {0.f, 0.f, 0.f, 0.f};
+  // two accumulators of one A fragment against two B fragments, round robin; with ONES also the A operand's row sums
+#define X6_MM2(AF, B0, B1, C0, C1)                                                                          \
+  C0 = mm(AF.m, B0.m, C0); C1 = mm(AF.m, B1.m, C1); C0 = mm(AF.h, B0.l, C0); C1 = mm(AF.h, B1.l, C1);      \
+  C0 = mm(AF.l, B0.h, C0); C1 = mm(AF.l, B1.h, C1); C0 = mm(AF.h, B0.m, C0); C1 = mm(AF.h, B1.m, C1);      \
+  C0 = mm(AF.m, B0.h, C0); C1 = mm(AF.m, B1.h, C1); C0 = mm(AF.h, B0.h, C0); C1 = mm(AF.h, B1.h, C1);
+  ST_DECL(15);
   for (long it = i_begin; it < i_end; ++it) {
     // ---------------- phase A
     x_finish<KC, CFT>(xv, xr, tab, a.CF, lane);
-    long tl = it * XNW + wave; if (tl > tiles - 1) tl = tiles - 1;
-    const i32x4* hp = hs + (((long)g * tiles + tl) * 2) * 384 + lane;
     const F3h dy3 = split4(dyn);
-    bs3 += dyn;
     f32x4 dh[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -373,101 +389,115 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {
       mm6h(w, dy3, dh[t]);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dh[t][r] = slot_pos(hi2[t >> 1], (t & 1) * 4 + r) ? dh[t][r] : 0.f;
-      bs2[t] += dh[t];
-    }
+      for (int r = 0; r < 4; ++r) dh[t][r] = h2f[t][r] > 0.f ? dh[t][r] : 0.f;
     F3 dh2f[2];
     dh2f[0] = split8(dh[0], dh[1]);
     dh2f[1] = split8(dh[2], dh[3]);
-    {
-      f32x4 acc[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tp = 0; tp < 2; ++tp) {               // feature tiles two at a time (two accumulators round robin)
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
-        F3 wa[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wa[t] = lds_f3(W2Ts, t * 2 + c2, lane);
-        mm6x4(wa, dh2f[c2], acc);
+        const F3 w0 = lds_f3(W2Ts, (2 * tp) * 2 + c2, lane), w1 = lds_f3(W2Ts, (2 * tp + 1) * 2 + c2, lane);
+        const F3& b = dh2f[c2];
+        a0 = mm(w0.m, b.m, a0); a1 = mm(w1.m, b.m, a1); a0 = mm(w0.h, b.l, a0); a1 = mm(w1.h, b.l, a1);
+        a0 = mm(w0.l, b.h, a0); a1 = mm(w1.l, b.h, a1); a0 = mm(w0.h, b.m, a0); a1 = mm(w1.h, b.m, a1);
+        a0 = mm(w0.m, b.h, a0); a1 = mm(w1.m, b.h, a1); a0 = mm(w0.h, b.h, a0); a1 = mm(w1.h, b.h, a1);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh[t][r] = slot_pos(hi1[t >> 1], (t & 1) * 4 + r) ? acc[t][r] : 0.f;
-    }
-    // image: [x columns of pass 0 | dh1]
-    img_put8(st, split8(dh[0], dh[1]), row, 64, q);
-    img_put8(st, split8(dh[2], dh[3]), row, 96, q);
-#pragma unroll
-    for (int pt = 0; pt < NP; ++pt) {
-      img_put8(st, split8(xv_or_zero<KC>(xv, 4 * pt), xv_or_zero<KC>(xv, 4 * pt + 1)), row, 0, q);
-      img_put8(st, split8(xv_or_zero<KC>(xv, 4 * pt + 2), xv_or_zero<KC>(xv, 4 * pt + 3)), row, 32, q);
-      if ((kone >> 6) == pt && q == 0) {              // ones column (same wave, later instruction: lands after the packed write)
-        const int c = kone & 63;
-        *reinterpret_cast<short*>(st + st_off(0, row, c >> 3, 2 * (c & 7))) = (short)0x3F80;
-        *reinterpret_cast<short*>(st + st_off(1, row, c >> 3, 2 * (c & 7))) = 0;
-        *reinterpret_cast<short*>(st + st_off(2, row, c >> 3, 2 * (c & 7))) = 0;
+      for (int r = 0; r < 4; ++r) {
+        dh[2 * tp][r] = h1f[2 * tp][r] > 0.f ? a0[r] : 0.f;
+        dh[2 * tp + 1][r] = h1f[2 * tp + 1][r] > 0.f ? a1[r] : 0.f;
       }
-      if (pt == NP - 1) {
-        // x is consumed: the next iteration's tile, dY elements and mask planes (unconditional; the last one re-reads its own)
-        issue_next(it + 1 < i_end ? it + 1 : it);
-      }
-      WG_BARRIER();
-      // dW1[feature tile tf][columns 64 pt + 16 (2 chh + u)] += dh1^T x over the 128 rows
-#pragma unroll
-      for (int kc = 0; kc < XR / 32; ++kc) {
-        const F3 af = img_tr3(st, 32 * kc, 64 + 16 * tf, lane);
-        const F3 b0 = img_tr3(st, 32 * kc, 16 * (2 * chh), lane);
-        const F3 b1 = img_tr3(st, 32 * kc, 16 * (2 * chh + 1), lane);
-        mm6(af, b0, dW1[pt][0]);
-        mm6(af, b1, dW1[pt][1]);
-      }
-      WG_BARRIER();
     }
-    // image: [h1 | dh2]   (all three planes of the kept h1)
-    {
-      F3 f0, f1;
-      // (hi1 / hi2 already hold the NEXT tile's planes: all three are read again - L2 hits)
-      f0.h = KEEP_LD(hp); f0.m = KEEP_LD(hp + 64); f0.l = KEEP_LD(hp + 128);
-      f1.h = KEEP_LD(hp + 192); f1.m = KEEP_LD(hp + 192 + 64); f1.l = KEEP_LD(hp + 192 + 128);
-      img_put8(st, f0, row, 0, q);
-      img_put8(st, f1, row, 32, q);
-      img_put8(st, dh2f[0], row, 64, q);
-      img_put8(st, dh2f[1], row, 96, q);
-    }
+    ST_MARK(0);
+    // ---------------- image [h1 | dh2]: dW2 (and the layer-2 bias gradient)
+    img_put8(st, pb, split8(h1f[0], h1f[1]), 0);
+    img_put8(st, pb, split8(h1f[2], h1f[3]), 32);
+    img_put8(st, pb, dh2f[0], 64);
+    img_put8(st, pb, dh2f[1], 96);
+    ST_MARK(1);
     WG_BARRIER();
+    ST_MARK(2);
 #pragma unroll
     for (int kc = 0; kc < XR / 32; ++kc) {
-      const F3 af = img_tr3(st, 32 * kc, 64 + 16 * tf, lane);
-      const F3 b0 = img_tr3(st, 32 * kc, 16 * (2 * chh), lane);
-      const F3 b1 = img_tr3(st, 32 * kc, 16 * (2 * chh + 1), lane);
-      mm6(af, b0, dW2[0]);
-      mm6(af, b1, dW2[1]);
-    }
-    WG_BARRIER();
-    // image: [h2 | dy]
-    {
-      F3 f0, f1;
-      f0.h = KEEP_LD(hp + 384); f0.m = KEEP_LD(hp + 384 + 64); f0.l = KEEP_LD(hp + 384 + 128);
-      f1.h = KEEP_LD(hp + 384 + 192); f1.m = KEEP_LD(hp + 384 + 192 + 64); f1.l = KEEP_LD(hp + 384 + 192 + 128);
-      img_put8(st, f0, row, 0, q);
-      img_put8(st, f1, row, 32, q);
-      img_put4(st, dy3, row, 64, q);
-    }
-    WG_BARRIER();
-    if (wave < 4) {
+      const F3 af = img_tr3(st, tA0, tA1, kc);
+      bs2 = mm(af.l, ones, bs2); bs2 = mm(af.m, ones, bs2); bs2 = mm(af.h, ones, bs2);
 #pragma unroll
-      for (int kc = 0; kc < XR / 32; ++kc) {
-        const F3 af = img_tr3(st, 32 * kc, 64, lane);
-        const F3 bf = img_tr3(st, 32 * kc, 16 * wave, lane);
-        mm6(af, bf, dW3);
+      for (int cp = 0; cp < 2; ++cp) {
+        const F3 b0 = img_tr3(st, tB0 ^ (32 * (2 * cp)), tB1 ^ (32 * (2 * cp)), kc);
+        const F3 b1 = img_tr3(st, tB0 ^ (32 * (2 * cp + 1)), tB1 ^ (32 * (2 * cp + 1)), kc);
+        X6_MM2(af, b0, b1, dW2[2 * cp], dW2[2 * cp + 1])
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    ST_MARK(3);
     WG_BARRIER();
+    ST_MARK(4);
+    // ---------------- image [h2 | dy]: dW3 (and the layer-3 bias gradient)
+    img_put8(st, pb, split8(h2f[0], h2f[1]), 0);
+    img_put8(st, pb, split8(h2f[2], h2f[3]), 32);
+    img_put4(st, pb, dy3, 64);
+#ifndef X6_EXP_NOH
+    issue_h(it + 1 < i_end ? it + 1 : it);          // kept activations of the next iteration's tile (land during the dW1 passes)
+#endif
+    ST_MARK(5);
+    WG_BARRIER();
+    ST_MARK(6);
+#pragma unroll
+    for (int kc = 0; kc < XR / 32; ++kc) {
+      const F3 af = img_tr3(st, tY0, tY1, kc);
+      const F3 bf = img_tr3(st, tH0, tH1, kc);
+      mm6(af, bf, dW3);
+      bs3 = mm(af.l, ones, bs3); bs3 = mm(af.m, ones, bs3); bs3 = mm(af.h, ones, bs3);
+    }
+    ST_MARK(7);
+    WG_BARRIER();
+    ST_MARK(8);
+    // ---------------- images [x columns 64 pt .. | dh1]: dW1 (the layer-1 bias gradient through the ones column of x)
+    img_put8(st, pb, split8(dh[0], dh[1]), 64);
+    img_put8(st, pb, split8(dh[2], dh[3]), 96);
+    ST_MARK(12);
+#pragma unroll
+    for (int pt = 0; pt < NP; ++pt) {
+#ifndef X6_EXP_NOPUTX
+      img_put8(st, pb, split8(xv_or_zero<KC>(xv, 4 * pt), xv_or_zero<KC>(xv, 4 * pt + 1)), 0);
+      img_put8(st, pb, split8(xv_or_zero<KC>(xv, 4 * pt + 2), xv_or_zero<KC>(xv, 4 * pt + 3)), 32);
+#endif
+      ST_MARK(13);
+      if ((kone >> 6) == pt && q == 0) {              // ones column (same wave, later instruction: lands after the packed write)
+        *reinterpret_cast<short*>(st + one_off) = (short)0x3F80;
+        *reinterpret_cast<short*>(st + one_off + PLS) = 0;
+        *reinterpret_cast<short*>(st + one_off + 2 * PLS) = 0;
+      }
+      ST_MARK(14);
+      // x is consumed: the next iteration's tile and dY elements (unconditional; the last one re-reads its own)
+#ifndef X6_EXP_NOX
+      if (pt == NP - 1) issue_x(it + 1 < i_end ? it + 1 : it);
+#endif
+      ST_MARK(9);
+      WG_BARRIER();
+      ST_MARK(10);
+#pragma unroll
+      for (int kc = 0; kc < XR / 32; ++kc) {
+        const F3 af = img_tr3(st, tA0, tA1, kc);
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const F3 b0 = img_tr3(st, tB0 ^ (32 * (2 * cp)), tB1 ^ (32 * (2 * cp)), kc);
+          const F3 b1 = img_tr3(st, tB0 ^ (32 * (2 * cp + 1)), tB1 ^ (32 * (2 * cp + 1)), kc);
+          X6_MM2(af, b0, b1, dW1[pt][2 * cp], dW1[pt][2 * cp + 1])
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      WG_BARRIER();
+      ST_MARK(11);
+    }
   }
+#undef X6_MM2
+  if (KC == 8) { ST_DUMP(15); }
 
   // ---------------- slab: [dW1 64 x (K1+1) | dW2 64 x 65 | dW3 16 x 65], bias gradient in the last column
   const int K1x = a.K1 + 1;
@@ -477,8 +507,8 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {
 #pragma unroll
   for (int pt = 0; pt < NP; ++pt)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int vc = 64 * pt + 16 * (2 * chh + u) + m;             // virtual column of this lane
+    for (int u = 0; u < 4; ++u) {
+      const int vc = 64 * pt + 16 * u + m;                          // virtual column of this lane
       const int k = vc == kone ? a.K1 : vcol(vc, a.x.k0, a.kpad);   // (the ones column carries the bias gradient)
       const bool ok = vc == kone || (k >= 0 && k < a.K1 && vc < a.KV);
 #pragma unroll
@@ -486,31 +516,17 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {
         if (ok) s1[(long)(16 * tf + 4 * q + r) * K1x + k] = dW1[pt][u][r];
     }
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s2[(16 * tf + 4 * q + r) * (HD + 1) + 16 * (2 * chh + u) + m] = dW2[u][r];
-  if (wave < 4) {
+    for (int r = 0; r < 4; ++r) s2[(16 * tf + 4 * q + r) * (HD + 1) + 16 * u + m] = dW2[u][r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s3[(4 * q + r) * (HD + 1) + 16 * wave + m] = dW3[r];
-  }
-  // bias sums of layers 2 and 3: over the 16 rows of a lane group and the 8 waves, through the (now free) image
-  float* red = reinterpret_cast<float*>(st);      // [8 waves][64 lanes][20]
+  for (int r = 0; r < 4; ++r) s3[(4 * q + r) * (HD + 1) + 16 * wave + m] = dW3[r];
+  if (m == 0) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 64 + lane) * 20 + 4 * t + r] = bs2[t][r];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) red[(wave * 64 + lane) * 20 + 16 + r] = bs3[r];
-  __syncthreads();
-  if (tid < 80) {
-    // feature f = 16t + 4q' + r of layer 2 (tid < 64) or output n3 = 4q' + r of layer 3: element e of the lanes (q', 0..15)
-    const int f = tid < 64 ? tid : tid - 64;
-    const int e = tid < 64 ? 4 * (f >> 4) + (f & 3) : 16 + (f & 3), qq = (f >> 2) & 3;
-    float sum = 0.f;
-    for (int w = 0; w < XNW; ++w)
-      for (int mm_ = 0; mm_ < 16; ++mm_) sum += red[(w * 64 + qq * 16 + mm_) * 20 + e];
-    if (tid < 64) s2[f * (HD + 1) + HD] = sum;
-    else s3[f * (HD + 1) + HD] = sum;
+    for (int r = 0; r < 4; ++r) {
+      s2[(16 * tf + 4 * q + r) * (HD + 1) + HD] = bs2[r];
+      if (wave == 0) s3[(4 * q + r) * (HD + 1) + HD] = bs3[r];
+    }
   }
 }
 
@@ -521,6 +537,8 @@ inline size_t x6_fwd_lds(int KC, int CF, bool three) {
 inline size_t x6_bwd_lds(int KC, int CF) { return (size_t)8 * 768 * 4 + 4 * 3 * 128 * 4 + (size_t)3 * XR * 256 + (size_t)(KC - CF) * 32 * 4; }
 
 }  // namespace
+
+ST_DEFINE_SETTER(marl_debug_stamps_mlp3x6)
 
 // three-layer heads with up to 16 outputs and up to 192 input columns whose padded width leaves a free column for the ones column
 extern "C" int marl_mlp3_x6_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups) {
@@ -533,15 +551,11 @@ extern "C" int marl_mlp3_x6_supported(const marl_src_t* x, int K1, int H1, int H
   return x6_fwd_lds(KC, CF, true) <= 160 * 1024 && x6_bwd_lds(KC, CF) <= 160 * 1024;
 }
 
-extern "C" size_t marl_mlp3_x6_save_floats(long M, int groups) {
-  return M <= 0 ? 0 : (size_t)groups * (size_t)((M + 15) / 16) * (size_t)x6_save_floats_per_tile(true);
-}
-
 extern "C" int marl_mlp3_x6_fwd_save(const marl_mlp3_weights_t* w, const marl_src_t* x, float* Y, long ldy, long gs_y,
                                      float* hsave, size_t hsave_floats, long M, int K1, int N3, int groups, void* stream) {
   if (M <= 0) return 0;
   if (!w->w2 || !marl_mlp3_x6_supported(x, K1, HD, HD, N3, groups)) return (int)hipErrorInvalidValue;
-  if (hsave && (hsave_floats < marl_mlp3_x6_save_floats(M, groups) || !aligned16(hsave))) return (int)hipErrorInvalidValue;
+  if (hsave && (hsave_floats < marl_mlp3_save_floats(M, 1, groups) || !aligned16(hsave))) return (int)hipErrorInvalidValue;
   if (!aligned16(w->b1) || w->gs_b1 % 4 || !aligned16(w->b2) || w->gs_b2 % 4) return (int)hipErrorInvalidValue;
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
@@ -568,13 +582,13 @@ extern "C" int marl_mlp3_x6_bwd_saved(const marl_mlp3_weights_t* w, const marl_s
                                       size_t hsave_floats, long M, int K1, int N3, int groups, void* stream) {
   if (M <= 0) return 0;
   if (!w->w2 || !grads->w2 || !hsave || !marl_mlp3_x6_supported(x, K1, HD, HD, N3, groups)) return (int)hipErrorInvalidValue;
-  if (hsave_floats < marl_mlp3_x6_save_floats(M, groups) || !aligned16(hsave)) return (int)hipErrorInvalidValue;
+  if (hsave_floats < marl_mlp3_save_floats(M, 1, groups) || !aligned16(hsave)) return (int)hipErrorInvalidValue;
   if (ws_bytes < marl_mlp3_bwd_workspace(M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws; a.hs = const_cast<float*>(hsave);
   const int KC = kc_bucket(a.KV);
-  a.nst = stripes((M + XR - 1) / XR, groups, 256);
+  a.nst = stripes((M + XR - 1) / XR, groups, 512);      // two workgroups per CU
   const size_t lds = x6_bwd_lds(KC, a.CF);
   const void* fn = MLP3_PICK(mlp3x6_bwd_kernel, true, -1);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

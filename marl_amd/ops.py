@@ -532,12 +532,9 @@ def mlp3_x6_supported(x, K1, H1, H2, N3, groups):
     return bool(_lib.load().marl_mlp3_x6_supported(C.byref(x), K1, H1, H2, N3, groups))
 
 
-def mlp3_save_floats(M, three, groups, x6=False):
-    """floats of the kept-activation buffer of one fused head family (layout private to the kernel pair; x6: the
-    split planes of the bf16x6 pair, 1.5 x the fp32 pair's)."""
-    if x6:
-        assert three
-        return int(_lib.load().marl_mlp3_x6_save_floats(M, groups))
+def mlp3_save_floats(M, three, groups):
+    """floats of the kept-activation buffer of one fused head family (layout private to the kernels; the fp32 and the
+    bf16x6 pair share it)."""
     return int(_lib.load().marl_mlp3_save_floats(M, 1 if three else 0, groups))
 
 

@@ -414,7 +414,7 @@ def test_mlp3_x6_split(dev, rows, S, NH, HW, N3, G, remap):
     res = {}
     for x6 in (True, False):
         Y = torch.full((rows, G * N3), 7.0, device=dev)
-        hs = torch.full((ops.mlp3_save_floats(rows, True, G, x6=x6),), float("nan"), device=dev)
+        hs = torch.full((ops.mlp3_save_floats(rows, True, G),), float("nan"), device=dev)
         ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G, hsave=hs, x6=x6)
         if x6:      # without keeping (target mixer): the same outputs
             Y0 = torch.full((rows, G * N3), 7.0, device=dev)

@@ -36,7 +36,7 @@ dY = torch.randn(rows, G * N3, generator=g)
 outs = []
 for rep in range(2):
     Y = torch.zeros(rows, G * N3, device=dev)
-    hs = torch.full((ops.mlp3_save_floats(rows, True, G, x6=True),), float("nan"), device=dev)
+    hs = torch.full((ops.mlp3_save_floats(rows, True, G),), float("nan"), device=dev)
     ops.mlp3_fwd(ops.mlp3_weights(heads), xs, Y, rows, K1, N3, G, hsave=hs, x6=True)
     gd.zero_()
     ops.mlp3_bwd(ops.mlp3_weights(heads), xs, dY.to(dev), ops.mlp3_weights(heads, grad=True), rows, K1, N3, G, hsave=hs, x6=True)

@@ -45,6 +45,11 @@ for name, K1, N3, x in (("key", S, 1, ops.src(s)), ("agents", S, N, ops.src(s)),
             ("bwd from kept h1,h2", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G, hsave=hs), bm)]
     if ops.mlp3_needs_kept(x, K1):
         del legs[1]
+    if ops.mlp3_x6_supported(x, K1, 64, 64, N3, G):      # the bf16x6 split pair (csrc/mlp3_x6.hip)
+        hs6 = torch.empty(ops.mlp3_save_floats(rows, True, G), device=dev)
+        legs += [("x6 fwd", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G, x6=True), 1.0),
+                 ("x6 fwd keeping", lambda: ops.mlp3_fwd(w, x, Y, rows, K1, N3, G, hsave=hs6, x6=True), 1.0),
+                 ("x6 bwd from kept", lambda: ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G, hsave=hs6, x6=True), bm)]
     for what, fn, mult in legs:
         for _ in range(2):
             fn()
