@@ -338,6 +338,11 @@ class DMAQ_SI_Weight(nn.Module):
         raise RuntimeError("DMAQ_SI_Weight is evaluated inside DMAQer.hip_forward (fused lambda-net path)")
 
 
+# args.gemm_mode when the caller's args do not carry one: "f32" (v_mfma_f32_16x16x4_f32 everywhere).  "bf16x6" is opt-in; the GPU test
+# suite sets this attribute to run every QPLEX parity case on the split kernels (tests/conftest.py, MARL_TEST_GEMM_MODE).
+DEFAULT_GEMM_MODE = "f32"
+
+
 def _keep_hidden():
     """the fused head families keep their hidden activations for the backward (MARL_MLP3_KEEP=0: recompute them there)"""
     return os.environ.get("MARL_MLP3_KEEP", "1") != "0"
@@ -404,6 +409,12 @@ class DMAQer(_Precision, nn.Module):
             return None
         return ops.mlp3_weights(heads, grad=grad)
 
+    def _x6(self, x_in, K1, nout, groups):
+        """the family runs on the bf16x6 split kernels (csrc/mlp3_x6.hip): opt-in args.gemm_mode = "bf16x6" - fp32-accurate
+        products on the bf16 matrix cores; the default "f32" keeps v_mfma_f32_16x16x4_f32"""
+        return (getattr(self.args, "gemm_mode", DEFAULT_GEMM_MODE) == "bf16x6" and _keep_hidden()
+                and ops.mlp3_x6_supported(x_in, K1, 64, 64, nout, groups))
+
     def _kept(self, name, rows, three, groups, dev):
         """buffer for the hidden activations a fused family keeps for its backward (MARL_MLP3_KEEP=0: recompute)."""
         if not _keep_hidden():
@@ -439,10 +450,12 @@ class DMAQer(_Precision, nn.Module):
                 # follows they are kept as the backward's MFMA fragments (streamed out once, read once) - recomputing
                 # layers 1-2 there was a third of its time
                 hs = self._kept(name, rows, True, K, dev) if keep is not None else None
-                ops.mlp3_fwd(fw, x_in, out, rows, ops.src_width(x_in), nout, K, hsave=hs)
+                x6 = self._x6(x_in, ops.src_width(x_in), nout, K)
+                ops.mlp3_fwd(fw, x_in, out, rows, ops.src_width(x_in), nout, K, hsave=hs, x6=x6)
                 if keep is not None:
                     keep[name + "_h"] = None
                     keep[name + "_hs"] = hs
+                    keep[name + "_x6"] = x6
                 continue
             nl = len(_linears(mods[0]))
             hs = []
@@ -532,7 +545,7 @@ class DMAQer(_Precision, nn.Module):
             if hs is None:      # fused forward: the backward recomputes the hidden activations on chip
                 ops.mlp3_bwd(self._fused_family(mods, x_in, nout), x_in, douts[name],
                              self._fused_family(mods, x_in, nout, grad=True), rows, ops.src_width(x_in), nout, K,
-                             hsave=ctx.get(name + "_hs"))
+                             hsave=ctx.get(name + "_hs"), x6=bool(ctx.get(name + "_x6")))
                 continue
             nl = len(_linears(mods[0]))
             dcur, dcur_gs, gate = douts[name], nout, None

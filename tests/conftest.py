@@ -11,6 +11,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # MARL_TEST_GEMM_MODE=bf16x6: the whole suite with the opt-in split kernels where they exist (same bounds; the margins
+    # table of such a run is committed beside the fp32 one)
+    mode = os.environ.get("MARL_TEST_GEMM_MODE")
+    if mode:
+        from marl_amd.network import mixer
+        mixer.DEFAULT_GEMM_MODE = mode
 
 
 @pytest.fixture(scope="session")

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--mixer-dtype", default="fp32")
     ap.add_argument("--tag", default="")
     ap.add_argument("--two-hyper", action="store_true", help="QMIX with two_hyper_layers=True (network/mixer.py:36-43)")
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x6"])
     o = ap.parse_args()
     from marl_amd import ops, _lib
     from marl_amd.controller.share_params import SharedMAC
@@ -32,6 +33,7 @@ def main():
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
     args = bench.make_args(o.alg, o.shape, 0)
     args.mixer_dtype = o.mixer_dtype
+    args.gemm_mode = o.gemm_mode
     if o.two_hyper:
         args.two_hyper_layers = True
     torch.manual_seed(0)

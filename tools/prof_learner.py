@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rollouts", type=int, default=0)
     ap.add_argument("--warmup", type=int, default=0, help="untimed updates before the timed ones (first-call allocations)")
     ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x6"])
     o = ap.parse_args()
     from marl_amd.controller.share_params import SharedMAC
     from marl_amd.algorithm.q_learner import QLearner
@@ -31,6 +32,7 @@ def main():
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
     args = bench.make_args(o.alg, o.shape, o.T)
     args.mixer_dtype = o.mixer_dtype
+    args.gemm_mode = o.gemm_mode
     torch.manual_seed(0)
     mac = SharedMAC(args)
     learner = QTRANLearner(mac, args) if o.alg.startswith("qtran") else QLearner(mac, args)
