@@ -13,9 +13,11 @@
 //   * v_mfma_f32_16x16x32_bf16: lane (g = l >> 4, i = l & 15) holds A[i][slot j] and B[slot j][i], j = 0..7; D register r =
 //     C[4g + r][i].  The slot -> k assignment is free as long as both operands use the same one.
 //   * transposed formulation (as mlp3_fused.hip): out^T[feature][row] = W[feature][k] in^T[k][row]; the WEIGHTS are the A operand
-//     (fragments pre-split once per workgroup, in LDS), the activations the B operand.  Two accumulator tiles of one layer
-//     (features 32c + 4g + r and 32c + 16 + 4g + r of row i) ARE the 8 k-slots of the next layer's chunk c: slot j < 4 <->
-//     k = 32c + 4g + j, slot j >= 4 <-> k = 32c + 16 + 4g + (j - 4) - the weight fragments are staged in that order.
+//     (fragments pre-split once per workgroup, in LDS), the activations the B operand.  Two accumulator tiles of one layer ARE the
+//     8 k-slots of the next layer's 32-chunk.  Which output feature an accumulator row holds is decided by the order in which the
+//     weight ROWS are staged, so they are staged permuted: row 4g + r of tile t holds feature 32 (t >> 1) + 8g + 4 (t & 1) + r -
+//     lane group g then owns the 8 CONSECUTIVE features 32c + 8g .. + 7 of chunk c (slot j <-> k = 32c + 8g + j, the natural
+//     order): fragments of x are two adjacent 16-byte loads, an image write is one 16-byte store per plane.
 //   * weight gradients reduce over ROWS: operands go through a [row][column] bf16 LDS image (each lane packs four consecutive
 //     columns of its row: one 8-byte write per plane) and come back with ds_read_b64_tr_b16, which hands lane (g, i) the column i of
 //     rows 8g .. 8g + 3 - the A / B fragment of a product that sums over the image's rows.  256-byte image rows, 16-byte chunks
@@ -102,17 +104,20 @@ __device__ __forceinline__ F3 lds_f3(const int* base, int item, int lane) {
   f.h = p[0]; f.m = p[64]; f.l = p[128];
   return f;
 }
-// A fragments of W (TR = false: A[i = row 16t + m of W][slot <-> virtual column of W]) or of W^T (TR = true: A[i = column 16t + m of
-// W][slot <-> row of W]), split into planes.  Slots: j < 4 <-> 32 c2 + 4q + j, j >= 4 <-> 32 c2 + 16 + 4q + (j - 4).
-template <bool TR, int NTHR>
+// feature held by accumulator row i = 4g + r of tile t (see the layout note at the top)
+__host__ __device__ inline int permf(int t, int i) { return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); }
+// A fragments of W (TR = false: A[i][slot] = W[row of tile t, i][virtual column of the slot]) or of W^T (TR = true: A[i][slot] =
+// W[row = slot][column of tile t, i]), split into planes.  Slot j of lane group g <-> 32 c2 + 8g + j.  PERM: the tile's rows / columns
+// are the permuted features permf(t, i) (hidden layers); else 16t + i (the output layer).
+template <bool TR, bool PERM, int NTHR>
 __device__ __forceinline__ void stage6(int* dst, const float* W, int ldw, int rows_valid, int K, int T, int KC2, int k0, int kpad) {
   for (int e = threadIdx.x; e < T * KC2 * 64; e += NTHR) {
     const int l = e & 63, tc = e >> 6, t = tc / KC2, c2 = tc - t * KC2;
-    const int n = 16 * t + (l & 15), qq = l >> 4;
+    const int n = PERM ? permf(t, l & 15) : 16 * t + (l & 15), qq = l >> 4;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int col = 32 * c2 + (j < 4 ? 0 : 16) + 4 * qq + (j & 3);
+      const int col = 32 * c2 + 8 * qq + j;
       float x = 0.f;
       if (TR) {
         if (col < rows_valid && n < K) x = W[(long)col * ldw + n];
@@ -128,10 +133,63 @@ __device__ __forceinline__ void stage6(int* dst, const float* W, int ldw, int ro
   }
 }
 
-template <int KC>
-__device__ __forceinline__ f32x4 xv_or_zero(const f32x4 (&xv)[KC], int c) {      // (c is a constant once the caller's loop is unrolled)
-  return c < KC ? xv[c < KC ? c : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+// ---- the x tile in the natural slot order: chunk c of lane group q = columns 32 (c >> 1) + 8q + 4 (c & 1) + (0..3)
+__device__ __forceinline__ int ncol(int c, int q) { return 32 * (c >> 1) + 8 * q + 4 * (c & 1); }
+// (build_tab / x_issue of mlp3_common.h with that column map; x_finish is shared - it only reads the table)
+__device__ __forceinline__ void build_tab_nat(int* tab, const ConcatSrc& x, int KV, int kpad, int CF, int KC, int nthreads) {
+  for (int e = threadIdx.x; e < (KC - CF) * 4; e += nthreads) {
+    const int gc = e >> 2, qq = e & 3;
+    const int kb = ncol(CF + gc, qq);
+    int off[4], cmp[4], kind = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int k = kb + i;
+      off[i] = 0; cmp[i] = 0xffff;
+      if (k >= KV) continue;
+      if (k < x.k0) { kind = 1; off[i] = 4 * k; }
+      else if (k < x.k0 + kpad) { kind = 1; continue; }      // pad column: reads column 0 (finite), meets a zero weight
+      else if ((k -= kpad) - x.k0 < x.k1) { kind = 3; off[i] = 4 * (k - x.k0); }
+      else {
+        k -= x.k0 + x.k1;
+        const int j = k / x.hot_w;
+        kind = 2; off[i] = 4 * j; cmp[i] = k - j * x.hot_w;
+      }
+    }
+    int* t = tab + e * 8;
+    t[0] = off[0]; t[1] = off[1]; t[2] = off[2]; t[3] = off[3];
+    t[4] = cmp[0] | (cmp[1] << 16); t[5] = cmp[2] | (cmp[3] << 16); t[6] = kind; t[7] = 0;
+  }
 }
+template <int KC, int CFT>
+__device__ __forceinline__ void x_issue_nat(f32x4 (&xv)[KC], const ConcatSrc& x, const XRow& r, const int* tab, int CFr, int lane) {
+  const int CF = CFT >= 0 ? CFT : CFr;
+  const int q = lane >> 4;
+  const char* d0 = reinterpret_cast<const char*>(x.p0 + r.r0c * x.ld0);
+  const char* d1 = x.p1 ? reinterpret_cast<const char*>(x.p1 + r.rowc * x.ld1) : d0;
+  const char* di = x.idx ? reinterpret_cast<const char*>(x.idx + r.ric * x.nhot) : d0;
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    if (c < CF) {
+      xv[c] = *reinterpret_cast<const f32x4*>(d0 + 4 * ncol(c, q));
+    } else {
+      const int* t = tab + ((c - CF) * 4 + q) * 8;
+      const uint4 off = *reinterpret_cast<const uint4*>(t);
+      const int kind = t[6];
+      const char* base = kind == 2 ? di : (kind == 3 ? d1 : d0);
+      xv[c][0] = __int_as_float(*reinterpret_cast<const int*>(base + off.x));
+      xv[c][1] = __int_as_float(*reinterpret_cast<const int*>(base + off.y));
+      xv[c][2] = __int_as_float(*reinterpret_cast<const int*>(base + off.z));
+      xv[c][3] = __int_as_float(*reinterpret_cast<const int*>(base + off.w));
+    }
+  }
+}
+// chunks wholly inside the 16-byte aligned part of dense0, in chunk PAIRS (a pair = 32 columns)
+inline int lead_chunks_nat(const marl_src_t* x) {
+  const bool al = x->p0 && (x->ld0 % 4 == 0) && aligned16(x->p0);
+  return al ? x->k0 / 32 * 2 : 0;
+}
+// chunk count of the split kernels: even (whole 32-column pairs), 4 / 8 / 12
+inline int kc_bucket_x6(int KV) { return (KV + 63) / 64 * 4; }
 
 // ------------------------------------------------------------------------------------------------- forward
 // 8 waves, each walks its own 16-row tiles (x of the next tile in flight); hidden activations never leave the wave.  a.hs != NULL:
@@ -139,7 +197,8 @@ __device__ __forceinline__ f32x4 xv_or_zero(const f32x4 (&xv)[KC], int c) {     
 template <int KC, bool THREE, int CFT>
 __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int KC2 = (KC + 1) / 2;
+  static_assert(KC % 4 == 0, "whole 64-column passes");
+  constexpr int KC2 = KC / 2;
   int stripe, g;
   if (!wg_map(a.groups, a.nst, stripe, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -148,15 +207,15 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
   int* W2s = W1s + 4 * KC2 * 768;                   // [4][2]
   int* W3s = W2s + (THREE ? 8 * 768 : 0);           // [1][2]  (rows >= N3 zero)
   int* tab = W3s + 2 * 768;
-  stage6<false, 64 * FNW>(W1s, a.W1 + g * a.gs_w1, a.K1, HD, a.K1, 4, KC2, a.x.k0, a.kpad);
-  if (THREE) stage6<false, 64 * FNW>(W2s, a.W2 + g * a.gs_w2, HD, HD, HD, 4, 2, 1 << 30, 0);
-  stage6<false, 64 * FNW>(W3s, a.W3 + g * a.gs_w3, HD, a.N3, HD, 1, 2, 1 << 30, 0);
-  build_tab(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * FNW);
+  stage6<false, true, 64 * FNW>(W1s, a.W1 + g * a.gs_w1, a.K1, HD, a.K1, 4, KC2, a.x.k0, a.kpad);
+  if (THREE) stage6<false, true, 64 * FNW>(W2s, a.W2 + g * a.gs_w2, HD, HD, HD, 4, 2, 1 << 30, 0);
+  stage6<false, false, 64 * FNW>(W3s, a.W3 + g * a.gs_w3, HD, a.N3, HD, 1, 2, 1 << 30, 0);
+  build_tab_nat(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * FNW);
   f32x4 b1v[4], b2v[4], b3v;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    b1v[t] = *reinterpret_cast<const f32x4*>(a.b1 + g * a.gs_b1 + 16 * t + 4 * q);
-    if (THREE) b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + 16 * t + 4 * q);
+    b1v[t] = *reinterpret_cast<const f32x4*>(a.b1 + g * a.gs_b1 + permf(t, 4 * q));
+    if (THREE) b2v[t] = *reinterpret_cast<const f32x4*>(a.b2 + g * a.gs_b2 + permf(t, 4 * q));
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) b3v[i] = 4 * q + i < a.N3 ? a.b3[g * a.gs_b3 + 4 * q + i] : 0.f;
@@ -172,7 +231,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
   long tile = t_begin + wave;
   if (tile >= t_end) return;
   XRow xr = x_row(a.x, tile * 16 + m, a.M);
-  x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
+  x_issue_nat<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
   for (; tile < t_end; tile += FNW) {
     x_finish<KC, CFT>(xv, xr, tab, a.CF, lane);
     const bool live = (xr.flags & 1) != 0;
@@ -182,7 +241,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
     for (int t = 0; t < 4; ++t) acc[t] = b1v[t];
 #pragma unroll
     for (int c2 = 0; c2 < KC2; ++c2) {
-      const F3 xb = split8(xv[2 * c2], xv_or_zero<KC>(xv, 2 * c2 + 1));
+      const F3 xb = split8(xv[2 * c2], xv[2 * c2 + 1]);
       F3 wa[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) wa[t] = lds_f3(W1s, t * KC2 + c2, lane);
@@ -192,7 +251,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
     {   // x is consumed: the next tile's loads (unconditional - the last iteration re-reads its own tile)
       const long nt = tile + FNW < t_end ? tile + FNW : tile;
       xr = x_row(a.x, nt * 16 + m, a.M);
-      x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
+      x_issue_nat<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
     }
     // kept for the backward: relu(h1), relu(h2) as the fp32 accumulator fragments, in the layout of the fp32 pair
     // ([head][tile][plane 0..7][lane] f32x4 - the two pairs' kept buffers are interchangeable)
@@ -254,18 +313,16 @@ __global__ __launch_bounds__(64 * FNW, 2) void mlp3x6_fwd_kernel(Mlp3Args a) {
 constexpr int XR = 64;                                // rows per iteration
 constexpr int XNW = 4;
 constexpr int PLS = XR * 256;                         // bytes per plane
-// a fragment's 8 slots of the lane's row -> columns cb + 4q + (0..3) and cb + 16 + 4q + (0..3)   (pb: the lane's put base)
+// a fragment's 8 slots of the lane's row -> columns cb + 8q + (0..7): one 16-byte chunk per plane   (pb: the lane's put base, cb % 32 == 0)
 __device__ __forceinline__ void img_put8(char* st, int pb, const F3& f, int cb) {
-  const int a0 = pb ^ (16 * (cb >> 3)), a1 = pb ^ (16 * ((cb >> 3) + 2));
-  *reinterpret_cast<i32x2*>(st + a0) = (i32x2){f.h[0], f.h[1]};
-  *reinterpret_cast<i32x2*>(st + a1) = (i32x2){f.h[2], f.h[3]};
-  *reinterpret_cast<i32x2*>(st + a0 + PLS) = (i32x2){f.m[0], f.m[1]};
-  *reinterpret_cast<i32x2*>(st + a1 + PLS) = (i32x2){f.m[2], f.m[3]};
-  *reinterpret_cast<i32x2*>(st + a0 + 2 * PLS) = (i32x2){f.l[0], f.l[1]};
-  *reinterpret_cast<i32x2*>(st + a1 + 2 * PLS) = (i32x2){f.l[2], f.l[3]};
-}
-__device__ __forceinline__ void img_put4(char* st, int pb, const F3h& f, int cb) {
   const int a0 = pb ^ (16 * (cb >> 3));
+  *reinterpret_cast<i32x4*>(st + a0) = f.h;
+  *reinterpret_cast<i32x4*>(st + a0 + PLS) = f.m;
+  *reinterpret_cast<i32x4*>(st + a0 + 2 * PLS) = f.l;
+}
+// four slots (dy: outputs 4q .. 4q + 3) -> columns cb + 4q + (0..3)   (pb4: the lane's base for 8-byte pieces)
+__device__ __forceinline__ void img_put4(char* st, int pb4, const F3h& f, int cb) {
+  const int a0 = pb4 ^ (16 * (cb >> 3));
   *reinterpret_cast<i32x2*>(st + a0) = f.h;
   *reinterpret_cast<i32x2*>(st + a0 + PLS) = f.m;
   *reinterpret_cast<i32x2*>(st + a0 + 2 * PLS) = f.l;
@@ -293,7 +350,7 @@ template <int KC, bool THREE, int CFT>
 __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {      // (2 waves per SIMD = two workgroups per CU)
   static_assert(THREE, "three-layer heads only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NP = (KC + 3) / 4;                  // passes of 64 x columns
+  constexpr int NP = KC / 4;                        // passes of 64 x columns
   int stripe, g;
   if (!wg_map(a.groups, a.nst, stripe, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,20 +361,20 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {  
   int* tab = reinterpret_cast<int*>(st + 3 * PLS);
   const float* W2 = a.W2 + g * a.gs_w2;
   const float* W3 = a.W3 + g * a.gs_w3;
-  stage6<true, 64 * XNW>(W2Ts, W2, HD, HD, HD, 4, 2, 1 << 30, 0);
+  stage6<true, true, 64 * XNW>(W2Ts, W2, HD, HD, HD, 4, 2, 1 << 30, 0);
   for (int e = tid; e < 4 * 64; e += 64 * XNW) {
     const int l = e & 63, t = e >> 6;
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n3 = 4 * (l >> 4) + j;
-      v[j] = n3 < a.N3 ? W3[(long)n3 * HD + 16 * t + (l & 15)] : 0.f;
+      v[j] = n3 < a.N3 ? W3[(long)n3 * HD + permf(t, l & 15)] : 0.f;
     }
     const F3h f = split4(v);
     i32x2* p = reinterpret_cast<i32x2*>(W3Ts) + t * 192 + l;
     p[0] = f.h; p[64] = f.m; p[128] = f.l;
   }
-  build_tab(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * XNW);
+  build_tab_nat(tab, a.x, a.KV, a.kpad, a.CF, KC, 64 * XNW);
   __syncthreads();
 
   const long its = (a.M + XR - 1) / XR;
@@ -340,7 +397,8 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {  
   const int kone = a.KV;
   // per-lane address parts (see the note above)
   const int row = 16 * wave + m;                   // this lane's row of the image
-  const int pb = row * 256 + 16 * ((q >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (q & 1);
+  const int pb = row * 256 + 16 * (q ^ (((row & 3) << 2) | ((row >> 2) & 3)));                        // chunk q of a 32-column group
+  const int pb4 = row * 256 + 16 * ((q >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (q & 1);   // 8-byte piece q of a 16-column group
   const int tB0 = tr_base(lane, 0, 0), tB1 = tr_base(lane, 0, 1);      // column tile 0; tile ct: ^ (32 * ct)  (the chunk of a tile is even)
   const int tA0 = tB0 ^ (32 * (4 + tf)), tA1 = tB1 ^ (32 * (4 + tf));  // dh1 / dh2: feature tile tf of the right block
   const int tY0 = tB0 ^ (32 * 4), tY1 = tB1 ^ (32 * 4);                // dy
@@ -353,7 +411,7 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {  
   f32x4 dyn;                       // dY[row m][4q .. 4q + 3]
   auto issue_x = [&](long it_) __attribute__((always_inline)) {
     xr = x_row(a.x, (it_ * XNW + wave) * 16 + m, a.M);
-    x_issue<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
+    x_issue_nat<KC, CFT>(xv, a.x, xr, tab, a.CF, lane);
     const bool lv = (xr.flags & 1) != 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) dyn[j] = (lv && 4 * q + j < a.N3) ? dY[xr.rowc * a.ldy + 4 * q + j] : 0.f;
@@ -440,7 +498,7 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {  
     // ---------------- image [h2 | dy]: dW3 (and the layer-3 bias gradient)
     img_put8(st, pb, split8(h2f[0], h2f[1]), 0);
     img_put8(st, pb, split8(h2f[2], h2f[3]), 32);
-    img_put4(st, pb, dy3, 64);
+    img_put4(st, pb4, dy3, 64);
 #ifndef X6_EXP_NOH
     issue_h(it + 1 < i_end ? it + 1 : it);          // kept activations of the next iteration's tile (land during the dW1 passes)
 #endif
@@ -464,8 +522,8 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {  
 #pragma unroll
     for (int pt = 0; pt < NP; ++pt) {
 #ifndef X6_EXP_NOPUTX
-      img_put8(st, pb, split8(xv_or_zero<KC>(xv, 4 * pt), xv_or_zero<KC>(xv, 4 * pt + 1)), 0);
-      img_put8(st, pb, split8(xv_or_zero<KC>(xv, 4 * pt + 2), xv_or_zero<KC>(xv, 4 * pt + 3)), 32);
+      img_put8(st, pb, split8(xv[4 * pt], xv[4 * pt + 1]), 0);
+      img_put8(st, pb, split8(xv[4 * pt + 2], xv[4 * pt + 3]), 32);
 #endif
       ST_MARK(13);
       if ((kone >> 6) == pt && q == 0) {              // ones column (same wave, later instruction: lands after the packed write)
@@ -531,7 +589,7 @@ __global__ __launch_bounds__(64 * XNW, 2) void mlp3x6_bwd_kernel(Mlp3Args a) {  
 }
 
 inline size_t x6_fwd_lds(int KC, int CF, bool three) {
-  const int KC2 = (KC + 1) / 2;
+  const int KC2 = KC / 2;
   return (size_t)(4 * KC2 + (three ? 8 : 0) + 2) * 768 * 4 + (size_t)(KC - CF) * 32 * 4;
 }
 inline size_t x6_bwd_lds(int KC, int CF) { return (size_t)8 * 768 * 4 + 4 * 3 * 128 * 4 + (size_t)3 * XR * 256 + (size_t)(KC - CF) * 32 * 4; }
@@ -545,9 +603,9 @@ extern "C" int marl_mlp3_x6_supported(const marl_src_t* x, int K1, int H1, int H
   if (!marl_mlp3_supported(x, K1, H1, H2, N3, groups)) return 0;
   if (H2 != HD || N3 > 16) return 0;
   const int KV = K1 + kpad_of(x);
-  const int KC = kc_bucket(KV);
+  const int KC = kc_bucket_x6(KV);
   if (KC > 12 || KV >= 16 * KC) return 0;
-  const int CF = lead_chunks(x);
+  const int CF = lead_chunks_nat(x);
   return x6_fwd_lds(KC, CF, true) <= 160 * 1024 && x6_bwd_lds(KC, CF) <= 160 * 1024;
 }
 
@@ -562,11 +620,13 @@ extern "C" int marl_mlp3_x6_fwd_save(const marl_mlp3_weights_t* w, const marl_sr
   a.Y = Y; a.ldy = ldy; a.gs_y = gs_y; a.ws = nullptr; a.hs = hsave;
   const long tiles = (M + 15) / 16;
   a.nst = stripes((tiles + FNW - 1) / FNW, groups);
-  const int KC = kc_bucket(a.KV);
+  const int KC = kc_bucket_x6(a.KV);
+  a.CF = lead_chunks_nat(x);
   const size_t lds = x6_fwd_lds(KC, a.CF, true);
-#define MLP3_PICK(K, ...) (KC == 4 ? (const void*)K<4, __VA_ARGS__> : KC == 8 ? (a.CF == 7 ? (const void*)K<8, MLP3_CF7(__VA_ARGS__)> : (const void*)K<8, __VA_ARGS__>) \
-                           : KC == 11 ? (a.CF == 7 ? (const void*)K<11, MLP3_CF7(__VA_ARGS__)> : (const void*)K<11, __VA_ARGS__>) : (const void*)K<12, __VA_ARGS__>)
-  const void* fn = MLP3_PICK(mlp3x6_fwd_kernel, true, -1);
+// (six leading full chunks = a 120-wide dense segment 0: the QPLEX heads on 2s3z-sized maps get the compile-time variants)
+#define X6_PICK(K) (KC == 4 ? (const void*)K<4, true, -1> : KC == 8 ? (a.CF == 6 ? (const void*)K<8, true, 6> : (const void*)K<8, true, -1>) \
+                    : (a.CF == 6 ? (const void*)K<12, true, 6> : (const void*)K<12, true, -1>))
+  const void* fn = X6_PICK(mlp3x6_fwd_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * FNW);
@@ -587,10 +647,11 @@ extern "C" int marl_mlp3_x6_bwd_saved(const marl_mlp3_weights_t* w, const marl_s
   Mlp3Args a;
   if (!fill_args(a, w, x, M, K1, N3, groups)) return (int)hipErrorInvalidValue;
   a.Y = const_cast<float*>(dY); a.ldy = lddy; a.gs_y = gs_dy; a.ws = ws; a.hs = const_cast<float*>(hsave);
-  const int KC = kc_bucket(a.KV);
+  const int KC = kc_bucket_x6(a.KV);
+  a.CF = lead_chunks_nat(x);
   a.nst = stripes((M + XR - 1) / XR, groups, 512);      // two workgroups per CU
   const size_t lds = x6_bwd_lds(KC, a.CF);
-  const void* fn = MLP3_PICK(mlp3x6_bwd_kernel, true, -1);
+  const void* fn = X6_PICK(mlp3x6_bwd_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((a.nst + 7) / 8 * 8 * groups)), block(64 * XNW);

@@ -43,5 +43,5 @@ for _ in range(2):
     buf.zero_()
     ops.mlp3_bwd(w, x, dY, gw, rows, K1, N3, G, hsave=hs, x6=True)
     torch.cuda.synchronize()
-its = (rows + 127) // 128 // 24
+its = (rows + 63) // 64 // 48
 show(buf.cpu().view(16, 16).numpy(), ["phaseA", "put h1", "bar", "dW2", "bar", "put h2", "bar", "dW3", "bar", "issue_x", "bar", "dW1+bar", "put dh1", "put x", "ones"], "mlp3 x6 backward", envs, its)
