@@ -128,6 +128,15 @@ class KernelTimers:
                 return (label, roc, f, f, 4.0 * rows * (S_ + N_ + 1))
             return m
 
+        def wide_fwd(ar, kw):
+            # the kernel this call launches depends on the shape and operand type (resident weights for bf16 at MMM2 sizes):
+            # ask the library for its name, so that the entry can be found in profiles/*_kernel_stats.csv
+            rows, N_, S_, E_ = ar[4:8]
+            roc = ops.qmix_wide_fwd_kernel(rows, N_, S_, bf16=bool(kw.get("bf16")))
+            f = 2.0 * rows * S_ * (N_ * E_ + 3 * E_)
+            extra = " + pack kernel + memset of q_tot in the timed interval" if "res" in roc else " + pack kernel in the timed interval"
+            return ("%s forward (hypernet GEMM + mixing%s)" % (roc.split("<")[0], extra), roc, f, f, 4.0 * rows * (S_ + N_ + 1))
+
         def mlp3(back):
             def m(ar, kw):
                 if back:
@@ -153,7 +162,7 @@ class KernelTimers:
                        "qmix_fused_fwd": qmix(1, "qmix_fused_kernel forward (target mixer)", "qmix_fused_kernel<false"),
                        "qmix_fused_bwd": qmix(2, "qmix_fused_kernel backward", "qmix_fused_kernel<true"),
                        "qmix_fused_loss_bwd": qmix(2, "qmix_fused_kernel forward + TD loss + backward", "qmix_fused_kernel<true"),
-                       "qmix_wide_fwd": qmix_kw(1, "qmix_wide_kernel forward", "qmix_wide_kernel<false", 4),
+                       "qmix_wide_fwd": wide_fwd,
                        "qmix_wide_bwd": qmix_kw(2, "qmix_wide backward (recompute + d(out)) + weight-gradient GEMM", "qmix_wide", 6),
                        "qmix_wide_loss_bwd": qmix_kw(2, "qmix_wide forward + TD loss + backward + weight-gradient GEMM", "qmix_wide", 12),
                        "mlp3_fwd": mlp3(False), "mlp3_bwd": mlp3(True), "synth_rollout": roll}
@@ -190,7 +199,7 @@ class KernelTimers:
             ms = [a.elapsed_time(b) for a, b in r["ev"]]
             avg = float(np.mean(ms))
             tf = r["exec"] / (avg * 1e-3) / 1e12
-            e = {"name": label, "rocprof_name": r["roc"], "launches_timed": len(ms), "ms": avg, "total_ms": float(np.sum(ms)),
+            e = {"name": label, "rocprof_name": r["roc"], "call": r["call"], "launches_timed": len(ms), "ms": avg, "total_ms": float(np.sum(ms)),
                  "executed_flop": r["exec"], "algorithmic_flop": r["alg"], "tflops": tf, "frac": tf / PEAK_F32_TFLOPS,
                  "algorithmic_bytes": r["bytes"], "hbm_gb": None, "hbm_frac": None}
             rows.append(e)
@@ -269,7 +278,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
             # kernel's time is not exclusive and its fraction of the WHOLE chip's peak understates it
             out["roofline"]["note"] = ("kernels overlap on two streams at this size (%.2f ms of kernel time per %.2f ms update): "
                                        "per-kernel fractions are against the whole chip's peak" % (busy, dt * 1e3))
-    mx = [e for e in kern if e["rocprof_name"] == "qmix_wide_kernel<false"]
+    mx = [e for e in kern if e["call"] == "qmix_wide_fwd"]
     if mx and mixer_dtype == "bf16":      # config 5's named roofline: the bf16 hypernet GEMM against the HBM read of the states
         m = mx[0]
         gbs = m["algorithmic_bytes"] / (m["ms"] * 1e-3) / 1e9
@@ -645,7 +654,7 @@ def main():
             # fused wide-state QMIX forward: one launch reads every state row once (4 S bytes), the chosen Qs (4 N) and
             # writes q_tot (4): algorithmic bytes = rows * (4 S + 4 N + 4), rows = envs per GPU * T (with bf16
             # operands the hypernet GEMM sits below the bf16 ridge, i.e. it is bound by this read)
-            mx = [e for e in kern if e["rocprof_name"] == "qmix_wide_kernel<false"]
+            mx = [e for e in kern if e["call"] == "qmix_wide_fwd"]
             if mx:
                 m = mx[0]
                 gbs = m["algorithmic_bytes"] / (m["ms"] * 1e-3) / 1e9

@@ -203,8 +203,15 @@ int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, 
  * flags & 1: bf16 operands for the hypernet GEMM (v_mfma_f32_16x16x32_bf16, fp32 accumulate; BASELINE config 5 "bf16
  * mixer with MFMA") - the forward kernel is then bound by reading the states from HBM; mixing arithmetic, gradients and
  * the weight-gradient GEMM stay fp32.  Workspace: packed weights (+ for backward: d(hypernet output) rows x (N*E+3E)
- * and the slabs).  Supported when marl_qmix_wide_supported(N, S, E) (E == 32, N <= 10, S <= 384). */
+ * and the slabs).  Supported when marl_qmix_wide_supported(N, S, E) (E == 32, N <= 10, S <= 384).
+ * CONTRACT on the row padding: the kernels read the columns S .. 4 ceil(S / 4) - 1 of every state row (the 16-byte loads of the
+ * last chunk) and multiply them by packed weights that are exactly zero, so these pad columns must hold FINITE values (0 * NaN
+ * would poison q_tot); EpisodeRecord zero-initialises them, a caller with its own buffers must do the same.
+ * marl_qmix_wide_fwd_kernel(): the name prefix (rocprofv3 kernel trace) of the forward kernel a call with this shape launches -
+ * "qmix_wide_kernel<false" (streaming), "qmix_wide_res_fwd_kernel" (bf16, weights resident in LDS: preceded by the pack kernel and
+ * a memset of q_tot) or "qmix_wide_res32_fwd_kernel". */
 int marl_qmix_wide_supported(int N, int S, int E);
+const char* marl_qmix_wide_fwd_kernel(long rows, int N, int S, int flags);
 size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward);
 int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot, float* ws,
                        size_t ws_bytes, long rows, int N, int S, int E, int flags, void* stream);

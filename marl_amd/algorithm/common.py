@@ -281,6 +281,20 @@ class PairedUnroll:
         self.side = None
         self.enabled = os.environ.get("MARL_NO_PAIR") != "1"      # experiments: MARL_NO_PAIR=1 launches them back to back
         self.chain = os.environ.get("MARL_NO_CHAIN") != "1"       # experiments: MARL_NO_CHAIN=1 keeps the plain pair + continuation
+        # experiments only: MARL_CHAIN_SPLIT=<CUs of the chain side>, read ONCE here; a multiple of 8 in [8, 248] (both launches
+        # need at least one XCD's worth of CUs, the library takes 1..256), 0 = never chain, anything else is ignored
+        self.forced_split = None
+        forced = os.environ.get("MARL_CHAIN_SPLIT")
+        if forced is not None:
+            try:
+                v = int(forced)
+            except ValueError:
+                v = -1
+            if v == 0 or 8 <= v <= 248:
+                self.forced_split = v
+            else:
+                import warnings
+                warnings.warn("MARL_CHAIN_SPLIT=%r ignored (want 0 or 8..248)" % forced)
 
     def applies(self, rows, T):
         return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES
@@ -314,9 +328,8 @@ class PairedUnroll:
         whole chip) is at least as fast by the step-time model."""
         if not self.chain or not self.applies(rows, T):
             return None
-        forced = os.environ.get("MARL_CHAIN_SPLIT")                 # experiments: CUs of the chain side (the model's choice otherwise)
-        if forced:
-            return (int(forced), 256 - int(forced)) if int(forced) > 0 else None
+        if self.forced_split is not None:                           # experiments: CUs of the chain side (the model's choice otherwise)
+            return (self.forced_split, 256 - self.forced_split) if self.forced_split > 0 else None
         tiles = (rows + 15) // 16
         cap = max(1, min(8, 2048 // (4 * max(obs_dim, 4))))          # row tiles per workgroup the unroll kernel can hold
         ceil = lambda a, b: -(-a // b)

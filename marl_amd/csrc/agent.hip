@@ -3,16 +3,17 @@
 //
 // Decomposition (MI355X-first, not one-thread-per-row):
 //   * a workgroup owns a block of (episode, agent) rows = RT tiles of 16 rows and keeps them
-//     for the whole unroll; 4 compute waves + 1 loader wave (320 threads);
-//   * compute wave w owns hidden units [16w, 16w+16): its slice of W_ih / W_hh / W_2 lives in
+//     for the whole unroll; 512 threads = 8 waves = 2 teams x 4 hidden-unit slices, two waves per SIMD;
+//   * wave (team, w) owns hidden units [16w, 16w+16): its slice of W_ih / W_hh / W_2 lives in
 //     VGPRs for the whole kernel as MFMA B-fragments (fc1's slice lives in LDS because its K
 //     depends on the map), so the only per-step operand traffic is the activation tiles in LDS;
+//     the teams split the row tiles (forward) or the products (backward);
 //   * all products run on v_mfma_f32_16x16x4_f32 (exact fp32, the fp32 roofline of the chip);
-//   * the loader wave streams the next step's observation tile HBM -> LDS while the gates run and
-//     synthesises the one-hot(last action) / agent-id columns, so HBM latency never sits on the
-//     recurrent critical path;
+//   * every thread carries 1/512 of the NEXT step's observation tile in float4 prefetch registers, issued a full
+//     step ahead (there is no loader wave), and the one-hot(last action) / agent-id columns are kept in place in the
+//     LDS input tile, so HBM latency never sits on the recurrent critical path;
 //   * GRU pointwise math is done on the accumulator (D) layout in registers; activations that the
-//     backward pass needs are written once, coalesced per 16-lane group.
+//     backward pass needs are written once, one 16-byte store per lane and plane (tile layout, below).
 // LDS tile pitches of THIS file: +4 floats.  The +8 of common.h halves the bank-conflict share of the b128 fragment reads
 // (tools/lds_pitch.py) but is time-neutral on 2s3z-sized tiles and COSTS the wide ones: QMIX on MMM2 / 1024 envs 159.6 -> 169.2
 // updates/s with +4 here, QTRAN-base 3s5z 282 -> 284, QMIX 2s3z within +-0.3 % (same box, alternating: profiles/r03_prescale_ab.txt, 8).
@@ -29,7 +30,6 @@ namespace {
 
 constexpr int H = 64;
 constexpr int HS = H + MARL_PAD_H;      // LDS row stride of 64-wide tiles (floats); +4 spreads banks
-constexpr int NT = 320;        // threads per workgroup
 
 struct FwdArgs {
   const float *W1, *b1, *Wih, *Whh, *bih, *bhh, *W2, *b2;

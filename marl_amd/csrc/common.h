@@ -5,13 +5,14 @@
 
 #define MARL_WAVE 64
 
-// LDS row pitches of the activation tiles, in floats beyond the tile width.  A wave reads an MFMA operand fragment with one
-// ds_read_b128 per lane (row m, columns 4q..4q+3 of a 16-chunk): gfx950 serves that instruction in four groups of 16 lanes over
-// 64 banks, and a pitch of 8 (mod 16) floats is the one that spreads every group over all banks (a pitch of 4 mod 16 - the
-// usual "+4" - is a 2-way conflict on every such read; tools/lds_pitch.py).  The accumulator-layout accesses (row 4q+i, column
-// m: ds_read/write_b32) are 2-way at that pitch instead - free for the writes, and the reads are few.  Time-neutral at the
-// headline shape (LDS is ~15 % busy there; A/B within the +-1.5 % run-to-run spread, profiles/r03_ab_variants.txt), it removes
-// the conflict cycles the counters show.
+// LDS row pitches of the activation tiles, in floats beyond the tile width - the DEFAULT (+8) for files that do not choose their
+// own: rollout_fused.hip keeps it (0-1 % ahead there), agent.hip overrides it with +4 (agent.hip:16-23: +8 costs the wide MMM2
+// tiles 6 % through the LDS it takes from the row-tile count).  Why +8: a wave reads an MFMA operand fragment with one
+// ds_read_b128 per lane (row m, columns 4q..4q+3 of a 16-chunk); gfx950 serves that instruction in four groups of 16 lanes over
+// 64 banks, and a pitch of 8 (mod 16) floats spreads every group over all banks (the usual "+4" is a 2-way conflict on every
+// such read; tools/lds_pitch.py), while the accumulator-layout accesses (row 4q+i, column m: ds_read/write_b32) become 2-way -
+// free for the writes, and the reads are few.  It halves the conflict share the counters show (profiles/r03_pmc_pitch8.json)
+// and is time-neutral on 2s3z-sized tiles (profiles/r03_ab_variants.txt).
 #ifndef MARL_PAD_H
 #define MARL_PAD_H 8
 #endif

@@ -101,4 +101,8 @@ extern "C" int marl_adam_step(float* p, const float* g, float* m, float* v, long
   return 0;
 }
 
-extern "C" const char* marl_hip_version(void) { return "marl_hip 0.1 (gfx950)"; }
+#ifndef MARL_SRC_HASH
+#define MARL_SRC_HASH "unknown"
+#endif
+// library version + a hash of the kernel sources it was built from (Makefile): the PMC evidence under profiles/ records it
+extern "C" const char* marl_hip_version(void) { return "marl_hip 0.4 (gfx950) src " MARL_SRC_HASH; }

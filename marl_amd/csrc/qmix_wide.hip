@@ -1006,6 +1006,17 @@ extern "C" size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward
   return f * sizeof(float);
 }
 
+// which forward kernel marl_qmix_wide_fwd launches for this shape (the prefix of its name in a rocprofv3 kernel trace), so that a
+// caller that times the call can name the kernel it timed (bench.py); the same dispatch rules as below
+extern "C" const char* marl_qmix_wide_fwd_kernel(long rows, int N, int S, int flags) {
+  const bool bf = (flags & 1) != 0;
+  const bool res_off = getenv("MARL_WIDE_RES") && getenv("MARL_WIDE_RES")[0] == '0';
+  const bool res32_on = getenv("MARL_WIDE_RES32") && getenv("MARL_WIDE_RES32")[0] == '1';
+  if (bf && N == 10 && (S + 15) / 16 == 21 && rows >= 128L * 16 * 16 && !res_off && res32_on) return "qmix_wide_res32_fwd_kernel";
+  if (bf && N == 10 && (S + 31) / 32 == 11 && rows >= 128L * 16 * 16 && !res_off) return "qmix_wide_res_fwd_kernel";
+  return "qmix_wide_kernel<false";
+}
+
 extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
                                   float* ws, size_t ws_bytes, long rows, int N, int S, int Eq, int flags, void* stream) {
   if (rows <= 0) return 0;

@@ -38,6 +38,10 @@ class _Scratch:
         key = (name, "flat")
         t = self.d.get(key)
         if t is None or t.device != device or t.numel() < n:
+            if t is not None:
+                # a captured hipGraph (algorithm/common.py:GraphedUpdate) has the old buffer's address baked in: moving the
+                # shared workspace generation makes it drop the graph and capture again instead of writing into freed storage
+                ops.WS.gen += 1
             t = torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
             self.d[key] = t
         return t
@@ -282,8 +286,14 @@ class QMixMixer(_Precision, nn.Module):
                                           ("w2", self.hyper_w2, ctx["hw2"], slice(N * E + E, N * E + 2 * E))):
                 hs = ctx["kept"].get(name)
                 if hs is not None:
-                    w, G, n3g = self._fused_hyper(seq, xs)
-                    ops.mlp3_bwd(w, xs, dhy[:, cols], self._fused_hyper(seq, xs, grad=True)[0], rows, a.state_shape, n3g, G, hsave=hs)
+                    wh, gh = self._fused_hyper(seq, xs), self._fused_hyper(seq, xs, grad=True)
+                    if wh is None or gh is None:
+                        # the forward kept only the fused kernels' fragments: there is nothing to fall back to
+                        raise RuntimeError("QMixMixer: the fused hypernet head %r kept its activations in the forward but its "
+                                           "backward cannot be launched (.grad tensors missing / not contiguous / not 16-byte "
+                                           "aligned, or MARL_MLP3_KEEP changed between forward and backward)" % name)
+                    w, G, n3g = wh
+                    ops.mlp3_bwd(w, xs, dhy[:, cols], gh[0], rows, a.state_shape, n3g, G, hsave=hs)
                     continue
                 l0, l2 = _linears(seq)
                 self._lin(l2).wgrad(dhy[:, cols], ops.src(hbuf), rows)

@@ -437,6 +437,11 @@ def qmix_wide_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, gr
                                       _p(ws), ws.numel() * 4, rows, N, S, E, 1 if bf16 else 0, _stream()), "marl_qmix_wide_loss_bwd")
 
 
+def qmix_wide_fwd_kernel(rows, N, S, bf16=False):
+    """name prefix (rocprofv3 kernel trace) of the forward kernel qmix_wide_fwd launches for this shape"""
+    return _lib.load().marl_qmix_wide_fwd_kernel(rows, N, S, 1 if bf16 else 0).decode()
+
+
 def qmix_wide_supported(N, S, E):
     return bool(_lib.load().marl_qmix_wide_supported(N, S, E))
 

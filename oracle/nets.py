@@ -15,6 +15,27 @@ def lin(p, prefix, x):
     return F.linear(x, p[prefix + ".weight"], p[prefix + ".bias"])
 
 
+class _LinBf16(torch.autograd.Function):
+    """y = r(x) r(W)^T + b with both GEMM operands rounded to bf16 and fp32 accumulation - the build's opt-in "bf16 mixer"
+    mode (BASELINE config 5), restated here so that the oracle can check it: products of bf16 values are exact in fp32, so only
+    the accumulation order differs from the matrix cores.  Backward as the build does it: dW = g^T x with the UNROUNDED input
+    (straight-through), db = colsum(g), no gradient into x (states)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x)
+        return F.linear(x.bfloat16().float(), W.bfloat16().float(), b)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return None, g.t() @ x, g.sum(0)
+
+
+def lin_bf16(p, prefix, x):
+    return _LinBf16.apply(x, p[prefix + ".weight"], p[prefix + ".bias"])
+
+
 # ---------------------------------------------------------------------------------
 # agent: RNNQNet (reference network/q_network.py:16-21; GRUCell gate order r,z,n)
 # ---------------------------------------------------------------------------------
@@ -82,17 +103,20 @@ def qmix(p, q_chosen, states, args):
     N, E, S = args.n_agents, args.qmix_hidden_dim, args.state_shape
     qv = q_chosen.reshape(-1, N)
     s = states.reshape(-1, S)
+    # mixer_dtype == "bf16" (build extension, not in the reference): the four state-conditioned hypernet GEMMs of the
+    # single-layer hypernets take bf16 operands; everything else stays fp32
+    slin = lin_bf16 if (getattr(args, "mixer_dtype", "fp32") == "bf16" and not args.two_hyper_layers) else lin
     if args.two_hyper_layers:
         w1 = lin(p, "hyper_w1.2", torch.relu(lin(p, "hyper_w1.0", s)))
         w2 = lin(p, "hyper_w2.2", torch.relu(lin(p, "hyper_w2.0", s)))
     else:
-        w1 = lin(p, "hyper_w1", s)
-        w2 = lin(p, "hyper_w2", s)
+        w1 = slin(p, "hyper_w1", s)
+        w2 = slin(p, "hyper_w2", s)
     w1 = w1.abs().view(-1, N, E)                       # agent-major: flat index n*E+e
-    b1 = lin(p, "hyper_b1", s)
+    b1 = slin(p, "hyper_b1", s)
     hid = F.elu((qv.unsqueeze(2) * w1).sum(1) + b1)    # (rows,E)
     w2 = w2.abs()
-    b2 = lin(p, "hyper_b2.2", torch.relu(lin(p, "hyper_b2.0", s)))  # (rows,1)
+    b2 = lin(p, "hyper_b2.2", torch.relu(slin(p, "hyper_b2.0", s)))  # (rows,1)
     q_tot = (hid * w2).sum(1, keepdim=True) + b2
     return q_tot.view(B, -1, 1)
 

@@ -233,6 +233,31 @@ def test_config5_qmix_mmm2_shard_fullsize():
     _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 511, 512, 700, 1023], Tm, "full:cfg5_qmix_MMM2_1024x120")
 
 
+def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle():
+    """BASELINE config 5 as it is quoted ("bf16 mixer with MFMA") at its per-GPU shard, learner level: QMIX on MMM2, 1024 envs x
+    T = 120, args.mixer_dtype = "bf16".  The reference has no such mode; the oracle restates it (oracle/nets.py:_LinBf16 - both
+    operands of the four state-conditioned hypernet GEMMs rounded to bf16, fp32 accumulation, weight gradient from the unrounded
+    states), which makes it an EXTERNAL check of the reduced-precision path at the north-star tolerance: products of bf16 values
+    are exact in fp32, only the accumulation order differs.  (a) what the FULL-batch launches produced (122 880 rows: the
+    resident-weights bf16 forward for the target mixer, the streaming bf16 kernel with the folded loss for the eval mixer) for
+    sampled episodes: q_evals, q_targets, q_tot, q_tot_target at 1e-4 of scale; (b) the sampled sub-batch with the loss numerator and
+    EVERY parameter gradient at 1e-4; (c) shard linearity."""
+    from marl_amd.hostutil import DeviceBatch
+    from marl_amd import ops
+    E5, T5 = 1024, 120
+    case, args, learner, rec = _shard_world("MMM2", "qmix", E5, T5, seed=29, over={"mixer_dtype": "bf16"})
+    assert learner.mixer._bf16() and args.mixer_dtype == "bf16"
+    assert ops.qmix_wide_fwd_kernel(E5 * T5, args.n_agents, args.state_shape, bf16=True) == "qmix_wide_res_fwd_kernel"
+    Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
+    assert Tm == T5
+    name = "full:cfg5_qmix_MMM2_1024x120_bf16mixer"
+    idx = [0, 1, 511, 512, 700, 1023]
+    _, dbg = _grads(learner, rec, Tm)
+    _full_batch_samples_vs_oracle(case, args, dbg, rec, idx, Tm, name)
+    _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name)
+    _linearity(learner, rec, Tm, E5, 2, name)
+
+
 def _full_batch_samples_vs_oracle(case, args, dbg, rec, idx, Tm, name, tol=1e-4):
     """Forward tensors the FULL-batch launch produced (whatever schedule and kernel variants its size selected) for the
     sampled episodes vs the CPU oracle run on those episodes alone (rows are independent)."""

@@ -103,8 +103,9 @@ def test_train_steps_vs_reference_and_oracle(case, golden_dir):
         loss = learner.train(learners.clone_batch(batch), ts)
         oloss, ograds, ointer = learners.train(ost, learners.clone_batch(batch), ts)
         # step 0 is held to the north-star 1e-4; later steps amplify fp32 rounding through RMSprop's 1/sqrt(v) (a
-        # parameter whose gradient is ~0 moves by lr * g / (sqrt(v) + 1e-8) with v ~ g^2): loosen progressively
-        rt = 1e-4 * (10 ** i)
+        # parameter whose gradient is ~0 moves by lr * g / (sqrt(v) + 1e-8) with v ~ g^2): 1e-3 for steps 1 / 200 / 201 - the
+        # achieved errors are ~1e-7 of scale, so a 1e-3 regression after the target sync is caught
+        rt = 1e-4 if i == 0 else 1e-3
         c = "train:%s/step%d" % (name, ts)
         parity.close(c, "loss vs reference", loss, fix["losses"][i], tol=rt)
         parity.close(c, "loss vs oracle", loss, oloss, tol=rt)
