@@ -135,6 +135,8 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
         dhs = g("dhs", (B, T, N, H))
         self.mixer.hip_backward(ctx_q, d_jq, BT, dhs.view(R, H), accumulate=False)
         self.v.hip_backward(ctx_v, d_v, BT, dhs.view(R, H), accumulate=True)
+        # (the heads' row-level weight gradients on a side stream beside the agent's backward pass were measured: 300 -> 284-293
+        # updates/s on the 512-env shard - the persistent BPTT workgroups hold every CU's LDS, the small launches only delay them)
         # the losses reach q_evals through two gathers per row - the taken action (L_nopt) and the greedy action (L_opt),
         # each with one gradient per (episode, step) shared by its agents: BPTT takes the two sparse (action, gradient)
         # pairs and the dense (B,T,N,A) gradient is never materialised

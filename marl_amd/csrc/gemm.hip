@@ -785,7 +785,7 @@ constexpr int TCH = 32;           // rows per chunk
 constexpr int TPT = 256;          // producer threads
 
 template <int KTT, int NX>        // k tiles (6: K <= 96, 10: K <= 160, 14: K <= 224); float4 of X a producer thread stages per chunk
-__global__ __launch_bounds__(512, 4) void wgrad_tall_kernel(WgradArgs a, int XP) {
+__global__ __launch_bounds__(512, NX >= 7 ? 2 : 4) void wgrad_tall_kernel(WgradArgs a, int XP) {      // (NX = 7: 84 KB of LDS, one workgroup per CU)
   extern __shared__ __attribute__((aligned(16))) float tsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool cons = wave < 4;
@@ -1005,17 +1005,21 @@ inline int try_wgrad_tall(WgradArgs& a, size_t ws_bytes, hipStream_t s) {
   static const bool off = getenv("MARL_WGRAD_TALL") && getenv("MARL_WGRAD_TALL")[0] == '0';      // A/B switch for measurements
   if (off) return -1;
   if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || !a.xvec || a.M < 4096 || a.x.k1 || a.x.m0 || !a.x.p0) return -1;
-  if (a.x.nhot > 1 || (a.x.k0 & 3) || a.x.k0 < 16 || a.x.k0 > 192) return -1;
+  if (a.x.nhot > 1 || (a.x.k0 & 3) || a.x.k0 < 16 || a.x.k0 > 224) return -1;
   const int KT = (a.K + 15) / 16;
   if (KT > 14) return -1;
   const int XP = tall_xp(a.K);
   const size_t lds = (size_t)2 * TCH * (TGP + XP) * sizeof(float) + 8 * TCH * (sizeof(long) + 2 * sizeof(int));
-  if (lds > 80 * 1024) return -1;
+  // (dense widths of 196 .. 224 columns - the 216 state columns of 3s5z under the first layer of QTRAN's heads - need seven
+  // float4 per producer thread and 84 KB of LDS: one workgroup per CU instead of two, still 2.5x the generic kernel's rate)
+  const bool wide = a.x.k0 > 192;
+  if (lds > (wide ? 160 : 80) * 1024) return -1;
   // two slabs per CU when the caller's workspace holds them (marl_linear_wgrad_workspace sizes it so for N == 64)
   int slabs = a.slabs;
   if (slabs == 256 && ws_bytes >= (size_t)512 * 64 * (a.K + 1) * sizeof(float)) slabs = 512;
   a.slabs = slabs;
-  const void* fn = KT <= 6 ? (const void*)wgrad_tall_kernel<6, 3> : KT <= 10 ? (const void*)wgrad_tall_kernel<10, 5> : (const void*)wgrad_tall_kernel<14, 6>;
+  const void* fn = KT <= 6 ? (const void*)wgrad_tall_kernel<6, 3> : KT <= 10 ? (const void*)wgrad_tall_kernel<10, 5>
+                   : wide ? (const void*)wgrad_tall_kernel<14, 7> : (const void*)wgrad_tall_kernel<14, 6>;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   int xp = XP;

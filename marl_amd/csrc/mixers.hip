@@ -86,6 +86,43 @@ __global__ __launch_bounds__(256) void q_double_select_kernel(const float* q_sel
   }
 }
 
+// q_masked_max with the staging of q_double_select_kernel: a wave copies 64 rows of q (and avail) into LDS with 16-byte coalesced
+// loads, then one lane per row scans its A values (the thread-per-row kernel above reads 44 - 72 byte rows at a lane stride of a
+// row: 50 us for 614 400 rows x 14 actions where the bytes are worth 12 us).  Same results (strict >: first index wins ties).
+__global__ __launch_bounds__(256) void q_masked_max_tiled_kernel(const float* q, const float* avail, float mask_val, float* out_max,
+                                                                 int* out_arg, long rows, int A) {
+  extern __shared__ __attribute__((aligned(16))) float ds_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int TS = (DS_ROWS * A + 3) & ~3;
+  float* Sq = ds_smem + (size_t)wave * 2 * TS;
+  float* Sa = Sq + TS;
+  const long tiles = (rows + DS_ROWS - 1) / DS_ROWS;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    const long r0 = tile * DS_ROWS;
+    const int n = (int)((rows - r0 < DS_ROWS ? rows - r0 : DS_ROWS) * A);
+    const float* gq = q + r0 * A;
+    const float* ga = avail ? avail + r0 * A : nullptr;
+    const int n4 = n >> 2;
+    for (int e = lane; e < n4; e += 64) {
+      reinterpret_cast<f32x4*>(Sq)[e] = reinterpret_cast<const f32x4*>(gq)[e];
+      reinterpret_cast<f32x4*>(Sa)[e] = ga ? reinterpret_cast<const f32x4*>(ga)[e] : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+    for (int e = 4 * n4 + lane; e < n; e += 64) { Sq[e] = gq[e]; Sa[e] = ga ? ga[e] : 1.f; }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                   // this wave's LDS writes (lgkmcnt(0)); no cross-wave sharing
+    const long r = r0 + lane;
+    if (r < rows) {
+      float best = 0.f; int arg = 0;
+      for (int a = 0; a < A; ++a) {
+        float v = Sq[lane * A + a];
+        if (Sa[lane * A + a] == 0.f) v = mask_val;
+        if (a == 0 || v > best) { best = v; arg = a; }
+      }
+      if (out_max) out_max[r] = best;
+      if (out_arg) out_arg[r] = arg;
+    }
+  }
+}
+
 __global__ void q_scatter_kernel(float* dq, const int* idx1, const float* g1, const int* idx2, const float* g2,
                                  long rows, int A, int gdiv) {
   for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long)gridDim.x * TPB) {
@@ -478,6 +515,17 @@ extern "C" int marl_q_gather(const float* q, const int* idx, const float* avail,
 extern "C" int marl_q_masked_max(const float* q, const float* avail, float mask_val, float* out_max, int* out_arg,
                                  long rows, int A, void* stream) {
   if (rows <= 0) return 0;
+  // 16-byte aligned operands (64 rows x A floats is a multiple of 16 bytes): the LDS-staged kernel
+  const size_t lds = (size_t)4 * 2 * ((DS_ROWS * A + 3) & ~3) * sizeof(float);
+  if (((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(avail)) & 15) == 0 && lds <= 64 * 1024 && rows >= 4096) {
+    const long tiles = (rows + DS_ROWS - 1) / DS_ROWS;
+    long nb = (tiles + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(q_masked_max_tiled_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, q, avail, mask_val,
+                       out_max, out_arg, rows, A);
+    MARL_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(q_masked_max_kernel, dim3(nblk(rows)), dim3(TPB), 0, (hipStream_t)stream, q, avail, mask_val,
                      out_max, out_arg, rows, A);
   MARL_CHECK_LAUNCH();

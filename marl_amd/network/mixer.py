@@ -659,6 +659,16 @@ class _QtranFusedHead:
             ctx.update(fused=True, s=s, hidden=hidden, u_idx=u_idx, s1=s1, e2=e2, y1=y1, y2=y2)
         return out
 
+    def _wgrad_split(self, lin, dY, s, e, BT, S):
+        """lin.weight.grad += dY^T [s | e], lin.bias.grad += colsum(dY): column blocks [0, S) and [S, S + width(e))"""
+        gw = lin.weight.grad
+        K = gw.shape[1]
+        if self._bf16() or S % 4:
+            self._lin(lin).wgrad(dY, ops.src(s, e), BT)
+            return
+        ops.linear_wgrad(dY, ops.src(s), gw[:, :S], lin.bias.grad, BT, gw.shape[0], S)
+        ops.linear_wgrad(dY, ops.src(e), gw[:, S:], None, BT, gw.shape[0], K - S)
+
     def _qt_backward(self, ctx, d_out, BT, dhidden, accumulate):
         N, A, AE, AEP, S = self._qt_dims()
         dev = d_out.device
@@ -671,7 +681,9 @@ class _QtranFusedHead:
         # row-level weight gradients: reductions over BT rows of tensors the kernel above has just written
         self._lin(q4).wgrad(d_out.view(BT, 1), ops.src(ctx["y2"]), BT)
         self._lin(q2).wgrad(dy2, ops.src(ctx["y1"]), BT)
-        self._lin(q0).wgrad(dy1, ops.src(ctx["s"], ctx["e2"][:, :AE]), BT)
+        # first head layer, [s | esum] -> 64: the state columns and the encoder columns as two reductions - the state part
+        # (216 columns on 3s5z) runs on the LDS-staged tall kernel, which the virtual concat of two dense segments does not
+        self._wgrad_split(q0, dy1, ctx["s"], ctx["e2"][:, :AE], BT, S)
         Lin(e2l.weight, None, self._bf16()).wgrad(de2[:, :AE], ops.src(ctx["s1"][:, :AE]), BT)
 
 

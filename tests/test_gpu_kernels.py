@@ -484,6 +484,26 @@ def test_wgrad_large_rows_and_remap(dev, B, O):
         close(Y, Xfull @ W.t(), 3e-4)
 
 
+@pytest.mark.parametrize("M,S,E_", [(5000, 216, 78), (4100, 200, 64), (9000, 224, 20), (4500, 120, 78)])
+def test_wgrad_split_state_and_encoder_columns(dev, M, S, E_):
+    """First layer of QTRAN's joint-Q / V heads (network/mixer.py:378-388): dW = dy1^T [s | esum] as two reductions into column
+    blocks of ONE weight-gradient tensor - the state block (up to 224 dense columns: the wide instantiation of the LDS-staged
+    tall kernel) with the bias gradient, the encoder block (a width that is not a multiple of 4) without; gradients accumulate."""
+    from marl_amd import ops
+    g = torch.Generator().manual_seed(M + S)
+    s, e = torch.randn(M, S, generator=g), torch.randn(M, (E_ + 3) // 4 * 4, generator=g)[:, :E_]
+    dY = torch.randn(M, 64, generator=g)
+    base_w, base_b = torch.randn(64, S + E_, generator=g), torch.randn(64, generator=g)
+    gw, gb = cu(base_w, dev), cu(base_b, dev)
+    ed = cu(torch.cat([e, torch.zeros(M, (-E_) % 4)], 1), dev)[:, :E_]       # rows padded to 16 bytes, as the kernels' scratch is
+    ops.linear_wgrad(cu(dY, dev), ops.src(cu(s, dev)), gw[:, :S], gb, M, 64, S)
+    ops.linear_wgrad(cu(dY, dev), ops.src(ed), gw[:, S:], None, M, 64, E_)
+    ref = dY.double().t() @ torch.cat([s, e], 1).double()
+    sc = float(ref.abs().max())
+    close((gw.cpu() - base_w) / sc, ref.float() / sc, 1e-4, 1e-4, msg="dW")
+    close(gb.cpu() - base_b, dY.sum(0), 1e-4 * float(dY.sum(0).abs().max()), 1e-4, msg="db")
+
+
 # ------------------------------------------------------------------------------------- agent
 def _agent_case(shape, B, T, dev, seed=0, with_h0=False):
     args = seeded.make_args(shape, "qmix", episode_limit=T)
@@ -741,6 +761,28 @@ def test_select_kernels(dev):
     ops.q_masked_max(qd, ad, -9999999.0, mx, am, R, A)
     close(mx, qm.max(1)[0], 0, 0)
     assert (am.cpu().long() == qm.argmax(1)).all()
+    # >= 4096 rows with 16-byte aligned operands: the LDS-staged kernel (ragged last tile, rows with nothing available, ties,
+    # no availability mask, 14 / 18 actions); an operand off the 16-byte grid keeps the row-per-thread kernel
+    for RR, AA in ((5003, 14), (4096, 18), (70001, 11)):
+        qq = torch.randn(RR, AA, generator=g)
+        av = (torch.rand(RR, AA, generator=g) < 0.6).float()
+        av[::9] = 0
+        qq[7, 2] = qq[7, AA - 1] = 11.0; av[7] = 1
+        for use_av in (True, False):
+            ref = qq.clone()
+            if use_av:
+                ref[av == 0] = -9999999.0
+            mx2, am2 = torch.empty(RR, device=dev), torch.empty(RR, dtype=torch.int32, device=dev)
+            ops.q_masked_max(cu(qq, dev), cu(av, dev) if use_av else None, -9999999.0, mx2, am2, RR, AA)
+            close(mx2, ref.max(1)[0], 0, 0)
+            assert (am2.cpu().long() == ref.argmax(1)).all()
+        un = torch.empty(RR * AA + 1, device=dev)
+        un[1:] = cu(qq, dev).reshape(-1)
+        mx3, am3 = torch.empty(RR, device=dev), torch.empty(RR, dtype=torch.int32, device=dev)
+        ops.q_masked_max(un[1:].view(RR, AA), cu(av, dev), -9999999.0, mx3, am3, RR, AA)
+        ref = qq.clone(); ref[av == 0] = -9999999.0
+        close(mx3, ref.max(1)[0], 0, 0)
+        assert (am3.cpu().long() == ref.argmax(1)).all()
     # fused double-Q selection: argmax of the masked eval-next Q, target Q gathered there (q_learner.py:104-117)
     for RR, AA in ((R, A), (4099, 18), (63, 3)):
         qs, qv = torch.randn(RR, AA, generator=g), torch.randn(RR, AA, generator=g)
