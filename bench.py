@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 SHAPES = {"2s3z": (5, 80, 120, 11, 120), "3s5z": (8, 128, 216, 14, 150), "MMM2": (10, 176, 322, 18, 120)}
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak; a bf16x6 split spends six bf16 products per fp32 product
 
 
 def make_args(alg, shape, T):
@@ -145,11 +146,14 @@ class KernelTimers:
                     w, x, Y, M, K1, N3, g = ar[:7]
                 three = bool(w.w2)
                 kept = kw.get("hsave") is not None      # h1 / h2 travel forward -> backward instead of being recomputed
+                x6 = bool(kw.get("x6"))                 # bf16x6 split kernels (csrc/mlp3_x6.hip, opt-in gemm_mode)
                 h2 = 64 * 64 if three else 0
                 ffw = 2.0 * M * g * (K1 * 64 + h2 + 64 * N3)
                 f = 2.0 * M * g * ((1 if kept else 2) * K1 * 64 + (2 if kept else 3) * h2 + 2 * 64 * N3) if back else ffw
-                return ("mlp3_%s_kernel (fused 64-wide heads, %d heads, K1=%d%s)" % ("bwd" if back else "fwd", g, K1, ", hidden activations kept" if kept else ""),
-                        "mlp3_bwd" if back else "mlp3_fwd", f, ffw * (3 if back else 1),
+                kn = ("mlp3x6_" if x6 else "mlp3_") + ("bwd" if back else "fwd")
+                return ("%s_kernel (fused 64-wide heads, %d heads, K1=%d%s%s)" % (kn, g, K1, ", hidden activations kept" if kept else "",
+                                                                                  ", fp32 products as six bf16 MFMA products" if x6 else ""),
+                        kn, f, ffw * (3 if back else 1),
                         4.0 * M * (K1 + g * N3) + (4.0 * M * g * (128 if three else 64) if kept else 0.0))
             return m
 
@@ -207,14 +211,47 @@ class KernelTimers:
         return rows
 
 
-# BASELINE.json configs[1..4] at their per-GPU shard sizes: (label, alg, shape, envs per GPU, mixer dtype)
-OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp32"),
-                 ("cfg3 QPLEX 2s3z 512 envs (shard of 4096 / 8 GPUs)", "qplex", "2s3z", 512, "fp32"),
-                 ("cfg4 QTRAN-base 3s5z 512 envs (shard of 2048 / 4 GPUs)", "qtran_base", "3s5z", 512, "fp32"),
-                 ("cfg5 QMIX MMM2 1024 envs (shard of 8192 / 8 GPUs), bf16 mixer", "qmix", "MMM2", 1024, "bf16")]
+# BASELINE.json configs[1..4] at their per-GPU shard sizes: (label, alg, shape, envs per GPU, mixer dtype,
+# gemm mode).  The last two are the opt-in bf16x6 legs (args.gemm_mode = "bf16x6": the QPLEX lambda-net on the split kernels,
+# csrc/mlp3_x6.hip) beside their fp32 twins - extra legs; the headline and configs[1..4] stay on v_mfma_f32_16x16x4_f32.
+OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp32", "f32"),
+                 ("cfg3 QPLEX 2s3z 512 envs (shard of 4096 / 8 GPUs)", "qplex", "2s3z", 512, "fp32", "f32"),
+                 ("cfg4 QTRAN-base 3s5z 512 envs (shard of 2048 / 4 GPUs)", "qtran_base", "3s5z", 512, "fp32", "f32"),
+                 ("cfg5 QMIX MMM2 1024 envs (shard of 8192 / 8 GPUs), bf16 mixer", "qmix", "MMM2", 1024, "bf16", "f32"),
+                 ("extra: cfg3 shard with gemm_mode bf16x6 (lambda-net products as six bf16 MFMA products each)", "qplex", "2s3z", 512, "fp32", "bf16x6"),
+                 ("extra: QPLEX 2s3z 4096 envs on one GPU, fp32 MFMA", "qplex", "2s3z", 4096, "fp32", "f32"),
+                 ("extra: QPLEX 2s3z 4096 envs on one GPU, gemm_mode bf16x6", "qplex", "2s3z", 4096, "fp32", "bf16x6")]
 
 
-def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
+def load_pmc(workload):
+    """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/r04_pmc_<workload>.json, written by
+    tools/summarize_profiles.py) - only when the file was taken with the library that is running now (marl_hip_version() carries
+    a hash of the kernel sources): numbers of an older build silently go stale when a kernel changes."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % workload)
+    if not os.path.exists(path):
+        return {}, "no PMC file for this workload"
+    d = json.load(open(path))
+    from marl_amd import _lib
+    ver = _lib.load().marl_hip_version().decode()
+    if d.get("lib_version") != ver:
+        return {}, "PMC file %s is from another build (%s, running %s): not used" % (os.path.relpath(path, ROOT), d.get("lib_version"), ver)
+    return d["kernels"], os.path.relpath(path, ROOT)
+
+
+def pmc_traffic(pmc, e):
+    """HBM bytes per launch of timed kernel entry e (None when the PMC file has no unique match for it)"""
+    hit = [v for k, v in pmc.items() if k.startswith(e["rocprof_name"]) and "hbm_bytes_per_launch" in v]
+    if e["rocprof_name"] == "agent_fwd" and hit:
+        # three instantiations share the prefix: match by what the launch does (save: most written; reuse: fewest MFMAs)
+        by = sorted(hit, key=lambda v: v.get("WRITE_SIZE", 0))
+        tag = e["name"].split("[")[1][:4]
+        rest = by[:-1]
+        key = lambda v: v.get("SQ_INSTS_MFMA", v.get("hbm_bytes_per_launch", 0))
+        hit = [by[-1]] if tag == "save" else ([min(rest, key=key)] if tag == "reus" else [max(rest, key=key)]) if rest else []
+    return hit[0] if len(hit) == 1 else None
+
+
+def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16, warmup=4, ktimed=4):
     """One learner-update leg of another BASELINE configuration at its per-GPU shard size (after the contract's timed
     region; record already in HBM): updates/s, transitions/s, the whole-update fraction of the fp32 MFMA peak (SURVEY 8d
     FLOP per transition) and the executed-FLOP roofline of the kernel the update spends the most time in."""
@@ -226,6 +263,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
     args = make_args(alg, shape, 0)
     args.mixer_dtype = mixer_dtype
+    args.gemm_mode = gemm_mode
     T = args.episode_limit
     torch.manual_seed(0)
     mac = SharedMAC(args)
@@ -244,12 +282,17 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
         gc.collect()
         gc.disable()
         try:
+            # rate: `updates` updates with no per-kernel events (their ~20 event records per update cost a small shard 4-15 %) ...
             t0 = time.perf_counter()
             for i in range(updates):
-                timers.on = i % 3 == 0          # (kernel timers on every third update: their event records cost a small update 4 %)
                 learner.train(ep, warmup + i)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / updates
+            # ... then the kernel table from a few updates with the HIP-event timers on
+            timers.on = True
+            for i in range(ktimed):
+                learner.train(ep, warmup + updates + i)
+            torch.cuda.synchronize()
             timers.on = False
         finally:
             gc.enable()
@@ -262,7 +305,10 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
         timers.close()
     fpt = learner_flops_per_transition(args, alg)
     upd_tf = fpt * envs * T / dt / 1e12
-    out = {"workload": "%s_%s_T%d_envs%d" % (alg, shape, T, envs), "what": label, "mixer_dtype": mixer_dtype,
+    workload = "%s_%s_T%d_envs%d%s%s" % (alg, shape, T, envs, "_bf16mixer" if mixer_dtype == "bf16" else "", "_bf16x6" if gemm_mode == "bf16x6" else "")
+    pmc, pmc_src = load_pmc(workload)
+    out = {"workload": workload, "what": label, "mixer_dtype": mixer_dtype, "gemm_mode": gemm_mode,
+           "dtype": "f32 via bf16x6 split, fp32 accumulate (lambda-net heads; everything else f32)" if gemm_mode == "bf16x6" else "f32",
            "learner_updates_per_sec": 1.0 / dt, "learner_transitions_per_sec": envs * T / dt,
            "rollout_env_steps_per_sec": steps / t_roll,
            "roofline_update": {"bound": "mfma", "flop_per_transition": fpt, "achieved": upd_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -270,9 +316,17 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
            "kernels": [{k: e[k] for k in ("name", "launches_timed", "ms", "executed_flop", "frac")} for e in kern[:5]]}
     if kern:
         d = kern[0]
-        out["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": d["tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": d["frac"], "avg_launch_ms": d["ms"], "traffic": None}
-        busy = sum(e["total_ms"] for e in kern) / ((updates + 2) // 3)
+        x6k = d["rocprof_name"].startswith("mlp3x6")
+        peak = PEAK_BF16_TFLOPS / 6.0 if x6k else PEAK_F32_TFLOPS
+        hit = pmc_traffic(pmc, d)
+        out["roofline"] = {"bound": "mfma", "kernel": d["name"], "rocprof_name": d["rocprof_name"], "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s",
+                           "frac": d["tflops"] / peak, "avg_launch_ms": d["ms"],
+                           "traffic": hit["hbm_bytes_per_launch"] if hit else None,
+                           "hbm_frac": (hit["hbm_bytes_per_launch"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if hit else None,
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)" % pmc_src}
+        if x6k:
+            out["roofline"]["peak_note"] = "dense bf16 MFMA peak / 6: a bf16x6 split spends six bf16 products per fp32 product"
+        busy = sum(e["total_ms"] for e in kern) / ktimed
         if busy > 1.05 * dt * 1e3:
             # small shards: the unrolls run side by side on two streams over parts of the chip (pair / chain schedule), so a
             # kernel's time is not exclusive and its fraction of the WHOLE chip's peak understates it
@@ -282,8 +336,11 @@ def config_leg(label, alg, shape, envs, mixer_dtype, updates=8, warmup=3):
     if mx and mixer_dtype == "bf16":      # config 5's named roofline: the bf16 hypernet GEMM against the HBM read of the states
         m = mx[0]
         gbs = m["algorithmic_bytes"] / (m["ms"] * 1e-3) / 1e9
-        out["roofline_mixer"] = {"bound": "hbm", "kernel": m["name"] + " (bf16 operands)", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": m["ms"], "bytes_per_launch": m["algorithmic_bytes"], "traffic": None}
+        hit = pmc_traffic(pmc, m)
+        out["roofline_mixer"] = {"bound": "hbm", "kernel": m["name"] + " (bf16 operands)", "rocprof_name": m["rocprof_name"], "achieved": gbs,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": m["ms"],
+                                 "bytes_per_launch": m["algorithmic_bytes"], "traffic": hit["hbm_bytes_per_launch"] if hit else None,
+                                 "traffic_unit": "HBM bytes per launch of the main kernel (PMC, %s)" % pmc_src}
     del learner, worker, env, mac, ep
     torch.cuda.empty_cache()
     return out
@@ -602,26 +659,18 @@ def main():
     if rank == 0:
         fpt = learner_flops_per_transition(args, o.alg)
         upd_tflops = fpt * (o.envs * T / t_learn) / 1e12
-        # HBM bytes per launch from the committed PMC passes (only when this run IS the workload they were taken on)
-        pmc_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc.json", "r02_pmc.json")) if os.path.exists(p)), "")
-        pmc = {}
-        if pmc_path and (o.alg, o.shape, o.envs, world, T, o.mixer_dtype) == ("qmix", "2s3z", 4096, 1, 120, "fp32"):
-            pmc = json.load(open(pmc_path))["kernels"]
+        # HBM bytes per launch from the committed PMC passes of this workload, taken with this very library (load_pmc)
+        workload = "%s_%s_T%d_envs%d%s" % (o.alg, o.shape, T, o.envs // world, "_bf16mixer" if o.mixer_dtype == "bf16" else "")
+        pmc, pmc_path = load_pmc(workload) if world == 1 else ({}, "multi-GPU run: per-GPU shard")
         kern = timers.table()
         # (with --hip-graph the learner's kernels are launched from inside the replayed graph: no per-launch events)
         for e in kern:
-            hit = [v for k, v in pmc.items() if k.startswith(e["rocprof_name"]) and "hbm_bytes_per_launch" in v]
-            if e["rocprof_name"] == "agent_fwd" and hit:
-                # three instantiations share the prefix: match by what the launch does (save: most written; reuse: <.., true, false>)
-                by = sorted(hit, key=lambda v: v.get("WRITE_SIZE", 0))
-                tag = e["name"].split("[")[1][:4]
-                hit = [by[-1]] if tag == "save" else ([v for v in by[:-1] if v.get("SQ_INSTS_MFMA", 0) == min(x.get("SQ_INSTS_MFMA", 0) for x in by[:-1])]
-                                                       if tag == "reus" else [v for v in by[:-1] if v.get("SQ_INSTS_MFMA", 0) == max(x.get("SQ_INSTS_MFMA", 0) for x in by[:-1])])
-            if len(hit) == 1:
-                e["hbm_gb"] = hit[0]["hbm_bytes_per_launch"] / 1e9
-                e["hbm_frac"] = hit[0]["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
-                if "SQ_INSTS_MFMA" in hit[0]:
-                    e["mfma_flop_pmc"] = hit[0]["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
+            hit = pmc_traffic(pmc, e)
+            if hit:
+                e["hbm_gb"] = hit["hbm_bytes_per_launch"] / 1e9
+                e["hbm_frac"] = hit["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+                if "SQ_INSTS_MFMA" in hit:
+                    e["mfma_flop_pmc"] = hit["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
         roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
         if kern:
             # the roofline object describes the kernel the timed region spent the most time in; `achieved` = FLOP that kernel
@@ -632,8 +681,7 @@ def main():
             roof.update(kernel=d["name"], rocprof_name=d["rocprof_name"], achieved=d["tflops"], frac=d["frac"],
                         avg_launch_ms=d["ms"], launches_timed=d["launches_timed"], flop_per_launch=d["executed_flop"],
                         traffic=(d["hbm_gb"] * 1e9 if d["hbm_gb"] else None), hbm_frac=d["hbm_frac"],
-                        traffic_unit="HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)"
-                                     % (os.path.relpath(pmc_path, ROOT) if pmc else "no PMC file for this workload"),
+                        traffic_unit="HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)" % pmc_path,
                         what="executed FLOP (tile padding excluded) of the kernel with the largest total time in the timed region")
             roof["kernels"] = [{k: e[k] for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "hbm_gb", "hbm_frac")}
                                for e in kern[:6]]
@@ -658,9 +706,10 @@ def main():
             if mx:
                 m = mx[0]
                 gbs = m["algorithmic_bytes"] / (m["ms"] * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": "qmix_wide_kernel forward (hypernet GEMM + mixing, %s operands)" % o.mixer_dtype,
+                hit = pmc_traffic(pmc, m)
+                roof = {"bound": "hbm", "kernel": m["name"] + " (%s operands)" % o.mixer_dtype, "rocprof_name": m["rocprof_name"],
                         "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "traffic": None, "avg_launch_ms": m["ms"], "launches_timed": m["launches_timed"], "bytes_per_launch": m["algorithmic_bytes"],
+                        "traffic": hit["hbm_bytes_per_launch"] if hit else None, "avg_launch_ms": m["ms"], "launches_timed": m["launches_timed"], "bytes_per_launch": m["algorithmic_bytes"],
                         "flop_per_launch": m["executed_flop"], "tflops": m["tflops"], "kernels": roof.get("kernels")}
         rccl = {"backend": "none (single process)", "world_seen": 1}
         if world > 1:
