@@ -571,6 +571,176 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
   }
 }
 
+// The same reduction with bf16 operands (flags & 1, BASELINE config 5 "bf16 mixer with MFMA"): dhy and the states are rounded to
+// bf16 where they are staged, a 32-row chunk is ONE k-step of v_mfma_f32_16x16x32_bf16 (21 MFMAs per wave and chunk instead of
+// 168 fp32 ones), and - the reduction index being the row - both operands come out of row-major [row][column] bf16 images
+// through ds_read_b64_tr_b16 (lane (g, i) receives column i of rows 8g .. 8g + 3: cdna_hip_programming.md T10).  The kernel is
+// then bound by streaming dhy and the states (55 KB per chunk and workgroup), not by the multiplies.  fp32 accumulation; the
+// bias gradient stays an exact fp32 column sum of dhy (taken where the chunk is staged).
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wg_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf4 __attribute__((ext_vector_type(4)));
+typedef int wg_i32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ inline int wgb_gb() { return 2 * 16 * WNT; }                  // bytes per image row of the dhy chunk (224)
+__host__ __device__ inline int wgb_xb(int KT) { return 2 * 16 * KT; }             // ... of the state chunk (672 at MMM2)
+
+__global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_bf16_kernel(WideWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, m = lane & 15;
+  const int GB = wgb_gb(), XB = wgb_xb(a.KT);
+  const int BUF = WCH * (GB + XB);                   // bytes per buffer
+  char* img = reinterpret_cast<char*>(smem);
+  long* rtab = reinterpret_cast<long*>(img + 2 * BUF);                      // [2][WCH] source offsets of the chunk's rows
+  const int grp = blockIdx.y, col0 = grp * 16 * WNT;
+  const int S4 = (a.S + 3) >> 2;
+  const long per = (a.rows + a.nslab - 1) / a.nslab;
+  const long r_begin = (long)blockIdx.x * per;
+  long r_end = r_begin + per; if (r_end > a.rows) r_end = a.rows;
+  const long nch = r_end > r_begin ? (r_end - r_begin + WCH - 1) / WCH : 0;
+  constexpr int G4 = 4 * WNT;
+  const int gi = WCH * G4, xi = WCH * S4;
+  constexpr int NG = (WCH * G4 + 64 * NW - 1) / (64 * NW);       // 2
+  constexpr int NX = 6;                                          // covers S <= 384
+  f32x4 pg[NG], px[NX], bsum[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) bsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float invS4 = 1.0f / (float)S4;
+  auto fetch = [&](long ch) {
+    const long rb = r_begin + ch * WCH;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      int e = tid + 64 * NW * i;
+      if (e > gi - 1) e = gi - 1;
+      const int r = e / G4, c4 = (e - r * G4) * 4;
+      long row = rb + r;
+      const bool live = row < r_end && col0 + c4 < a.C && tid + 64 * NW * i < gi;
+      if (row > a.rows - 1) row = a.rows - 1;
+      const int cc = col0 + c4 < a.C ? col0 + c4 : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.dhy + row * a.C + cc);
+      if (!live) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      pg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      int e = tid + 64 * NW * i;
+      if (e > xi - 1) e = xi - 1;
+      const int r = (int)(((float)e + 0.5f) * invS4);
+      const int c4 = (e - r * S4) * 4;
+      px[i] = *reinterpret_cast<const f32x4*>(a.s.p0 + rtab[(ch & 1) * WCH + r] + c4);
+    }
+  };
+  auto resolve = [&](long ch) {
+    if (tid < WCH) {
+      long row = r_begin + ch * WCH + tid;
+      if (row > a.rows - 1) row = a.rows - 1;
+      const ConcatRow cr = concat_row(a.s, row);
+      rtab[(ch & 1) * WCH + tid] = cr.r0 * a.s.ld0;
+    }
+  };
+  auto pack4 = [](const f32x4& v) { return __builtin_bit_cast(wg_i32x2, __builtin_convertvector(v, wg_bf4)); };
+  auto stash = [&](int b) {
+    char* G = img + b * BUF;
+    char* X = G + WCH * GB;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int e = tid + 64 * NW * i;
+      bsum[i] += pg[i];                              // exact fp32 column sums (rows past the slab were zeroed in fetch)
+      if (e < gi) { const int r = e / G4, c4 = (e - r * G4) * 4; *reinterpret_cast<wg_i32x2*>(G + r * GB + 2 * c4) = pack4(pg[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 64 * NW * i;
+      if (e < xi) {
+        const int r = (int)(((float)e + 0.5f) * invS4);
+        const int c4 = (e - r * S4) * 4;
+        f32x4 v = px[i];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) if (c4 + cc >= a.S) v[cc] = 0.f;
+        *reinterpret_cast<wg_i32x2*>(X + r * XB + 2 * c4) = pack4(v);
+      }
+    }
+  };
+  // zero the never-written pad columns of both state images (k padding up to 16 KT)
+  for (int b = 0; b < 2; ++b)
+    for (int e = tid; e < WCH * (16 * a.KT - 4 * S4); e += 64 * NW) {
+      const int w = 16 * a.KT - 4 * S4;
+      *reinterpret_cast<short*>(img + b * BUF + WCH * GB + (e / w) * XB + 2 * (4 * S4 + e % w)) = 0;
+    }
+  f32x4 acc[WNT][WKT];
+#pragma unroll
+  for (int t = 0; t < WNT; ++t)
+#pragma unroll
+    for (int k = 0; k < WKT; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // transposed-read addresses of this lane: rows 8g + qq (+ 4), 8 bytes at column c0 + 4p
+  const int qq = m >> 2, pp = m & 3;
+  const int gA = (8 * q + qq) * GB + 8 * pp, xA = (8 * q + qq) * XB + 8 * pp;
+  typedef __attribute__((address_space(3))) wg_s16x4 lds_s16x4;
+  auto tr8 = [&](const char* base, int off, int pitch) __attribute__((always_inline)) {
+    const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+    const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + 4 * pitch));
+    return __builtin_bit_cast(wg_bf8, (wg_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  resolve(0);
+  resolve(1);
+  __syncthreads();
+  if (nch > 0) fetch(0);
+  __syncthreads();
+  if (nch > 0) stash(0);
+  for (long ch = 0; ch < nch; ++ch) {
+    const int b = (int)(ch & 1);
+    WG_BARRIER();                                  // chunk ch is in buffer b; buffer b^1 is free (read two chunks ago)
+    if (ch + 1 < nch) fetch(ch + 1);
+    if (ch + 2 < nch) resolve(ch + 2);
+    const char* G = img + b * BUF;
+    const char* X = G + WCH * GB;
+    wg_bf8 xb[WKT];
+#pragma unroll
+    for (int k = 0; k < WKT; ++k) {
+      const int kt = wave + NW * k;
+      xb[k] = tr8(X, xA + 32 * (kt < a.KT ? kt : 0), XB);
+    }
+#pragma unroll
+    for (int t = 0; t < WNT; ++t) {
+      const wg_bf8 ga = tr8(G, gA + 32 * t, GB);
+#pragma unroll
+      for (int k = 0; k < WKT; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, xb[k], acc[t][k], 0, 0, 0);
+    }
+    if (ch + 1 < nch) stash(b ^ 1);
+  }
+  // ---- slab: rows = columns of the hypernet output, bias gradient in column 16 KT
+  const int Kx = 16 * a.KT + 1;
+  float* slab = a.ws + (long)blockIdx.x * a.C * Kx;
+#pragma unroll
+  for (int t = 0; t < WNT; ++t)
+#pragma unroll
+    for (int k = 0; k < WKT; ++k) {
+      const int kt = wave + NW * k;
+      if (kt >= a.KT) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = col0 + 16 * t + 4 * q + i;
+        if (c < a.C) slab[(long)c * Kx + 16 * kt + m] = acc[t][k][i];
+      }
+    }
+  // bias: the per-thread column sums (thread e -> chunk row e / G4, columns 4 (e % G4) ..) added over the 32 chunk rows
+  __syncthreads();
+  float* red = smem;                                 // [WCH][16 WNT]
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int e = tid + 64 * NW * i;
+    if (e < gi) { const int r = e / G4, c4 = (e - r * G4) * 4; *reinterpret_cast<f32x4*>(red + r * (16 * WNT) + c4) = bsum[i]; }
+  }
+  __syncthreads();
+  if (tid < 16 * WNT) {
+    float v = 0.f;
+    for (int r = 0; r < WCH; ++r) v += red[r * (16 * WNT) + tid];
+    const int c = col0 + tid;
+    if (c < a.C) slab[(long)c * Kx + 16 * a.KT] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Forward with bf16 operands and the weights RESIDENT in LDS (BASELINE config 5: "bf16 mixer with MFMA" - the kernel SURVEY 8d
 // prices against the HBM read of the states).  The streaming kernel above re-stages all 26 column tiles per 128-row block
@@ -1105,11 +1275,21 @@ static int wide_bwd_impl(const marl_qmix_weights_t* w, const marl_src_t* s, cons
   if (rc) return rc;
   WideWgArgs g;
   g.dhy = dhy; g.s = a.s; g.ws = wslab; g.rows = rows; g.S = S; g.C = C; g.KT = KT; g.nslab = nslab;
-  const size_t lds = (size_t)2 * WCH * (wg_gp() + wg_xp(KT)) * sizeof(float) + 2 * WCH * sizeof(long);
-  hipError_t e = hipFuncSetAttribute((const void*)qmix_wide_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(qmix_wide_wgrad_kernel, dim3(nslab, wg_groups(C)), dim3(64 * NW), lds, st, g);
-  MARL_CHECK_LAUNCH();
+  if (bf) {      // bf16 operands: one k-step of the bf16 MFMA per 32-row chunk, transposed LDS reads
+    size_t lds = (size_t)2 * WCH * (wgb_gb() + wgb_xb(KT)) + 2 * WCH * sizeof(long);
+    const size_t red = (size_t)WCH * 16 * WNT * sizeof(float);
+    if (lds < red) lds = red;
+    hipError_t e = hipFuncSetAttribute((const void*)qmix_wide_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(qmix_wide_wgrad_bf16_kernel, dim3(nslab, wg_groups(C)), dim3(64 * NW), lds, st, g);
+    MARL_CHECK_LAUNCH();
+  } else {
+    const size_t lds = (size_t)2 * WCH * (wg_gp() + wg_xp(KT)) * sizeof(float) + 2 * WCH * sizeof(long);
+    hipError_t e = hipFuncSetAttribute((const void*)qmix_wide_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(qmix_wide_wgrad_kernel, dim3(nslab, wg_groups(C)), dim3(64 * NW), lds, st, g);
+    MARL_CHECK_LAUNCH();
+  }
   WideRedArgs r;
   r.ws = wslab; r.slab2 = bslab; r.nslab = nslab; r.nwg = (int)grid; r.N = N; r.S = S; r.C = C; r.KT = KT;
   r.loss2 = L ? L->loss2 : nullptr;

@@ -18,8 +18,9 @@ def lin(p, prefix, x):
 class _LinBf16(torch.autograd.Function):
     """y = r(x) r(W)^T + b with both GEMM operands rounded to bf16 and fp32 accumulation - the build's opt-in "bf16 mixer"
     mode (BASELINE config 5), restated here so that the oracle can check it: products of bf16 values are exact in fp32, so only
-    the accumulation order differs from the matrix cores.  Backward as the build does it: dW = g^T x with the UNROUNDED input
-    (straight-through), db = colsum(g), no gradient into x (states)."""
+    the accumulation order differs from the matrix cores.  Backward as the build does it: dW = r(g)^T r(x) - the weight-gradient
+    GEMM takes bf16 operands too (round 4) -, db = colsum(g) in fp32, no gradient into x (states); the gradient that flows on
+    into the mixing arithmetic (and from there into the agents) is formed from the forward's values in fp32."""
 
     @staticmethod
     def forward(ctx, x, W, b):
@@ -29,7 +30,7 @@ class _LinBf16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        return None, g.t() @ x, g.sum(0)
+        return None, g.bfloat16().float().t() @ x.bfloat16().float(), g.sum(0)
 
 
 def lin_bf16(p, prefix, x):

@@ -236,8 +236,8 @@ def test_config5_qmix_mmm2_shard_fullsize():
 def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle():
     """BASELINE config 5 as it is quoted ("bf16 mixer with MFMA") at its per-GPU shard, learner level: QMIX on MMM2, 1024 envs x
     T = 120, args.mixer_dtype = "bf16".  The reference has no such mode; the oracle restates it (oracle/nets.py:_LinBf16 - both
-    operands of the four state-conditioned hypernet GEMMs rounded to bf16, fp32 accumulation, weight gradient from the unrounded
-    states), which makes it an EXTERNAL check of the reduced-precision path at the north-star tolerance: products of bf16 values
+    operands of the four state-conditioned hypernet GEMMs rounded to bf16, fp32 accumulation, forward AND weight gradient), which
+    makes it an EXTERNAL check of the reduced-precision path at the north-star tolerance: products of bf16 values
     are exact in fp32, only the accumulation order differs.  (a) what the FULL-batch launches produced (122 880 rows: the
     resident-weights bf16 forward for the target mixer, the streaming bf16 kernel with the folded loss for the eval mixer) for
     sampled episodes: q_evals, q_targets, q_tot, q_tot_target at 1e-4 of scale; (b) the sampled sub-batch with the loss numerator and
