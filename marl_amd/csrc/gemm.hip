@@ -791,7 +791,10 @@ __global__ __launch_bounds__(512, NX >= 7 ? 2 : 4) void wgrad_tall_kernel(WgradA
   const bool cons = wave < 4;
   const int ptid = tid - 256;                                   // producer thread index (negative in consumers)
   const int q = lane >> 4, m = lane & 15;
-  const int K = a.K, k0 = a.x.k0;
+  // k0: the dense width rounded up to whole float4 groups - a width that is not a multiple of 4 (QTRAN's 78-wide encoder sums) is
+  // allowed for plain dense sources whose rows are padded to 16 bytes: the pad columns are staged like data (any value - they only
+  // meet the accumulators of columns >= K, which are never stored)
+  const int K = a.K, k0 = (a.x.k0 + 3) & ~3;
   const int BUF = TCH * (TGP + XP);
   long* rtab = reinterpret_cast<long*>(tsm + 2 * BUF);          // [8][TCH] source offset (floats) of the dense row, by chunk & 7
   int* htab = reinterpret_cast<int*>(rtab + 8 * TCH);           // [8][TCH] column of the one-hot 1 (or -1)
@@ -1005,7 +1008,8 @@ inline int try_wgrad_tall(WgradArgs& a, size_t ws_bytes, hipStream_t s) {
   static const bool off = getenv("MARL_WGRAD_TALL") && getenv("MARL_WGRAD_TALL")[0] == '0';      // A/B switch for measurements
   if (off) return -1;
   if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || !a.xvec || a.M < 4096 || a.x.k1 || a.x.m0 || !a.x.p0) return -1;
-  if (a.x.nhot > 1 || (a.x.k0 & 3) || a.x.k0 < 16 || a.x.k0 > 224) return -1;
+  if (a.x.nhot > 1 || a.x.k0 < 16 || a.x.k0 > 224) return -1;
+  if ((a.x.k0 & 3) && (a.x.nhot || a.x.nid || (a.x.ld0 & 3))) return -1;      // ragged dense width: plain dense rows padded to 16 bytes only
   const int KT = (a.K + 15) / 16;
   if (KT > 14) return -1;
   const int XP = tall_xp(a.K);
