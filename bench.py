@@ -241,6 +241,13 @@ def load_pmc(workload):
 def pmc_traffic(pmc, e):
     """HBM bytes per launch of timed kernel entry e (None when the PMC file has no unique match for it)"""
     hit = [v for k, v in pmc.items() if k.startswith(e["rocprof_name"]) and "hbm_bytes_per_launch" in v]
+    if e["rocprof_name"].startswith("mlp3") and len(hit) > 1:
+        # one instantiation per padded input width: <8, ...> for K1 <= 128, <11, ...> (fp32) / <12, ...> (bf16x6) beyond; three-layer heads
+        import re
+        k1 = int(re.search(r"K1=(\d+)", e["name"]).group(1))
+        kc = 8 if k1 <= 128 else (12 if "x6" in e["rocprof_name"] else 11)
+        pre = "%s_kernel<%d, true" % (e["rocprof_name"], kc)
+        hit = [v for k, v in pmc.items() if k.startswith(pre) and "hbm_bytes_per_launch" in v]
     if e["rocprof_name"] == "agent_fwd" and hit:
         # three instantiations share the prefix: match by what the launch does (save: most written; reuse: fewest MFMAs)
         by = sorted(hit, key=lambda v: v.get("WRITE_SIZE", 0))

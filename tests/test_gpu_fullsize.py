@@ -148,7 +148,7 @@ def _shard_world(shape, alg, envs, T, seed, over=None):
     return case, args, learner, ep.record
 
 
-def _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, tol=1e-4):
+def _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, tol=1e-4, grad_tol=None):
     """The product on the sampled episodes alone (full T loop: same trip count, BPTT variant and dispatch as the full
     batch) vs the CPU oracle on the same episodes: forward tensors, loss numerators and EVERY parameter gradient."""
     import parity
@@ -188,7 +188,7 @@ def _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, tol=1e-4):
         if og is None:
             assert np.all(g == 0), pn
             continue
-        parity.close(name, "grad " + pn, g, og.detach().numpy(), tol=tol)
+        parity.close(name, "grad " + pn, g, og.detach().numpy(), tol=grad_tol(pn) if grad_tol else tol)
 
 
 def _linearity(learner, rec, Tm, E_, nstats, name, tol=5e-5):
@@ -241,7 +241,7 @@ def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle():
     are exact in fp32, only the accumulation order differs.  (a) what the FULL-batch launches produced (122 880 rows: the
     resident-weights bf16 forward for the target mixer, the streaming bf16 kernel with the folded loss for the eval mixer) for
     sampled episodes: q_evals, q_targets, q_tot, q_tot_target at 1e-4 of scale; (b) the sampled sub-batch with the loss numerator and
-    EVERY parameter gradient at 1e-4; (c) shard linearity."""
+    every parameter gradient (1e-4; the four bf16 weight-gradient GEMMs at the mode's 2e-2); (c) shard linearity."""
     from marl_amd.hostutil import DeviceBatch
     from marl_amd import ops
     E5, T5 = 1024, 120
@@ -254,7 +254,12 @@ def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle():
     idx = [0, 1, 511, 512, 700, 1023]
     _, dbg = _grads(learner, rec, Tm)
     _full_batch_samples_vs_oracle(case, args, dbg, rec, idx, Tm, name)
-    _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name)
+    # the weight gradients of the four bf16 GEMMs round dhy and the states to bf16 before multiplying: a 1e-7 difference in dhy
+    # between two correct evaluations can move an element across a bf16 rounding boundary (2^-8 of that term), so these four
+    # tensors are compared at the 2e-2 test_qmix_wide states for the mode (measured: 2e-3); everything else - the loss, dq and
+    # with it every agent gradient, the biases, hyper_b2.2 - at 1e-4
+    bf_w = ("mixer.hyper_w1.weight", "mixer.hyper_b1.weight", "mixer.hyper_w2.weight", "mixer.hyper_b2.0.weight")
+    _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, grad_tol=lambda pn: 2e-2 if pn in bf_w else 1e-4)
     _linearity(learner, rec, Tm, E5, 2, name)
 
 

@@ -13,7 +13,7 @@ python3 -c "from marl_amd import _lib; print(_lib.load().marl_hip_version().deco
 rm -rf $OUT/${TAG}_bench $OUT/${TAG}_pmc_*
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -o p -- python3 bench.py --no-cpu-baseline --no-configs > $OUT/${TAG}_bench.log 2>&1
 grep '^{"metric"' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench_line.json
-P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU"
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 pmc() {   # workload-name  full(0/1)  prof_learner args...
   local W=$1 FULL=$2; shift 2
   local i=0
