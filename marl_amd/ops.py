@@ -173,6 +173,20 @@ def agent_unroll_fwd(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last
           "marl_agent_unroll_fwd")
 
 
+def agent_unroll_x6_supported(B, T, N, O, A, last_action=True, reuse_network=True):
+    return bool(_lib.load().marl_agent_unroll_x6_supported(B, T, N, O, A, 1 if last_action else 0, 1 if reuse_network else 0))
+
+
+def agent_unroll_fwd_x6(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, B, T, N, O, A, last_action=True,
+                        reuse_network=True, ep_len=None, ep_map=None):
+    """the forward-only unroll on the bf16x6 split kernels (csrc/agent_x6.hip; opt-in args.gemm_mode = "bf16x6"): same
+    arguments as agent_unroll_fwd without `saved` / gate sums / CU budget"""
+    check(_lib.load().marl_agent_unroll_fwd_x6(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
+                                               _p(_i32(ep_map)) if ep_map is not None else None, _p(h0), _p(_f32(q)), _p(hs),
+                                               _p(h_last), B, T, N, O, A, 1 if last_action else 0, 1 if reuse_network else 0,
+                                               _stream()), "marl_agent_unroll_fwd_x6")
+
+
 def saved_shape(T, B, N, planes=6, H=64):
     """Shape of the activation buffer an unroll saves for BPTT (planes = 6) or of its input-side gate sums (planes = 3):
     the kernels use a tile layout [T][16-row tile][plane][column tile][lane][4] (csrc/agent.hip: sv_off), so the row count is

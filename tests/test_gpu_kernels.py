@@ -674,6 +674,51 @@ def test_saving_unroll_variants_equal_register_prefetch_bitwise(dev, shape, B, T
                 assert torch.equal(x, y), "%s: plane %d (t0=%d)" % (other, k, t0)
 
 
+@pytest.mark.parametrize("B,T,with_h0,ragged", [(7, 5, False, False), (70, 6, True, True), (3, 4, True, False), (900, 9, False, True),
+                                                 (2100, 12, True, True)])
+def test_agent_unroll_x6_split(dev, B, T, with_h0, ragged):
+    """Forward-only unroll on the bf16x6 split kernels (csrc/agent_x6.hip, opt-in gemm_mode): q, hs and the final hidden state
+    against the CPU oracle at the bound of test_agent_unroll_fwd (1e-4), and beside the fp32 MFMA kernel on the same inputs -
+    (T+1)-slot storage read through an episode map with the shifted last action, ragged episode lengths (rows past their end
+    feed zeros), a carried hidden state, partial last row tile, one and two row tiles per workgroup (> 256 tiles)."""
+    from marl_amd import ops
+    args, p_np, _, _, _ = _agent_case("2s3z", B, T, dev, with_h0=with_h0)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    assert ops.agent_unroll_x6_supported(B, T, N, O, A)
+    rng = np.random.default_rng(B + T)
+    E = B + 2
+    store = rng.standard_normal((E, T + 1, N, O)).astype(np.float32)
+    u = rng.integers(-1, A, size=(B, T, N))
+    emap = rng.permutation(E)[:B]
+    lens = rng.integers(1, T + 1, size=B) if ragged else np.full(B, T)
+    lens[0] = T
+    h0 = (rng.standard_normal((B * N, 64)).astype(np.float32) * 0.3) if with_h0 else None
+    w = ops.agent_weights({k: cu(v, dev) for k, v in p_np.items()})
+    sd, ud, ed = cu(store, dev), cu(u, dev, torch.int32), cu(emap, dev, torch.int32)
+    ld = cu(lens, dev, torch.int32)
+    outs = {}
+    for mode in ("x6", "f32"):
+        q, hs, hl = torch.full((B, T, N, A), 9.0, device=dev), torch.full((B, T, N, 64), 9.0, device=dev), torch.full((B * N, 64), 9.0, device=dev)
+        h0d = cu(h0, dev) if h0 is not None else None
+        if mode == "x6":
+            ops.agent_unroll_fwd_x6(w, sd, (T + 1) * N, 1, ud, T * N, 0, h0d, q, hs, hl, B, T, N, O, A, ep_len=ld, ep_map=ed)
+        else:
+            ops.agent_unroll_fwd(w, sd, (T + 1) * N, 1, ud, T * N, 0, h0d, q, hs, hl, None, B, T, N, O, A, ep_len=ld, ep_map=ed)
+        outs[mode] = (q.cpu(), hs.cpu(), hl.cpu())
+    obs = store[emap][:, 1:T + 1].copy()
+    for b in range(B):
+        obs[b, lens[b]:] = 0          # steps t >= ep_len feed zeros
+    with torch.no_grad():
+        _, q_ref, hs_ref, hl_ref = _oracle_unroll(args, p_np, obs, u, h0)
+    for mode in ("x6", "f32"):
+        close(outs[mode][0], q_ref, 1e-4, msg=mode + " q")
+        close(outs[mode][1], hs_ref, 1e-4, msg=mode + " hs")
+        close(outs[mode][2], hl_ref, 1e-4, msg=mode + " h_last")
+    e6 = float((outs["x6"][0].double() - q_ref.double()).abs().max())
+    e32 = float((outs["f32"][0].double() - q_ref.double()).abs().max())
+    print("agent unroll B=%d T=%d: max |q - oracle|: bf16x6 %.2e, fp32 MFMA %.2e" % (B, T, e6, e32))
+
+
 @pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
 def test_agent_unroll_bwd(dev, shape, B, T):
     """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll.  Up to four row tiles per workgroup a
