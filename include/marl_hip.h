@@ -269,17 +269,20 @@ int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const
                         const marl_mlp3_weights_t* grads, float* ws, size_t ws_bytes, const float* hsave,
                         size_t hsave_floats, long M, int K1, int N3, int groups, void* stream);
 
-/* ---- agent unroll, forward only, with the multiplies as an fp32-accurate split on the bf16 matrix cores (agent_x6.hip) ----------
- * Opt-in (args.gemm_mode = "bf16x6"): the same T-step unroll as marl_agent_unroll_fwd for launches that save nothing - the target
- * network's pass of a Q-learning update (controller/share_params.py:147-168; network/q_network.py:16-21) - with every fp32 product
- * as six bf16 MFMA products (see the mlp3_x6 block below for the arithmetic).  Same argument meaning as marl_agent_unroll_fwd; no
- * `saved`, no gate-sum reuse.  marl_agent_unroll_x6_supported(): H = 64, A <= 16, O a multiple of 8, O + A + N <= 96, T >= 4
- * (2s3z-sized agents); the caller uses marl_agent_unroll_fwd otherwise. */
+/* ---- agent unroll, forward, with the multiplies as an fp32-accurate split on the bf16 matrix cores (agent_x6.hip) ----------------
+ * Opt-in (args.gemm_mode = "bf16x6"): the same T-step unroll as marl_agent_unroll_fwd (controller/share_params.py:147-168;
+ * network/q_network.py:16-21) with every fp32 product as six bf16 MFMA products (see the mlp3_x6 block below for the arithmetic).
+ * Same arguments, same meaning: `saved` (the six activation planes per row-step the fp32 BPTT kernel marl_agent_unroll_bwd reads,
+ * same tile layout), `gi_out` / `gi_in` (the input-side gate sums one unroll stores and the double-Q continuation reads; these
+ * hold PLAIN sums here - a pair of launches that shares them must both be this entry), `cu_budget` (two row tiles per workgroup
+ * once there are more tiles than that many CUs).  marl_agent_unroll_x6_supported(): H = 64, A <= 16, O a multiple of 8,
+ * O + A + N <= 96, T >= 4 (2s3z-sized agents); the caller uses marl_agent_unroll_fwd otherwise. */
 int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A, int last_action, int reuse_network);
 int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                              const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
-                             const float* h0, float* q, float* hs, float* h_last, int B, int T, int N, int O, int A,
-                             int last_action, int reuse_network, void* stream);
+                             const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T, int N,
+                             int O, int A, int last_action, int reuse_network, int cu_budget, float* gi_out,
+                             const float* gi_in, void* stream);
 
 /* ---- the same heads with the multiplies as an fp32-accurate SPLIT on the bf16 matrix cores (mlp3_x6.hip) -------------
  * Opt-in (args.gemm_mode = "bf16x6"; the default is the pair above on v_mfma_f32_16x16x4_f32).  Every fp32 operand is split

@@ -117,7 +117,8 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         if a.double_q:
             shifted = on is oc and on_bs == oc_bs and on_t0 == oc_t0 + 1
             split = self.pair.chain_split(B * N, T, a.obs_shape)
-            if shifted and ops.agent_unroll_reuse_supported(B, T, N, a.obs_shape, A, split[0] if split else 256):
+            if shifted and (self.eval_net.unroll_x6(B, T) or
+                            ops.agent_unroll_reuse_supported(B, T, N, a.obs_shape, A, split[0] if split else 256)):
                 gi = g("gi", ops.saved_shape(T, B, N, planes=3))
             cont = lambda cu: self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last,
                                                    ep_len=db.ep_len, ep_map=emap, cu_budget=cu, gi_in=gi)

@@ -106,6 +106,14 @@ class SharedMAC:
         return torch.argmax(q_value)
 
     # ------------------------------------------------------------------ batched primitives
+    def unroll_x6(self, B, T):
+        """True when a T-step unroll over B episodes runs on the bf16x6 split kernel (args.gemm_mode = "bf16x6" and a shape
+        csrc/agent_x6.hip covers)."""
+        from ..network import mixer as _mixer
+        return (T >= 4 and getattr(self.args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6"
+                and ops.agent_unroll_x6_supported(B, T, self.n_agents, self.obs_shape, self.n_actions, self.args.last_action,
+                                                  self.args.reuse_network))
+
     def unroll(self, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, B, T, q, hs=None, h_last=None, saved=None, h0="state",
                ep_len=None, ep_map=None, cu_budget=0, gi_out=None, gi_in=None):
         """T-step unroll over B episodes starting from self.hidden_states (or zeros if None)."""
@@ -113,6 +121,13 @@ class SharedMAC:
         N, A, O = self.n_agents, self.n_actions, self.obs_shape
         if h0 == "state":
             h0 = None if self.hidden_states is None else self.hidden_states.reshape(B * N, -1).contiguous()
+        if self.unroll_x6(B, T):
+            # opt-in: every product of the unroll as six bf16 MFMA products (csrc/agent_x6.hip); same `saved` layout, so the
+            # fp32 BPTT kernel runs from it; gi_out / gi_in pair up because every unroll of these dimensions comes here
+            ops.agent_unroll_fwd_x6(self.agent.weights(), obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
+                                    B, T, N, O, A, self.args.last_action, self.args.reuse_network, ep_len=ep_len, ep_map=ep_map,
+                                    cu_budget=cu_budget, gi_out=gi_out, gi_in=gi_in)
+            return
         ops.agent_unroll_fwd(self.agent.weights(), obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,
                              B, T, N, O, A, self.args.last_action, self.args.reuse_network, ep_len=ep_len, ep_map=ep_map,
                              cu_budget=cu_budget, gi_out=gi_out, gi_in=gi_in)

@@ -33,8 +33,12 @@ struct X6Args {
   const int* ep_len; const int* ep_map;
   const float* h0;
   float *q, *hs, *h_last;
+  float* saved;            // SAVE: (T+1) * R16 * 6 * 64 floats in agent.hip's tile layout
+  float* gi_out;           // SAVE: input-side gate sums for a later XS launch, or null
+  const float* gi_in;      // XS: gi_out of the eval unroll (its step t + 1 is this unroll's step t)
   int B, T, N, O, A, I, KI;        // KI: input width rounded up to 32
   int has_act, has_id, RT;
+  int n_full;              // workgroups that hold RT row tiles; the rest hold one
   long R;
 };
 
@@ -61,25 +65,57 @@ __device__ __forceinline__ F3 bfrag(const short* pl, int pitch, int ps, int c, i
   f.l = *reinterpret_cast<const i32x4*>(p + 2 * ps);
   return f;
 }
-// accumulator tile (units col + r of row m, r = 0..3) -> planes: four consecutive columns of row m, 8 bytes per plane
-__device__ __forceinline__ void put4(short* pl, int pitch, int ps, int col, int m, const f32x4& v) {
+// accumulator tile (rows row0 + r, r = 0..3, of column col) -> planes: one 2-byte write per row and plane
+__device__ __forceinline__ void put4(short* pl, int pitch, int ps, int row0, int col, const f32x4& v) {
   const F3h f = split4(v);
-  short* p = pl + m * pitch + col;
-  *reinterpret_cast<i32x2*>(p) = f.h;
-  *reinterpret_cast<i32x2*>(p + ps) = f.m;
-  *reinterpret_cast<i32x2*>(p + 2 * ps) = f.l;
+  short* p = pl + row0 * pitch + col;
+  const int d[3][2] = {{f.h[0], f.h[1]}, {f.m[0], f.m[1]}, {f.l[0], f.l[1]}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    p[k * ps] = (short)d[k][0];
+    p[k * ps + pitch] = (short)((unsigned)d[k][0] >> 16);
+    p[k * ps + 2 * pitch] = (short)d[k][1];
+    p[k * ps + 3 * pitch] = (short)((unsigned)d[k][1] >> 16);
+  }
 }
 __device__ __forceinline__ f32x4 relu4x(const f32x4& v) { return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+__device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
+// GRU gate math (common.h: gru_point_plain) with every fused / unfused operation spelled out: all instantiations round the same
+// way, so the launch that reads stored gate sums == the one that computes them, bit for bit, whatever the compiler would contract
+__device__ __forceinline__ void gru_point_x6(float ar, float az, float ain, float ahn, float hp, float& r, float& z, float& n, float& h) {
+  r = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(ar, -1.4426950408889634f))));
+  z = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(az, -1.4426950408889634f))));
+  const float e = __builtin_amdgcn_exp2f(__fmul_rn(__fmaf_rn(r, ahn, ain), 2.8853900817779268f));
+  n = __fmaf_rn(-2.0f, __builtin_amdgcn_rcpf(__fadd_rn(e, 1.0f)), 1.0f);
+  h = __fmaf_rn(z, hp, __fmul_rn(__fsub_rn(1.0f, z), n));
+}
+// offset (floats) into the tile layout of agent.hip's saved activations / gate sums: [t][row tile][plane][column tile c][lane][4]
+__device__ __forceinline__ long sv_off(long tile_t, int planes, int plane, int c, int lane) {
+  return ((tile_t * planes + plane) * 4 + c) * 256 + lane * 4;
+}
 
-template <int RTC>
+// Products are  D[row][unit] = act[row][k] W[unit][k]  (activations = A operand, weights = B operand): the accumulator layout -
+// lane (q, m): rows 4q + r of unit 16s + m - is the layout of agent.hip, so the saved activations (SAVE: six planes per row-step for
+// the fp32 BPTT kernel), the input-side gate sums an unroll stores (gi_out) and a later one reads (XS: gi_in) keep their formats.
+// SAVE: the eval network's pass.  XS: the double-Q continuation - team I computes only the steps flagged in xmask (the last step and
+// steps at which a row has ep_len - 1 == t), the other steps' sums come from gi_in (the eval pass's step t + 1).
+//
+// The two teams run DIFFERENT loops (same barrier sequence): each keeps only its own weights and working set in registers, and
+// the memory traffic of a loop is arranged so that no wave waits for a store to complete in the steady state -
+//   team I (not XS): observation loads (4 per thread, consumed one step later) and a FIXED number of stores per step (x plane and
+//          gate sums of RTC tiles; steps past the end and row tiles past the batch recompute the last valid one and store the
+//          same values again), so the wait for the loads is a counted vmcnt, not vmcnt(0);
+//   team R (not XS): stores only (saved planes, hs, q);      team R (XS): loads only (gate sums) - fc2 / q move to team I, which
+//          is idle in that variant except for the few steps it computes in full.
+template <int RTC, bool SAVE, bool XS, bool GIO = false>
 __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
+  static_assert(!(SAVE && XS) && (SAVE || !GIO), "XS: no saving; GIO: the saving pass also stores its input-side gate sums");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, s = wave & 3;      // team 0 = R (recurrent), team 1 = I (input side); hidden-unit slice s
   const int q = lane >> 4, m = lane & 15;
   const int rows = RTC * 16;
   const int IP = a.KI + 8;                        // pitch of the input planes
-  // LDS carve (bytes): per buffer parity b
   const int IN_B = 3 * rows * IP * 2, XP_B = 3 * rows * HP * 2, GI_B = RTC * 4 * 3 * 1024;
   short* In0 = reinterpret_cast<short*>(smem);                          // [2][3][rows][IP]
   short* Xp0 = reinterpret_cast<short*>(smem + 2 * IN_B);               // [2][3][rows][HP]
@@ -91,14 +127,18 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   int* rown = rowidx + rows;
   int* rowlen = rown + rows;
   int* rowrho = rowlen + rows;
-  // plane p of buffer b of a [2][3][rows][pitch] array: base + (b * 3 + p) * rows * pitch
+  int* xmask = rowrho + rows;                     // [T] (XS): step t is computed in full
   auto inp = [&](int b) { return In0 + b * 3 * rows * IP; };
   auto xpp = [&](int b) { return Xp0 + b * 3 * rows * HP; };
   auto hpp = [&](int b) { return Hp0 + b * 3 * rows * HP; };
 
+  // workgroups [0, n_full) hold RTC row tiles, the ones after them one tile each (the last round of a launch that runs in rounds)
   const long NTILES = (a.R + 15) >> 4;
-  const long row0 = (long)blockIdx.x * rows;
-  const int RTW = (int)((NTILES - (long)blockIdx.x * RTC) < RTC ? (NTILES - (long)blockIdx.x * RTC) : RTC);
+  const long bx = blockIdx.x;
+  const long tile0 = bx < a.n_full ? bx * RTC : (long)a.n_full * RTC + (bx - a.n_full);
+  const long row0 = tile0 * 16;
+  const int cap = bx < a.n_full ? RTC : 1;
+  const int RTW = (int)((NTILES - tile0) < cap ? (NTILES - tile0) : cap);
   for (int r = tid; r < rows; r += XNT) {
     long rho = row0 + r;
     if (rho > a.R - 1) rho = a.R - 1;             // clamped duplicates: same loads, same values, same stores
@@ -111,86 +151,11 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     rowlen[r] = a.ep_len ? a.ep_len[b] : 0x7fffffff;
     rowrho[r] = (int)rho;
   }
+  if (XS) for (int e = tid; e < a.T; e += XNT) xmask[e] = e == a.T - 1 ? 1 : 0;
   __syncthreads();
-
-  // ---- weights: registers, as pre-split A fragments
-  F3 wA[9];                                        // team I: fc1 (3 or 4 chunks... <= 3 here) + W_ih (3 gates x 2 chunks); team R: W_hh (6) + fc2 (2)
-  const int KC1 = a.KI >> 5;                       // k-chunks of fc1 (<= 3: I <= 96)
-  f32x4 bias_a, bias_r, bias_z, bias_n;            // team I: b1 | b_ir + b_hr, b_iz + b_hz, b_in ;  team R: b2 | b_hn in bias_n
-  {
-    const int u0 = 16 * s + 4 * q;
-    if (team == 1) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) wA[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wA[3 + 2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
-      bias_a = *reinterpret_cast<const f32x4*>(a.b1 + u0);
-      bias_r = *reinterpret_cast<const f32x4*>(a.bih + u0) + *reinterpret_cast<const f32x4*>(a.bhh + u0);
-      bias_z = *reinterpret_cast<const f32x4*>(a.bih + H + u0) + *reinterpret_cast<const f32x4*>(a.bhh + H + u0);
-      bias_n = *reinterpret_cast<const f32x4*>(a.bih + 2 * H + u0);
-    } else {
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wA[2 * g + c] = wfrag(a.Whh, H, g * H + 16 * s, 3 * H, H, c, lane);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) wA[6 + c] = wfrag(a.W2, H, 0, a.A, H, c, lane);
-      wA[8] = F3{};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bias_a[r] = 4 * q + r < a.A ? a.b2[4 * q + r] : 0.f;
-      bias_n = *reinterpret_cast<const f32x4*>(a.bhh + 2 * H + u0);
-      bias_r = bias_z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  }
-
-  // ---- observation prefetch: thread -> (row, 4-column group) of the tile, the same every step
-  const int O = a.O, O4 = O >> 2, n4 = rows * O4;
-  const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
-  f32x4 pf[NLD];
-  long goff[NLD]; int loff[NLD], plen[NLD];
-  int pt = 0, pu = -1, pu_lds0 = -1, pu_lds1 = -1;      // one-hot column currently set in each input buffer
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    int e = tid + XNT * i;
-    if (e > n4 - 1) e = n4 - 1;
-    const int r = (int)(((float)e + 0.5f) * invO4);
-    const int k4 = e - r * O4;
-    loff[i] = r * IP + 4 * k4;
-    goff[i] = rowobs[r] + 4 * k4;
-    plen[i] = rowlen[r];
-  }
-  const long urow = tid < rows ? rowu[tid] : 0;
-  auto issue = [&](int t) {
-    const long toff = (long)(t + a.obs_t0) * a.N * O;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
-    pt = t;
-    int u = -1;
-    if (tid < rows && a.ufed && t + a.u_t0 >= 0) u = a.ufed[urow + (long)(t + a.u_t0) * a.N];
-    pu = u;
-  };
-  auto commit = [&](int b, int& pu_lds) {          // prefetch registers -> input planes of buffer b (split once, here)
-    short* P = inp(b);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const f32x4 v = pt < plen[i] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      const F3h f = split4(v);
-      *reinterpret_cast<i32x2*>(P + loff[i]) = f.h;
-      *reinterpret_cast<i32x2*>(P + rows * IP + loff[i]) = f.m;
-      *reinterpret_cast<i32x2*>(P + 2 * rows * IP + loff[i]) = f.l;
-    }
-    if (a.has_act && tid < rows) {                 // one-hot(last action): bf16 1.0 in the hi plane, flipped in place
-      const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
-      if (pn != pu_lds) {
-        if (pu_lds >= 0) P[tid * IP + O + pu_lds] = 0;
-        if (pn >= 0) P[tid * IP + O + pn] = (short)0x3F80;
-        pu_lds = pn;
-      }
-    }
-  };
+  if (XS && tid < RTW * 16) { const int L = rowlen[tid]; if (L >= 1 && L - 1 < a.T) xmask[L - 1] = 1; }
   // constant columns of both input buffers: empty one-hot, agent id, zero pad - all three planes
+  const int O = a.O;
   for (int e = tid; e < 2 * 3 * rows * (a.KI - O); e += XNT) {
     const int w = a.KI - O, rr = e / w, k = O + e % w;        // rr = (b * 3 + plane) * rows + row
     const int plane = (rr / rows) % 3, r = rr % rows;
@@ -198,107 +163,255 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     if (plane == 0 && a.has_id && k >= a.I - a.N && k < a.I && rown[r] == k - (a.I - a.N)) v = (short)0x3F80;
     In0[rr * IP + k] = v;
   }
-  // initial hidden state: fp32 registers of team R (units 16s + 4q + r of row m) and planes Hp[0]
-  f32x4 hreg[RTC];
-#pragma unroll
-  for (int rt = 0; rt < RTC; ++rt) {
-    hreg[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.h0) hreg[rt] = *reinterpret_cast<const f32x4*>(a.h0 + (long)rowrho[rt * 16 + m] * H + 16 * s + 4 * q);
-    if (team == 0) put4(hpp(0) + rt * 16 * HP, HP, rows * HP, 16 * s + 4 * q, m, hreg[rt]);
-  }
-  __syncthreads();
   const int Tm1 = a.T - 1;
-  issue(0); commit(0, pu_lds0);
-  issue(Tm1 < 1 ? Tm1 : 1); commit(1, pu_lds1);
-  issue(Tm1 < 2 ? Tm1 : 2);
-  WG_BARRIER();
+  const int KC1 = a.KI >> 5;
+  const int u = 16 * s + m;
+  auto full = [&](int t) { return !XS || xmask[t < Tm1 ? t : Tm1] != 0; };      // step t's input side is computed here
+  ST_DECL(4);
 
-  // x(ts) = relu(fc1(in)) of every row tile: this wave's 16 units -> planes Xp[bx]
-  auto fc1 = [&](int bin, int bx) __attribute__((always_inline)) {
+  if (team == 1) {
+    // =============================== team I: everything that depends only on a step's input ===============================
+    const int ti = tid - 256;
+    F3 w1[3], wi[6], w2[2];                        // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
 #pragma unroll
-    for (int rt = 0; rt < RTC; ++rt) {
-      if (rt >= RTW) break;
-      f32x4 acc = bias_a;
+    for (int c = 0; c < 3; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (c < KC1) mm6(wA[c], bfrag(inp(bin) + rt * 16 * IP, IP, rows * IP, c, lane), acc);
-      put4(xpp(bx) + rt * 16 * HP, HP, rows * HP, 16 * s + 4 * q, m, relu4x(acc));
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wi[2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
+    if (XS) { w2[0] = wfrag(a.W2, H, 0, a.A, H, 0, lane); w2[1] = wfrag(a.W2, H, 0, a.A, H, 1, lane); }
+    const float bias_1 = a.b1[u], bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u];
+    const float bias_2 = XS && m < a.A ? a.b2[m] : 0.f;
+
+    // observation prefetch: thread -> (row, 4-column group) of the tile, the same every step
+    const int O4 = O >> 2, n4 = rows * O4;
+    const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
+    f32x4 pf[NLD];
+    long goff[NLD]; int prk[NLD];                  // (row << 16) | first column of the thread's float4
+    int pt = 0, pu = -1, pu_lds0 = -1, pu_lds1 = -1;      // one-hot column currently set in each input buffer
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int e = ti + 256 * i;
+      if (e > n4 - 1) e = n4 - 1;
+      const int r = (int)(((float)e + 0.5f) * invO4);
+      const int k4 = e - r * O4;
+      prk[i] = (r << 16) | (4 * k4);
+      goff[i] = rowobs[r] + 4 * k4;
     }
-  };
-  // gi(ts) = bias + x W_ih of every row tile -> GI[bg] (accumulator layout, for the R wave of this slice)
-  auto gih = [&](int bx, int bg) __attribute__((always_inline)) {
+    const long urow = ti < rows ? rowu[ti] : 0;
+    auto issue = [&](int t) {
+      const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
-    for (int rt = 0; rt < RTC; ++rt) {
-      if (rt >= RTW) break;
-      f32x4 ar = bias_r, az = bias_z, an = bias_n;
+      for (int i = 0; i < NLD; ++i) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
+      pt = t;
+      int uu = -1;
+      if (ti < rows && a.ufed && t + a.u_t0 >= 0) uu = a.ufed[urow + (long)(t + a.u_t0) * a.N];
+      pu = uu;
+    };
+    auto commit = [&](int b, int& pu_lds) {        // prefetch registers -> input planes of buffer b (split once, here)
+      short* P = inp(b);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const F3 xb = bfrag(xpp(bx) + rt * 16 * HP, HP, rows * HP, c, lane);
-        mm6(wA[3 + c], xb, ar); mm6(wA[5 + c], xb, az); mm6(wA[7 + c], xb, an);
+      for (int i = 0; i < NLD; ++i) {
+        const int r = prk[i] >> 16, lo = r * IP + (prk[i] & 0xffff);
+        const f32x4 v = pt < rowlen[r] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const F3h f = split4(v);
+        *reinterpret_cast<i32x2*>(P + lo) = f.h;
+        *reinterpret_cast<i32x2*>(P + rows * IP + lo) = f.m;
+        *reinterpret_cast<i32x2*>(P + 2 * rows * IP + lo) = f.l;
       }
-      f32x4* gp = reinterpret_cast<f32x4*>(GI0) + ((bg * RTC + rt) * 4 + s) * 192 + lane;
-      gp[0] = ar; gp[64] = az; gp[128] = an;
+      if (a.has_act && ti < rows) {                // one-hot(last action): bf16 1.0 in the hi plane, flipped in place
+        const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
+        if (pn != pu_lds) {
+          if (pu_lds >= 0) P[ti * IP + O + pu_lds] = 0;
+          if (pn >= 0) P[ti * IP + O + pn] = (short)0x3F80;
+          pu_lds = pn;
+        }
+      }
+    };
+    // x(ts) = relu(fc1(in)) of every row tile: this wave's 16 units -> planes Xp[bx] (and plane 1 of the saved activations).
+    // Row tiles past the batch recompute the last valid one (a fixed number of stores per call, see above).
+    auto fc1 = [&](int bin, int bxx, int ts) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+        const int rr = rt < RTW ? rt : RTW - 1;
+        f32x4 acc = splat(bias_1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (c < KC1) mm6(bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c, lane), w1[c], acc);
+        acc = relu4x(acc);
+        put4(xpp(bxx), HP, rows * HP, rr * 16 + 4 * q, u, acc);
+        if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off((long)ts * NTILES + tile0 + rr, 6, 1, s, lane)) = acc;
+      }
+    };
+    // gi(ts) = bias + x W_ih of every row tile -> GI[bg] (for the R wave of this slice) and gi_out
+    auto gih = [&](int bxx, int bg, int ts) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+        const int rr = rt < RTW ? rt : RTW - 1;
+        f32x4 ar = splat(bias_r), az = splat(bias_z), an = splat(bias_n);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const F3 xb = bfrag(xpp(bxx) + rr * 16 * HP, HP, rows * HP, c, lane);
+          mm6(xb, wi[c], ar); mm6(xb, wi[2 + c], az); mm6(xb, wi[4 + c], an);
+        }
+        f32x4* gp = reinterpret_cast<f32x4*>(GI0) + ((bg * RTC + rr) * 4 + s) * 192 + lane;
+        gp[0] = ar; gp[64] = az; gp[128] = an;
+        if (GIO) {
+          float* const go = a.gi_out + sv_off((long)ts * NTILES + tile0 + rr, 3, 0, s, lane);
+          *reinterpret_cast<f32x4*>(go) = ar;
+          *reinterpret_cast<f32x4*>(go + 1024) = az;
+          *reinterpret_cast<f32x4*>(go + 2048) = an;
+        }
+      }
+    };
+    // XS: q(ts) = fc2(h) of row tile rt from planes Hp[bh]
+    auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
+      f32x4 acc = splat(bias_2);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) mm6(bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane), w2[c], acc);
+      if (m < a.A) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + m] = acc[r];
+      }
+    };
+
+    __syncthreads();                               // constant columns, h0 planes (team R), step flags
+    issue(0); commit(0, pu_lds0);
+    issue(Tm1 < 1 ? Tm1 : 1); commit(1, pu_lds1);
+    issue(Tm1 < 2 ? Tm1 : 2);
+    WG_BARRIER();                                  // A: input planes of steps 0 and 1
+    if (full(0)) fc1(0, 0, 0);
+    if (full(1)) fc1(1, 1, 1);
+    WG_BARRIER();                                  // B: x(0), x(1)
+    commit(0, pu_lds0);                            // input(2)
+    if (!XS) issue(Tm1 < 3 ? Tm1 : 3);
+    if (full(0)) gih(0, 0, 0);
+    WG_BARRIER();                                  // C: gi(0), input(2)
+    for (int t = 0; t < a.T; ++t) {
+      const int par = t & 1;
+      if (!XS) {
+        // steps past the end recompute step T - 1 (its input tile is what the clamped loads brought) and store the same values
+        gih(par ^ 1, par ^ 1, t + 1 < a.T ? t + 1 : Tm1);        // gi(t+1) from x(t+1)
+        ST_MARK(0);
+        fc1(par, par, t + 2 < a.T ? t + 2 : Tm1);                // x(t+2) from input(t+2) -> the buffer x(t) has left
+        ST_MARK(1);
+        // input tile of step t+3 -> the buffer fc1(t+1) finished with in the previous step; start the loads of step t+4
+        if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
+        issue(t + 4 < a.T ? t + 4 : Tm1);
+        ST_MARK(2);
+      } else {
+        if (t + 1 < a.T && full(t + 1)) gih(par ^ 1, par ^ 1, t + 1);
+        if (t + 2 < a.T && full(t + 2)) fc1(par, par, t + 2);
+        if (t > 0 && s < RTW) fc2(par, t - 1, s);                // q(t-1) from h fed into step t (RTC <= 4 tiles: one per wave)
+        if (t + 3 < a.T && xmask[t + 3]) {         // rare: the load is not hidden behind a step
+          issue(t + 3);
+          if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
+        }
+      }
+      WG_BARRIER();
+      ST_MARK(3);
     }
-  };
-  // q(ts) = fc2(h) of row tile rt from planes Hp[bh]
-  auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
-    f32x4 acc = bias_a;
+    if (XS && s < RTW) fc2(a.T & 1, a.T - 1, s);   // q of the last step
+    ST_DUMP(4);
+  } else {
+    // =============================== team R: the recurrent part of a step ===============================
+    F3 wh[6], w2[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) mm6(wA[6 + c], bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane), acc);
-    const int ri = rowidx[rt * 16 + m];
-    float* qp = a.q + ((long)ri + (long)ts * a.N) * a.A + 4 * q;
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * q + r < a.A) qp[r] = acc[r];
-  };
-
-  // prologue: x(0), x(1) by team I; then input(2) -> In[0], gi(0)
-  if (team == 1) { fc1(0, 0); if (a.T > 1) fc1(1, 1); }
-  WG_BARRIER();
-  commit(0, pu_lds0);
-  issue(Tm1 < 3 ? Tm1 : 3);
-  if (team == 1) gih(0, 0);
-  WG_BARRIER();
-
-  for (int t = 0; t < a.T; ++t) {
-    const int par = t & 1;
-    if (team == 1) {
-      if (t + 1 < a.T) gih(par ^ 1, par ^ 1);                 // gi(t+1) from x(t+1)
-      if (t + 2 < a.T) fc1(par, par);                         // x(t+2) from input(t+2) -> the buffer x(t) has left
-    } else {
+      for (int c = 0; c < 2; ++c) wh[2 * g + c] = wfrag(a.Whh, H, g * H + 16 * s, 3 * H, H, c, lane);
+    if (!XS) { w2[0] = wfrag(a.W2, H, 0, a.A, H, 0, lane); w2[1] = wfrag(a.W2, H, 0, a.A, H, 1, lane); }
+    const float bias_hn = a.bhh[2 * H + u];
+    const float bias_2 = !XS && m < a.A ? a.b2[m] : 0.f;
+    // initial hidden state: fp32 registers (rows 4q + r of unit 16s + m) and planes Hp[0]
+    f32x4 hreg[RTC];
+#pragma unroll
+    for (int rt = 0; rt < RTC; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hreg[rt][r] = a.h0 ? a.h0[(long)rowrho[rt * 16 + 4 * q + r] * H + u] : 0.f;
+      put4(hpp(0), HP, rows * HP, rt * 16 + 4 * q, u, hreg[rt]);
+    }
+    auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
+      f32x4 acc = splat(bias_2);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) mm6(bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane), w2[c], acc);
+      if (m < a.A) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + m] = acc[r];
+      }
+    };
+    // XS: stored input-side sums of the NEXT row tile (accumulator layout = the storing kernel's), a tile ahead
+    f32x4 gB[3];
+    auto gissue = [&](int ts, int rt) {
+      if (XS) {
+        const float* gp = a.gi_in + sv_off((long)ts * NTILES + tile0 + rt, 3, 0, s, lane);
+        gB[0] = *reinterpret_cast<const f32x4*>(gp);
+        gB[1] = *reinterpret_cast<const f32x4*>(gp + 1024);
+        gB[2] = *reinterpret_cast<const f32x4*>(gp + 2048);
+      }
+    };
+    __syncthreads();
+    if (XS) gissue(Tm1 < 1 ? Tm1 : 1, 0);          // (step 0's sums = the storing unroll's step 1)
+    WG_BARRIER();                                  // A
+    WG_BARRIER();                                  // B
+    WG_BARRIER();                                  // C
+    for (int t = 0; t < a.T; ++t) {
+      const int par = t & 1;
+      const bool fl = full(t);
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         if (rt >= RTW) break;
         const f32x4* gp = reinterpret_cast<const f32x4*>(GI0) + ((par * RTC + rt) * 4 + s) * 192 + lane;
-        f32x4 ar = gp[0], az = gp[64], an = gp[128], ahn = bias_n;
+        f32x4 ar, az, an, ahn = splat(bias_hn);
+        if (fl) { ar = gp[0]; az = gp[64]; an = gp[128]; }
+        else { ar = gB[0]; az = gB[1]; an = gB[2]; }
+        if (XS) {                                    // the next tile: this step's, or tile 0 of the next step (stored step + 1)
+          const bool same = rt + 1 < RTW;
+          const int nts = same ? t + 1 : t + 2;
+          if (nts < a.T) gissue(nts, same ? rt + 1 : 0);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const F3 hb = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, c, lane);
-          mm6(wA[c], hb, ar); mm6(wA[2 + c], hb, az); mm6(wA[4 + c], hb, ahn);
+          mm6(hb, wh[c], ar); mm6(hb, wh[2 + c], az); mm6(hb, wh[4 + c], ahn);
         }
-        f32x4 hn;
+        ST_MARK(0);
+        f32x4 vr, vz, vn, hn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float r_, z_, n_, h_;
-          gru_point_plain(ar[r], az[r], an[r], ahn[r], hreg[rt][r], r_, z_, n_, h_);
-          hn[r] = h_;
+          gru_point_x6(ar[r], az[r], an[r], ahn[r], hreg[rt][r], r_, z_, n_, h_);
+          vr[r] = r_; vz[r] = z_; vn[r] = n_; hn[r] = h_;
+        }
+        put4(hpp(par ^ 1), HP, rows * HP, rt * 16 + 4 * q, u, hn);
+        ST_MARK(1);
+        if (SAVE) {
+          float* const sp = a.saved + sv_off((long)t * NTILES + tile0 + rt, 6, 0, s, lane);      // plane k at sp + 1024 k
+          *reinterpret_cast<f32x4*>(sp) = hreg[rt];
+          *reinterpret_cast<f32x4*>(sp + 2 * 1024) = vr;
+          *reinterpret_cast<f32x4*>(sp + 3 * 1024) = vz;
+          *reinterpret_cast<f32x4*>(sp + 4 * 1024) = vn;
+          *reinterpret_cast<f32x4*>(sp + 5 * 1024) = ahn;
+          if (t == a.T - 1) *reinterpret_cast<f32x4*>(sp + NTILES * (6 * 1024)) = hn;      // h after the last step: plane 0 of step T
         }
         hreg[rt] = hn;
-        put4(hpp(par ^ 1) + rt * 16 * HP, HP, rows * HP, 16 * s + 4 * q, m, hn);
-        const int ri = rowidx[rt * 16 + m];
-        if (a.hs) *reinterpret_cast<f32x4*>(a.hs + ((long)ri + (long)t * a.N) * H + 16 * s + 4 * q) = hn;
-        if (t == a.T - 1 && a.h_last) *reinterpret_cast<f32x4*>(a.h_last + (long)rowrho[rt * 16 + m] * H + 16 * s + 4 * q) = hn;
+        if (a.hs) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a.hs[((long)rowidx[rt * 16 + 4 * q + r] + (long)t * a.N) * H + u] = hn[r];
+        }
+        if (t == a.T - 1 && a.h_last) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a.h_last[(long)rowrho[rt * 16 + 4 * q + r] * H + u] = hn[r];
+        }
       }
-      if (t > 0)
-        for (int rt = s; rt < RTW; rt += 4) fc2(par, t - 1, rt);     // q(t-1) from h fed into step t
+      if (!XS && t > 0 && s < RTW) fc2(par, t - 1, s);           // q(t-1) from h fed into step t
+      ST_MARK(2);
+      WG_BARRIER();
+      ST_MARK(3);
     }
-    // input tile of step t+3 -> the buffer fc1(t+1) finished with in the previous step; start the loads of step t+4
-    if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
-    issue(t + 4 < a.T ? t + 4 : Tm1);
-    WG_BARRIER();
+    if (!XS && s < RTW) fc2(a.T & 1, a.T - 1, s);                // q of the last step
+    ST_DUMP(4);
   }
-  if (team == 0)
-    for (int rt = s; rt < RTW; rt += 4) fc2(a.T & 1, a.T - 1, rt);   // q of the last step
 }
 
 }  // namespace
@@ -314,38 +427,55 @@ extern "C" int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A,
 
 extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                                         const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
-                                        const float* h0, float* q, float* hs, float* h_last, int B, int T, int N, int O, int A,
-                                        int last_action, int reuse_network, void* stream) {
+                                        const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T, int N,
+                                        int O, int A, int last_action, int reuse_network, int cu_budget, float* gi_out,
+                                        const float* gi_in, void* stream) {
   if (B <= 0 || T <= 0) return 0;
-  if (w->H != H || !marl_agent_unroll_x6_supported(B, T, N, O, A, last_action, reuse_network)) return (int)hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(obs) & 15) || (reinterpret_cast<uintptr_t>(w->b_ih) & 15) || (reinterpret_cast<uintptr_t>(w->b_hh) & 15) ||
-      (reinterpret_cast<uintptr_t>(w->fc1_b) & 15) || (h0 && (reinterpret_cast<uintptr_t>(h0) & 15)) || (hs && (reinterpret_cast<uintptr_t>(hs) & 15)) ||
-      (h_last && (reinterpret_cast<uintptr_t>(h_last) & 15)))
+  if (w->H != H || cu_budget < 0 || cu_budget > 256 || !marl_agent_unroll_x6_supported(B, T, N, O, A, last_action, reuse_network))
     return (int)hipErrorInvalidValue;
+  if (saved && gi_in) return (int)hipErrorInvalidValue;      // a launch stores the input-side sums or reads them
+  if ((reinterpret_cast<uintptr_t>(obs) & 15) || (h0 && (reinterpret_cast<uintptr_t>(h0) & 3)) || (saved && (reinterpret_cast<uintptr_t>(saved) & 15)) ||
+      (gi_out && (reinterpret_cast<uintptr_t>(gi_out) & 15)) || (gi_in && (reinterpret_cast<uintptr_t>(gi_in) & 15)))
+    return (int)hipErrorInvalidValue;
+  if (cu_budget == 0) cu_budget = 256;
   X6Args a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh; a.W2 = w->fc2_w; a.b2 = w->fc2_b;
   a.obs = obs; a.obs_bs = obs_bs; a.obs_t0 = obs_t0; a.ufed = ufed; a.u_bs = u_bs; a.u_t0 = u_t0; a.ep_len = ep_len; a.ep_map = ep_map;
-  a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last;
+  a.h0 = h0; a.q = q; a.hs = hs; a.h_last = h_last; a.saved = saved; a.gi_out = saved ? gi_out : nullptr; a.gi_in = gi_in;
   a.B = B; a.T = T; a.N = N; a.O = O; a.A = A;
   a.has_act = last_action ? 1 : 0; a.has_id = reuse_network ? 1 : 0;
   a.I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   a.KI = (a.I + 31) / 32 * 32;
   a.R = (long)B * N;
   const long tiles = (a.R + 15) / 16;
-  // two row tiles per workgroup once there are more tiles than CUs (the prefetch registers cover NLD * 512 float4 = 2 tiles of O <= 256)
-  const int rt = tiles > 256 && 2 * 16 * (O / 4) <= NLD * XNT ? 2 : 1;
-  if (rt * 16 * (O / 4) > NLD * XNT) return (int)hipErrorInvalidValue;
+  // two row tiles per workgroup once there are more tiles than CUs this launch may occupy (more than two do not fit LDS: larger
+  // batches run in rounds of workgroups, and when the last round is at most one tile per CU its workgroups hold one tile each)
+  const int rt = tiles > cu_budget ? 2 : 1;
+  if (rt * 16 * (O / 4) > NLD * 256) return (int)hipErrorInvalidValue;      // (team I's 256 threads prefetch the observation tile)
   a.RT = rt;
+  long n_wg = (tiles + rt - 1) / rt;
+  a.n_full = (int)n_wg;
+  if (rt == 2) {
+    const long k = (tiles + 2 * cu_budget - 1) / (2 * cu_budget), rem = tiles - 2L * cu_budget * (k - 1);
+    if (rem <= cu_budget) { a.n_full = (int)(cu_budget * (k - 1)); n_wg = a.n_full + rem; }
+  }
   const int rows = rt * 16, IP = a.KI + 8;
-  const size_t lds = (size_t)2 * 3 * rows * IP * 2 + (size_t)4 * 3 * rows * HP * 2 + (size_t)2 * rt * 4 * 3 * 1024 + (size_t)rows * (2 * 8 + 4 * 4);
+  const size_t lds = (size_t)2 * 3 * rows * IP * 2 + (size_t)4 * 3 * rows * HP * 2 + (size_t)2 * rt * 4 * 3 * 1024 + (size_t)rows * (2 * 8 + 4 * 4) +
+                     (((size_t)T * 4 + 15) & ~(size_t)15);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  const void* fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2> : (const void*)agent_fwd_x6_kernel<1>;
+  const void* fn;
+  if (saved && a.gi_out) fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, true, false, true> : (const void*)agent_fwd_x6_kernel<1, true, false, true>;
+  else if (saved) fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, true, false> : (const void*)agent_fwd_x6_kernel<1, true, false>;
+  else if (gi_in) fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, false, true> : (const void*)agent_fwd_x6_kernel<1, false, true>;
+  else fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, false, false> : (const void*)agent_fwd_x6_kernel<1, false, false>;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  dim3 grid((unsigned)((tiles + rt - 1) / rt)), block(XNT);
+  dim3 grid((unsigned)n_wg), block(XNT);
   void* kargs[] = {(void*)&a};
   e = hipLaunchKernel(fn, grid, block, kargs, lds, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   MARL_CHECK_LAUNCH();
   return 0;
 }
+
+ST_DEFINE_SETTER(marl_debug_stamps_agent_x6)

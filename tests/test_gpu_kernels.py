@@ -677,7 +677,7 @@ def test_saving_unroll_variants_equal_register_prefetch_bitwise(dev, shape, B, T
 @pytest.mark.parametrize("B,T,with_h0,ragged", [(7, 5, False, False), (70, 6, True, True), (3, 4, True, False), (900, 9, False, True),
                                                  (2100, 12, True, True)])
 def test_agent_unroll_x6_split(dev, B, T, with_h0, ragged):
-    """Forward-only unroll on the bf16x6 split kernels (csrc/agent_x6.hip, opt-in gemm_mode): q, hs and the final hidden state
+    """Unroll that saves nothing on the bf16x6 split kernels (csrc/agent_x6.hip, opt-in gemm_mode): q, hs and the final hidden state
     against the CPU oracle at the bound of test_agent_unroll_fwd (1e-4), and beside the fp32 MFMA kernel on the same inputs -
     (T+1)-slot storage read through an episode map with the shifted last action, ragged episode lengths (rows past their end
     feed zeros), a carried hidden state, partial last row tile, one and two row tiles per workgroup (> 256 tiles)."""
@@ -701,7 +701,7 @@ def test_agent_unroll_x6_split(dev, B, T, with_h0, ragged):
         q, hs, hl = torch.full((B, T, N, A), 9.0, device=dev), torch.full((B, T, N, 64), 9.0, device=dev), torch.full((B * N, 64), 9.0, device=dev)
         h0d = cu(h0, dev) if h0 is not None else None
         if mode == "x6":
-            ops.agent_unroll_fwd_x6(w, sd, (T + 1) * N, 1, ud, T * N, 0, h0d, q, hs, hl, B, T, N, O, A, ep_len=ld, ep_map=ed)
+            ops.agent_unroll_fwd_x6(w, sd, (T + 1) * N, 1, ud, T * N, 0, h0d, q, hs, hl, None, B, T, N, O, A, ep_len=ld, ep_map=ed)
         else:
             ops.agent_unroll_fwd(w, sd, (T + 1) * N, 1, ud, T * N, 0, h0d, q, hs, hl, None, B, T, N, O, A, ep_len=ld, ep_map=ed)
         outs[mode] = (q.cpu(), hs.cpu(), hl.cpu())
@@ -717,6 +717,87 @@ def test_agent_unroll_x6_split(dev, B, T, with_h0, ragged):
     e6 = float((outs["x6"][0].double() - q_ref.double()).abs().max())
     e32 = float((outs["f32"][0].double() - q_ref.double()).abs().max())
     print("agent unroll B=%d T=%d: max |q - oracle|: bf16x6 %.2e, fp32 MFMA %.2e" % (B, T, e6, e32))
+
+
+@pytest.mark.parametrize("B,T,cus", [(37, 5, 0), (700, 6, 48), (9, 4, 2), (300, 7, 256), (1700, 5, 128)])
+def test_agent_unroll_x6_saved_planes_and_gate_sum_reuse(dev, B, T, cus):
+    """The activation-saving and the gate-sum-reading variants of the split unroll (csrc/agent_x6.hip):
+      * the six saved planes, the stored input-side sums, q and the final hidden state of the eval pass == the fp32 MFMA
+        kernel's within 1e-4 (same tile layout: decoded with ops.saved_plane);
+      * the continuation over slots 1..T that READS the stored sums == the same launch computing everything, bit for bit
+        (ragged episode lengths: steps ep_len - 1 and T - 1 are computed in full; episode map; carried hidden state;
+        partial last row tile; one and two row tiles per workgroup by CU budget)."""
+    from marl_amd import ops
+    args, p_np, _, _, _ = _agent_case("2s3z", B, T, dev)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    rng = np.random.default_rng(B + T)
+    E = B + 3
+    store = cu(rng.standard_normal((E, T + 1, N, O)).astype(np.float32), dev)
+    u = cu(rng.integers(-1, A, size=(B, T, N)), dev, torch.int32)
+    emap = cu(rng.permutation(E)[:B], dev, torch.int32)
+    lens = rng.integers(1, T + 1, size=B)
+    lens[0], lens[-1] = T, 1
+    ep_len = cu(lens, dev, torch.int32)
+    w = ops.agent_weights({k: cu(v, dev) for k, v in p_np.items()})
+    rows = B * N
+    ev = {}
+    for mode in ("x6", "f32"):
+        saved = torch.full(ops.saved_shape(T, B, N), float("nan"), device=dev)
+        gi = torch.full(ops.saved_shape(T, B, N, planes=3), float("nan"), device=dev)
+        q0, h_last = torch.empty(B, T, N, A, device=dev), torch.empty(B * N, 64, device=dev)
+        fn = ops.agent_unroll_fwd_x6 if mode == "x6" else ops.agent_unroll_fwd
+        fn(w, store, (T + 1) * N, 0, u, T * N, -1, None, q0, None, h_last, saved, B, T, N, O, A,
+           ep_len=ep_len, ep_map=emap, cu_budget=cus, gi_out=gi)
+        ev[mode] = (q0, h_last, saved, gi)
+    close(ev["x6"][0], ev["f32"][0], 1e-4, msg="q")
+    close(ev["x6"][1], ev["f32"][1], 1e-4, msg="h_last")
+    for k in range(6):
+        close(ops.saved_plane(ev["x6"][2], k, rows), ops.saved_plane(ev["f32"][2], k, rows), 1e-4, msg="saved plane %d" % k)
+    for k in range(3):
+        close(ops.saved_plane(ev["x6"][3], k, rows), ops.saved_plane(ev["f32"][3], k, rows), 1e-4, msg="gate sums %d" % k)
+    _, h_last, _, gi = ev["x6"]
+    outs = []
+    for reuse in (True, False):
+        q, hl = torch.empty(B, T, N, A, device=dev), torch.empty(B * N, 64, device=dev)
+        ops.agent_unroll_fwd_x6(w, store, (T + 1) * N, 1, u, T * N, 0, h_last, q, None, hl, None, B, T, N, O, A,
+                                ep_len=ep_len, ep_map=emap, cu_budget=cus, gi_in=gi if reuse else None)
+        outs.append((q.cpu(), hl.cpu()))
+    assert torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("B,T", [(7, 5), (40, 6), (700, 4)])
+def test_agent_unroll_bwd_from_x6_saved(dev, B, T):
+    """BPTT (the fp32 kernels) from the activations the split unroll saved: gradients vs torch autograd of the oracle unroll at
+    the bounds of test_agent_unroll_bwd."""
+    from marl_amd import ops
+    args, p_np, obs, ufed, h0 = _agent_case("2s3z", B, T, dev, seed=1)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    I = O + A + N
+    p, q_ref, hs_ref, _ = _oracle_unroll(args, p_np, obs, ufed, None, requires_grad=True)
+    g = torch.Generator().manual_seed(2)
+    dq = torch.randn(B, T, N, A, generator=g)
+    dhs = torch.randn(B, T, N, 64, generator=g) * 0.3
+    ((q_ref * dq).sum() + (hs_ref * dhs).sum()).backward()
+    pd = {k: cu(v, dev) for k, v in p_np.items()}
+    w = ops.agent_weights(pd)
+    q, hs = torch.empty(B, T, N, A, device=dev), torch.empty(B, T, N, 64, device=dev)
+    saved = torch.empty(ops.saved_shape(T, B, N), device=dev)
+    obs_d, u_d = cu(obs, dev), cu(ufed, dev, torch.int32)
+    ops.agent_unroll_fwd_x6(w, obs_d, T * N, 0, u_d, T * N, 0, None, q, hs, None, saved, B, T, N, O, A)
+    close(q, q_ref.detach(), 1e-4, msg="q")
+    dxp = torch.empty(B, T, N, 64, device=dev)
+    M = B * T * N
+    grads = {k: torch.zeros_like(v) for k, v in pd.items()}
+    ops.agent_unroll_bwd(w, cu(dq, dev), cu(dhs, dev), saved, hs, dxp, None,
+                         {k: grads[k] for k in ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh",
+                                                "fc2.weight", "fc2.bias")}, B, T, N, A)
+    ops.linear_wgrad(dxp.view(M, 64), ops.src(obs_d.view(M, O), idx=u_d.view(M, 1), nhot=1, hot_w=A, nid=N),
+                     grads["fc1.weight"], grads["fc1.bias"], M, 64, I)
+    for k in p:
+        ref = p[k].grad
+        scale = max(1.0, float(ref.abs().max()))
+        close(grads[k] / scale, ref / scale, 2e-4, 1e-3, msg=k)
 
 
 @pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
