@@ -43,6 +43,8 @@ struct X6Args {
 };
 
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// the six products of a split multiply, smallest first (x6.h: mm6), for schedules that interleave several accumulators
+#define X6_TERMS(OP) OP(m, m) OP(h, l) OP(l, h) OP(h, m) OP(m, h) OP(h, h)
 
 // A fragment of W (row-major, ldw floats per row): A[i][slot j] = W[row0 + i][32 c + 8g + j]  (rows >= rows_valid and columns >= K: 0)
 __device__ __forceinline__ F3 wfrag(const float* W, int ldw, int row0, int rows_valid, int K, int c, int lane) {
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     // observation prefetch: thread -> (row, 4-column group) of the tile, the same every step
     const int O4 = O >> 2, n4 = rows * O4;
     const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
+    const int NS = (n4 + 255) >> 8;               // prefetch slots (float4 per thread) the tile fills
     f32x4 pf[NLD];
     long goff[NLD]; int prk[NLD];                  // (row << 16) | first column of the thread's float4
     int pt = 0, pu = -1, pu_lds0 = -1, pu_lds1 = -1;      // one-hot column currently set in each input buffer
@@ -202,7 +205,8 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     auto issue = [&](int t) {
       const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
+      for (int i = 0; i < NLD; ++i)
+        if (i < NS) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
       pt = t;
       int uu = -1;
       if (ti < rows && a.ufed && t + a.u_t0 >= 0) uu = a.ufed[urow + (long)(t + a.u_t0) * a.N];
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       short* P = inp(b);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
+        if (i >= NS) break;
         const int r = prk[i] >> 16, lo = r * IP + (prk[i] & 0xffff);
         const f32x4 v = pt < rowlen[r] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
         const F3h f = split4(v);
@@ -234,13 +239,24 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         const int rr = rt < RTW ? rt : RTW - 1;
-        f32x4 acc = splat(bias_1);
+        // one accumulator per 32-wide k chunk: three independent chains of six products, issued round robin; chunks past the
+        // input width multiply chunk 0 by zero weights
+        // (XS: the few steps computed in full - one chunk at a time, fewer registers; the same sums in the same order)
+        f32x4 acc[3] = {splat(bias_1), splat(0.f), splat(0.f)};
+        if (XS) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          if (c < KC1) mm6(bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c, lane), w1[c], acc);
-        acc = relu4x(acc);
-        put4(xpp(bxx), HP, rows * HP, rr * 16 + 4 * q, u, acc);
-        if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off((long)ts * NTILES + tile0 + rr, 6, 1, s, lane)) = acc;
+          for (int c = 0; c < 3; ++c) mm6(bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c < KC1 ? c : 0, lane), w1[c], acc[c]);
+        } else {
+          F3 xi[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xi[c] = bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c < KC1 ? c : 0, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) acc[c] = mm(xi[c].p_, w1[c].q_, acc[c]);
+          X6_TERMS(OP)
+#undef OP
+        }
+        const f32x4 x = relu4x((acc[0] + acc[1]) + acc[2]);
+        put4(xpp(bxx), HP, rows * HP, rr * 16 + 4 * q, u, x);
+        if (SAVE) *reinterpret_cast<f32x4*>(a.saved + sv_off((long)ts * NTILES + tile0 + rr, 6, 1, s, lane)) = x;
       }
     };
     // gi(ts) = bias + x W_ih of every row tile -> GI[bg] (for the R wave of this slice) and gi_out
@@ -248,27 +264,34 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         const int rr = rt < RTW ? rt : RTW - 1;
-        f32x4 ar = splat(bias_r), az = splat(bias_z), an = splat(bias_n);
+        f32x4 ag[3] = {splat(bias_r), splat(bias_z), splat(bias_n)};      // three gates = three chains, round robin
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const F3 xb = bfrag(xpp(bxx) + rr * 16 * HP, HP, rows * HP, c, lane);
-          mm6(xb, wi[c], ar); mm6(xb, wi[2 + c], az); mm6(xb, wi[4 + c], an);
+#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ag[g] = mm(xb.p_, wi[2 * g + c].q_, ag[g]);
+          X6_TERMS(OP)
+#undef OP
         }
         f32x4* gp = reinterpret_cast<f32x4*>(GI0) + ((bg * RTC + rr) * 4 + s) * 192 + lane;
-        gp[0] = ar; gp[64] = az; gp[128] = an;
+        gp[0] = ag[0]; gp[64] = ag[1]; gp[128] = ag[2];
         if (GIO) {
           float* const go = a.gi_out + sv_off((long)ts * NTILES + tile0 + rr, 3, 0, s, lane);
-          *reinterpret_cast<f32x4*>(go) = ar;
-          *reinterpret_cast<f32x4*>(go + 1024) = az;
-          *reinterpret_cast<f32x4*>(go + 2048) = an;
+          *reinterpret_cast<f32x4*>(go) = ag[0];
+          *reinterpret_cast<f32x4*>(go + 1024) = ag[1];
+          *reinterpret_cast<f32x4*>(go + 2048) = ag[2];
         }
       }
     };
     // XS: q(ts) = fc2(h) of row tile rt from planes Hp[bh]
     auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
-      f32x4 acc = splat(bias_2);
+      f32x4 ac[2] = {splat(bias_2), splat(0.f)};     // one chain per k chunk
+      F3 hb[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) mm6(bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane), w2[c], acc);
+      for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
+      X6_TERMS(OP)
+#undef OP
+      const f32x4 acc = ac[0] + ac[1];
       if (m < a.A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + m] = acc[r];
@@ -332,9 +355,14 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       put4(hpp(0), HP, rows * HP, rt * 16 + 4 * q, u, hreg[rt]);
     }
     auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
-      f32x4 acc = splat(bias_2);
+      f32x4 ac[2] = {splat(bias_2), splat(0.f)};     // one chain per k chunk
+      F3 hb[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) mm6(bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane), w2[c], acc);
+      for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
+      X6_TERMS(OP)
+#undef OP
+      const f32x4 acc = ac[0] + ac[1];
       if (m < a.A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + m] = acc[r];
@@ -362,9 +390,10 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       for (int rt = 0; rt < RTC; ++rt) {
         if (rt >= RTW) break;
         const f32x4* gp = reinterpret_cast<const f32x4*>(GI0) + ((par * RTC + rt) * 4 + s) * 192 + lane;
-        f32x4 ar, az, an, ahn = splat(bias_hn);
-        if (fl) { ar = gp[0]; az = gp[64]; an = gp[128]; }
-        else { ar = gB[0]; az = gB[1]; an = gB[2]; }
+        f32x4 ah[3], an;                             // r, z (on top of the input-side sums) and the candidate's hidden side
+        ah[2] = splat(bias_hn);
+        if (fl) { ah[0] = gp[0]; ah[1] = gp[64]; an = gp[128]; }
+        else { ah[0] = gB[0]; ah[1] = gB[1]; an = gB[2]; }
         if (XS) {                                    // the next tile: this step's, or tile 0 of the next step (stored step + 1)
           const bool same = rt + 1 < RTW;
           const int nts = same ? t + 1 : t + 2;
@@ -373,8 +402,11 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const F3 hb = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, c, lane);
-          mm6(hb, wh[c], ar); mm6(hb, wh[2 + c], az); mm6(hb, wh[4 + c], ahn);
+#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ah[g] = mm(hb.p_, wh[2 * g + c].q_, ah[g]);
+          X6_TERMS(OP)
+#undef OP
         }
+        const f32x4 ar = ah[0], az = ah[1], ahn = ah[2];
         ST_MARK(0);
         f32x4 vr, vz, vn, hn;
 #pragma unroll
