@@ -97,6 +97,12 @@ class KernelTimers:
                         "agent_fwd", Fa * rows, Fa * rows, 4.0 * rows * (O + A_ + 6 * H + (3 * H if kw.get("gi_out") is not None else 0)))
             return ("agent_fwd_kernel[plain: target unroll]", "agent_fwd", Fa * rows, Fa * rows, 4.0 * rows * (O + A_))
 
+        def fwd_x6(ar, kw):
+            m = fwd(ar, kw)          # same arguments as agent_unroll_fwd; the kernel is agent_fwd_x6_kernel (csrc/agent_x6.hip)
+            if m is None:
+                return None
+            return (m[0].replace("agent_fwd_kernel", "agent_fwd_x6_kernel") + " fp32 products as six bf16 MFMA products", "agent_fwd_x6") + m[2:]
+
         def bwd(ar, kw):
             B, T, N_, A_ = ar[8], ar[9], ar[10], ar[11]
             rows = B * T * N_
@@ -162,7 +168,7 @@ class KernelTimers:
             f = float(Fa) * E_ * T_ * N_
             return ("synth_rollout_kernel (whole rollout, T lock-steps)", "synth_rollout", f, f, 4.0 * E_ * (T_ + 1) * (N_ * O + S + N_ * A))
 
-        self.models = {"agent_unroll_fwd": fwd, "agent_unroll_bwd": bwd, "linear_wgrad": wgrad, "linear": lin,
+        self.models = {"agent_unroll_fwd": fwd, "agent_unroll_fwd_x6": fwd_x6, "agent_unroll_bwd": bwd, "linear_wgrad": wgrad, "linear": lin,
                        "qmix_fused_fwd": qmix(1, "qmix_fused_kernel forward (target mixer)", "qmix_fused_kernel<false"),
                        "qmix_fused_bwd": qmix(2, "qmix_fused_kernel backward", "qmix_fused_kernel<true"),
                        "qmix_fused_loss_bwd": qmix(2, "qmix_fused_kernel forward + TD loss + backward", "qmix_fused_kernel<true"),
@@ -212,15 +218,20 @@ class KernelTimers:
 
 
 # BASELINE.json configs[1..4] at their per-GPU shard sizes: (label, alg, shape, envs per GPU, mixer dtype,
-# gemm mode).  The last two are the opt-in bf16x6 legs (args.gemm_mode = "bf16x6": the QPLEX lambda-net on the split kernels,
-# csrc/mlp3_x6.hip) beside their fp32 twins - extra legs; the headline and configs[1..4] stay on v_mfma_f32_16x16x4_f32.
+# gemm mode).  The "extra" ones are the opt-in bf16x6 legs (args.gemm_mode = "bf16x6": the agent unrolls and the QPLEX lambda-net on
+# the split kernels, csrc/agent_x6.hip / mlp3_x6.hip) beside their fp32 twins; the headline and configs[1..4] stay on
+# v_mfma_f32_16x16x4_f32.
 OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp32", "f32"),
                  ("cfg3 QPLEX 2s3z 512 envs (shard of 4096 / 8 GPUs)", "qplex", "2s3z", 512, "fp32", "f32"),
                  ("cfg4 QTRAN-base 3s5z 512 envs (shard of 2048 / 4 GPUs)", "qtran_base", "3s5z", 512, "fp32", "f32"),
                  ("cfg5 QMIX MMM2 1024 envs (shard of 8192 / 8 GPUs), bf16 mixer", "qmix", "MMM2", 1024, "bf16", "f32"),
                  ("extra: cfg3 shard with gemm_mode bf16x6 (lambda-net products as six bf16 MFMA products each)", "qplex", "2s3z", 512, "fp32", "bf16x6"),
                  ("extra: QPLEX 2s3z 4096 envs on one GPU, fp32 MFMA", "qplex", "2s3z", 4096, "fp32", "f32"),
-                 ("extra: QPLEX 2s3z 4096 envs on one GPU, gemm_mode bf16x6", "qplex", "2s3z", 4096, "fp32", "bf16x6")]
+                 ("extra: QPLEX 2s3z 4096 envs on one GPU, gemm_mode bf16x6", "qplex", "2s3z", 4096, "fp32", "bf16x6"),
+                 ("extra: headline learner (QMIX 2s3z 4096 envs) with gemm_mode bf16x6 (agent unrolls on the split kernels)", "qmix", "2s3z", 4096, "fp32", "bf16x6"),
+                 ("extra: cfg2 with gemm_mode bf16x6", "qmix", "2s3z", 1024, "fp32", "bf16x6"),
+                 ("extra: QMIX 2s3z 512 envs (shard of 4096 / 8 GPUs), fp32 MFMA", "qmix", "2s3z", 512, "fp32", "f32"),
+                 ("extra: QMIX 2s3z 512 envs (shard of 4096 / 8 GPUs), gemm_mode bf16x6", "qmix", "2s3z", 512, "fp32", "bf16x6")]
 
 
 def load_pmc(workload):
@@ -315,7 +326,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
     workload = "%s_%s_T%d_envs%d%s%s" % (alg, shape, T, envs, "_bf16mixer" if mixer_dtype == "bf16" else "", "_bf16x6" if gemm_mode == "bf16x6" else "")
     pmc, pmc_src = load_pmc(workload)
     out = {"workload": workload, "what": label, "mixer_dtype": mixer_dtype, "gemm_mode": gemm_mode,
-           "dtype": "f32 via bf16x6 split, fp32 accumulate (lambda-net heads; everything else f32)" if gemm_mode == "bf16x6" else "f32",
+           "dtype": "f32 via bf16x6 split, fp32 accumulate (agent unrolls, lambda-net heads; everything else f32)" if gemm_mode == "bf16x6" else "f32",
            "learner_updates_per_sec": 1.0 / dt, "learner_transitions_per_sec": envs * T / dt,
            "rollout_env_steps_per_sec": steps / t_roll,
            "roofline_update": {"bound": "mfma", "flop_per_transition": fpt, "achieved": upd_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -323,7 +334,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
            "kernels": [{k: e[k] for k in ("name", "launches_timed", "ms", "executed_flop", "frac")} for e in kern[:5]]}
     if kern:
         d = kern[0]
-        x6k = d["rocprof_name"].startswith("mlp3x6")
+        x6k = "x6" in d["rocprof_name"]
         peak = PEAK_BF16_TFLOPS / 6.0 if x6k else PEAK_F32_TFLOPS
         hit = pmc_traffic(pmc, d)
         out["roofline"] = {"bound": "mfma", "kernel": d["name"], "rocprof_name": d["rocprof_name"], "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s",
@@ -470,6 +481,8 @@ def main():
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: mixer GEMMs on the bf16 matrix cores (config 5)")
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x6"], help="bf16x6: opt-in split arithmetic (fp32 products as six "
+                    "bf16 MFMA products, fp32 accumulate) for the agent unrolls / lambda-net heads of THIS run; the default line stays f32")
     ap.add_argument("--blocking-loss", "--blocking-readbacks", dest="blocking_loss", action="store_true",
                     help="read every update's loss and every rollout's statistics back at once (default: the copies are enqueued "
                          "and read at the end of the timed region - same device work, no host stall between steps)")
@@ -551,6 +564,7 @@ def main():
 
     args = make_args(o.alg, o.shape, o.T)
     args.mixer_dtype = o.mixer_dtype
+    args.gemm_mode = o.gemm_mode
     args.hip_graph = o.hip_graph
     args.lazy_loss = not o.blocking_loss
     T, N = args.episode_limit, args.n_agents
@@ -667,7 +681,8 @@ def main():
         fpt = learner_flops_per_transition(args, o.alg)
         upd_tflops = fpt * (o.envs * T / t_learn) / 1e12
         # HBM bytes per launch from the committed PMC passes of this workload, taken with this very library (load_pmc)
-        workload = "%s_%s_T%d_envs%d%s" % (o.alg, o.shape, T, o.envs // world, "_bf16mixer" if o.mixer_dtype == "bf16" else "")
+        workload = "%s_%s_T%d_envs%d%s%s" % (o.alg, o.shape, T, o.envs // world, "_bf16mixer" if o.mixer_dtype == "bf16" else "",
+                                             "_bf16x6" if o.gemm_mode == "bf16x6" else "")
         pmc, pmc_path = load_pmc(workload) if world == 1 else ({}, "multi-GPU run: per-GPU shard")
         kern = timers.table()
         # (with --hip-graph the learner's kernels are launched from inside the replayed graph: no per-launch events)
@@ -692,7 +707,10 @@ def main():
                         what="executed FLOP (tile padding excluded) of the kernel with the largest total time in the timed region")
             roof["kernels"] = [{k: e[k] for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "hbm_gb", "hbm_frac")}
                                for e in kern[:6]]
-            un = [e for e in kern if e["rocprof_name"] == "agent_fwd"]
+            if "x6" in d["rocprof_name"]:      # opt-in run on the split kernels: six bf16 products per fp32 product
+                roof.update(peak=PEAK_BF16_TFLOPS / 6.0, frac=d["tflops"] / (PEAK_BF16_TFLOPS / 6.0),
+                            peak_note="dense bf16 MFMA peak / 6: a bf16x6 split spends six bf16 products per fp32 product")
+            un = [e for e in kern if e["rocprof_name"] in ("agent_fwd", "agent_fwd_x6")]
             if un:
                 t_un = sum(e["total_ms"] for e in un)
                 roof["algorithmic_rate"] = {
@@ -725,7 +743,9 @@ def main():
         out = {
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if o.gemm_mode == "f32" else "f32 via bf16x6 split, fp32 accumulate (agent unrolls of the update; the rollout and everything else f32)",
+            "data": "synthetic",
             "config": {"workload": "%s_%s_T%d_envs%d" % (o.alg, o.shape, T, o.envs), "alg": o.alg, "shape": o.shape,
                        "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
                        "n_actions": args.n_actions, "episode_limit": T, "global_envs": o.envs, "envs_per_gpu": E,
