@@ -284,6 +284,18 @@ int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, lo
                              int O, int A, int last_action, int reuse_network, int cu_budget, float* gi_out,
                              const float* gi_in, void* stream);
 
+/* ---- BPTT of the unroll on the same split arithmetic (agent_bwd_x6.hip) -------------------------------------------------------
+ * Opt-in (args.gemm_mode = "bf16x6"): marl_agent_unroll_bwd with every fp32 product - the delta pass and the weight-gradient
+ * reductions over rows - as six bf16 MFMA products; bias gradients are exact fp32 sums.  Same argument meaning (no dense dq and no
+ * `hs`: the Q-learning losses reach q through one or two (column, value) pairs per row); `saved` is what either forward entry
+ * stored.  marl_agent_unroll_bwd_x6_supported(): H = 64, A <= 16, sparse dq, T >= 3; the caller uses marl_agent_unroll_bwd
+ * otherwise.  Workspace: marl_agent_bwd_x6_workspace() bytes (one slab per 32 rows). */
+int marl_agent_unroll_bwd_x6_supported(int B, int T, int N, int A, int sparse_dq);
+size_t marl_agent_bwd_x6_workspace(int B, int N, int A);
+int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int* dq_idx, const float* dq_val, const int* dq_idx2,
+                             const float* dq_val2, int dq_gdiv, const float* dhs, const float* saved, float* dxp, float* dh0,
+                             const marl_agent_grads_t* g, float* ws, size_t ws_bytes, int B, int T, int N, int A, void* stream);
+
 /* ---- the same heads with the multiplies as an fp32-accurate SPLIT on the bf16 matrix cores (mlp3_x6.hip) -------------
  * Opt-in (args.gemm_mode = "bf16x6"; the default is the pair above on v_mfma_f32_16x16x4_f32).  Every fp32 operand is split
  * exactly into three bf16 terms (hi + mid + lo) and a product is the six bf16 products hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid

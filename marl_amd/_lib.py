@@ -76,6 +76,9 @@ SIGNATURES = {
     "marl_agent_unroll_x6_supported": (I, [I, I, I, I, I, I, I]),
     "marl_agent_unroll_fwd_x6": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P, P]),
     "marl_agent_bwd_workspace": (SZ, [I, I, I]),
+    "marl_agent_unroll_bwd_x6_supported": (I, [I, I, I, I, I]),
+    "marl_agent_bwd_x6_workspace": (SZ, [I, I, I]),
+    "marl_agent_unroll_bwd_x6": (I, [AW, P, P, P, P, I, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, I, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_replay_gather": (I, [P, I, I, I, I] + [P] * 16 + [P]),
     "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),

@@ -1,0 +1,494 @@
+// Backward through time of the GRU-agent unroll with every fp32 product as six bf16 MFMA products (x6.h) - opt-in
+// args.gemm_mode = "bf16x6"; the default is agent_bwd_kernel / agent_bwd_pipe_kernel (agent.hip) on v_mfma_f32_16x16x4_f32.
+// Autograd of controller/share_params.py:125-146 + network/q_network.py:16-21 (reference q_learner.py:171 loss.backward()):
+// per step the delta pass (dh carry, gate gradients, dx) AND the weight-gradient reductions of W_ih, W_hh, W_2 and their biases.
+//
+// One workgroup = 32 rows (two 16-row tiles of the saved-activation layout) = one k block of v_mfma_f32_16x16x32_bf16 for the
+// reductions over rows; 8 waves = 2 teams x 4 hidden-unit slices (wave s of a team: units 16s .. 16s+15), one barrier per step:
+//   team R (waves 0-3), the dependent chain:  dh = carry + dhs + dq W_2 -> gate gradients (fp32, accumulator layout: lane (q, m) =
+//          rows 4q + r of unit 16s + m, the layout of the saved planes) -> G image in LDS | barrier |
+//          carry' = dh z + [drp|dzp|dhn] W_hh ;  dW_hh += [drp|dzp|dhn]^T h_prev ;  bias sums (exact fp32)
+//   team I (waves 4-7), off the chain:        dx = [drp|dzp|dnp] W_ih -> relu gate -> dxp ;  dW_ih += [drp|dzp|dnp]^T x ;  dW_2 += dq^T h
+// The gate-gradient image G^T[gate column 0..255 = drp|dzp|dnp|dhn][row 0..31] holds three bf16 planes (each element split once,
+// where it is produced): a product that CONTRACTS over gate columns (dx, carry') reads it transposed (ds_read_b64_tr_b16: lane i =
+// row), a product with gate columns as OUTPUT rows (the weight gradients, contraction over the 32 rows) reads it plainly - the k
+// slots of a lane are rows 4g .. 4g+3 of tile 0 then of tile 1, which is exactly how a lane of the saved tile layout holds h_prev
+// and x: those operands are split8(tile 0 value, tile 1 value) of what the owning wave loaded anyway, passed on as ready fragments.
+// Image addressing: byte(plane, column k, piece p of 8 bytes = 4 rows) = plane * 16384 + k * 64 + 8 * (p ^ 2 ((k >> 2) & 3)),
+// p = 4 tile + (row >> 2) & 3: writes (lane (q, m): column m, piece q), transposed reads (lane (g; qq, p): column 8g + .. + qq)
+// and plain reads (lane (g, i): column i, piece g) all spread a 32-lane pass over the 64 banks.
+#include "x6.h"
+#include <cstdlib>
+#include "../../include/marl_hip.h"
+
+namespace {
+
+constexpr int H = 64;
+constexpr int BNT = 512;
+constexpr int GPL = 256 * 64;       // bytes per plane of the gate-gradient image
+constexpr int GBUF = 3 * GPL;       // one image (three planes)
+constexpr int FRB = 4 * 3 * 1024;   // ready-made operand fragments of the four column tiles of h_prev (or x): [tile][plane][lane] 16 bytes
+
+struct BX6Args {
+  const float *Wih, *Whh, *W2;
+  const int* dq_idx; const float* dq_val;       // (B,T,N): row (b,t,n) has the non-zero dq_val[row / gdiv] in column dq_idx
+  const int* dq_idx2; const float* dq_val2;     // optional second pair per row
+  int dq_gdiv;
+  const float* dhs;        // (B,T,N,64) external gradient on hs[t], or null
+  const float* saved;      // [T+1][row tile][6][4][64][4]
+  float* dxp;              // (B,T,N,64)
+  float* dh0;              // (B*N,64) or null
+  float* ws;               // [n_wg][slab]
+  int B, T, N, A;
+  long R;
+};
+
+__host__ __device__ inline long slab_floats(int A) { return 2L * 192 * 64 + (long)A * 64 + 2 * 192 + A; }
+
+#define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define X6_TERMS(OP) OP(m, m) OP(h, l) OP(l, h) OP(h, m) OP(m, h) OP(h, h)
+// two split multiplies (A0 B0, A1 B1) on four accumulators: the small products on c0 / c1, the large ones on c2 / c3
+#define X6_TERMS4(A0, B0, A1, B1, c0, c1, c2, c3)                                                                   \
+  c0 = mm(A0.m, B0.m, c0); c1 = mm(A1.m, B1.m, c1); c2 = mm(A0.h, B0.m, c2); c3 = mm(A1.h, B1.m, c3);               \
+  c0 = mm(A0.h, B0.l, c0); c1 = mm(A1.h, B1.l, c1); c2 = mm(A0.m, B0.h, c2); c3 = mm(A1.m, B1.h, c3);               \
+  c0 = mm(A0.l, B0.h, c0); c1 = mm(A1.l, B1.h, c1); c2 = mm(A0.h, B0.h, c2); c3 = mm(A1.h, B1.h, c3);
+
+__device__ __forceinline__ long sv_off(long tile_t, int plane, int c, int lane) { return ((tile_t * 6 + plane) * 4 + c) * 256 + lane * 4; }
+__device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
+
+// B fragment of W^T for  out[row][unit] = sum_k G[row][k] W[k][unit]:  lane (g, j): W[32 c + 8g + (0..7)][u0 + j]  (W: [192][64])
+__device__ __forceinline__ F3 wTfrag(const float* W, int c, int u0, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  float v[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) v[jj] = W[(long)(32 * c + 8 * g + jj) * H + u0 + j];
+  return split8((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4], v[5], v[6], v[7]});
+}
+// A fragment (lane i = row of tile `tile`, k slots = gate columns k0 + 8g + (0..7)) from the image at `img`: transposed reads
+// tb0 / tb1: the lane's bases for the column quads 8g + (0..3) / 8g + (4..7)
+__device__ __forceinline__ i32x4 g_tr(const char* img, int tb0, int tb1, int off, int tile) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off + (tb0 ^ (32 * tile))));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off + (tb1 ^ (32 * tile))));
+  return __builtin_bit_cast(i32x4, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ F3 g_tr3(const char* img, int tb0, int tb1, int k0, int tile) {
+  F3 f;
+  f.h = g_tr(img, tb0, tb1, k0 * 64, tile); f.m = g_tr(img, tb0, tb1, k0 * 64 + GPL, tile); f.l = g_tr(img, tb0, tb1, k0 * 64 + 2 * GPL, tile);
+  return f;
+}
+// A fragment with gate columns as the OUTPUT rows (lane i = column k0 + i, k slots = rows 4g .. 4g+3 of tile 0, then of tile 1)
+__device__ __forceinline__ F3 g_cols(const char* img, int rb, int k0) {
+  F3 f;
+  const char* p = img + k0 * 64;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const i32x2 t0 = *reinterpret_cast<const i32x2*>(p + pl * GPL + rb);
+    const i32x2 t1 = *reinterpret_cast<const i32x2*>(p + pl * GPL + (rb ^ 32));
+    const i32x4 v = (i32x4){t0[0], t0[1], t1[0], t1[1]};
+    if (pl == 0) f.h = v; else if (pl == 1) f.m = v; else f.l = v;
+  }
+  return f;
+}
+// the four rows 4q .. 4q+3 (tile `tile`) of column k0 + m -> the image
+__device__ __forceinline__ void g_put(char* img, int wb, int k0, int tile, const F3h& f) {
+  char* p = img + k0 * 64 + (wb ^ (32 * tile));
+  *reinterpret_cast<i32x2*>(p) = f.h;
+  *reinterpret_cast<i32x2*>(p + GPL) = f.m;
+  *reinterpret_cast<i32x2*>(p + 2 * GPL) = f.l;
+}
+__device__ __forceinline__ void fr_put(char* fr, int tile, int lane, const F3& f) {
+  i32x4* p = reinterpret_cast<i32x4*>(fr) + tile * 192 + lane;
+  p[0] = f.h; p[64] = f.m; p[128] = f.l;
+}
+__device__ __forceinline__ F3 fr_get(const char* fr, int tile, int lane) {
+  const i32x4* p = reinterpret_cast<const i32x4*>(fr) + tile * 192 + lane;
+  F3 f;
+  f.h = p[0]; f.m = p[64]; f.l = p[128];
+  return f;
+}
+
+template <bool DHS, bool TWO>
+__global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, s = wave & 3;
+  const int q = lane >> 4, m = lane & 15, u = 16 * s + m;
+  char* Gt = smem;                                   // [2][3][256][64 B]
+  char* HB = Gt + 2 * GBUF;                          // [2] fragments of h_prev(t) column tiles
+  char* XB = HB + 2 * FRB;                           // [2] fragments of x(t) column tiles
+  float* W2s = reinterpret_cast<float*>(XB + 2 * FRB);      // [16][64]
+  int4* QT = reinterpret_cast<int4*>(W2s + 16 * H);   // [3][32]: (idx, val, idx2, val2) of a row at a step
+  int* rowidx = reinterpret_cast<int*>(QT + 3 * 32);  // [32]: index of (b, 0, n) in (B,T,N) or -1
+  int* rowrho = rowidx + 32;                          // [32]
+
+  const long NTILES = (a.R + 15) >> 4;
+  const long tile0 = 2L * blockIdx.x;
+  const long tl[2] = {tile0, tile0 + 1 < NTILES ? tile0 + 1 : tile0};      // (a missing second tile reads the first: its gradients are zero)
+  if (tid < 32) {
+    const long rho = tile0 * 16 + tid;
+    const bool ok = rho < a.R;
+    rowidx[tid] = ok ? (int)((rho / a.N) * a.T * a.N + rho % a.N) : -1;
+    rowrho[tid] = ok ? (int)rho : -1;
+  }
+  for (int e = tid; e < 16 * H; e += BNT) W2s[e] = e < a.A * H ? a.W2[e] : 0.f;
+  __syncthreads();
+  const int T = a.T;
+  // (idx, val, idx2, val2) of row r at step t
+  auto qload = [&](int r, int t) {
+    int4 e = make_int4(0, 0, 0, 0);                   // an absent pair is (column 0, value 0): no branches where it is used
+    const int ri = rowidx[r];
+    if (ri >= 0 && t >= 0) {
+      const long k = (long)ri + (long)t * a.N;
+      const int i1 = a.dq_idx[k];
+      if (i1 >= 0 && i1 < a.A) { e.x = i1; e.y = __float_as_int(a.dq_val[k / a.dq_gdiv]); }
+      if (a.dq_idx2) {
+        const int i2 = a.dq_idx2[k];
+        if (i2 >= 0 && i2 < a.A) { e.z = i2; e.w = __float_as_int(a.dq_val2[k / a.dq_gdiv]); }
+      }
+    }
+    return e;
+  };
+  // per-lane address parts of the image - worked out again in every step from the lane number (a dozen integer instructions) rather
+  // than kept in registers across the loop: both teams run at the 256-register ceiling
+  auto lane_parts = [&](int& wb_, int& tb0_, int& tb1_) {
+    int l = lane;
+    asm volatile("" : "+v"(l));                      // (opaque: not hoisted out of the loop)
+    const int q_ = l >> 4, m_ = l & 15, qq = m_ >> 2, p4 = m_ & 3;
+    wb_ = m_ * 64 + 8 * (q_ ^ (2 * ((m_ >> 2) & 3)));                              // put / plain read: column (k0 + m), piece q (tile 0; ^32: tile 1)
+    tb0_ = (8 * q_ + qq) * 64 + 8 * (p4 ^ (2 * ((2 * q_) & 3)));                    // transposed read: columns 8g + qq (g = q), half 0
+    tb1_ = (8 * q_ + 4 + qq) * 64 + 8 * (p4 ^ (2 * ((2 * q_ + 1) & 3)));            // half 1
+  };
+  ST_DECL(4);
+  if (team == 0) {
+    // =============================== team R: the chain, dW_hh, the bias sums ===============================
+    F3 whT[6];      // k chunks of [drp | dzp | dhn] <-> rows 0..191 of W_hh (r | z | n)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) whT[c] = wTfrag(a.Whh, c, 16 * s, lane);
+    f32x4 accW[3][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accW[b][c] = splat(0.f);
+    f32x4 carry[2] = {splat(0.f), splat(0.f)};
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};               // column sums of drp, dzp, dnp, dhn (this lane's 8 rows)
+    f32x4 sv[2][5];                                    // saved planes of the step: h_prev, r, z, n, W_hn h + b_hn
+    f32x4 dhsv[2];
+    auto svload = [&](int t, int tt) {
+      const float* sp = a.saved + sv_off((long)t * NTILES + tl[tt], 0, s, lane);
+      sv[tt][0] = *reinterpret_cast<const f32x4*>(sp);
+      sv[tt][1] = *reinterpret_cast<const f32x4*>(sp + 2 * 1024);
+      sv[tt][2] = *reinterpret_cast<const f32x4*>(sp + 3 * 1024);
+      sv[tt][3] = *reinterpret_cast<const f32x4*>(sp + 4 * 1024);
+      sv[tt][4] = *reinterpret_cast<const f32x4*>(sp + 5 * 1024);
+      if (DHS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ri = rowidx[16 * tt + 4 * q + r];
+          dhsv[tt][r] = ri >= 0 ? a.dhs[((long)ri + (long)t * a.N) * H + u] : 0.f;
+        }
+      }
+    };
+    svload(T - 1, 0); svload(T - 1, 1);
+    if (tid < 32) { QT[((T - 1) % 3) * 32 + tid] = qload(tid, T - 1); QT[((T - 2 + 3) % 3) * 32 + tid] = qload(tid, T - 2); }
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+      const int par = t & 1;
+      char* img = Gt + par * GBUF;
+      const int4* qt = QT + (t % 3) * 32;
+      int wb, tb0, tb1;
+      lane_parts(wb, tb0, tb1);
+      const int rb = wb;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        f32x4 drp, dzp, dnp, dhn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int4 e = qt[16 * tt + 4 * q + r];
+          float dh = carry[tt][r];
+          if (DHS) dh += dhsv[tt][r];
+          dh = __fmaf_rn(__int_as_float(e.y), W2s[e.x * H + u], dh);
+          if (TWO) dh = __fmaf_rn(__int_as_float(e.w), W2s[e.z * H + u], dh);
+          const float hp = sv[tt][0][r], rg = sv[tt][1][r], zg = sv[tt][2][r], ng = sv[tt][3][r], hn = sv[tt][4][r];
+          const float dn = dh * (1.f - zg);
+          const float dz = dh * (hp - ng);
+          carry[tt][r] = dh * zg;                    // the direct path h_prev -> h; the W_hh products are added after the barrier
+          const float dnp_ = dn * (1.f - ng * ng);
+          const float dr = dnp_ * hn;
+          dnp[r] = dnp_;
+          dhn[r] = dnp_ * rg;
+          drp[r] = dr * rg * (1.f - rg);
+          dzp[r] = dz * zg * (1.f - zg);
+        }
+        bs[0] += (drp[0] + drp[1]) + (drp[2] + drp[3]);
+        bs[1] += (dzp[0] + dzp[1]) + (dzp[2] + dzp[3]);
+        bs[2] += (dnp[0] + dnp[1]) + (dnp[2] + dnp[3]);
+        bs[3] += (dhn[0] + dhn[1]) + (dhn[2] + dhn[3]);
+        g_put(img, wb, 0 * 64 + 16 * s, tt, split4(drp));
+        g_put(img, wb, 1 * 64 + 16 * s, tt, split4(dzp));
+        g_put(img, wb, 2 * 64 + 16 * s, tt, split4(dnp));
+        g_put(img, wb, 3 * 64 + 16 * s, tt, split4(dhn));
+      }
+      fr_put(HB + par * FRB, s, lane, split8(sv[0][0], sv[1][0]));      // h_prev, column tile s, as a ready B fragment
+      ST_MARK(0);
+      WG_BARRIER();
+      ST_MARK(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) { svload(t - 1, 0); svload(t - 1, 1); }      // in flight under the chain and dW_hh
+      __builtin_amdgcn_sched_barrier(0);
+      // carry' = dh z + [drp | dzp | dhn] W_hh : a tile at a time, (even, odd k chunks) = two chains
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        // four independent accumulators (two k chunks x alternate products): a dependent MFMA issues at a fraction of the pipe's
+        // rate, and the gaps it leaves are too short for the other wave of the SIMD to use
+        f32x4 ca = carry[tt], cb = splat(0.f), cc = splat(0.f), cd = splat(0.f);
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {
+          const int k0 = (cp == 2 ? 192 : 64 * cp);
+          const F3 a0 = g_tr3(img, tb0, tb1, k0, tt), a1 = g_tr3(img, tb0, tb1, k0 + 32, tt);
+          X6_TERMS4(a0, whT[2 * cp], a1, whT[2 * cp + 1], ca, cb, cc, cd)
+        }
+        carry[tt] = (ca + cb) + (cc + cd);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ST_MARK(2);
+      // dW_hh[this wave's 16 columns of r | z | n][all 64] += G^T h_prev
+      {
+        const F3 ar = g_cols(img, rb, 0 * 64 + 16 * s), az = g_cols(img, rb, 1 * 64 + 16 * s), an = g_cols(img, rb, 3 * 64 + 16 * s);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const F3 hb = fr_get(HB + par * FRB, c, lane);
+#define OP(p_, q_) accW[0][c] = mm(ar.p_, hb.q_, accW[0][c]); accW[1][c] = mm(az.p_, hb.q_, accW[1][c]); accW[2][c] = mm(an.p_, hb.q_, accW[2][c]);
+          X6_TERMS(OP)
+#undef OP
+        }
+      }
+      ST_MARK(3);
+    }
+    ST_DUMP(4);
+    // ---- epilogue: dh0, the slab of this workgroup
+    if (a.dh0) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rho = rowrho[16 * tt + 4 * q + r];
+          if (rho >= 0 && (tt == 0 || tile0 + 1 < NTILES)) a.dh0[(long)rho * H + u] = carry[tt][r];
+        }
+    }
+    float* slab = a.ws + (long)blockIdx.x * slab_floats(a.A);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[192 * 64 + (long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accW[b][c][r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bs[k] += __shfl_xor(bs[k], 16);
+      bs[k] += __shfl_xor(bs[k], 32);
+    }
+    if (q == 0) {
+      float* db = slab + 2 * 192 * 64 + (long)a.A * H;
+      db[0 * 64 + u] = bs[0]; db[1 * 64 + u] = bs[1]; db[2 * 64 + u] = bs[2];                     // db_ih: r | z | n (input side)
+      db[192 + 0 * 64 + u] = bs[0]; db[192 + 1 * 64 + u] = bs[1]; db[192 + 2 * 64 + u] = bs[3];   // db_hh: r | z | n (hidden side)
+    }
+  } else {
+    // =============================== team I: dx, dW_ih, dW_2 ===============================
+    const int ti = tid - 256;
+    F3 wiT[6];      // k chunks of [drp | dzp | dnp] <-> rows 0..191 of W_ih
+#pragma unroll
+    for (int c = 0; c < 6; ++c) wiT[c] = wTfrag(a.Wih, c, 16 * s, lane);
+    f32x4 accW[3][4], acc2 = splat(0.f);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accW[b][c] = splat(0.f);
+    float bs2 = 0.f;
+    f32x4 xn[2];                                      // x of the step to come (in flight across the barrier)
+    auto xload = [&](int t) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) xn[tt] = *reinterpret_cast<const f32x4*>(a.saved + sv_off((long)t * NTILES + tl[tt], 1, s, lane));
+    };
+    // x(t) -> ready B fragments of dW_ih for the whole team + the relu mask of this lane's 8 elements (bit 4 tt + r)
+    auto xpublish = [&](int t) {
+      fr_put(XB + (t & 1) * FRB, s, lane, split8(xn[0], xn[1]));
+      unsigned mk = 0;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk |= xn[tt][r] > 0.f ? 1u << (4 * tt + r) : 0u;
+      return mk;
+    };
+    auto dw2 = [&](const int4* qt, const F3& hb) {
+      f32x4 d0, d1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int4 e0 = qt[4 * q + r], e1 = qt[16 + 4 * q + r];
+        d0[r] = (e0.x == m ? __int_as_float(e0.y) : 0.f) + (TWO && e0.z == m ? __int_as_float(e0.w) : 0.f);
+        d1[r] = (e1.x == m ? __int_as_float(e1.y) : 0.f) + (TWO && e1.z == m ? __int_as_float(e1.w) : 0.f);
+      }
+      bs2 += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
+      mm6(split8(d0, d1), hb, acc2);
+    };
+    xload(T - 1);
+    unsigned xmask = xpublish(T - 1), xmask_next = 0;
+    xload(T - 2);
+    int4 qn = make_int4(0, 0, 0, 0);
+    if (ti < 32) qn = qload(ti, T - 3);
+    __syncthreads();
+    {      // the last step's dq meets h(T-1), the hidden state after the last step (plane 0 of step T)
+      f32x4 hT[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) hT[tt] = *reinterpret_cast<const f32x4*>(a.saved + sv_off((long)T * NTILES + tl[tt], 0, s, lane));
+      dw2(QT + ((T - 1) % 3) * 32, split8(hT[0], hT[1]));
+    }
+    for (int t = T - 1; t >= 0; --t) {
+      const int par = t & 1;
+      const char* img = Gt + par * GBUF;
+      WG_BARRIER();
+      ST_MARK(0);
+      int rb, tb0, tb1;
+      lane_parts(rb, tb0, tb1);
+      if (t > 0) xmask_next = xpublish(t - 1);       // (loaded during the previous step; XB[par ^ 1] was last read before this barrier)
+      if (t > 1) xload(t - 2);
+      __builtin_amdgcn_sched_barrier(0);
+      // dx = [drp | dzp | dnp] W_ih -> relu gate -> dxp
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        f32x4 ca = splat(0.f), cb = splat(0.f), cc = splat(0.f), cd = splat(0.f);
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {
+          const int k0 = 64 * cp;
+          const F3 a0 = g_tr3(img, tb0, tb1, k0, tt), a1 = g_tr3(img, tb0, tb1, k0 + 32, tt);
+          X6_TERMS4(a0, wiT[2 * cp], a1, wiT[2 * cp + 1], ca, cb, cc, cd)
+        }
+        const f32x4 dx = (ca + cb) + (cc + cd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ri = rowidx[16 * tt + 4 * q + r];
+          if (ri >= 0 && (tt == 0 || tile0 + 1 < NTILES)) a.dxp[((long)ri + (long)t * a.N) * H + u] = (xmask >> (4 * tt + r)) & 1u ? dx[r] : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ST_MARK(1);
+      // dW_ih[this wave's 16 columns of r | z | n][all 64] += G^T x
+      {
+        const F3 ar = g_cols(img, rb, 0 * 64 + 16 * s), az = g_cols(img, rb, 1 * 64 + 16 * s), an = g_cols(img, rb, 2 * 64 + 16 * s);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const F3 xb = fr_get(XB + par * FRB, c, lane);
+#define OP(p_, q_) accW[0][c] = mm(ar.p_, xb.q_, accW[0][c]); accW[1][c] = mm(az.p_, xb.q_, accW[1][c]); accW[2][c] = mm(an.p_, xb.q_, accW[2][c]);
+          X6_TERMS(OP)
+#undef OP
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ST_MARK(2);
+      // dW_2[action][this wave's 16 columns] += dq(t-1)^T h(t-1): h(t-1) = h_prev of THIS step, whose ready fragments team R published
+      // before the barrier (HB[par], stable until the next one).  Lane (g, i): action i, k slots = rows 4g .. 4g+3 of tile 0, then tile 1
+      if (t > 0) dw2(QT + ((t - 1) % 3) * 32, fr_get(HB + par * FRB, s, lane));
+      // the steps to come: the dq pairs of step t-2 handed over
+      xmask = xmask_next;
+      if (ti < 32) {
+        if (t >= 2) QT[((t - 2) % 3) * 32 + ti] = qn;
+        qn = qload(ti, t - 3);
+      }
+      ST_MARK(3);
+    }
+    ST_DUMP(4);
+    float* slab = a.ws + (long)blockIdx.x * slab_floats(a.A);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accW[b][c][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * q + r < a.A) slab[2 * 192 * 64 + (long)(4 * q + r) * H + u] = acc2[r];
+    bs2 += __shfl_xor(bs2, 16);
+    bs2 += __shfl_xor(bs2, 32);
+    if (s == 0 && q == 0 && m < a.A) slab[2 * 192 * 64 + (long)a.A * H + 2 * 192 + m] = bs2;
+  }
+}
+
+struct RedArgs {
+  const float* ws; int nwg; int A;
+  float *dWih, *dWhh, *dW2, *dbih, *dbhh, *db2;
+};
+// fixed-order sum of the workgroups' slabs into the gradient tensors (accumulated into)
+__global__ __launch_bounds__(256) void agent_bwd_x6_reduce_kernel(RedArgs a) {
+  __shared__ float part[4][64];
+  const long slab = slab_floats(a.A);
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (e < slab)
+    for (int w = sg; w < a.nwg; w += 4) s += a.ws[(long)w * slab + e];
+  part[sg][el] = s;
+  __syncthreads();
+  if (sg != 0 || e >= slab) return;
+  s = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+  long k = e;
+  if (k < 192 * 64) { a.dWih[k] += s; return; }
+  k -= 192 * 64;
+  if (k < 192 * 64) { a.dWhh[k] += s; return; }
+  k -= 192 * 64;
+  if (k < (long)a.A * 64) { a.dW2[k] += s; return; }
+  k -= (long)a.A * 64;
+  if (k < 192) { a.dbih[k] += s; return; }
+  k -= 192;
+  if (k < 192) { a.dbhh[k] += s; return; }
+  k -= 192;
+  a.db2[k] += s;
+}
+
+}  // namespace
+
+// shapes the split BPTT covers: H = 64, <= 16 actions, a sparse dq (one or two (column, value) pairs per row), T >= 3
+extern "C" int marl_agent_unroll_bwd_x6_supported(int B, int T, int N, int A, int sparse_dq) {
+  if (B < 1 || T < 3 || N < 1 || A < 1 || A > 16 || !sparse_dq) return 0;
+  if ((double)B * T * N * H * 4.0 >= 4294967296.0) return 0;
+  return 1;
+}
+
+extern "C" size_t marl_agent_bwd_x6_workspace(int B, int N, int A) {
+  const long R = (long)B * N;
+  return (size_t)((R + 31) / 32) * slab_floats(A) * sizeof(float);
+}
+
+extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int* dq_idx, const float* dq_val, const int* dq_idx2,
+                                        const float* dq_val2, int dq_gdiv, const float* dhs, const float* saved, float* dxp,
+                                        float* dh0, const marl_agent_grads_t* g, float* ws, size_t ws_bytes, int B, int T, int N,
+                                        int A, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (w->H != H || !marl_agent_unroll_bwd_x6_supported(B, T, N, A, dq_idx != nullptr) || !dq_val || (dq_idx2 && !dq_val2))
+    return (int)hipErrorInvalidValue;
+  if (ws_bytes < marl_agent_bwd_x6_workspace(B, N, A) || (reinterpret_cast<uintptr_t>(saved) & 15)) return (int)hipErrorInvalidValue;
+  BX6Args a;
+  a.Wih = w->w_ih; a.Whh = w->w_hh; a.W2 = w->fc2_w;
+  a.dq_idx = dq_idx; a.dq_val = dq_val; a.dq_idx2 = dq_idx2; a.dq_val2 = dq_val2; a.dq_gdiv = dq_gdiv > 1 ? dq_gdiv : 1;
+  a.dhs = dhs; a.saved = saved; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
+  a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
+  const unsigned nwg = (unsigned)((a.R + 31) / 32);
+  const size_t lds = (size_t)2 * GBUF + 4 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4;
+  const void* fn = dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true> : (const void*)agent_bwd_x6_kernel<true, false>)
+                       : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true> : (const void*)agent_bwd_x6_kernel<false, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipStream_t st = (hipStream_t)stream;
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3(nwg), dim3(BNT), kargs, lds, st);
+  if (e != hipSuccess) return (int)e;
+  MARL_CHECK_LAUNCH();
+  RedArgs r;
+  r.ws = ws; r.nwg = (int)nwg; r.A = A;
+  r.dWih = g->w_ih; r.dWhh = g->w_hh; r.dW2 = g->fc2_w; r.dbih = g->b_ih; r.dbhh = g->b_hh; r.db2 = g->fc2_b;
+  const long slab = slab_floats(A);
+  hipLaunchKernelGGL(agent_bwd_x6_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, st, r);
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+ST_DEFINE_SETTER(marl_debug_stamps_agent_bwd_x6)

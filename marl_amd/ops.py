@@ -209,8 +209,12 @@ def agent_unroll_reuse_supported(B, T, N, O, A, cu_budget=0):
     return bool(_lib.load().marl_agent_unroll_reuse_supported(B, T, N, O, A, int(cu_budget)))
 
 
+def agent_unroll_bwd_x6_supported(B, T, N, A, sparse_dq=True):
+    return bool(_lib.load().marl_agent_unroll_bwd_x6_supported(B, T, N, A, 1 if sparse_dq else 0))
+
+
 def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=None, dq_val=None, dq_idx2=None,
-                     dq_val2=None, dq_gdiv=1):
+                     dq_val2=None, dq_gdiv=1, x6=False):
     """grads: dict name -> gradient tensor for rnn.weight_ih/hh, rnn.bias_ih/hh, fc2.weight/bias (accumulated)."""
     lib = _lib.load()
     g = MarlAgentGrads()
@@ -219,6 +223,17 @@ def agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, dh0, grads, B, T, N, A, dq_idx=
     g.fc2_w, g.fc2_b = grads["fc2.weight"].data_ptr(), grads["fc2.bias"].data_ptr()
     for v in grads.values():
         assert v.is_contiguous() and v.dtype == torch.float32 and v.is_cuda
+    if x6:      # the split kernels (csrc/agent_bwd_x6.hip; opt-in args.gemm_mode = "bf16x6"): sparse dq only
+        assert dq is None and dq_idx is not None and dq_val is not None and dq_idx.is_contiguous() and dq_val.is_contiguous()
+        _i32(dq_idx); _f32(dq_val)
+        if dq_idx2 is not None:
+            assert dq_val2 is not None and dq_idx2.is_contiguous() and dq_val2.is_contiguous()
+            _i32(dq_idx2); _f32(dq_val2)
+        ws = WS.get("agent_bwd_x6", lib.marl_agent_bwd_x6_workspace(B, N, A), saved.device)
+        check(lib.marl_agent_unroll_bwd_x6(C.byref(w), _p(dq_idx), _p(dq_val), _p(dq_idx2), _p(dq_val2), int(dq_gdiv), _p(dhs),
+                                           _p(_f32(saved)), _p(_f32(dxp)), _p(dh0), C.byref(g), _p(ws), ws.numel() * 4, B, T, N, A,
+                                           _stream()), "marl_agent_unroll_bwd_x6")
+        return
     ws = WS.get("agent_bwd", lib.marl_agent_bwd_workspace(B, N, A), saved.device)
     if dq_idx is not None:
         assert dq is None and dq_val is not None and dq_idx.is_contiguous() and dq_val.is_contiguous()

@@ -800,6 +800,65 @@ def test_agent_unroll_bwd_from_x6_saved(dev, B, T):
         close(grads[k] / scale, ref / scale, 2e-4, 1e-3, msg=k)
 
 
+@pytest.mark.parametrize("B,T,pairs,with_dhs", [(7, 5, 1, False), (40, 6, 2, True), (700, 4, 1, False), (333, 3, 2, True), (13, 9, 1, True)])
+def test_agent_unroll_bwd_x6_split(dev, B, T, pairs, with_dhs):
+    """BPTT on the bf16x6 split kernels (csrc/agent_bwd_x6.hip, opt-in gemm_mode): one or two sparse (action, value) pairs per row
+    (the second pair with one value per (episode, step) shared by its agents, as QTRAN uses it), an optional external gradient on
+    hs, row counts that leave the last 32-row workgroup with a partial or a missing second tile - every gradient and dxp against
+    torch autograd of the oracle unroll at the bounds of test_agent_unroll_bwd, beside the fp32 MFMA kernel on the same inputs."""
+    from marl_amd import ops
+    args, p_np, obs, ufed, h0 = _agent_case("2s3z", B, T, dev, seed=3)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    I = O + A + N
+    assert ops.agent_unroll_bwd_x6_supported(B, T, N, A)
+    p, q_ref, hs_ref, _ = _oracle_unroll(args, p_np, obs, ufed, None, requires_grad=True)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, A, (B, T, N), generator=g)
+    gdiv = N if pairs == 2 else 1
+    v1 = torch.randn(B, T, generator=g) if pairs == 2 else torch.randn(B, T, N, generator=g)
+    e1 = v1[..., None].expand(B, T, N) if pairs == 2 else v1
+    dense = torch.zeros(B, T, N, A).scatter_add_(3, idx[..., None], e1[..., None].contiguous())
+    idx2 = v2 = None
+    if pairs == 2:
+        idx2 = torch.randint(0, A, (B, T, N), generator=g)
+        idx2[0, 0] = idx[0, 0]                                # coinciding columns add
+        v2 = torch.randn(B, T, generator=g)
+        dense.scatter_add_(3, idx2[..., None], v2[..., None, None].expand(B, T, N, 1).contiguous())
+    dhs = torch.randn(B, T, N, 64, generator=g) * 0.3 if with_dhs else None
+    loss = (q_ref * dense).sum()
+    if dhs is not None:
+        loss = loss + (hs_ref * dhs).sum()
+    loss.backward()
+    pd = {k: cu(v, dev) for k, v in p_np.items()}
+    w = ops.agent_weights(pd)
+    q, hs = torch.empty(B, T, N, A, device=dev), torch.empty(B, T, N, 64, device=dev)
+    saved = torch.empty(ops.saved_shape(T, B, N), device=dev)
+    obs_d, u_d = cu(obs, dev), cu(ufed, dev, torch.int32)
+    ops.agent_unroll_fwd(w, obs_d, T * N, 0, u_d, T * N, 0, None, q, hs, None, saved, B, T, N, O, A)
+    names = ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh", "fc2.weight", "fc2.bias")
+    M = B * T * N
+    out = {}
+    for mode in ("x6", "f32"):
+        grads = {k: torch.zeros_like(v) for k, v in pd.items()}
+        dxp = torch.full((B, T, N, 64), float("nan"), device=dev)
+        dh0 = torch.full((B * N, 64), float("nan"), device=dev)
+        ops.agent_unroll_bwd(w, None, cu(dhs, dev) if dhs is not None else None, saved, hs, dxp, dh0, {k: grads[k] for k in names},
+                             B, T, N, A, dq_idx=cu(idx, dev, torch.int32), dq_val=cu(v1, dev),
+                             dq_idx2=cu(idx2, dev, torch.int32) if idx2 is not None else None,
+                             dq_val2=cu(v2, dev) if v2 is not None else None, dq_gdiv=gdiv, x6=(mode == "x6"))
+        ops.linear_wgrad(dxp.view(M, 64), ops.src(obs_d.view(M, O), idx=u_d.view(M, 1), nhot=1, hot_w=A, nid=N),
+                         grads["fc1.weight"], grads["fc1.bias"], M, 64, I)
+        out[mode] = (grads, dxp, dh0)
+        for k in p:
+            ref = p[k].grad
+            scale = max(1.0, float(ref.abs().max()))
+            close(grads[k] / scale, ref / scale, 2e-4, 1e-3, msg=mode + " " + k)
+    close(out["x6"][1], out["f32"][1], 1e-5, 1e-4, msg="dxp")
+    close(out["x6"][2], out["f32"][2], 1e-5, 1e-4, msg="dh0")
+    worst = {m: max(float(((out[m][0][k].cpu() - p[k].grad).abs().max() / max(1.0, float(p[k].grad.abs().max())))) for k in p) for m in out}
+    print("BPTT B=%d T=%d: worst scaled gradient error vs autograd: bf16x6 %.2e, fp32 MFMA %.2e" % (B, T, worst["x6"], worst["f32"]))
+
+
 @pytest.mark.parametrize("shape,B,T", [("2s3z", 7, 5), ("MMM2", 3, 3), ("matrix", 9, 1), ("2s3z", 40, 6), ("2s3z", 3300, 3)])
 def test_agent_unroll_bwd(dev, shape, B, T):
     """BPTT delta kernel + wgrad reductions vs torch autograd of the oracle unroll.  Up to four row tiles per workgroup a

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a step of the split unroll (csrc/agent_x6.hip) spends its cycles, per wave of workgroup 0 (diagnostic build
-`make -C marl_amd/csrc stamps`):  python tools/stamps_unroll_x6.py [envs] [plain|save|read]
-team R (waves 0-3): h W_hh products | gate math + h planes | stores + fc2 | barrier;  team I (waves 4-7): gi | fc1 | input tile | barrier"""
+`make -C marl_amd/csrc stamps`):  python tools/stamps_unroll_x6.py [envs] [plain|save|read|bwd]
+team R (waves 0-3): h W_hh products | gate math + h planes | stores + fc2 | barrier;  team I (waves 4-7): gi | fc1 | input tile | barrier
+mode bwd (csrc/agent_bwd_x6.hip): team R: gate gradients + image | barrier | carry chain | dW_hh;  team I: barrier | dx | dW_ih | dW_2 + hand-offs"""
 import os, sys, ctypes
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["MARL_HIP_LIB"] = os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so")
@@ -15,9 +16,9 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "plain"
 dev = torch.device("cuda:0")
 lib = _lib.load()
 buf = torch.zeros(16 * 16, dtype=torch.int64, device=dev)
-fn = lib.marl_debug_stamps_agent_x6
-fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
-assert fn(buf.data_ptr()) == 0
+for fn in (lib.marl_debug_stamps_agent_x6, lib.marl_debug_stamps_agent_bwd_x6):
+    fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
+    assert fn(buf.data_ptr()) == 0
 N, O, S, A, T = bench.SHAPES["2s3z"]
 g = torch.Generator().manual_seed(0)
 P = {"fc1.weight": torch.randn(64, O + A + N, generator=g) * 0.1, "fc1.bias": torch.randn(64, generator=g) * 0.1,
@@ -38,6 +39,13 @@ for _ in range(2):
     buf.zero_()
     if mode == "plain":
         x6(w, obs, (T + 1) * N, 1, u, T * N, 0, None, q, None, None, None, B, T, N, O, A, cu_budget=cus)
+    elif mode == "bwd":
+        pd = {k: v.to(dev) for k, v in P.items()}
+        names = ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh", "fc2.weight", "fc2.bias")
+        grads = {k: torch.zeros_like(pd[k]) for k in names}
+        dxp = torch.empty(B, T, N, 64, device=dev)
+        di, dv = torch.randint(0, A, (B, T, N), device=dev, dtype=torch.int32), torch.randn(B, T, N, device=dev)
+        ops.agent_unroll_bwd(w, None, None, saved, None, dxp, None, grads, B, T, N, A, dq_idx=di, dq_val=dv, x6=True)
     elif mode == "save":
         x6(w, obs, (T + 1) * N, 0, u, T * N, -1, None, q, None, hl, saved, B, T, N, O, A, cu_budget=cus, gi_out=gi)
     else:

@@ -30,6 +30,15 @@ for B in [int(x) for x in sys.argv[1:]] or [4096, 1024, 512]:
             ("bf16x6 saving    ", lambda: x6(w, obs, (T + 1) * N, 0, u, T * N, -1, None, q6, None, hl, saved, B, T, N, O, A, cu_budget=cus, gi_out=gi6)),
             ("fp32 MFMA reading", lambda: f32(w, obs, (T + 1) * N, 1, u, T * N, 0, hl, q, None, None, None, B, T, N, O, A, cu_budget=cus, gi_in=gi)),
             ("bf16x6 reading   ", lambda: x6(w, obs, (T + 1) * N, 1, u, T * N, 0, hl, q6, None, None, None, B, T, N, O, A, cu_budget=cus, gi_in=gi6))]
+    hs = None
+    pd = {k: v.to(dev) for k, v in P.items()}
+    names = ("rnn.weight_ih", "rnn.weight_hh", "rnn.bias_ih", "rnn.bias_hh", "fc2.weight", "fc2.bias")
+    grads = {k: torch.zeros_like(pd[k]) for k in names}
+    dxp = torch.empty(B, T, N, 64, device=dev)
+    di, dv = torch.randint(0, A, (B, T, N), device=dev, dtype=torch.int32), torch.randn(B, T, N, device=dev)
+    bw = lambda x6_: ops.agent_unroll_bwd(w, None, None, saved, hs, dxp, None, grads, B, T, N, A, dq_idx=di, dq_val=dv, x6=x6_)
+    if os.environ.get("BWD", "1") == "1":
+        legs += [("fp32 MFMA BPTT   ", lambda: bw(False)), ("bf16x6 BPTT      ", lambda: bw(True))]
     for name, fn in legs:
         for _ in range(2): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
