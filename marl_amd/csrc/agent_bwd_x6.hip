@@ -4,11 +4,14 @@
 // per step the delta pass (dh carry, gate gradients, dx) AND the weight-gradient reductions of W_ih, W_hh, W_2 and their biases.
 //
 // One workgroup = 32 rows (two 16-row tiles of the saved-activation layout) = one k block of v_mfma_f32_16x16x32_bf16 for the
-// reductions over rows; 8 waves = 2 teams x 4 hidden-unit slices (wave s of a team: units 16s .. 16s+15), one barrier per step:
+// reductions over rows; 8 waves = 2 teams x 4 hidden-unit slices (wave s of a team: units 16s .. 16s+15), two barriers per step
+// (image filled | image read):
 //   team R (waves 0-3), the dependent chain:  dh = carry + dhs + dq W_2 -> gate gradients (fp32, accumulator layout: lane (q, m) =
 //          rows 4q + r of unit 16s + m, the layout of the saved planes) -> G image in LDS | barrier |
-//          carry' = dh z + [drp|dzp|dhn] W_hh ;  dW_hh += [drp|dzp|dhn]^T h_prev ;  bias sums (exact fp32)
-//   team I (waves 4-7), off the chain:        dx = [drp|dzp|dnp] W_ih -> relu gate -> dxp ;  dW_ih += [drp|dzp|dnp]^T x ;  dW_2 += dq^T h
+//          carry' = dh z + [drp|dzp|dhn] W_hh  and  dx = [drp|dzp|dnp] W_ih -> relu gate -> dxp (the contractions over gate columns:
+//          both sets of weight fragments live in this team's registers);  bias sums (exact fp32)
+//   team I (waves 4-7), off the chain, no weights, 100 accumulator registers:  dW_ih += [drp|dzp|dnp]^T x ;  dW_hh += [drp|dzp|dhn]^T h_prev ;
+//          dW_2 += dq^T h ;  it also loads x / h_prev, splits them once into ready operand fragments and publishes relu'(x)
 // The gate-gradient image G^T[gate column 0..255 = drp|dzp|dnp|dhn][row 0..31] holds three bf16 planes (each element split once,
 // where it is produced): a product that CONTRACTS over gate columns (dx, carry') reads it transposed (ds_read_b64_tr_b16: lane i =
 // row), a product with gate columns as OUTPUT rows (the weight gradients, contraction over the 32 rows) reads it plainly - the k
@@ -114,13 +117,15 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, s = wave & 3;
   const int q = lane >> 4, m = lane & 15, u = 16 * s + m;
-  char* Gt = smem;                                   // [2][3][256][64 B]
-  char* HB = Gt + 2 * GBUF;                          // [2] fragments of h_prev(t) column tiles
+  char* Gt = smem;                                   // [3][256][64 B]: one image, freed for the next step by the second barrier
+  char* WL = Gt + GBUF;                              // [4 waves][4] weight fragments of team R that do not fit its registers
+  char* HB = WL + 4 * FRB;                           // [2] fragments of h_prev(t) column tiles
   char* XB = HB + 2 * FRB;                           // [2] fragments of x(t) column tiles
   float* W2s = reinterpret_cast<float*>(XB + 2 * FRB);      // [16][64]
   int4* QT = reinterpret_cast<int4*>(W2s + 16 * H);   // [3][32]: (idx, val, idx2, val2) of a row at a step
   int* rowidx = reinterpret_cast<int*>(QT + 3 * 32);  // [32]: index of (b, 0, n) in (B,T,N) or -1
   int* rowrho = rowidx + 32;                          // [32]
+  unsigned* XM = reinterpret_cast<unsigned*>(rowrho + 32);      // [2][4][64]: relu'(x) bits of a lane's 8 elements, by step parity
 
   const long NTILES = (a.R + 15) >> 4;
   const long tile0 = 2L * blockIdx.x;
@@ -161,15 +166,15 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   };
   ST_DECL(4);
   if (team == 0) {
-    // =============================== team R: the chain, dW_hh, the bias sums ===============================
-    F3 whT[6];      // k chunks of [drp | dzp | dhn] <-> rows 0..191 of W_hh (r | z | n)
+    // =============================== team R: gate gradients, the carry chain, dx; the bias sums ===============================
+    // k chunks of [drp | dzp | dhn] <-> rows of W_hh (r | z | n);  of [drp | dzp | dnp] <-> rows of W_ih.  Chunks 0..3 of both in
+    // registers (96), chunks 4, 5 (the n rows) as ready fragments in LDS: with all twelve the saved planes in flight would spill
+    F3 whT[4], wiT[4];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) whT[c] = wTfrag(a.Whh, c, 16 * s, lane);
-    f32x4 accW[3][4];
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) accW[b][c] = splat(0.f);
+    for (int c = 0; c < 4; ++c) { whT[c] = wTfrag(a.Whh, c, 16 * s, lane); wiT[c] = wTfrag(a.Wih, c, 16 * s, lane); }
+    char* wl = WL + s * FRB;
+    fr_put(wl, 0, lane, wTfrag(a.Whh, 4, 16 * s, lane)); fr_put(wl, 1, lane, wTfrag(a.Whh, 5, 16 * s, lane));
+    fr_put(wl, 2, lane, wTfrag(a.Wih, 4, 16 * s, lane)); fr_put(wl, 3, lane, wTfrag(a.Wih, 5, 16 * s, lane));
     f32x4 carry[2] = {splat(0.f), splat(0.f)};
     float bs[4] = {0.f, 0.f, 0.f, 0.f};               // column sums of drp, dzp, dnp, dhn (this lane's 8 rows)
     f32x4 sv[2][5];                                    // saved planes of the step: h_prev, r, z, n, W_hn h + b_hn
@@ -194,11 +199,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
       const int par = t & 1;
-      char* img = Gt + par * GBUF;
+      char* img = Gt;
       const int4* qt = QT + (t % 3) * 32;
       int wb, tb0, tb1;
       lane_parts(wb, tb0, tb1);
-      const int rb = wb;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         f32x4 drp, dzp, dnp, dhn;
@@ -229,60 +233,67 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         g_put(img, wb, 2 * 64 + 16 * s, tt, split4(dnp));
         g_put(img, wb, 3 * 64 + 16 * s, tt, split4(dhn));
       }
-      fr_put(HB + par * FRB, s, lane, split8(sv[0][0], sv[1][0]));      // h_prev, column tile s, as a ready B fragment
       ST_MARK(0);
       WG_BARRIER();
       ST_MARK(1);
       __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) { svload(t - 1, 0); svload(t - 1, 1); }      // in flight under the chain and dW_hh
+      if (t > 0) { svload(t - 1, 0); svload(t - 1, 1); }      // in flight under the products below
+      const unsigned xmask = XM[par * 256 + s * 64 + lane];    // relu'(x(t)) of this lane's 8 elements (team I published it)
       __builtin_amdgcn_sched_barrier(0);
-      // carry' = dh z + [drp | dzp | dhn] W_hh : a tile at a time, (even, odd k chunks) = two chains
+      // carry' = dh z + [drp | dzp | dhn] W_hh  and  dx = [drp | dzp | dnp] W_ih -> relu gate -> dxp : a tile at a time; the fragments
+      // of drp and dzp serve both products
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        // four independent accumulators (two k chunks x alternate products): a dependent MFMA issues at a fraction of the pipe's
-        // rate, and the gaps it leaves are too short for the other wave of the SIMD to use
-        f32x4 ca = carry[tt], cb = splat(0.f), cc = splat(0.f), cd = splat(0.f);
+        f32x4 ca = carry[tt], cb = splat(0.f), da = splat(0.f), db = splat(0.f);
 #pragma unroll
-        for (int cp = 0; cp < 3; ++cp) {
-          const int k0 = (cp == 2 ? 192 : 64 * cp);
-          const F3 a0 = g_tr3(img, tb0, tb1, k0, tt), a1 = g_tr3(img, tb0, tb1, k0 + 32, tt);
-          X6_TERMS4(a0, whT[2 * cp], a1, whT[2 * cp + 1], ca, cb, cc, cd)
+        for (int cp = 0; cp < 2; ++cp) {
+          const F3 a0 = g_tr3(img, tb0, tb1, 64 * cp, tt), a1 = g_tr3(img, tb0, tb1, 64 * cp + 32, tt);
+#define OP(p_, q_) ca = mm(a0.p_, whT[2 * cp].q_, ca); cb = mm(a1.p_, whT[2 * cp + 1].q_, cb); da = mm(a0.p_, wiT[2 * cp].q_, da); db = mm(a1.p_, wiT[2 * cp + 1].q_, db);
+          X6_TERMS(OP)
+#undef OP
+          __builtin_amdgcn_sched_barrier(0);          // (keeps the next chunk's fragments from being fetched early: registers)
         }
-        carry[tt] = (ca + cb) + (cc + cd);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      ST_MARK(2);
-      // dW_hh[this wave's 16 columns of r | z | n][all 64] += G^T h_prev
-      {
-        const F3 ar = g_cols(img, rb, 0 * 64 + 16 * s), az = g_cols(img, rb, 1 * 64 + 16 * s), an = g_cols(img, rb, 3 * 64 + 16 * s);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const F3 hb = fr_get(HB + par * FRB, c, lane);
-#define OP(p_, q_) accW[0][c] = mm(ar.p_, hb.q_, accW[0][c]); accW[1][c] = mm(az.p_, hb.q_, accW[1][c]); accW[2][c] = mm(an.p_, hb.q_, accW[2][c]);
+        {
+          const F3 a0 = g_tr3(img, tb0, tb1, 192, tt), a1 = g_tr3(img, tb0, tb1, 192 + 32, tt);
+          const F3 w4 = fr_get(wl, 0, lane), w5 = fr_get(wl, 1, lane);
+#define OP(p_, q_) ca = mm(a0.p_, w4.q_, ca); cb = mm(a1.p_, w5.q_, cb);
           X6_TERMS(OP)
 #undef OP
         }
+        carry[tt] = ca + cb;
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const F3 a0 = g_tr3(img, tb0, tb1, 128, tt), a1 = g_tr3(img, tb0, tb1, 128 + 32, tt);
+          const F3 w4 = fr_get(wl, 2, lane), w5 = fr_get(wl, 3, lane);
+#define OP(p_, q_) da = mm(a0.p_, w4.q_, da); db = mm(a1.p_, w5.q_, db);
+          X6_TERMS(OP)
+#undef OP
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 dx = da + db;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ri = rowidx[16 * tt + 4 * q + r];
+          if (ri >= 0) a.dxp[((long)ri + (long)t * a.N) * H + u] = (xmask >> (4 * tt + r)) & 1u ? dx[r] : 0.f;
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      ST_MARK(2);
+      WG_BARRIER();                                  // second barrier of the step: everybody has read the image, the next step may fill it
       ST_MARK(3);
     }
     ST_DUMP(4);
-    // ---- epilogue: dh0, the slab of this workgroup
+    // ---- epilogue: dh0, the bias sums of this workgroup's slab
     if (a.dh0) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rho = rowrho[16 * tt + 4 * q + r];
-          if (rho >= 0 && (tt == 0 || tile0 + 1 < NTILES)) a.dh0[(long)rho * H + u] = carry[tt][r];
+          if (rho >= 0) a.dh0[(long)rho * H + u] = carry[tt][r];
         }
     }
     float* slab = a.ws + (long)blockIdx.x * slab_floats(a.A);
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[192 * 64 + (long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accW[b][c][r];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       bs[k] += __shfl_xor(bs[k], 16);
@@ -294,31 +305,33 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       db[192 + 0 * 64 + u] = bs[0]; db[192 + 1 * 64 + u] = bs[1]; db[192 + 2 * 64 + u] = bs[3];   // db_hh: r | z | n (hidden side)
     }
   } else {
-    // =============================== team I: dx, dW_ih, dW_2 ===============================
+    // =============================== team I: the weight gradients dW_ih, dW_hh, dW_2 ===============================
     const int ti = tid - 256;
-    F3 wiT[6];      // k chunks of [drp | dzp | dnp] <-> rows 0..191 of W_ih
-#pragma unroll
-    for (int c = 0; c < 6; ++c) wiT[c] = wTfrag(a.Wih, c, 16 * s, lane);
-    f32x4 accW[3][4], acc2 = splat(0.f);
+    f32x4 accI[3][4], accH[3][4], acc2 = splat(0.f);
 #pragma unroll
     for (int b = 0; b < 3; ++b)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) accW[b][c] = splat(0.f);
+      for (int c = 0; c < 4; ++c) { accI[b][c] = splat(0.f); accH[b][c] = splat(0.f); }
     float bs2 = 0.f;
-    f32x4 xn[2];                                      // x of the step to come (in flight across the barrier)
-    auto xload = [&](int t) {
+    f32x4 xn[2], hn[2];                               // x and h_prev of the step to come, column tile s (in flight across the barrier)
+    auto xhload = [&](int t) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) xn[tt] = *reinterpret_cast<const f32x4*>(a.saved + sv_off((long)t * NTILES + tl[tt], 1, s, lane));
+      for (int tt = 0; tt < 2; ++tt) {
+        const float* sp = a.saved + sv_off((long)t * NTILES + tl[tt], 0, s, lane);
+        hn[tt] = *reinterpret_cast<const f32x4*>(sp);
+        xn[tt] = *reinterpret_cast<const f32x4*>(sp + 1024);
+      }
     };
-    // x(t) -> ready B fragments of dW_ih for the whole team + the relu mask of this lane's 8 elements (bit 4 tt + r)
-    auto xpublish = [&](int t) {
+    // x(t), h_prev(t) of column tile s -> ready B fragments of the weight gradients for the whole team; relu'(x) for team R's dx
+    auto publish = [&](int t) {
       fr_put(XB + (t & 1) * FRB, s, lane, split8(xn[0], xn[1]));
+      fr_put(HB + (t & 1) * FRB, s, lane, split8(hn[0], hn[1]));
       unsigned mk = 0;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mk |= xn[tt][r] > 0.f ? 1u << (4 * tt + r) : 0u;
-      return mk;
+      XM[(t & 1) * 256 + s * 64 + lane] = mk;
     };
     auto dw2 = [&](const int4* qt, const F3& hb) {
       f32x4 d0, d1;
@@ -331,9 +344,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       bs2 += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
       mm6(split8(d0, d1), hb, acc2);
     };
-    xload(T - 1);
-    unsigned xmask = xpublish(T - 1), xmask_next = 0;
-    xload(T - 2);
+    xhload(T - 1);
+    publish(T - 1);
+    xhload(T - 2);
     int4 qn = make_int4(0, 0, 0, 0);
     if (ti < 32) qn = qload(ti, T - 3);
     __syncthreads();
@@ -345,51 +358,47 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     }
     for (int t = T - 1; t >= 0; --t) {
       const int par = t & 1;
-      const char* img = Gt + par * GBUF;
+      const char* img = Gt;
       WG_BARRIER();
       ST_MARK(0);
       int rb, tb0, tb1;
       lane_parts(rb, tb0, tb1);
-      if (t > 0) xmask_next = xpublish(t - 1);       // (loaded during the previous step; XB[par ^ 1] was last read before this barrier)
-      if (t > 1) xload(t - 2);
+      if (t > 0) publish(t - 1);                     // (loaded during the previous step; the buffers were last read before this barrier)
+      if (t > 1) xhload(t - 2);
       __builtin_amdgcn_sched_barrier(0);
-      // dx = [drp | dzp | dnp] W_ih -> relu gate -> dxp
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        f32x4 ca = splat(0.f), cb = splat(0.f), cc = splat(0.f), cd = splat(0.f);
-#pragma unroll
-        for (int cp = 0; cp < 3; ++cp) {
-          const int k0 = 64 * cp;
-          const F3 a0 = g_tr3(img, tb0, tb1, k0, tt), a1 = g_tr3(img, tb0, tb1, k0 + 32, tt);
-          X6_TERMS4(a0, wiT[2 * cp], a1, wiT[2 * cp + 1], ca, cb, cc, cd)
-        }
-        const f32x4 dx = (ca + cb) + (cc + cd);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ri = rowidx[16 * tt + 4 * q + r];
-          if (ri >= 0 && (tt == 0 || tile0 + 1 < NTILES)) a.dxp[((long)ri + (long)t * a.N) * H + u] = (xmask >> (4 * tt + r)) & 1u ? dx[r] : 0.f;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      ST_MARK(1);
-      // dW_ih[this wave's 16 columns of r | z | n][all 64] += G^T x
+      // dW_ih[this wave's 16 columns of r | z | n][all 64] += [drp | dzp | dnp]^T x ;  dW_hh[...] += [drp | dzp | dhn]^T h_prev
       {
-        const F3 ar = g_cols(img, rb, 0 * 64 + 16 * s), az = g_cols(img, rb, 1 * 64 + 16 * s), an = g_cols(img, rb, 2 * 64 + 16 * s);
+        const F3 ar = g_cols(img, rb, 0 * 64 + 16 * s), az = g_cols(img, rb, 1 * 64 + 16 * s);
+        {
+          const F3 an = g_cols(img, rb, 2 * 64 + 16 * s);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const F3 xb = fr_get(XB + par * FRB, c, lane);
-#define OP(p_, q_) accW[0][c] = mm(ar.p_, xb.q_, accW[0][c]); accW[1][c] = mm(az.p_, xb.q_, accW[1][c]); accW[2][c] = mm(an.p_, xb.q_, accW[2][c]);
-          X6_TERMS(OP)
+          for (int c = 0; c < 4; ++c) {
+            const F3 xb = fr_get(XB + par * FRB, c, lane);
+#define OP(p_, q_) accI[0][c] = mm(ar.p_, xb.q_, accI[0][c]); accI[1][c] = mm(az.p_, xb.q_, accI[1][c]); accI[2][c] = mm(an.p_, xb.q_, accI[2][c]);
+            X6_TERMS(OP)
 #undef OP
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ST_MARK(1);
+        {
+          const F3 an = g_cols(img, rb, 3 * 64 + 16 * s);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const F3 hb = fr_get(HB + par * FRB, c, lane);
+#define OP(p_, q_) accH[0][c] = mm(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mm(az.p_, hb.q_, accH[1][c]); accH[2][c] = mm(an.p_, hb.q_, accH[2][c]);
+            X6_TERMS(OP)
+#undef OP
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       ST_MARK(2);
-      // dW_2[action][this wave's 16 columns] += dq(t-1)^T h(t-1): h(t-1) = h_prev of THIS step, whose ready fragments team R published
-      // before the barrier (HB[par], stable until the next one).  Lane (g, i): action i, k slots = rows 4g .. 4g+3 of tile 0, then tile 1
+      // dW_2[action][this wave's 16 columns] += dq(t-1)^T h(t-1): h(t-1) = h_prev of THIS step (HB[par], stable until the next barrier).
+      // Lane (g, i): action i, k slots = rows 4g .. 4g+3 of tile 0, then of tile 1
       if (t > 0) dw2(QT + ((t - 1) % 3) * 32, fr_get(HB + par * FRB, s, lane));
+      WG_BARRIER();                                  // second barrier of the step (the image has been read)
       // the steps to come: the dq pairs of step t-2 handed over
-      xmask = xmask_next;
       if (ti < 32) {
         if (t >= 2) QT[((t - 2) % 3) * 32 + ti] = qn;
         qn = qload(ti, t - 3);
@@ -403,7 +412,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accW[b][c][r];
+        for (int r = 0; r < 4; ++r) {
+          slab[(long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accI[b][c][r];
+          slab[192 * 64 + (long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accH[b][c][r];
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (4 * q + r < a.A) slab[2 * 192 * 64 + (long)(4 * q + r) * H + u] = acc2[r];
@@ -472,7 +484,7 @@ extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int
   a.dhs = dhs; a.saved = saved; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const unsigned nwg = (unsigned)((a.R + 31) / 32);
-  const size_t lds = (size_t)2 * GBUF + 4 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4;
+  const size_t lds = (size_t)GBUF + 8 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4;
   const void* fn = dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true> : (const void*)agent_bwd_x6_kernel<true, false>)
                        : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true> : (const void*)agent_bwd_x6_kernel<false, false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
