@@ -199,7 +199,7 @@ class Scratch:
         return t
 
 
-X6_BWD_MIN_WG = int(os.environ.get("MARL_X6_BWD_MIN_WG", "120"))      # workgroups from which the split BPTT kernel is used (A/B switch)
+X6_BWD_MIN_WG = int(os.environ.get("MARL_X6_BWD_MIN_WG", "1"))      # 32-row groups from which the split BPTT kernel is used (A/B switch)
 
 
 def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=None, dq_idx2=None, dq_val2=None, dq_gdiv=1):
@@ -217,8 +217,8 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=
     grads = {"rnn.weight_ih": ag.rnn.weight_ih.grad, "rnn.weight_hh": ag.rnn.weight_hh.grad,
              "rnn.bias_ih": ag.rnn.bias_ih.grad, "rnn.bias_hh": ag.rnn.bias_hh.grad,
              "fc2.weight": ag.fc2.weight.grad, "fc2.bias": ag.fc2.bias.grad}
-    # opt-in args.gemm_mode = "bf16x6": the split BPTT kernel (csrc/agent_bwd_x6.hip; one workgroup per 32 rows) where it has the
-    # workgroups to fill the chip - below ~120 of them the fp32 pipelined kernel (one per 16 rows) is the faster one
+    # opt-in args.gemm_mode = "bf16x6": the split BPTT kernel (csrc/agent_bwd_x6.hip; one workgroup per 16 rows up to 256 row tiles,
+    # per 32 rows beyond) - faster than the fp32 kernels at every size measured (profiles/r04_unroll_x6_times.txt)
     from ..network import mixer as _mixer
     x6 = (getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6" and dq is None and dq_idx is not None
           and (B * N + 31) // 32 >= X6_BWD_MIN_WG and ops.agent_unroll_bwd_x6_supported(B, T, N, A))

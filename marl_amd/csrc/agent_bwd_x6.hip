@@ -111,8 +111,41 @@ __device__ __forceinline__ F3 fr_get(const char* fr, int tile, int lane) {
   return f;
 }
 
-template <bool DHS, bool TWO>
+// one row tile per workgroup (NT = 1, the small shards): the reductions over rows run on v_mfma_f32_16x16x16_bf16 - k slots = rows
+// 4g .. 4g+3 of the one tile, fragments of 8 bytes per lane and plane
+template <int NT> struct FW;
+template <> struct FW<2> { typedef F3 T; };
+template <> struct FW<1> { typedef F3h T; };
+__device__ __forceinline__ f32x4 mmx(const i32x4& a, const i32x4& b, f32x4 c) { return mm(a, b, c); }
+__device__ __forceinline__ f32x4 mmx(const i32x2& a, const i32x2& b, f32x4 c) { return mmh(a, b, c); }
+__device__ __forceinline__ void mm6x(const F3& a, const F3& b, f32x4& c) { mm6(a, b, c); }
+__device__ __forceinline__ void mm6x(const F3h& a, const F3h& b, f32x4& c) { mm6h(a, b, c); }
+__device__ __forceinline__ void fr_put(char* fr, int tile, int lane, const F3h& f) {
+  i32x2* p = reinterpret_cast<i32x2*>(fr) + tile * 192 + lane;
+  p[0] = f.h; p[64] = f.m; p[128] = f.l;
+}
+template <int NT> __device__ __forceinline__ typename FW<NT>::T fr_getn(const char* fr, int tile, int lane);
+template <> __device__ __forceinline__ F3 fr_getn<2>(const char* fr, int tile, int lane) { return fr_get(fr, tile, lane); }
+template <> __device__ __forceinline__ F3h fr_getn<1>(const char* fr, int tile, int lane) {
+  const i32x2* p = reinterpret_cast<const i32x2*>(fr) + tile * 192 + lane;
+  F3h f;
+  f.h = p[0]; f.m = p[64]; f.l = p[128];
+  return f;
+}
+template <int NT> __device__ __forceinline__ typename FW<NT>::T g_colsn(const char* img, int rb, int k0);
+template <> __device__ __forceinline__ F3 g_colsn<2>(const char* img, int rb, int k0) { return g_cols(img, rb, k0); }
+template <> __device__ __forceinline__ F3h g_colsn<1>(const char* img, int rb, int k0) {
+  const char* p = img + k0 * 64 + rb;
+  F3h f;
+  f.h = *reinterpret_cast<const i32x2*>(p); f.m = *reinterpret_cast<const i32x2*>(p + GPL); f.l = *reinterpret_cast<const i32x2*>(p + 2 * GPL);
+  return f;
+}
+__device__ __forceinline__ F3 splitn(const f32x4 (&x)[2]) { return split8(x[0], x[1]); }
+__device__ __forceinline__ F3h splitn(const f32x4 (&x)[1]) { return split4(x[0]); }
+
+template <bool DHS, bool TWO, int NT>
 __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
+  typedef typename FW<NT>::T FWT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, s = wave & 3;
@@ -128,9 +161,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   unsigned* XM = reinterpret_cast<unsigned*>(rowrho + 32);      // [2][4][64]: relu'(x) bits of a lane's 8 elements, by step parity
 
   const long NTILES = (a.R + 15) >> 4;
-  const long tile0 = 2L * blockIdx.x;
+  const long tile0 = (long)NT * blockIdx.x;
   const long tl[2] = {tile0, tile0 + 1 < NTILES ? tile0 + 1 : tile0};      // (a missing second tile reads the first: its gradients are zero)
-  if (tid < 32) {
+  if (tid < 16 * NT) {
     const long rho = tile0 * 16 + tid;
     const bool ok = rho < a.R;
     rowidx[tid] = ok ? (int)((rho / a.N) * a.T * a.N + rho % a.N) : -1;
@@ -175,10 +208,12 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     char* wl = WL + s * FRB;
     fr_put(wl, 0, lane, wTfrag(a.Whh, 4, 16 * s, lane)); fr_put(wl, 1, lane, wTfrag(a.Whh, 5, 16 * s, lane));
     fr_put(wl, 2, lane, wTfrag(a.Wih, 4, 16 * s, lane)); fr_put(wl, 3, lane, wTfrag(a.Wih, 5, 16 * s, lane));
-    f32x4 carry[2] = {splat(0.f), splat(0.f)};
+    f32x4 carry[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) carry[tt] = splat(0.f);
     float bs[4] = {0.f, 0.f, 0.f, 0.f};               // column sums of drp, dzp, dnp, dhn (this lane's 8 rows)
-    f32x4 sv[2][5];                                    // saved planes of the step: h_prev, r, z, n, W_hn h + b_hn
-    f32x4 dhsv[2];
+    f32x4 sv[NT][5];                                    // saved planes of the step: h_prev, r, z, n, W_hn h + b_hn
+    f32x4 dhsv[NT];
     auto svload = [&](int t, int tt) {
       const float* sp = a.saved + sv_off((long)t * NTILES + tl[tt], 0, s, lane);
       sv[tt][0] = *reinterpret_cast<const f32x4*>(sp);
@@ -194,8 +229,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         }
       }
     };
-    svload(T - 1, 0); svload(T - 1, 1);
-    if (tid < 32) { QT[((T - 1) % 3) * 32 + tid] = qload(tid, T - 1); QT[((T - 2 + 3) % 3) * 32 + tid] = qload(tid, T - 2); }
+    svload(T - 1, 0);
+    if (NT == 2) svload(T - 1, NT - 1);
+    if (tid < 16 * NT) { QT[((T - 1) % 3) * 32 + tid] = qload(tid, T - 1); QT[((T - 2 + 3) % 3) * 32 + tid] = qload(tid, T - 2); }
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
       const int par = t & 1;
@@ -204,7 +240,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       int wb, tb0, tb1;
       lane_parts(wb, tb0, tb1);
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
+      for (int tt = 0; tt < NT; ++tt) {
         f32x4 drp, dzp, dnp, dhn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -237,13 +273,13 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       WG_BARRIER();
       ST_MARK(1);
       __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) { svload(t - 1, 0); svload(t - 1, 1); }      // in flight under the products below
+      if (t > 0) { svload(t - 1, 0); if (NT == 2) svload(t - 1, NT - 1); }      // in flight under the products below
       const unsigned xmask = XM[par * 256 + s * 64 + lane];    // relu'(x(t)) of this lane's 8 elements (team I published it)
       __builtin_amdgcn_sched_barrier(0);
       // carry' = dh z + [drp | dzp | dhn] W_hh  and  dx = [drp | dzp | dnp] W_ih -> relu gate -> dxp : a tile at a time; the fragments
       // of drp and dzp serve both products
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
+      for (int tt = 0; tt < NT; ++tt) {
         f32x4 ca = carry[tt], cb = splat(0.f), da = splat(0.f), db = splat(0.f);
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
@@ -286,7 +322,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     // ---- epilogue: dh0, the bias sums of this workgroup's slab
     if (a.dh0) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rho = rowrho[16 * tt + 4 * q + r];
@@ -313,10 +349,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) { accI[b][c] = splat(0.f); accH[b][c] = splat(0.f); }
     float bs2 = 0.f;
-    f32x4 xn[2], hn[2];                               // x and h_prev of the step to come, column tile s (in flight across the barrier)
+    f32x4 xn[NT], hn[NT];                             // x and h_prev of the step to come, column tile s (in flight across the barrier)
     auto xhload = [&](int t) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
+      for (int tt = 0; tt < NT; ++tt) {
         const float* sp = a.saved + sv_off((long)t * NTILES + tl[tt], 0, s, lane);
         hn[tt] = *reinterpret_cast<const f32x4*>(sp);
         xn[tt] = *reinterpret_cast<const f32x4*>(sp + 1024);
@@ -324,37 +360,41 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     };
     // x(t), h_prev(t) of column tile s -> ready B fragments of the weight gradients for the whole team; relu'(x) for team R's dx
     auto publish = [&](int t) {
-      fr_put(XB + (t & 1) * FRB, s, lane, split8(xn[0], xn[1]));
-      fr_put(HB + (t & 1) * FRB, s, lane, split8(hn[0], hn[1]));
+      fr_put(XB + (t & 1) * FRB, s, lane, splitn(xn));
+      fr_put(HB + (t & 1) * FRB, s, lane, splitn(hn));
       unsigned mk = 0;
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mk |= xn[tt][r] > 0.f ? 1u << (4 * tt + r) : 0u;
       XM[(t & 1) * 256 + s * 64 + lane] = mk;
     };
-    auto dw2 = [&](const int4* qt, const F3& hb) {
-      f32x4 d0, d1;
+    auto dw2 = [&](const int4* qt, const FWT& hb) {
+      f32x4 d[NT];
+      float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int4 e0 = qt[4 * q + r], e1 = qt[16 + 4 * q + r];
-        d0[r] = (e0.x == m ? __int_as_float(e0.y) : 0.f) + (TWO && e0.z == m ? __int_as_float(e0.w) : 0.f);
-        d1[r] = (e1.x == m ? __int_as_float(e1.y) : 0.f) + (TWO && e1.z == m ? __int_as_float(e1.w) : 0.f);
+      for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int4 e = qt[16 * tt + 4 * q + r];
+          d[tt][r] = (e.x == m ? __int_as_float(e.y) : 0.f) + (TWO && e.z == m ? __int_as_float(e.w) : 0.f);
+        }
+        sum += (d[tt][0] + d[tt][1]) + (d[tt][2] + d[tt][3]);
       }
-      bs2 += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
-      mm6(split8(d0, d1), hb, acc2);
+      bs2 += sum;
+      mm6x(splitn(d), hb, acc2);
     };
     xhload(T - 1);
     publish(T - 1);
     xhload(T - 2);
     int4 qn = make_int4(0, 0, 0, 0);
-    if (ti < 32) qn = qload(ti, T - 3);
+    if (ti < 16 * NT) qn = qload(ti, T - 3);
     __syncthreads();
     {      // the last step's dq meets h(T-1), the hidden state after the last step (plane 0 of step T)
-      f32x4 hT[2];
+      f32x4 hT[NT];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) hT[tt] = *reinterpret_cast<const f32x4*>(a.saved + sv_off((long)T * NTILES + tl[tt], 0, s, lane));
-      dw2(QT + ((T - 1) % 3) * 32, split8(hT[0], hT[1]));
+      for (int tt = 0; tt < NT; ++tt) hT[tt] = *reinterpret_cast<const f32x4*>(a.saved + sv_off((long)T * NTILES + tl[tt], 0, s, lane));
+      dw2(QT + ((T - 1) % 3) * 32, splitn(hT));
     }
     for (int t = T - 1; t >= 0; --t) {
       const int par = t & 1;
@@ -368,13 +408,13 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       __builtin_amdgcn_sched_barrier(0);
       // dW_ih[this wave's 16 columns of r | z | n][all 64] += [drp | dzp | dnp]^T x ;  dW_hh[...] += [drp | dzp | dhn]^T h_prev
       {
-        const F3 ar = g_cols(img, rb, 0 * 64 + 16 * s), az = g_cols(img, rb, 1 * 64 + 16 * s);
+        const FWT ar = g_colsn<NT>(img, rb, 0 * 64 + 16 * s), az = g_colsn<NT>(img, rb, 1 * 64 + 16 * s);
         {
-          const F3 an = g_cols(img, rb, 2 * 64 + 16 * s);
+          const FWT an = g_colsn<NT>(img, rb, 2 * 64 + 16 * s);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const F3 xb = fr_get(XB + par * FRB, c, lane);
-#define OP(p_, q_) accI[0][c] = mm(ar.p_, xb.q_, accI[0][c]); accI[1][c] = mm(az.p_, xb.q_, accI[1][c]); accI[2][c] = mm(an.p_, xb.q_, accI[2][c]);
+            const FWT xb = fr_getn<NT>(XB + par * FRB, c, lane);
+#define OP(p_, q_) accI[0][c] = mmx(ar.p_, xb.q_, accI[0][c]); accI[1][c] = mmx(az.p_, xb.q_, accI[1][c]); accI[2][c] = mmx(an.p_, xb.q_, accI[2][c]);
             X6_TERMS(OP)
 #undef OP
           }
@@ -382,11 +422,11 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         __builtin_amdgcn_sched_barrier(0);
         ST_MARK(1);
         {
-          const F3 an = g_cols(img, rb, 3 * 64 + 16 * s);
+          const FWT an = g_colsn<NT>(img, rb, 3 * 64 + 16 * s);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const F3 hb = fr_get(HB + par * FRB, c, lane);
-#define OP(p_, q_) accH[0][c] = mm(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mm(az.p_, hb.q_, accH[1][c]); accH[2][c] = mm(an.p_, hb.q_, accH[2][c]);
+            const FWT hb = fr_getn<NT>(HB + par * FRB, c, lane);
+#define OP(p_, q_) accH[0][c] = mmx(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mmx(az.p_, hb.q_, accH[1][c]); accH[2][c] = mmx(an.p_, hb.q_, accH[2][c]);
             X6_TERMS(OP)
 #undef OP
           }
@@ -396,10 +436,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       ST_MARK(2);
       // dW_2[action][this wave's 16 columns] += dq(t-1)^T h(t-1): h(t-1) = h_prev of THIS step (HB[par], stable until the next barrier).
       // Lane (g, i): action i, k slots = rows 4g .. 4g+3 of tile 0, then of tile 1
-      if (t > 0) dw2(QT + ((t - 1) % 3) * 32, fr_get(HB + par * FRB, s, lane));
+      if (t > 0) dw2(QT + ((t - 1) % 3) * 32, fr_getn<NT>(HB + par * FRB, s, lane));
       WG_BARRIER();                                  // second barrier of the step (the image has been read)
       // the steps to come: the dq pairs of step t-2 handed over
-      if (ti < 32) {
+      if (ti < 16 * NT) {
         if (t >= 2) QT[((t - 2) % 3) * 32 + ti] = qn;
         qn = qload(ti, t - 3);
       }
@@ -465,9 +505,13 @@ extern "C" int marl_agent_unroll_bwd_x6_supported(int B, int T, int N, int A, in
   return 1;
 }
 
+// row tiles per workgroup: one while that fills at most one round of workgroups (the small shards), two beyond
+static int bx6_nt(long R) { return (R + 15) / 16 <= 256 ? 1 : 2; }
+
 extern "C" size_t marl_agent_bwd_x6_workspace(int B, int N, int A) {
   const long R = (long)B * N;
-  return (size_t)((R + 31) / 32) * slab_floats(A) * sizeof(float);
+  const int nt = bx6_nt(R);
+  return (size_t)((R + 16 * nt - 1) / (16 * nt)) * slab_floats(A) * sizeof(float);
 }
 
 extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int* dq_idx, const float* dq_val, const int* dq_idx2,
@@ -483,10 +527,13 @@ extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int
   a.dq_idx = dq_idx; a.dq_val = dq_val; a.dq_idx2 = dq_idx2; a.dq_val2 = dq_val2; a.dq_gdiv = dq_gdiv > 1 ? dq_gdiv : 1;
   a.dhs = dhs; a.saved = saved; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
-  const unsigned nwg = (unsigned)((a.R + 31) / 32);
+  const int nt = bx6_nt(a.R);
+  const unsigned nwg = (unsigned)((a.R + 16 * nt - 1) / (16 * nt));
   const size_t lds = (size_t)GBUF + 8 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4;
-  const void* fn = dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true> : (const void*)agent_bwd_x6_kernel<true, false>)
-                       : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true> : (const void*)agent_bwd_x6_kernel<false, false>);
+#define BX6_PICK(NT_) (dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true, NT_> : (const void*)agent_bwd_x6_kernel<true, false, NT_>) \
+                           : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true, NT_> : (const void*)agent_bwd_x6_kernel<false, false, NT_>))
+  const void* fn = nt == 1 ? BX6_PICK(1) : BX6_PICK(2);
+#undef BX6_PICK
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipStream_t st = (hipStream_t)stream;
