@@ -107,6 +107,9 @@ class KernelTimers:
             B, T, N_, A_ = ar[8], ar[9], ar[10], ar[11]
             rows = B * T * N_
             f = (8 * 3 * H * H + 4 * A_ * H) * rows   # dx, dh_prev, dW_ih, dW_hh (2*192*64 each) + dq->dh and dW_2 (2*A*64 each)
+            if kw.get("x6"):      # csrc/agent_bwd_x6.hip (opt-in gemm_mode)
+                return ("agent_bwd_x6_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2, fp32 products as six bf16 MFMA products)", "agent_bwd_x6_kernel",
+                        f, f, 4.0 * rows * (10 * H + H))
             return ("agent_bwd_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2)", "agent_bwd_kernel", f, f, 4.0 * rows * (10 * H + H))
 
         def wgrad(ar, kw):
@@ -252,6 +255,13 @@ def load_pmc(workload):
 def pmc_traffic(pmc, e):
     """HBM bytes per launch of timed kernel entry e (None when the PMC file has no unique match for it)"""
     hit = [v for k, v in pmc.items() if k.startswith(e["rocprof_name"]) and "hbm_bytes_per_launch" in v]
+    if e["rocprof_name"] == "agent_fwd":
+        hit = [v for k, v in pmc.items() if k.startswith("agent_fwd") and not k.startswith("agent_fwd_x6") and "hbm_bytes_per_launch" in v]
+    if e["rocprof_name"] == "agent_fwd_x6":
+        # agent_fwd_x6_kernel<tiles, SAVE, XS, GIO>: match by what the launch does
+        tag = e["name"].split("[")[1][:4]
+        want = {"save": ", true, false, ", "reus": ", false, true, ", "plai": ", false, false, false"}[tag]
+        hit = [v for k, v in pmc.items() if k.startswith("agent_fwd_x6_kernel<") and want in k and "hbm_bytes_per_launch" in v]
     if e["rocprof_name"].startswith("mlp3") and len(hit) > 1:
         # one instantiation per padded input width: <8, ...> for K1 <= 128, <11, ...> (fp32) / <12, ...> (bf16x6) beyond; three-layer heads
         import re

@@ -1,6 +1,7 @@
-// GRU-agent unroll with every fp32 product as six bf16 MFMA products (x6.h) - opt-in args.gemm_mode = "bf16x6", forward only, no
-// saved activations: the TARGET network's unroll of a Q-learning update (reference controller/share_params.py:147-168,
-// network/q_network.py:16-21).  The default path is agent.hip on v_mfma_f32_16x16x4_f32.
+// GRU-agent unroll with every fp32 product as six bf16 MFMA products (x6.h) - opt-in args.gemm_mode = "bf16x6": the three forward
+// unrolls of a Q-learning update (reference controller/share_params.py:125-168, network/q_network.py:16-21; q_learner.py:96-117) -
+// the eval pass that saves activations for BPTT, the target pass, the double-Q continuation that reads the eval pass's input-side
+// gate sums.  The default path is agent.hip on v_mfma_f32_16x16x4_f32.
 //
 // Why another decomposition: as bf16 triples the weight fragments of a hidden-unit slice no longer fit one wave
 // beside its working set (W_ih + W_hh + fc1 + fc2 slices = 204 registers), and 190 KB of pre-split weights do not fit LDS.  So the
@@ -9,12 +10,14 @@
 //          x(t+2) = relu(fc1(in(t+2))) and the input-side gate sums gi(t+1) = bias + x(t+1) W_ih, one / two steps ahead of the chain;
 //   team R (waves 0-3, slice s): W_hh and fc2 fragments (96 registers) - the recurrent part of step t: accumulators start from the
 //          handed gi(t), += h W_hh, gate math, h' (kept in fp32 registers for the blend of the next step), q(t-1) = fc2(h).
-// Transposed formulation (mlp3_x6.hip): out^T[unit][row] = W[unit][k] in^T[k][row] - weights are the MFMA A operand, activations the
-// B operand, read as 16 bytes per lane (row m, 8 consecutive k) from bf16 PLANES in LDS: every activation element is split once,
-// where it is produced, and shared by the four slice waves that consume it (5.5 vector instructions per element, once).
+// Products are out[row][unit] = act[row][k] W[unit][k]: activations are the MFMA A operand, read as 16 bytes per lane (row m, 8
+// consecutive k) from bf16 PLANES in LDS - every activation element is split once, where it is produced, and shared by the four
+// slice waves that consume it (5.5 vector instructions per element, once); weights are the B operand, pre-split in registers.  The
+// accumulator layout (lane (q, m): rows 4q + r of unit 16s + m) is agent.hip's, so saved activations and gate sums keep their formats.
 // One workgroup barrier per step; every LDS buffer is double-buffered by step parity:
 //   In[b]  input tile of step t+2 (planes)     Xp[b]  x(t+1) (planes)     Hp[b]  h fed into step t (planes)     GI[b]  gi(t) (fp32, accumulator layout)
-// ~70 KB of LDS per 16-row tile: one or two row tiles per workgroup, as many workgroups as that takes (they run in rounds).
+// ~70 KB of LDS per 16-row tile: one or two row tiles per workgroup, as many workgroups as that takes (they run in rounds; the
+// last round of a launch holds one tile per workgroup).
 #include "x6.h"
 #include <cstdlib>
 #include "../../include/marl_hip.h"

@@ -16,7 +16,7 @@ def cp(src, dst):
 
 
 cp(os.path.join(G, tag + "_bench", "p_kernel_stats.csv"), os.path.join(P, tag + "_bench_kernel_stats.csv"))
-for sub in ("qplex_f32", "qplex_bf16x6", "qtran", "mmm2_bf16"):
+for sub in ("qplex_f32", "qplex_bf16x6", "qmix_bf16x6", "qtran", "mmm2_bf16"):
     cp(os.path.join(G, "%s_%s" % (tag, sub), "p_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, sub)))
 for name in ("_bench_line.json", "_bench_full_line.json"):
     src = os.path.join(G, tag + name)
@@ -24,7 +24,7 @@ for name in ("_bench_line.json", "_bench_full_line.json"):
         line = open(src).read().strip()
         json.loads(line)
         open(os.path.join(P, tag + name), "w").write(line + "\n")
-for name in ("_mlp3_times.txt", "_learner_rates.txt", "_shard_steps.txt", "_soak.txt"):
+for name in ("_mlp3_times.txt", "_unroll_x6_times.txt", "_bptt_x6_ab.txt", "_learner_rates.txt", "_shard_steps.txt", "_soak.txt"):
     cp(os.path.join(G, tag + name), os.path.join(P, tag + name))
 ver = open(os.path.join(G, tag + "_lib_version.txt")).read().strip()
 
