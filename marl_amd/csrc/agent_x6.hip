@@ -143,7 +143,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   const long tile0 = bx < a.n_full ? bx * RTC : (long)a.n_full * RTC + (bx - a.n_full);
   const long row0 = tile0 * 16;
   const int cap = bx < a.n_full ? RTC : 1;
-  const int RTW = (int)((NTILES - tile0) < cap ? (NTILES - tile0) : cap);
+  const int RTW = RTC == 1 ? 1 : (int)((NTILES - tile0) < cap ? (NTILES - tile0) : cap);      // (one tile per workgroup: it exists)
   for (int r = tid; r < rows; r += XNT) {
     long rho = row0 + r;
     if (rho > a.R - 1) rho = a.R - 1;             // clamped duplicates: same loads, same values, same stores
@@ -174,9 +174,70 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   auto full = [&](int t) { return !XS || xmask[t < Tm1 ? t : Tm1] != 0; };      // step t's input side is computed here
   ST_DECL(4);
 
+  // ---- observation prefetch: thread -> (row, 4-column group) of the tile, the same every step.  ALLP: every thread of the workgroup
+  // takes part (team R's waves wait at the step barrier for a third of a step; team I is the longer one) - except where team R would
+  // then wait for its own stores: the saving variant with two row tiles (its store count per step is not a constant) and XS
+  // (which loads an input tile for a few steps only, slot by slot, in team I)
+  constexpr bool ALLP = !XS && !(SAVE && RTC == 2);
+  constexpr int NLDK = ALLP ? 2 : NLD;
+  const int PT = ALLP ? XNT : 256, pti = ALLP ? tid : tid - 256;      // participating threads, this thread's index among them
+  const bool pfw = ALLP || team == 1;
+  const int O4 = O >> 2, n4 = rows * O4;
+  const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
+  const int NS = (n4 + PT - 1) / PT;               // prefetch slots (float4 per thread) the tile fills
+  f32x4 pf[NLDK];
+  long goff[NLDK]; int prk[NLDK];                   // (row << 16) | first column of the thread's float4
+  int pt = 0, pu = -1, pu_lds0 = -1, pu_lds1 = -1;      // one-hot column currently set in each input buffer
+  auto slot = [&](int i, int& prk_, long& goff_) {
+    int e = pti + PT * i;
+    if (e > n4 - 1) e = n4 - 1;
+    if (e < 0) e = 0;
+    const int r = (int)(((float)e + 0.5f) * invO4);
+    const int k4 = e - r * O4;
+    prk_ = (r << 16) | (4 * k4);
+    goff_ = rowobs[r] + 4 * k4;
+  };
+  if (pfw) {
+#pragma unroll
+    for (int i = 0; i < NLDK; ++i) slot(i, prk[i], goff[i]);
+  }
+  const long urow = pfw && pti < rows ? rowu[pti] : 0;
+  // (a wave whose 64 elements of a slot all lie past the tile skips the slot - wave-uniform)
+  auto wave_has = [&](int i) { return i < NS && (pti & ~63) + PT * i < n4; };
+  auto issue = [&](int t) {
+    const long toff = (long)(t + a.obs_t0) * a.N * O;
+#pragma unroll
+    for (int i = 0; i < NLDK; ++i)
+      if (wave_has(i)) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
+    pt = t;
+    int uu = -1;
+    if (pti < rows && a.ufed && t + a.u_t0 >= 0) uu = a.ufed[urow + (long)(t + a.u_t0) * a.N];
+    pu = uu;
+  };
+  auto commit = [&](int b, int& pu_lds) {          // prefetch registers -> input planes of buffer b (split once, here)
+    short* P = inp(b);
+#pragma unroll
+    for (int i = 0; i < NLDK; ++i) {
+      if (!wave_has(i)) break;
+      const int r = prk[i] >> 16, lo = r * IP + (prk[i] & 0xffff);
+      const f32x4 v = pt < rowlen[r] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const F3h f = split4(v);
+      *reinterpret_cast<i32x2*>(P + lo) = f.h;
+      *reinterpret_cast<i32x2*>(P + rows * IP + lo) = f.m;
+      *reinterpret_cast<i32x2*>(P + 2 * rows * IP + lo) = f.l;
+    }
+    if (a.has_act && pti < rows) {                 // one-hot(last action): bf16 1.0 in the hi plane, flipped in place
+      const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
+      if (pn != pu_lds) {
+        if (pu_lds >= 0) P[pti * IP + O + pu_lds] = 0;
+        if (pn >= 0) P[pti * IP + O + pn] = (short)0x3F80;
+        pu_lds = pn;
+      }
+    }
+  };
+
   if (team == 1) {
     // =============================== team I: everything that depends only on a step's input ===============================
-    const int ti = tid - 256;
     F3 w1[3], wi[6], w2[2];                        // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
 #pragma unroll
     for (int c = 0; c < 3; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
@@ -188,54 +249,6 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     const float bias_1 = a.b1[u], bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u];
     const float bias_2 = XS && m < a.A ? a.b2[m] : 0.f;
 
-    // observation prefetch: thread -> (row, 4-column group) of the tile, the same every step
-    const int O4 = O >> 2, n4 = rows * O4;
-    const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
-    const int NS = (n4 + 255) >> 8;               // prefetch slots (float4 per thread) the tile fills
-    f32x4 pf[NLD];
-    long goff[NLD]; int prk[NLD];                  // (row << 16) | first column of the thread's float4
-    int pt = 0, pu = -1, pu_lds0 = -1, pu_lds1 = -1;      // one-hot column currently set in each input buffer
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      int e = ti + 256 * i;
-      if (e > n4 - 1) e = n4 - 1;
-      const int r = (int)(((float)e + 0.5f) * invO4);
-      const int k4 = e - r * O4;
-      prk[i] = (r << 16) | (4 * k4);
-      goff[i] = rowobs[r] + 4 * k4;
-    }
-    const long urow = ti < rows ? rowu[ti] : 0;
-    auto issue = [&](int t) {
-      const long toff = (long)(t + a.obs_t0) * a.N * O;
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        if (i < NS) pf[i] = *reinterpret_cast<const f32x4*>(a.obs + goff[i] + toff);
-      pt = t;
-      int uu = -1;
-      if (ti < rows && a.ufed && t + a.u_t0 >= 0) uu = a.ufed[urow + (long)(t + a.u_t0) * a.N];
-      pu = uu;
-    };
-    auto commit = [&](int b, int& pu_lds) {        // prefetch registers -> input planes of buffer b (split once, here)
-      short* P = inp(b);
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        if (i >= NS) break;
-        const int r = prk[i] >> 16, lo = r * IP + (prk[i] & 0xffff);
-        const f32x4 v = pt < rowlen[r] ? pf[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        const F3h f = split4(v);
-        *reinterpret_cast<i32x2*>(P + lo) = f.h;
-        *reinterpret_cast<i32x2*>(P + rows * IP + lo) = f.m;
-        *reinterpret_cast<i32x2*>(P + 2 * rows * IP + lo) = f.l;
-      }
-      if (a.has_act && ti < rows) {                // one-hot(last action): bf16 1.0 in the hi plane, flipped in place
-        const int pn = (pu >= 0 && pu < a.A) ? pu : -1;
-        if (pn != pu_lds) {
-          if (pu_lds >= 0) P[ti * IP + O + pu_lds] = 0;
-          if (pn >= 0) P[ti * IP + O + pn] = (short)0x3F80;
-          pu_lds = pn;
-        }
-      }
-    };
     // x(ts) = relu(fc1(in)) of every row tile: this wave's 16 units -> planes Xp[bx] (and plane 1 of the saved activations).
     // Row tiles past the batch recompute the last valid one (a fixed number of stores per call, see above).
     auto fc1 = [&](int bin, int bxx, int ts) __attribute__((always_inline)) {
@@ -383,8 +396,14 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     };
     __syncthreads();
     if (XS) gissue(Tm1 < 1 ? Tm1 : 1, 0);          // (step 0's sums = the storing unroll's step 1)
+    if (ALLP) {                                    // this team's share of the input tiles: the same calls at the same points as team I
+      issue(0); commit(0, pu_lds0);
+      issue(Tm1 < 1 ? Tm1 : 1); commit(1, pu_lds1);
+      issue(Tm1 < 2 ? Tm1 : 2);
+    }
     WG_BARRIER();                                  // A
     WG_BARRIER();                                  // B
+    if (ALLP) { commit(0, pu_lds0); issue(Tm1 < 3 ? Tm1 : 3); }
     WG_BARRIER();                                  // C
     for (int t = 0; t < a.T; ++t) {
       const int par = t & 1;
@@ -441,6 +460,10 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       }
       if (!XS && t > 0 && s < RTW) fc2(par, t - 1, s);           // q(t-1) from h fed into step t
       ST_MARK(2);
+      if (ALLP) {                                  // input tile of step t+3, loads of step t+4 (see team I)
+        if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
+        issue(t + 4 < a.T ? t + 4 : Tm1);
+      }
       WG_BARRIER();
       ST_MARK(3);
     }
@@ -486,7 +509,7 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
   // two row tiles per workgroup once there are more tiles than CUs this launch may occupy (more than two do not fit LDS: larger
   // batches run in rounds of workgroups, and when the last round is at most one tile per CU its workgroups hold one tile each)
   const int rt = tiles > cu_budget ? 2 : 1;
-  if (rt * 16 * (O / 4) > NLD * 256) return (int)hipErrorInvalidValue;      // (team I's 256 threads prefetch the observation tile)
+  if (rt * 16 * (O / 4) > 2 * XNT) return (int)hipErrorInvalidValue;        // (the prefetch registers: two float4 per thread of the workgroup, four of team I alone)
   a.RT = rt;
   long n_wg = (tiles + rt - 1) / rt;
   a.n_full = (int)n_wg;
