@@ -159,6 +159,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   int* rowidx = reinterpret_cast<int*>(QT + 3 * 32);  // [32]: index of (b, 0, n) in (B,T,N) or -1
   int* rowrho = rowidx + 32;                          // [32]
   unsigned* XM = reinterpret_cast<unsigned*>(rowrho + 32);      // [2][4][64]: relu'(x) bits of a lane's 8 elements, by step parity
+  float* BS = reinterpret_cast<float*>(XM + 512);               // [4][256]: team R's bias sums, one slot per thread
 
   const long NTILES = (a.R + 15) >> 4;
   const long tile0 = (long)NT * blockIdx.x;
@@ -211,7 +212,16 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     f32x4 carry[NT];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) carry[tt] = splat(0.f);
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};               // column sums of drp, dzp, dnp, dhn (this lane's 8 rows)
+    // column sums of drp, dzp, dnp, dhn over this lane's rows: thread-private fp32 slots in LDS, not registers (this team runs at
+    // the register ceiling, and a spilled register's reload waits for every prefetched plane in flight)
+    // (the variants that fit keep them in registers)
+    constexpr bool BSL = DHS || NT == 1;
+    float* bsl = BS + tid;
+    float bsr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BSL) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bsl[256 * k] = 0.f;
+    }
     f32x4 sv[NT][5];                                    // saved planes of the step: h_prev, r, z, n, W_hn h + b_hn
     f32x4 dhsv[NT];
     auto svload = [&](int t, int tt) {
@@ -224,8 +234,8 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       if (DHS) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ri = rowidx[16 * tt + 4 * q + r];
-          dhsv[tt][r] = ri >= 0 ? a.dhs[((long)ri + (long)t * a.N) * H + u] : 0.f;
+          const int ri = rowidx[16 * tt + 4 * q + r];      // (32-bit element offsets: B T N H 4 < 2^32, checked by the host)
+          dhsv[tt][r] = ri >= 0 ? a.dhs[(unsigned)(ri + t * a.N) * (unsigned)H + (unsigned)u] : 0.f;
         }
       }
     };
@@ -260,10 +270,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
           drp[r] = dr * rg * (1.f - rg);
           dzp[r] = dz * zg * (1.f - zg);
         }
-        bs[0] += (drp[0] + drp[1]) + (drp[2] + drp[3]);
-        bs[1] += (dzp[0] + dzp[1]) + (dzp[2] + dzp[3]);
-        bs[2] += (dnp[0] + dnp[1]) + (dnp[2] + dnp[3]);
-        bs[3] += (dhn[0] + dhn[1]) + (dhn[2] + dhn[3]);
+        const float s0 = (drp[0] + drp[1]) + (drp[2] + drp[3]), s1 = (dzp[0] + dzp[1]) + (dzp[2] + dzp[3]);
+        const float s2 = (dnp[0] + dnp[1]) + (dnp[2] + dnp[3]), s3 = (dhn[0] + dhn[1]) + (dhn[2] + dhn[3]);
+        if (BSL) { bsl[0] += s0; bsl[256] += s1; bsl[512] += s2; bsl[768] += s3; }
+        else { bsr[0] += s0; bsr[1] += s1; bsr[2] += s2; bsr[3] += s3; }
         g_put(img, wb, 0 * 64 + 16 * s, tt, split4(drp));
         g_put(img, wb, 1 * 64 + 16 * s, tt, split4(dzp));
         g_put(img, wb, 2 * 64 + 16 * s, tt, split4(dnp));
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ri = rowidx[16 * tt + 4 * q + r];
-          if (ri >= 0) a.dxp[((long)ri + (long)t * a.N) * H + u] = (xmask >> (4 * tt + r)) & 1u ? dx[r] : 0.f;
+          if (ri >= 0) a.dxp[(unsigned)(ri + t * a.N) * (unsigned)H + (unsigned)u] = (xmask >> (4 * tt + r)) & 1u ? dx[r] : 0.f;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -330,8 +340,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         }
     }
     float* slab = a.ws + (long)blockIdx.x * slab_floats(a.A);
+    float bs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      bs[k] = BSL ? bsl[256 * k] : bsr[k];
       bs[k] += __shfl_xor(bs[k], 16);
       bs[k] += __shfl_xor(bs[k], 32);
     }
@@ -529,7 +541,7 @@ extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int nt = bx6_nt(a.R);
   const unsigned nwg = (unsigned)((a.R + 16 * nt - 1) / (16 * nt));
-  const size_t lds = (size_t)GBUF + 8 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4;
+  const size_t lds = (size_t)GBUF + 8 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4 + 4 * 256 * 4;
 #define BX6_PICK(NT_) (dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true, NT_> : (const void*)agent_bwd_x6_kernel<true, false, NT_>) \
                            : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true, NT_> : (const void*)agent_bwd_x6_kernel<false, false, NT_>))
   const void* fn = nt == 1 ? BX6_PICK(1) : BX6_PICK(2);
