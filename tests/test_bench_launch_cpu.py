@@ -47,3 +47,31 @@ def test_plain_invocation_with_gpus_gt_1_takes_the_launch_path(monkeypatch):
     except SystemExit as e:
         assert e.code == 0
     assert called == [8]
+
+
+def test_pmc_traffic_picks_the_instantiation_a_timed_call_launched():
+    """bench.py matches a timed C-ABI call to ONE kernel of the committed PMC file: the three forward unrolls share a name prefix in
+    either arithmetic (fp32: by what the launch writes / multiplies; split kernels: by template arguments), the fused heads differ by
+    their padded input width, and a name that matches several kernels yields no traffic rather than a wrong one."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    k = lambda b, **kw: dict(hbm_bytes_per_launch=b, **kw)
+    pmc = {"agent_fwd_kernel<1, true, true, 4, false, false, false, false>": k(6.7e9, WRITE_SIZE=5e6, SQ_INSTS_MFMA=9e6),
+           "agent_fwd_kernel<1, false, true, 4, false, false, false, false>": k(2.0e9, WRITE_SIZE=1e5, SQ_INSTS_MFMA=9e6),
+           "agent_fwd_kernel<1, false, true, 4, true, false, false, false>": k(2.1e9, WRITE_SIZE=1e5, SQ_INSTS_MFMA=4e6),
+           "agent_fwd_x6_kernel<2, true, false, true>": k(6.8e9), "agent_fwd_x6_kernel<2, false, false, false>": k(2.0e9),
+           "agent_fwd_x6_kernel<2, false, true, false>": k(2.03e9),
+           "agent_bwd_kernel<1, false, 1>": k(5.2e9), "agent_bwd_x6_kernel<false, false, 2>": k(4.5e9),
+           "mlp3x6_fwd_kernel<8, true, 6>": k(1.5e9), "mlp3x6_fwd_kernel<12, true, 6>": k(1.9e9)}
+    e = lambda name, roc: {"name": name, "rocprof_name": roc}
+    assert bench.pmc_traffic(pmc, e("agent_fwd_kernel[save: eval unroll ...]", "agent_fwd"))["hbm_bytes_per_launch"] == 6.7e9
+    assert bench.pmc_traffic(pmc, e("agent_fwd_kernel[plain: target unroll]", "agent_fwd"))["hbm_bytes_per_launch"] == 2.0e9
+    assert bench.pmc_traffic(pmc, e("agent_fwd_kernel[reuse: double-Q unroll ...]", "agent_fwd"))["hbm_bytes_per_launch"] == 2.1e9
+    assert bench.pmc_traffic(pmc, e("agent_fwd_x6_kernel[save: eval unroll ...]", "agent_fwd_x6"))["hbm_bytes_per_launch"] == 6.8e9
+    assert bench.pmc_traffic(pmc, e("agent_fwd_x6_kernel[plain: target unroll]", "agent_fwd_x6"))["hbm_bytes_per_launch"] == 2.0e9
+    assert bench.pmc_traffic(pmc, e("agent_fwd_x6_kernel[reuse: double-Q unroll ...]", "agent_fwd_x6"))["hbm_bytes_per_launch"] == 2.03e9
+    assert bench.pmc_traffic(pmc, e("agent_bwd_kernel (BPTT ...)", "agent_bwd_kernel"))["hbm_bytes_per_launch"] == 5.2e9
+    assert bench.pmc_traffic(pmc, e("agent_bwd_x6_kernel (BPTT ...)", "agent_bwd_x6_kernel"))["hbm_bytes_per_launch"] == 4.5e9
+    assert bench.pmc_traffic(pmc, e("mlp3x6_fwd_kernel (fused 64-wide heads, 10 heads, K1=175)", "mlp3x6_fwd"))["hbm_bytes_per_launch"] == 1.9e9
+    assert bench.pmc_traffic(pmc, e("mlp3x6_fwd_kernel (fused 64-wide heads, 10 heads, K1=120)", "mlp3x6_fwd"))["hbm_bytes_per_launch"] == 1.5e9
+    assert bench.pmc_traffic({}, e("agent_bwd_kernel (BPTT ...)", "agent_bwd_kernel")) is None
