@@ -228,10 +228,10 @@ OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp3
                  ("cfg3 QPLEX 2s3z 512 envs (shard of 4096 / 8 GPUs)", "qplex", "2s3z", 512, "fp32", "f32"),
                  ("cfg4 QTRAN-base 3s5z 512 envs (shard of 2048 / 4 GPUs)", "qtran_base", "3s5z", 512, "fp32", "f32"),
                  ("cfg5 QMIX MMM2 1024 envs (shard of 8192 / 8 GPUs), bf16 mixer", "qmix", "MMM2", 1024, "bf16", "f32"),
-                 ("extra: cfg3 shard with gemm_mode bf16x6 (lambda-net products as six bf16 MFMA products each)", "qplex", "2s3z", 512, "fp32", "bf16x6"),
+                 ("extra: cfg3 shard with gemm_mode bf16x6 (agent unrolls, BPTT, lambda-net: fp32 products as six bf16 MFMA products each)", "qplex", "2s3z", 512, "fp32", "bf16x6"),
                  ("extra: QPLEX 2s3z 4096 envs on one GPU, fp32 MFMA", "qplex", "2s3z", 4096, "fp32", "f32"),
                  ("extra: QPLEX 2s3z 4096 envs on one GPU, gemm_mode bf16x6", "qplex", "2s3z", 4096, "fp32", "bf16x6"),
-                 ("extra: headline learner (QMIX 2s3z 4096 envs) with gemm_mode bf16x6 (agent unrolls on the split kernels)", "qmix", "2s3z", 4096, "fp32", "bf16x6"),
+                 ("extra: headline learner (QMIX 2s3z 4096 envs) with gemm_mode bf16x6 (agent unrolls and BPTT on the split kernels)", "qmix", "2s3z", 4096, "fp32", "bf16x6"),
                  ("extra: cfg2 with gemm_mode bf16x6", "qmix", "2s3z", 1024, "fp32", "bf16x6"),
                  ("extra: QMIX 2s3z 512 envs (shard of 4096 / 8 GPUs), fp32 MFMA", "qmix", "2s3z", 512, "fp32", "f32"),
                  ("extra: QMIX 2s3z 512 envs (shard of 4096 / 8 GPUs), gemm_mode bf16x6", "qmix", "2s3z", 512, "fp32", "bf16x6")]
@@ -336,7 +336,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
     workload = "%s_%s_T%d_envs%d%s%s" % (alg, shape, T, envs, "_bf16mixer" if mixer_dtype == "bf16" else "", "_bf16x6" if gemm_mode == "bf16x6" else "")
     pmc, pmc_src = load_pmc(workload)
     out = {"workload": workload, "what": label, "mixer_dtype": mixer_dtype, "gemm_mode": gemm_mode,
-           "dtype": "f32 via bf16x6 split, fp32 accumulate (agent unrolls, lambda-net heads; everything else f32)" if gemm_mode == "bf16x6" else "f32",
+           "dtype": "f32 via bf16x6 split, fp32 accumulate (agent unrolls, BPTT, lambda-net heads; everything else f32)" if gemm_mode == "bf16x6" else "f32",
            "learner_updates_per_sec": 1.0 / dt, "learner_transitions_per_sec": envs * T / dt,
            "rollout_env_steps_per_sec": steps / t_roll,
            "roofline_update": {"bound": "mfma", "flop_per_transition": fpt, "achieved": upd_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -754,7 +754,7 @@ def main():
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if o.gemm_mode == "f32" else "f32 via bf16x6 split, fp32 accumulate (agent unrolls of the update; the rollout and everything else f32)",
+            "dtype": "f32" if o.gemm_mode == "f32" else "f32 via bf16x6 split, fp32 accumulate (agent unrolls and BPTT of the update; the rollout and everything else f32)",
             "data": "synthetic",
             "config": {"workload": "%s_%s_T%d_envs%d" % (o.alg, o.shape, T, o.envs), "alg": o.alg, "shape": o.shape,
                        "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
