@@ -288,7 +288,7 @@ int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, lo
  * Opt-in (args.gemm_mode = "bf16x6"): marl_agent_unroll_bwd with every fp32 product - the delta pass and the weight-gradient
  * reductions over rows - as six bf16 MFMA products; bias gradients are exact fp32 sums.  Same argument meaning (no dense dq and no
  * `hs`: the Q-learning losses reach q through one or two (column, value) pairs per row); `saved` is what either forward entry
- * stored.  marl_agent_unroll_bwd_x6_supported(): H = 64, A <= 16, sparse dq, T >= 3; the caller uses marl_agent_unroll_bwd
+ * stored.  marl_agent_unroll_bwd_x6_supported(): H = 64, A <= 32, sparse dq, T >= 3; the caller uses marl_agent_unroll_bwd
  * otherwise.  Workspace: marl_agent_bwd_x6_workspace() bytes (one slab per 32 rows). */
 int marl_agent_unroll_bwd_x6_supported(int B, int T, int N, int A, int sparse_dq);
 size_t marl_agent_bwd_x6_workspace(int B, int N, int A);

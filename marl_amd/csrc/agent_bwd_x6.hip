@@ -154,8 +154,8 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   char* WL = Gt + GBUF;                              // [4 waves][4] weight fragments of team R that do not fit its registers
   char* HB = WL + 4 * FRB;                           // [2] fragments of h_prev(t) column tiles
   char* XB = HB + 2 * FRB;                           // [2] fragments of x(t) column tiles
-  float* W2s = reinterpret_cast<float*>(XB + 2 * FRB);      // [16][64]
-  int4* QT = reinterpret_cast<int4*>(W2s + 16 * H);   // [3][32]: (idx, val, idx2, val2) of a row at a step
+  float* W2s = reinterpret_cast<float*>(XB + 2 * FRB);      // [32][64]
+  int4* QT = reinterpret_cast<int4*>(W2s + 32 * H);   // [3][32]: (idx, val, idx2, val2) of a row at a step
   int* rowidx = reinterpret_cast<int*>(QT + 3 * 32);  // [32]: index of (b, 0, n) in (B,T,N) or -1
   int* rowrho = rowidx + 32;                          // [32]
   unsigned* XM = reinterpret_cast<unsigned*>(rowrho + 32);      // [2][4][64]: relu'(x) bits of a lane's 8 elements, by step parity
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     rowidx[tid] = ok ? (int)((rho / a.N) * a.T * a.N + rho % a.N) : -1;
     rowrho[tid] = ok ? (int)rho : -1;
   }
-  for (int e = tid; e < 16 * H; e += BNT) W2s[e] = e < a.A * H ? a.W2[e] : 0.f;
+  for (int e = tid; e < 32 * H; e += BNT) W2s[e] = e < a.A * H ? a.W2[e] : 0.f;
   __syncthreads();
   const int T = a.T;
   // (idx, val, idx2, val2) of row r at step t
@@ -355,12 +355,12 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   } else {
     // =============================== team I: the weight gradients dW_ih, dW_hh, dW_2 ===============================
     const int ti = tid - 256;
-    f32x4 accI[3][4], accH[3][4], acc2 = splat(0.f);
+    f32x4 accI[3][4], accH[3][4], acc2[2] = {splat(0.f), splat(0.f)};      // (acc2[1]: actions 16 .. 31)
 #pragma unroll
     for (int b = 0; b < 3; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) { accI[b][c] = splat(0.f); accH[b][c] = splat(0.f); }
-    float bs2 = 0.f;
+    float bs2[2] = {0.f, 0.f};
     f32x4 xn[NT], hn[NT];                             // x and h_prev of the step to come, column tile s (in flight across the barrier)
     auto xhload = [&](int t) {
 #pragma unroll
@@ -382,19 +382,24 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       XM[(t & 1) * 256 + s * 64 + lane] = mk;
     };
     auto dw2 = [&](const int4* qt, const FWT& hb) {
-      f32x4 d[NT];
-      float sum = 0.f;
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
+      for (int ac = 0; ac < 2; ++ac) {
+        if (ac == 1 && a.A <= 16) break;
+        const int col = 16 * ac + m;
+        f32x4 d[NT];
+        float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int4 e = qt[16 * tt + 4 * q + r];
-          d[tt][r] = (e.x == m ? __int_as_float(e.y) : 0.f) + (TWO && e.z == m ? __int_as_float(e.w) : 0.f);
+        for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int4 e = qt[16 * tt + 4 * q + r];
+            d[tt][r] = (e.x == col ? __int_as_float(e.y) : 0.f) + (TWO && e.z == col ? __int_as_float(e.w) : 0.f);
+          }
+          sum += (d[tt][0] + d[tt][1]) + (d[tt][2] + d[tt][3]);
         }
-        sum += (d[tt][0] + d[tt][1]) + (d[tt][2] + d[tt][3]);
+        bs2[ac] += sum;
+        mm6x(splitn(d), hb, acc2[ac]);
       }
-      bs2 += sum;
-      mm6x(splitn(d), hb, acc2);
     };
     xhload(T - 1);
     publish(T - 1);
@@ -469,11 +474,15 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
           slab[192 * 64 + (long)(64 * b + 16 * s + 4 * q + r) * H + 16 * c + m] = accH[b][c][r];
         }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * q + r < a.A) slab[2 * 192 * 64 + (long)(4 * q + r) * H + u] = acc2[r];
-    bs2 += __shfl_xor(bs2, 16);
-    bs2 += __shfl_xor(bs2, 32);
-    if (s == 0 && q == 0 && m < a.A) slab[2 * 192 * 64 + (long)a.A * H + 2 * 192 + m] = bs2;
+    for (int ac = 0; ac < 2; ++ac) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ac + 4 * q + r < a.A) slab[2 * 192 * 64 + (long)(16 * ac + 4 * q + r) * H + u] = acc2[ac][r];
+      float b = bs2[ac];
+      b += __shfl_xor(b, 16);
+      b += __shfl_xor(b, 32);
+      if (s == 0 && q == 0 && 16 * ac + m < a.A) slab[2 * 192 * 64 + (long)a.A * H + 2 * 192 + 16 * ac + m] = b;
+    }
   }
 }
 
@@ -510,9 +519,9 @@ __global__ __launch_bounds__(256) void agent_bwd_x6_reduce_kernel(RedArgs a) {
 
 }  // namespace
 
-// shapes the split BPTT covers: H = 64, <= 16 actions, a sparse dq (one or two (column, value) pairs per row), T >= 3
+// shapes the split BPTT covers: H = 64, <= 32 actions, a sparse dq (one or two (column, value) pairs per row), T >= 3
 extern "C" int marl_agent_unroll_bwd_x6_supported(int B, int T, int N, int A, int sparse_dq) {
-  if (B < 1 || T < 3 || N < 1 || A < 1 || A > 16 || !sparse_dq) return 0;
+  if (B < 1 || T < 3 || N < 1 || A < 1 || A > 32 || !sparse_dq) return 0;
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return 0;
   return 1;
 }
@@ -541,7 +550,7 @@ extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
   const int nt = bx6_nt(a.R);
   const unsigned nwg = (unsigned)((a.R + 16 * nt - 1) / (16 * nt));
-  const size_t lds = (size_t)GBUF + 8 * FRB + 16 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4 + 4 * 256 * 4;
+  const size_t lds = (size_t)GBUF + 8 * FRB + 32 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4 + 4 * 256 * 4;
 #define BX6_PICK(NT_) (dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true, NT_> : (const void*)agent_bwd_x6_kernel<true, false, NT_>) \
                            : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true, NT_> : (const void*)agent_bwd_x6_kernel<false, false, NT_>))
   const void* fn = nt == 1 ? BX6_PICK(1) : BX6_PICK(2);

@@ -800,17 +800,19 @@ def test_agent_unroll_bwd_from_x6_saved(dev, B, T):
         close(grads[k] / scale, ref / scale, 2e-4, 1e-3, msg=k)
 
 
-@pytest.mark.parametrize("B,T,pairs,with_dhs", [(7, 5, 1, False), (40, 6, 2, True), (700, 4, 1, False), (333, 3, 2, True), (13, 9, 1, True),
-                                                 (900, 3, 1, False), (1003, 4, 2, True)])
-def test_agent_unroll_bwd_x6_split(dev, B, T, pairs, with_dhs):
+@pytest.mark.parametrize("shape,B,T,pairs,with_dhs", [("2s3z", 7, 5, 1, False), ("2s3z", 40, 6, 2, True), ("2s3z", 700, 4, 1, False),
+                                                       ("2s3z", 333, 3, 2, True), ("2s3z", 13, 9, 1, True), ("2s3z", 900, 3, 1, False),
+                                                       ("2s3z", 1003, 4, 2, True), ("MMM2", 30, 4, 1, False), ("MMM2", 450, 3, 2, True),
+                                                       ("3s5z", 61, 5, 2, True)])
+def test_agent_unroll_bwd_x6_split(dev, shape, B, T, pairs, with_dhs):
     """BPTT on the bf16x6 split kernels (csrc/agent_bwd_x6.hip, opt-in gemm_mode): one or two sparse (action, value) pairs per row
     (the second pair with one value per (episode, step) shared by its agents, as QTRAN uses it), an optional external gradient on
     hs, one row tile per workgroup (up to 256 tiles) and two (beyond; row counts that leave the last workgroup with a partial or a
     missing second tile) - every gradient and dxp against
     torch autograd of the oracle unroll at the bounds of test_agent_unroll_bwd, beside the fp32 MFMA kernel on the same inputs."""
     from marl_amd import ops
-    args, p_np, obs, ufed, h0 = _agent_case("2s3z", B, T, dev, seed=3)
-    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    args, p_np, obs, ufed, h0 = _agent_case(shape, B, T, dev, seed=3)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions      # (MMM2: 18 actions = two action tiles of the fc2 gradient)
     I = O + A + N
     assert ops.agent_unroll_bwd_x6_supported(B, T, N, A)
     p, q_ref, hs_ref, _ = _oracle_unroll(args, p_np, obs, ufed, None, requires_grad=True)
