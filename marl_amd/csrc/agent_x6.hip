@@ -112,7 +112,9 @@ __device__ __forceinline__ long sv_off(long tile_t, int planes, int plane, int c
 //          same values again), so the wait for the loads is a counted vmcnt, not vmcnt(0);
 //   team R (not XS): stores only (saved planes, hs, q);      team R (XS): loads only (gate sums) - fc2 / q move to team I, which
 //          is idle in that variant except for the few steps it computes in full.
-template <int RTC, bool SAVE, bool XS, bool GIO = false>
+// NK1: 32-wide k chunks of fc1 whose weight fragments the kernel holds (3: inputs up to 96 wide - 2s3z; 5: up to 160 - 3s5z, one row
+// tile per workgroup only: the input planes grow with the width)
+template <int RTC, bool SAVE, bool XS, bool GIO = false, int NK1 = 3>
 __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   static_assert(!(SAVE && XS) && (SAVE || !GIO), "XS: no saving; GIO: the saving pass also stores its input-side gate sums");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 
   if (team == 1) {
     // =============================== team I: everything that depends only on a step's input ===============================
-    F3 w1[3], wi[6], w2[2];                        // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
+    F3 w1[NK1], wi[6], w2[2];                      // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
 #pragma unroll
-    for (int c = 0; c < 3; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
+    for (int c = 0; c < NK1; ++c) w1[c] = !(XS && NK1 > 3) && c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};      // (XS with wide inputs: loaded where used, see fc1)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -255,20 +257,27 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         const int rr = rt < RTW ? rt : RTW - 1;
-        // one accumulator per 32-wide k chunk: three independent chains of six products, issued round robin; chunks past the
-        // input width multiply chunk 0 by zero weights
+        // three accumulators, chunk c on accumulator c % 3: independent chains of six products, issued round robin, three chunks'
+        // fragments in registers at a time; chunks past the input width multiply chunk 0 by zero weights
         // (XS: the few steps computed in full - one chunk at a time, fewer registers; the same sums in the same order)
         f32x4 acc[3] = {splat(bias_1), splat(0.f), splat(0.f)};
         if (XS) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) mm6(bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c < KC1 ? c : 0, lane), w1[c], acc[c]);
+          for (int c = 0; c < NK1; ++c) {
+            const F3 wc = NK1 > 3 ? (c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{}) : w1[c];      // (wide inputs: not kept in registers in this variant)
+            mm6(bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c < KC1 ? c : 0, lane), wc, acc[c % 3]);
+          }
         } else {
-          F3 xi[3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) xi[c] = bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c < KC1 ? c : 0, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) acc[c] = mm(xi[c].p_, w1[c].q_, acc[c]);
-          X6_TERMS(OP)
+          for (int c0 = 0; c0 < NK1; c0 += 3) {
+            F3 xi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              if (c0 + c < NK1) xi[c] = bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c0 + c < KC1 ? c0 + c : 0, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c0 + c < NK1) acc[c] = mm(xi[c].p_, w1[c0 + c].q_, acc[c]);
+            X6_TERMS(OP)
 #undef OP
+          }
         }
         const f32x4 x = relu4x((acc[0] + acc[1]) + acc[2]);
         put4(xpp(bxx), HP, rows * HP, rr * 16 + 4 * q, u, x);
@@ -474,11 +483,12 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 
 }  // namespace
 
-// shapes the split unroll covers: H = 64, <= 16 actions, observation width a multiple of 8, input width <= 96, T >= 4, rows
+// shapes the split unroll covers: H = 64, <= 16 actions, observation width a multiple of 8, input width <= 160, T >= 4, rows
 // addressed with 32-bit offsets
 extern "C" int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A, int last_action, int reuse_network) {
   const int I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
-  if (A < 1 || A > 16 || O < 8 || (O & 7) || I > 96 || T < 4 || B < 1) return 0;
+  if (A < 1 || A > 16 || O < 8 || (O & 7) || I > 160 || T < 4 || B < 1) return 0;
+  if (I > 96 && 16 * (O / 4) > 2 * XNT) return 0;      // (wide inputs: one row tile per workgroup, its observations in the prefetch registers)
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return 0;
   return 1;
 }
@@ -508,7 +518,8 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
   const long tiles = (a.R + 15) / 16;
   // two row tiles per workgroup once there are more tiles than CUs this launch may occupy (more than two do not fit LDS: larger
   // batches run in rounds of workgroups, and when the last round is at most one tile per CU its workgroups hold one tile each)
-  const int rt = tiles > cu_budget ? 2 : 1;
+  const bool wide = a.KI > 96;                     // five fc1 chunks: one row tile per workgroup (LDS), any number of rounds
+  const int rt = tiles > cu_budget && !wide ? 2 : 1;
   if (rt * 16 * (O / 4) > 2 * XNT) return (int)hipErrorInvalidValue;        // (the prefetch registers: two float4 per thread of the workgroup, four of team I alone)
   a.RT = rt;
   long n_wg = (tiles + rt - 1) / rt;
@@ -522,10 +533,13 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
                      (((size_t)T * 4 + 15) & ~(size_t)15);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const void* fn;
-  if (saved && a.gi_out) fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, true, false, true> : (const void*)agent_fwd_x6_kernel<1, true, false, true>;
-  else if (saved) fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, true, false> : (const void*)agent_fwd_x6_kernel<1, true, false>;
-  else if (gi_in) fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, false, true> : (const void*)agent_fwd_x6_kernel<1, false, true>;
-  else fn = rt == 2 ? (const void*)agent_fwd_x6_kernel<2, false, false> : (const void*)agent_fwd_x6_kernel<1, false, false>;
+#define X6_PICKF(SAVE_, XS_, GIO_) (wide ? (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 5> : rt == 2 ? (const void*)agent_fwd_x6_kernel<2, SAVE_, XS_, GIO_, 3> \
+                                                                                                    : (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 3>)
+  if (saved && a.gi_out) fn = X6_PICKF(true, false, true);
+  else if (saved) fn = X6_PICKF(true, false, false);
+  else if (gi_in) fn = X6_PICKF(false, true, false);
+  else fn = X6_PICKF(false, false, false);
+#undef X6_PICKF
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)n_wg), block(XNT);

@@ -674,15 +674,16 @@ def test_saving_unroll_variants_equal_register_prefetch_bitwise(dev, shape, B, T
                 assert torch.equal(x, y), "%s: plane %d (t0=%d)" % (other, k, t0)
 
 
-@pytest.mark.parametrize("B,T,with_h0,ragged", [(7, 5, False, False), (70, 6, True, True), (3, 4, True, False), (900, 9, False, True),
-                                                 (2100, 12, True, True)])
-def test_agent_unroll_x6_split(dev, B, T, with_h0, ragged):
+@pytest.mark.parametrize("shape,B,T,with_h0,ragged", [("2s3z", 7, 5, False, False), ("2s3z", 70, 6, True, True), ("2s3z", 3, 4, True, False),
+                                                       ("2s3z", 900, 9, False, True), ("2s3z", 2100, 12, True, True),
+                                                       ("3s5z", 9, 5, True, True), ("3s5z", 600, 4, False, True)])
+def test_agent_unroll_x6_split(dev, shape, B, T, with_h0, ragged):
     """Unroll that saves nothing on the bf16x6 split kernels (csrc/agent_x6.hip, opt-in gemm_mode): q, hs and the final hidden state
     against the CPU oracle at the bound of test_agent_unroll_fwd (1e-4), and beside the fp32 MFMA kernel on the same inputs -
     (T+1)-slot storage read through an episode map with the shifted last action, ragged episode lengths (rows past their end
     feed zeros), a carried hidden state, partial last row tile, one and two row tiles per workgroup (> 256 tiles)."""
     from marl_amd import ops
-    args, p_np, _, _, _ = _agent_case("2s3z", B, T, dev, with_h0=with_h0)
+    args, p_np, _, _, _ = _agent_case(shape, B, T, dev, with_h0=with_h0)      # (3s5z: 150 input columns = five fc1 chunks, one row tile per workgroup)
     N, O, A = args.n_agents, args.obs_shape, args.n_actions
     assert ops.agent_unroll_x6_supported(B, T, N, O, A)
     rng = np.random.default_rng(B + T)
@@ -719,8 +720,9 @@ def test_agent_unroll_x6_split(dev, B, T, with_h0, ragged):
     print("agent unroll B=%d T=%d: max |q - oracle|: bf16x6 %.2e, fp32 MFMA %.2e" % (B, T, e6, e32))
 
 
-@pytest.mark.parametrize("B,T,cus", [(37, 5, 0), (700, 6, 48), (9, 4, 2), (300, 7, 256), (1700, 5, 128)])
-def test_agent_unroll_x6_saved_planes_and_gate_sum_reuse(dev, B, T, cus):
+@pytest.mark.parametrize("shape,B,T,cus", [("2s3z", 37, 5, 0), ("2s3z", 700, 6, 48), ("2s3z", 9, 4, 2), ("2s3z", 300, 7, 256), ("2s3z", 1700, 5, 128),
+                                            ("3s5z", 21, 5, 0), ("3s5z", 400, 4, 128)])
+def test_agent_unroll_x6_saved_planes_and_gate_sum_reuse(dev, shape, B, T, cus):
     """The activation-saving and the gate-sum-reading variants of the split unroll (csrc/agent_x6.hip):
       * the six saved planes, the stored input-side sums, q and the final hidden state of the eval pass == the fp32 MFMA
         kernel's within 1e-4 (same tile layout: decoded with ops.saved_plane);
@@ -728,8 +730,9 @@ def test_agent_unroll_x6_saved_planes_and_gate_sum_reuse(dev, B, T, cus):
         (ragged episode lengths: steps ep_len - 1 and T - 1 are computed in full; episode map; carried hidden state;
         partial last row tile; one and two row tiles per workgroup by CU budget)."""
     from marl_amd import ops
-    args, p_np, _, _, _ = _agent_case("2s3z", B, T, dev)
+    args, p_np, _, _, _ = _agent_case(shape, B, T, dev)
     N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    assert ops.agent_unroll_x6_supported(B, T, N, O, A)
     rng = np.random.default_rng(B + T)
     E = B + 3
     store = cu(rng.standard_normal((E, T + 1, N, O)).astype(np.float32), dev)
