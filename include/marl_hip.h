@@ -276,8 +276,8 @@ int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const
  * same tile layout), `gi_out` / `gi_in` (the input-side gate sums one unroll stores and the double-Q continuation reads; these
  * hold PLAIN sums here - a pair of launches that shares them must both be this entry), `cu_budget` (two row tiles per workgroup
  * once there are more tiles than that many CUs).  marl_agent_unroll_x6_supported(): H = 64, A <= 16, O a multiple of 8,
- * O + A + N <= 160, T >= 4 (2s3z- and 3s5z-sized agents; beyond 96 input columns one row tile per workgroup); the caller uses
- * marl_agent_unroll_fwd otherwise. */
+ * O + A + N <= 224, T >= 4, A <= 16 (A <= 32 when the input is wider than 160 columns): 2s3z-, 3s5z- and MMM2-sized agents;
+ * beyond 96 input columns one row tile per workgroup.  The caller uses marl_agent_unroll_fwd otherwise. */
 int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A, int last_action, int reuse_network);
 int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                              const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,

@@ -112,9 +112,9 @@ __device__ __forceinline__ long sv_off(long tile_t, int planes, int plane, int c
 //          same values again), so the wait for the loads is a counted vmcnt, not vmcnt(0);
 //   team R (not XS): stores only (saved planes, hs, q);      team R (XS): loads only (gate sums) - fc2 / q move to team I, which
 //          is idle in that variant except for the few steps it computes in full.
-// NK1: 32-wide k chunks of fc1 whose weight fragments the kernel holds (3: inputs up to 96 wide - 2s3z; 5: up to 160 - 3s5z, one row
-// tile per workgroup only: the input planes grow with the width)
-template <int RTC, bool SAVE, bool XS, bool GIO = false, int NK1 = 3>
+// NK1: 32-wide k chunks of fc1 whose weight fragments the kernel holds (3: inputs up to 96 wide - 2s3z; 5: up to 160 - 3s5z; 7: up to
+// 224 - MMM2; beyond 3 one row tile per workgroup only: the input planes grow with the width).  AC: 16-wide action tiles of fc2
+template <int RTC, bool SAVE, bool XS, bool GIO = false, int NK1 = 3, int AC = 1>
 __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   static_assert(!(SAVE && XS) && (SAVE || !GIO), "XS: no saving; GIO: the saving pass also stores its input-side gate sums");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,16 +240,20 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 
   if (team == 1) {
     // =============================== team I: everything that depends only on a step's input ===============================
-    F3 w1[NK1], wi[6], w2[2];                      // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
+    F3 w1[NK1], wi[6], w2[AC][2];                  // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
 #pragma unroll
     for (int c = 0; c < NK1; ++c) w1[c] = !(XS && NK1 > 3) && c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};      // (XS with wide inputs: loaded where used, see fc1)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int c = 0; c < 2; ++c) wi[2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
-    if (XS) { w2[0] = wfrag(a.W2, H, 0, a.A, H, 0, lane); w2[1] = wfrag(a.W2, H, 0, a.A, H, 1, lane); }
+    float bias_2[AC];
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      if (XS) { w2[ac][0] = wfrag(a.W2, H, 16 * ac, a.A, H, 0, lane); w2[ac][1] = wfrag(a.W2, H, 16 * ac, a.A, H, 1, lane); }
+      bias_2[ac] = XS && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
+    }
     const float bias_1 = a.b1[u], bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u];
-    const float bias_2 = XS && m < a.A ? a.b2[m] : 0.f;
 
     // x(ts) = relu(fc1(in)) of every row tile: this wave's 16 units -> planes Xp[bx] (and plane 1 of the saved activations).
     // Row tiles past the batch recompute the last valid one (a fixed number of stores per call, see above).
@@ -309,17 +313,20 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     };
     // XS: q(ts) = fc2(h) of row tile rt from planes Hp[bh]
     auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
-      f32x4 ac[2] = {splat(bias_2), splat(0.f)};     // one chain per k chunk
       F3 hb[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
-      X6_TERMS(OP)
-#undef OP
-      const f32x4 acc = ac[0] + ac[1];
-      if (m < a.A) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + m] = acc[r];
+      for (int at = 0; at < AC; ++at) {              // action tiles of 16
+        f32x4 ac[2] = {splat(bias_2[at]), splat(0.f)};     // one chain per k chunk
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[at][c].q_, ac[c]);
+        X6_TERMS(OP)
+#undef OP
+        const f32x4 acc = ac[0] + ac[1];
+        if (16 * at + m < a.A) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + 16 * at + m] = acc[r];
+        }
       }
     };
 
@@ -363,14 +370,18 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     ST_DUMP(4);
   } else {
     // =============================== team R: the recurrent part of a step ===============================
-    F3 wh[6], w2[2];
+    F3 wh[6], w2[AC][2];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int c = 0; c < 2; ++c) wh[2 * g + c] = wfrag(a.Whh, H, g * H + 16 * s, 3 * H, H, c, lane);
-    if (!XS) { w2[0] = wfrag(a.W2, H, 0, a.A, H, 0, lane); w2[1] = wfrag(a.W2, H, 0, a.A, H, 1, lane); }
+    float bias_2[AC];
+#pragma unroll
+    for (int ac = 0; ac < AC; ++ac) {
+      if (!XS) { w2[ac][0] = wfrag(a.W2, H, 16 * ac, a.A, H, 0, lane); w2[ac][1] = wfrag(a.W2, H, 16 * ac, a.A, H, 1, lane); }
+      bias_2[ac] = !XS && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
+    }
     const float bias_hn = a.bhh[2 * H + u];
-    const float bias_2 = !XS && m < a.A ? a.b2[m] : 0.f;
     // initial hidden state: fp32 registers (rows 4q + r of unit 16s + m) and planes Hp[0]
     f32x4 hreg[RTC];
 #pragma unroll
@@ -380,17 +391,20 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       put4(hpp(0), HP, rows * HP, rt * 16 + 4 * q, u, hreg[rt]);
     }
     auto fc2 = [&](int bh, int ts, int rt) __attribute__((always_inline)) {
-      f32x4 ac[2] = {splat(bias_2), splat(0.f)};     // one chain per k chunk
       F3 hb[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(bh) + rt * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
-      X6_TERMS(OP)
-#undef OP
-      const f32x4 acc = ac[0] + ac[1];
-      if (m < a.A) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + m] = acc[r];
+      for (int at = 0; at < AC; ++at) {              // action tiles of 16
+        f32x4 ac[2] = {splat(bias_2[at]), splat(0.f)};     // one chain per k chunk
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[at][c].q_, ac[c]);
+        X6_TERMS(OP)
+#undef OP
+        const f32x4 acc = ac[0] + ac[1];
+        if (16 * at + m < a.A) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + 16 * at + m] = acc[r];
+        }
       }
     };
     // XS: stored input-side sums of the NEXT row tile (accumulator layout = the storing kernel's), a tile ahead
@@ -483,11 +497,13 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 
 }  // namespace
 
-// shapes the split unroll covers: H = 64, <= 16 actions, observation width a multiple of 8, input width <= 160, T >= 4, rows
+// shapes the split unroll covers: H = 64, observation width a multiple of 8, input width <= 224 (<= 16 actions up to 160, <= 32
+// beyond), T >= 4, rows
 // addressed with 32-bit offsets
 extern "C" int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A, int last_action, int reuse_network) {
   const int I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
-  if (A < 1 || A > 16 || O < 8 || (O & 7) || I > 160 || T < 4 || B < 1) return 0;
+  if (A < 1 || O < 8 || (O & 7) || I > 224 || T < 4 || B < 1) return 0;
+  if (A > (I > 160 ? 32 : 16)) return 0;               // (two action tiles of fc2 only in the widest instantiation)
   if (I > 96 && 16 * (O / 4) > 2 * XNT) return 0;      // (wide inputs: one row tile per workgroup, its observations in the prefetch registers)
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return 0;
   return 1;
@@ -518,7 +534,7 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
   const long tiles = (a.R + 15) / 16;
   // two row tiles per workgroup once there are more tiles than CUs this launch may occupy (more than two do not fit LDS: larger
   // batches run in rounds of workgroups, and when the last round is at most one tile per CU its workgroups hold one tile each)
-  const bool wide = a.KI > 96;                     // five fc1 chunks: one row tile per workgroup (LDS), any number of rounds
+  const int wide = a.KI > 160 ? 2 : a.KI > 96 ? 1 : 0;      // five / seven fc1 chunks: one row tile per workgroup (LDS), any number of rounds
   const int rt = tiles > cu_budget && !wide ? 2 : 1;
   if (rt * 16 * (O / 4) > 2 * XNT) return (int)hipErrorInvalidValue;        // (the prefetch registers: two float4 per thread of the workgroup, four of team I alone)
   a.RT = rt;
@@ -533,8 +549,9 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
                      (((size_t)T * 4 + 15) & ~(size_t)15);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const void* fn;
-#define X6_PICKF(SAVE_, XS_, GIO_) (wide ? (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 5> : rt == 2 ? (const void*)agent_fwd_x6_kernel<2, SAVE_, XS_, GIO_, 3> \
-                                                                                                    : (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 3>)
+#define X6_PICKF(SAVE_, XS_, GIO_) (wide == 2 ? (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 7, 2>                         \
+                                    : wide == 1 ? (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 5, 1>                       \
+                                    : rt == 2 ? (const void*)agent_fwd_x6_kernel<2, SAVE_, XS_, GIO_, 3, 1> : (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 3, 1>)
   if (saved && a.gi_out) fn = X6_PICKF(true, false, true);
   else if (saved) fn = X6_PICKF(true, false, false);
   else if (gi_in) fn = X6_PICKF(false, true, false);
