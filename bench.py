@@ -234,6 +234,7 @@ OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp3
                  ("extra: headline learner (QMIX 2s3z 4096 envs) with gemm_mode bf16x6 (agent unrolls and BPTT on the split kernels)", "qmix", "2s3z", 4096, "fp32", "bf16x6"),
                  ("extra: cfg2 with gemm_mode bf16x6", "qmix", "2s3z", 1024, "fp32", "bf16x6"),
                  ("extra: cfg4 with gemm_mode bf16x6 (agent unrolls and BPTT on the split kernels; the QTRAN heads stay fp32)", "qtran_base", "3s5z", 512, "fp32", "bf16x6"),
+                 ("extra: cfg5 with gemm_mode bf16x6 (agent unrolls and BPTT on the split kernels beside the bf16 mixer)", "qmix", "MMM2", 1024, "bf16", "bf16x6"),
                  ("extra: QMIX 2s3z 512 envs (shard of 4096 / 8 GPUs), fp32 MFMA", "qmix", "2s3z", 512, "fp32", "f32"),
                  ("extra: QMIX 2s3z 512 envs (shard of 4096 / 8 GPUs), gemm_mode bf16x6", "qmix", "2s3z", 512, "fp32", "bf16x6")]
 

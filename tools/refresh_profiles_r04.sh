@@ -36,6 +36,7 @@ pmc qmix_2s3z_T120_envs1024_bf16x6 0 --envs 1024 --gemm-mode bf16x6
 pmc qmix_2s3z_T120_envs512 0 --envs 512
 pmc qmix_2s3z_T120_envs512_bf16x6 0 --envs 512 --gemm-mode bf16x6
 pmc qtran_base_3s5z_T150_envs512_bf16x6 0 --alg qtran_base --shape 3s5z --envs 512 --gemm-mode bf16x6
+pmc qmix_MMM2_T120_envs1024_bf16mixer_bf16x6 0 --shape MMM2 --envs 1024 --mixer-dtype bf16 --gemm-mode bf16x6
 # kernel stats of the QMIX / QPLEX updates in both modes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qmix_bf16x6 -o p -- python3 tools/prof_learner.py --alg qmix --envs 4096 --updates 6 --warmup 2 --gemm-mode bf16x6 > $OUT/${TAG}_qmix_bf16x6.log 2>&1
 for M in f32 bf16x6; do
@@ -46,10 +47,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_mmm2_bf16 -o
 # timings
 python3 tools/time_mlp3.py 4096 > $OUT/${TAG}_mlp3_times.txt 2>&1
 python3 tools/time_unroll_x6.py 4096 1024 512 256 > $OUT/${TAG}_unroll_x6_times.txt 2>&1
+SHAPE=3s5z python3 tools/time_unroll_x6.py 512 2048 >> $OUT/${TAG}_unroll_x6_times.txt 2>&1
+SHAPE=MMM2 python3 tools/time_unroll_x6.py 1024 >> $OUT/${TAG}_unroll_x6_times.txt 2>&1
 ( for a in "--alg qmix --envs 512" "--alg qmix --envs 4096" "--alg qplex --envs 512" "--alg qplex --envs 4096"; do for w in 1 100000; do
     echo -n "$a --gemm-mode bf16x6, split BPTT $([ $w = 1 ] && echo on || echo off) : "; MARL_X6_BWD_MIN_WG=$w python3 tools/prof_learner.py $a --gemm-mode bf16x6 --warmup 5 --updates 30 2>/dev/null | tail -1; done; done ) > $OUT/${TAG}_bptt_x6_ab.txt
 ( for a in "--alg qmix --envs 1024" "--alg qmix --envs 4096" "--alg vdn --envs 4096" "--alg qplex --envs 512" "--alg qplex --envs 512 --gemm-mode bf16x6" "--alg qplex --envs 4096" \
-           "--alg qplex --envs 4096 --gemm-mode bf16x6" "--alg qmix --envs 512" "--alg qmix --envs 512 --gemm-mode bf16x6" "--alg qmix --envs 1024 --gemm-mode bf16x6" "--alg qmix --envs 4096 --gemm-mode bf16x6" "--alg qtran_base --shape 3s5z --envs 512" "--alg qtran_base --shape 3s5z --envs 512 --gemm-mode bf16x6" "--alg qtran_base --shape 3s5z --envs 2048" "--shape MMM2 --envs 1024" "--shape MMM2 --envs 1024 --mixer-dtype bf16"; do
+           "--alg qplex --envs 4096 --gemm-mode bf16x6" "--alg qmix --envs 512" "--alg qmix --envs 512 --gemm-mode bf16x6" "--alg qmix --envs 1024 --gemm-mode bf16x6" "--alg qmix --envs 4096 --gemm-mode bf16x6" "--alg qtran_base --shape 3s5z --envs 512" "--alg qtran_base --shape 3s5z --envs 512 --gemm-mode bf16x6" "--alg qtran_base --shape 3s5z --envs 2048" "--shape MMM2 --envs 1024" "--shape MMM2 --envs 1024 --mixer-dtype bf16" "--shape MMM2 --envs 1024 --mixer-dtype bf16 --gemm-mode bf16x6" "--alg qmix --shape 3s5z --envs 1024" "--alg qmix --shape 3s5z --envs 1024 --gemm-mode bf16x6"; do
     echo -n "$a : "; python3 tools/prof_learner.py $a --warmup 5 --updates 20 2>/dev/null | tail -1; done ) > $OUT/${TAG}_learner_rates.txt
 for e in 512 1024 2048 4096; do python3 bench.py --envs $e --no-cpu-baseline --no-configs --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('envs_per_gpu=%d : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['envs_per_gpu'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"; done > $OUT/${TAG}_shard_steps.txt
 for e in 512 1024 2048 4096; do python3 bench.py --envs $e --gemm-mode bf16x6 --no-cpu-baseline --no-configs --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('envs_per_gpu=%d gemm_mode=bf16x6 : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['envs_per_gpu'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"; done >> $OUT/${TAG}_shard_steps.txt

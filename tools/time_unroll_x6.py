@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Agent unroll (plain / activation-saving / gate-sum-reading): fp32 MFMA kernel (agent.hip) vs the bf16x6 split kernel (agent_x6.hip), 2s3z-sized agent, T = 120.
-    [CUS=128] python tools/time_unroll_x6.py [envs ...]"""
+    [CUS=128] [SHAPE=2s3z|3s5z|MMM2] python tools/time_unroll_x6.py [envs ...]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marl_amd import ops
 import bench
 dev = torch.device("cuda:0")
-N, O, S, A, T = bench.SHAPES["2s3z"]
+SHAPE = os.environ.get("SHAPE", "2s3z")
+N, O, S, A, T = bench.SHAPES[SHAPE]
 g = torch.Generator().manual_seed(0)
 P = {"fc1.weight": torch.randn(64, O + A + N, generator=g) * 0.1, "fc1.bias": torch.randn(64, generator=g) * 0.1,
      "rnn.weight_ih": torch.randn(192, 64, generator=g) * 0.1, "rnn.weight_hh": torch.randn(192, 64, generator=g) * 0.1,
