@@ -262,8 +262,9 @@ def pmc_traffic(pmc, e):
     if e["rocprof_name"] == "agent_fwd_x6":
         # agent_fwd_x6_kernel<tiles, SAVE, XS, GIO>: match by what the launch does
         tag = e["name"].split("[")[1][:4]
-        want = {"save": ", true, false, ", "reus": ", false, true, ", "plai": ", false, false, false"}[tag]
-        hit = [v for k, v in pmc.items() if k.startswith("agent_fwd_x6_kernel<") and want in k and "hbm_bytes_per_launch" in v]
+        want = {"save": ("true", "false"), "reus": ("false", "true"), "plai": ("false", "false")}[tag]      # (SAVE, XS)
+        hit = [v for k, v in pmc.items() if k.startswith("agent_fwd_x6_kernel<") and "hbm_bytes_per_launch" in v
+               and tuple(k[k.index("<") + 1:k.rindex(">")].split(", ")[1:3]) == want]
     if e["rocprof_name"].startswith("mlp3") and len(hit) > 1:
         # one instantiation per padded input width: <8, ...> for K1 <= 128, <11, ...> (fp32) / <12, ...> (bf16x6) beyond; three-layer heads
         import re

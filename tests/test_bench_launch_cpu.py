@@ -59,8 +59,8 @@ def test_pmc_traffic_picks_the_instantiation_a_timed_call_launched():
     pmc = {"agent_fwd_kernel<1, true, true, 4, false, false, false, false>": k(6.7e9, WRITE_SIZE=5e6, SQ_INSTS_MFMA=9e6),
            "agent_fwd_kernel<1, false, true, 4, false, false, false, false>": k(2.0e9, WRITE_SIZE=1e5, SQ_INSTS_MFMA=9e6),
            "agent_fwd_kernel<1, false, true, 4, true, false, false, false>": k(2.1e9, WRITE_SIZE=1e5, SQ_INSTS_MFMA=4e6),
-           "agent_fwd_x6_kernel<2, true, false, true>": k(6.8e9), "agent_fwd_x6_kernel<2, false, false, false>": k(2.0e9),
-           "agent_fwd_x6_kernel<2, false, true, false>": k(2.03e9),
+           "agent_fwd_x6_kernel<2, true, false, true, 7, 2>": k(6.8e9), "agent_fwd_x6_kernel<2, false, false, false, 7, 2>": k(2.0e9),
+           "agent_fwd_x6_kernel<2, false, true, false, 7, 2>": k(2.03e9),
            "agent_bwd_kernel<1, false, 1>": k(5.2e9), "agent_bwd_x6_kernel<false, false, 2>": k(4.5e9),
            "mlp3x6_fwd_kernel<8, true, 6>": k(1.5e9), "mlp3x6_fwd_kernel<12, true, 6>": k(1.9e9)}
     e = lambda name, roc: {"name": name, "rocprof_name": roc}
