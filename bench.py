@@ -10,6 +10,7 @@ Workload (BASELINE.json metric): QMIX, synthetic 2s3z shape (N=5, O=80, S=120, A
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -292,6 +293,13 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
     from marl_amd.algorithm.qtran_learner import QTRANLearner
     from marl_amd.rollout import RolloutWorker
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    # every leg starts from a device heap without the previous legs' cached blocks and workspaces.  (The 512-env bf16x6 leg is
+    # bound by the HOST's launch path - its kernels add up to 1.18 ms per update, a fresh process runs it at 805-837 updates/s, this
+    # process at 650-800 depending on what ran before it with the same per-kernel times: tools/leg_seq.py.)
+    ops.WS.bufs.clear()
+    ops.WS.gen += 1
+    gc.collect()
+    torch.cuda.empty_cache()
     args = make_args(alg, shape, 0)
     args.mixer_dtype = mixer_dtype
     args.gemm_mode = gemm_mode
@@ -309,7 +317,6 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
         torch.cuda.synchronize()
         # (a generation-2 garbage collection - the previous legs' objects - costs 35-60 ms: inside eight timed updates it
         # turned 172 updates/s into 105 on some runs)
-        import gc
         gc.collect()
         gc.disable()
         try:
@@ -626,7 +633,6 @@ def main():
         one_step()
     # a full (generation-2) Python garbage collection costs ~35 ms here - three pipeline steps; collect now and
     # keep the collector off inside the timed regions (what timeit does)
-    import gc
     gc.collect()
     gc.disable()
     barrier()
@@ -642,7 +648,6 @@ def main():
         env_steps += s
         if os.environ.get("MARL_BENCH_DEBUG"):
             torch.cuda.synchronize()
-            import gc
             ms = torch.cuda.memory_stats()
             print("step %.2f ms gc=%s segs=%d reserved=%.2fGB allocs=%d" % ((time.perf_counter() - ts) * 1e3, gc.get_count(),
                   ms["segment.all.current"], ms["reserved_bytes.all.current"] / 2**30, ms["allocation.all.allocated"]), file=sys.stderr)
