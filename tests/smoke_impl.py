@@ -31,4 +31,14 @@ def run():
     st = learners.LearnerState(args, agent, mixer)
     oloss, _, _ = learners.train(st, d, 0)
     assert abs(loss - oloss) <= 1e-4 * max(1.0, abs(oloss)), (loss, oloss)
-    print("smoke ok: steps=%d loss=%.6f oracle=%.6f" % (steps, loss, oloss))
+    # the same update with the agent unrolls and BPTT on the split kernels (opt-in args.gemm_mode = "bf16x6"): same bound
+    args6 = seeded.make_args("2s3z", "qmix", episode_limit=T, epsilon=0.3, seed=1)
+    args6.gemm_mode = "bf16x6"
+    mac6 = SharedMAC(args6)
+    mac6.agent.load_state_dict(t(agent))
+    learner6 = QLearner(mac6, args6)
+    learner6.mixer.load_state_dict(t(mixer))
+    learner6.target_mixer.load_state_dict(t(mixer))
+    loss6 = learner6.train(ep, 0)
+    assert abs(loss6 - oloss) <= 1e-4 * max(1.0, abs(oloss)), (loss6, oloss)
+    print("smoke ok: steps=%d loss=%.6f (bf16x6 mode: %.6f) oracle=%.6f" % (steps, loss, loss6, oloss))
