@@ -135,6 +135,8 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   int* rowlen = rown + rows;
   int* rowrho = rowlen + rows;
   int* xmask = rowrho + rows;                     // [T] (XS): step t is computed in full
+  constexpr int NK1R = NK1 > 5 ? 5 : NK1;         // fc1 chunks whose fragments stay in registers; the others as ready fragments in LDS
+  char* WL1 = reinterpret_cast<char*>(xmask + ((a.T + 3) & ~3));      // [4 slices][NK1 - NK1R][3 planes][64 lanes] 16 bytes
   auto inp = [&](int b) { return In0 + b * 3 * rows * IP; };
   auto xpp = [&](int b) { return Xp0 + b * 3 * rows * HP; };
   auto hpp = [&](int b) { return Hp0 + b * 3 * rows * HP; };
@@ -240,9 +242,24 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 
   if (team == 1) {
     // =============================== team I: everything that depends only on a step's input ===============================
-    F3 w1[NK1], wi[6], w2[AC][2];                  // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
+    F3 w1[NK1R], wi[6], w2[AC][2];                 // pre-split B fragments (lane (g, j): W[unit j][k = 32 c + 8g ..])
 #pragma unroll
-    for (int c = 0; c < NK1; ++c) w1[c] = !(XS && NK1 > 3) && c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};      // (XS with wide inputs: loaded where used, see fc1)
+    for (int c = 0; c < NK1R; ++c) w1[c] = !(XS && NK1 > 3) && c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};      // (XS with wide inputs: loaded where used, see fc1)
+    if (!XS) {
+#pragma unroll
+      for (int c = NK1R; c < NK1; ++c) {
+        const F3 f = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
+        i32x4* p = reinterpret_cast<i32x4*>(WL1) + (s * (NK1 - NK1R) + (c - NK1R)) * 192 + lane;
+        p[0] = f.h; p[64] = f.m; p[128] = f.l;
+      }
+    }
+    auto w1f = [&](int c) __attribute__((always_inline)) {      // (compile-time c after unrolling)
+      if (c < NK1R) return w1[c < NK1R ? c : 0];
+      const i32x4* p = reinterpret_cast<const i32x4*>(WL1) + (s * (NK1 - NK1R) + (c - NK1R)) * 192 + lane;
+      F3 f;
+      f.h = p[0]; f.m = p[64]; f.l = p[128];
+      return f;
+    };
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -268,17 +285,17 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         if (XS) {
 #pragma unroll
           for (int c = 0; c < NK1; ++c) {
-            const F3 wc = NK1 > 3 ? (c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{}) : w1[c];      // (wide inputs: not kept in registers in this variant)
+            const F3 wc = NK1 > 3 ? (c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{}) : w1[c < NK1R ? c : 0];      // (wide inputs: not kept in registers in this variant)
             mm6(bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c < KC1 ? c : 0, lane), wc, acc[c % 3]);
           }
         } else {
 #pragma unroll
           for (int c0 = 0; c0 < NK1; c0 += 3) {
-            F3 xi[3];
+            F3 xi[3], wf[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-              if (c0 + c < NK1) xi[c] = bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c0 + c < KC1 ? c0 + c : 0, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c0 + c < NK1) acc[c] = mm(xi[c].p_, w1[c0 + c].q_, acc[c]);
+              if (c0 + c < NK1) { xi[c] = bfrag(inp(bin) + rr * 16 * IP, IP, rows * IP, c0 + c < KC1 ? c0 + c : 0, lane); wf[c] = w1f(c0 + c); }
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c0 + c < NK1) acc[c] = mm(xi[c].p_, wf[c].q_, acc[c]);
             X6_TERMS(OP)
 #undef OP
           }
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         const f32x4 acc = ac[0] + ac[1];
         if (16 * at + m < a.A) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + 16 * at + m] = acc[r];
+          for (int r = 0; r < 4; ++r) a.q[(unsigned)(rowidx[rt * 16 + 4 * q + r] + ts * a.N) * (unsigned)a.A + (unsigned)(16 * at + m)] = acc[r];      // (32-bit element offsets: the host checks B T N H 4 < 2^32)
         }
       }
     };
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         const f32x4 acc = ac[0] + ac[1];
         if (16 * at + m < a.A) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a.q[((long)rowidx[rt * 16 + 4 * q + r] + (long)ts * a.N) * a.A + 16 * at + m] = acc[r];
+          for (int r = 0; r < 4; ++r) a.q[(unsigned)(rowidx[rt * 16 + 4 * q + r] + ts * a.N) * (unsigned)a.A + (unsigned)(16 * at + m)] = acc[r];      // (32-bit element offsets: the host checks B T N H 4 < 2^32)
         }
       }
     };
@@ -474,11 +491,11 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         hreg[rt] = hn;
         if (a.hs) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a.hs[((long)rowidx[rt * 16 + 4 * q + r] + (long)t * a.N) * H + u] = hn[r];
+          for (int r = 0; r < 4; ++r) a.hs[(unsigned)(rowidx[rt * 16 + 4 * q + r] + t * a.N) * (unsigned)H + (unsigned)u] = hn[r];
         }
         if (t == a.T - 1 && a.h_last) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a.h_last[(long)rowrho[rt * 16 + 4 * q + r] * H + u] = hn[r];
+          for (int r = 0; r < 4; ++r) a.h_last[(unsigned)rowrho[rt * 16 + 4 * q + r] * (unsigned)H + (unsigned)u] = hn[r];
         }
       }
       if (!XS && t > 0 && s < RTW) fc2(par, t - 1, s);           // q(t-1) from h fed into step t
@@ -546,7 +563,7 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
   }
   const int rows = rt * 16, IP = a.KI + 8;
   const size_t lds = (size_t)2 * 3 * rows * IP * 2 + (size_t)4 * 3 * rows * HP * 2 + (size_t)2 * rt * 4 * 3 * 1024 + (size_t)rows * (2 * 8 + 4 * 4) +
-                     (((size_t)T * 4 + 15) & ~(size_t)15);
+                     (((size_t)T * 4 + 15) & ~(size_t)15) + (wide == 2 ? (size_t)4 * 2 * 3 * 1024 : 0);      // (+ the fc1 fragments of the widest instantiation that live in LDS)
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const void* fn;
 #define X6_PICKF(SAVE_, XS_, GIO_) (wide == 2 ? (const void*)agent_fwd_x6_kernel<1, SAVE_, XS_, GIO_, 7, 2>                         \
