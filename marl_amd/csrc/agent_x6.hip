@@ -182,6 +182,10 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   // takes part (team R's waves wait at the step barrier for a third of a step; team I is the longer one) - except where team R would
   // then wait for its own stores: the saving variant with two row tiles (its store count per step is not a constant) and XS
   // (which loads an input tile for a few steps only, slot by slot, in team I)
+  // NGR: the candidate gate's input-side product x W_in runs in team R (a step ahead, off its chain) - team I is the longer team, and
+  // team R waits a third of a step at the barrier.  Not in XS, where team I is idle anyway.  (Same products in the same order on
+  // either team: the gate sums stay bit-identical between the variants.)
+  constexpr bool NGR = !XS && AC == 1;      // (two action tiles: team R has no registers to spare)
   constexpr bool ALLP = !XS && !(SAVE && RTC == 2);
   constexpr int NLDK = ALLP ? 2 : NLD;
   const int PT = ALLP ? XNT : 256, pti = ALLP ? tid : tid - 256;      // participating threads, this thread's index among them
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) wi[2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
+      for (int c = 0; c < 2; ++c) wi[2 * g + c] = (NGR && g == 2) ? F3{} : wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
     float bias_2[AC];
 #pragma unroll
     for (int ac = 0; ac < AC; ++ac) {
@@ -310,21 +314,23 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         const int rr = rt < RTW ? rt : RTW - 1;
-        f32x4 ag[3] = {splat(bias_r), splat(bias_z), splat(bias_n)};      // three gates = three chains, round robin
+        constexpr int NG = NGR ? 2 : 3;              // gates computed here = independent chains, round robin
+        f32x4 ag[3] = {splat(bias_r), splat(bias_z), splat(bias_n)};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const F3 xb = bfrag(xpp(bxx) + rr * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ag[g] = mm(xb.p_, wi[2 * g + c].q_, ag[g]);
+#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < NG; ++g) ag[g] = mm(xb.p_, wi[2 * g + c].q_, ag[g]);
           X6_TERMS(OP)
 #undef OP
         }
         f32x4* gp = reinterpret_cast<f32x4*>(GI0) + ((bg * RTC + rr) * 4 + s) * 192 + lane;
-        gp[0] = ag[0]; gp[64] = ag[1]; gp[128] = ag[2];
+        gp[0] = ag[0]; gp[64] = ag[1];
+        if (!NGR) gp[128] = ag[2];
         if (GIO) {
           float* const go = a.gi_out + sv_off((long)ts * NTILES + tile0 + rr, 3, 0, s, lane);
           *reinterpret_cast<f32x4*>(go) = ag[0];
           *reinterpret_cast<f32x4*>(go + 1024) = ag[1];
-          *reinterpret_cast<f32x4*>(go + 2048) = ag[2];
+          if (!NGR) *reinterpret_cast<f32x4*>(go + 2048) = ag[2];
         }
       }
     };
@@ -399,6 +405,22 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       bias_2[ac] = !XS && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
     }
     const float bias_hn = a.bhh[2 * H + u];
+    F3 win[2];                                      // NGR: W_in fragments (the n rows of W_ih), this wave's 16 units
+    if (NGR) { win[0] = wfrag(a.Wih, H, 2 * H + 16 * s, 3 * H, H, 0, lane); win[1] = wfrag(a.Wih, H, 2 * H + 16 * s, 3 * H, H, 1, lane); }
+    const float bias_nin = a.bih[2 * H + u];
+    f32x4 anx[RTC];                                 // NGR: bias + x W_in of the step to come (computed during the step before it)
+    // bias + x(ts) W_in of every row tile from planes Xp[bxx] (+ the n plane of gi_out): the products of team I's gih, same order
+    auto nin = [&](int bxx, int ts) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+        if (rt >= RTW) break;
+        f32x4 an = splat(bias_nin);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) mm6(bfrag(xpp(bxx) + rt * 16 * HP, HP, rows * HP, c, lane), win[c], an);
+        anx[rt] = an;
+        if (GIO) *reinterpret_cast<f32x4*>(a.gi_out + sv_off((long)ts * NTILES + tile0 + rt, 3, 2, s, lane)) = an;
+      }
+    };
     // initial hidden state: fp32 registers (rows 4q + r of unit 16s + m) and planes Hp[0]
     f32x4 hreg[RTC];
 #pragma unroll
@@ -444,6 +466,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     WG_BARRIER();                                  // A
     WG_BARRIER();                                  // B
     if (ALLP) { commit(0, pu_lds0); issue(Tm1 < 3 ? Tm1 : 3); }
+    if (NGR) nin(0, 0);                            // x(0) is in Xp[0] since barrier B
     WG_BARRIER();                                  // C
     for (int t = 0; t < a.T; ++t) {
       const int par = t & 1;
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         const f32x4* gp = reinterpret_cast<const f32x4*>(GI0) + ((par * RTC + rt) * 4 + s) * 192 + lane;
         f32x4 ah[3], an;                             // r, z (on top of the input-side sums) and the candidate's hidden side
         ah[2] = splat(bias_hn);
-        if (fl) { ah[0] = gp[0]; ah[1] = gp[64]; an = gp[128]; }
+        if (fl) { ah[0] = gp[0]; ah[1] = gp[64]; an = NGR ? anx[rt] : gp[128]; }
         else { ah[0] = gB[0]; ah[1] = gB[1]; an = gB[2]; }
         if (XS) {                                    // the next tile: this step's, or tile 0 of the next step (stored step + 1)
           const bool same = rt + 1 < RTW;
@@ -499,6 +522,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         }
       }
       if (!XS && t > 0 && s < RTW) fc2(par, t - 1, s);           // q(t-1) from h fed into step t
+      if (NGR && t + 1 < a.T) nin(par ^ 1, t + 1);               // off the chain: the next step's candidate input side (x(t+1) is in Xp[par ^ 1])
       ST_MARK(2);
       if (ALLP) {                                  // input tile of step t+3, loads of step t+4 (see team I)
         if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
