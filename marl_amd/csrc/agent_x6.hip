@@ -178,18 +178,22 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   auto full = [&](int t) { return !XS || xmask[t < Tm1 ? t : Tm1] != 0; };      // step t's input side is computed here
   ST_DECL(4);
 
-  // ---- observation prefetch: thread -> (row, 4-column group) of the tile, the same every step.  ALLP: every thread of the workgroup
-  // takes part (team R's waves wait at the step barrier for a third of a step; team I is the longer one) - except where team R would
-  // then wait for its own stores: the saving variant with two row tiles (its store count per step is not a constant) and XS
-  // (which loads an input tile for a few steps only, slot by slot, in team I)
+  // ---- observation prefetch: thread -> (row, 4-column group) of the tile, the same every step.  ALLP: the whole prefetch (loads a step
+  // ahead, split into the input planes) is TEAM R's - its waves wait a third of a step at the barrier, team I is the longer team and
+  // keeps none of it - except where team R would then wait for its own stores: the saving variant with two row tiles (its store count
+  // per step is not a constant) and XS (which loads an input tile for a few steps only, slot by slot); there it is team I's.
   // NGR: the candidate gate's input-side product x W_in runs in team R (a step ahead, off its chain) - team I is the longer team, and
   // team R waits a third of a step at the barrier.  Not in XS, where team I is idle anyway.  (Same products in the same order on
   // either team: the gate sums stay bit-identical between the variants.)
   constexpr bool NGR = !XS && AC == 1;      // (two action tiles: team R has no registers to spare)
   constexpr bool ALLP = !XS && !(SAVE && RTC == 2);
-  constexpr int NLDK = ALLP ? 2 : NLD;
-  const int PT = ALLP ? XNT : 256, pti = ALLP ? tid : tid - 256;      // participating threads, this thread's index among them
-  const bool pfw = ALLP || team == 1;
+  // FC2I: fc2 / q in team I - in XS (team R then has loads only) and wherever team I has no loads to count stores against (ALLP): the
+  // one wave per row tile that carries fc2 would otherwise be team R's longest, on the chain
+  constexpr bool FC2I = XS || (ALLP && AC == 1);
+  constexpr int NLDK = ALLP ? 3 : NLD;
+  constexpr int PT = 256;                          // participating threads: one team
+  const int pti = ALLP ? tid : tid - 256;          // this thread's index among them
+  const bool pfw = ALLP ? team == 0 : team == 1;
   const int O4 = O >> 2, n4 = rows * O4;
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1);
   const int NS = (n4 + PT - 1) / PT;               // prefetch slots (float4 per thread) the tile fills
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   long goff[NLDK]; int prk[NLDK];                   // (row << 16) | first column of the thread's float4
   int pt = 0, pu = -1, pu_lds0 = -1, pu_lds1 = -1;      // one-hot column currently set in each input buffer
   auto slot = [&](int i, int& prk_, long& goff_) {
-    int e = pti + PT * i;
+    int e = PT * i + ((pti - 64 * i) & (PT - 1));      // (slot i rotated by i waves: a partly filled last slot is not wave 0's, which has fc2)
     if (e > n4 - 1) e = n4 - 1;
     if (e < 0) e = 0;
     const int r = (int)(((float)e + 0.5f) * invO4);
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   }
   const long urow = pfw && pti < rows ? rowu[pti] : 0;
   // (a wave whose 64 elements of a slot all lie past the tile skips the slot - wave-uniform)
-  auto wave_has = [&](int i) { return i < NS && (pti & ~63) + PT * i < n4; };
+  auto wave_has = [&](int i) { return i < NS && PT * i + (((pti & ~63) - 64 * i) & (PT - 1)) < n4; };
   auto issue = [&](int t) {
     const long toff = (long)(t + a.obs_t0) * a.N * O;
 #pragma unroll
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     float bias_2[AC];
 #pragma unroll
     for (int ac = 0; ac < AC; ++ac) {
-      if (XS) { w2[ac][0] = wfrag(a.W2, H, 16 * ac, a.A, H, 0, lane); w2[ac][1] = wfrag(a.W2, H, 16 * ac, a.A, H, 1, lane); }
-      bias_2[ac] = XS && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
+      if (FC2I) { w2[ac][0] = wfrag(a.W2, H, 16 * ac, a.A, H, 0, lane); w2[ac][1] = wfrag(a.W2, H, 16 * ac, a.A, H, 1, lane); }
+      bias_2[ac] = FC2I && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
     }
     const float bias_1 = a.b1[u], bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u];
 
@@ -354,15 +358,17 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     };
 
     __syncthreads();                               // constant columns, h0 planes (team R), step flags
-    issue(0); commit(0, pu_lds0);
-    issue(Tm1 < 1 ? Tm1 : 1); commit(1, pu_lds1);
-    issue(Tm1 < 2 ? Tm1 : 2);
+    if (!ALLP) {
+      issue(0); commit(0, pu_lds0);
+      issue(Tm1 < 1 ? Tm1 : 1); commit(1, pu_lds1);
+      issue(Tm1 < 2 ? Tm1 : 2);
+    }
     WG_BARRIER();                                  // A: input planes of steps 0 and 1
     if (full(0)) fc1(0, 0, 0);
     if (full(1)) fc1(1, 1, 1);
     WG_BARRIER();                                  // B: x(0), x(1)
-    commit(0, pu_lds0);                            // input(2)
-    if (!XS) issue(Tm1 < 3 ? Tm1 : 3);
+    if (!ALLP) commit(0, pu_lds0);                 // input(2)
+    if (!XS && !ALLP) issue(Tm1 < 3 ? Tm1 : 3);
     if (full(0)) gih(0, 0, 0);
     WG_BARRIER();                                  // C: gi(0), input(2)
     for (int t = 0; t < a.T; ++t) {
@@ -372,10 +378,13 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         gih(par ^ 1, par ^ 1, t + 1 < a.T ? t + 1 : Tm1);        // gi(t+1) from x(t+1)
         ST_MARK(0);
         fc1(par, par, t + 2 < a.T ? t + 2 : Tm1);                // x(t+2) from input(t+2) -> the buffer x(t) has left
+        if (FC2I && t > 0 && s < RTW) fc2(par, t - 1, s);        // q(t-1) from h fed into step t
         ST_MARK(1);
         // input tile of step t+3 -> the buffer fc1(t+1) finished with in the previous step; start the loads of step t+4
-        if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
-        issue(t + 4 < a.T ? t + 4 : Tm1);
+        if (!ALLP) {
+          if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
+          issue(t + 4 < a.T ? t + 4 : Tm1);
+        }
         ST_MARK(2);
       } else {
         if (t + 1 < a.T && full(t + 1)) gih(par ^ 1, par ^ 1, t + 1);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
       WG_BARRIER();
       ST_MARK(3);
     }
-    if (XS && s < RTW) fc2(a.T & 1, a.T - 1, s);   // q of the last step
+    if (FC2I && s < RTW) fc2(a.T & 1, a.T - 1, s);   // q of the last step
     ST_DUMP(4);
   } else {
     // =============================== team R: the recurrent part of a step ===============================
@@ -401,8 +410,8 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     float bias_2[AC];
 #pragma unroll
     for (int ac = 0; ac < AC; ++ac) {
-      if (!XS) { w2[ac][0] = wfrag(a.W2, H, 16 * ac, a.A, H, 0, lane); w2[ac][1] = wfrag(a.W2, H, 16 * ac, a.A, H, 1, lane); }
-      bias_2[ac] = !XS && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
+      if (!FC2I) { w2[ac][0] = wfrag(a.W2, H, 16 * ac, a.A, H, 0, lane); w2[ac][1] = wfrag(a.W2, H, 16 * ac, a.A, H, 1, lane); }
+      bias_2[ac] = !FC2I && 16 * ac + m < a.A ? a.b2[16 * ac + m] : 0.f;
     }
     const float bias_hn = a.bhh[2 * H + u];
     F3 win[2];                                      // NGR: W_in fragments (the n rows of W_ih), this wave's 16 units
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
     };
     __syncthreads();
     if (XS) gissue(Tm1 < 1 ? Tm1 : 1, 0);          // (step 0's sums = the storing unroll's step 1)
-    if (ALLP) {                                    // this team's share of the input tiles: the same calls at the same points as team I
+    if (ALLP) {                                    // the input tiles are this team's
       issue(0); commit(0, pu_lds0);
       issue(Tm1 < 1 ? Tm1 : 1); commit(1, pu_lds1);
       issue(Tm1 < 2 ? Tm1 : 2);
@@ -521,17 +530,17 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
           for (int r = 0; r < 4; ++r) a.h_last[(unsigned)rowrho[rt * 16 + 4 * q + r] * (unsigned)H + (unsigned)u] = hn[r];
         }
       }
-      if (!XS && t > 0 && s < RTW) fc2(par, t - 1, s);           // q(t-1) from h fed into step t
+      if (!FC2I && t > 0 && s < RTW) fc2(par, t - 1, s);         // q(t-1) from h fed into step t
       if (NGR && t + 1 < a.T) nin(par ^ 1, t + 1);               // off the chain: the next step's candidate input side (x(t+1) is in Xp[par ^ 1])
       ST_MARK(2);
-      if (ALLP) {                                  // input tile of step t+3, loads of step t+4 (see team I)
+      if (ALLP) {                                  // input tile of step t+3 -> the buffer fc1(t+1) finished with in the previous step; loads of step t+4
         if (par) commit(0, pu_lds0); else commit(1, pu_lds1);
         issue(t + 4 < a.T ? t + 4 : Tm1);
       }
       WG_BARRIER();
       ST_MARK(3);
     }
-    if (!XS && s < RTW) fc2(a.T & 1, a.T - 1, s);                // q of the last step
+    if (!FC2I && s < RTW) fc2(a.T & 1, a.T - 1, s);              // q of the last step
     ST_DUMP(4);
   }
 }
@@ -545,7 +554,7 @@ extern "C" int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A,
   const int I = O + (last_action ? A : 0) + (reuse_network ? N : 0);
   if (A < 1 || O < 8 || (O & 7) || I > 224 || T < 4 || B < 1) return 0;
   if (A > (I > 160 ? 32 : 16)) return 0;               // (two action tiles of fc2 only in the widest instantiation)
-  if (I > 96 && 16 * (O / 4) > 2 * XNT) return 0;      // (wide inputs: one row tile per workgroup, its observations in the prefetch registers)
+  if (16 * (O / 4) > 3 * 256) return 0;                // (a row tile's observations fit the prefetch registers of one team)
   if ((double)B * T * N * H * 4.0 >= 4294967296.0) return 0;
   return 1;
 }
@@ -577,7 +586,7 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
   // batches run in rounds of workgroups, and when the last round is at most one tile per CU its workgroups hold one tile each)
   const int wide = a.KI > 160 ? 2 : a.KI > 96 ? 1 : 0;      // five / seven fc1 chunks: one row tile per workgroup (LDS), any number of rounds
   const int rt = tiles > cu_budget && !wide ? 2 : 1;
-  if (rt * 16 * (O / 4) > 2 * XNT) return (int)hipErrorInvalidValue;        // (the prefetch registers: two float4 per thread of the workgroup, four of team I alone)
+  if (rt * 16 * (O / 4) > 3 * 256) return (int)hipErrorInvalidValue;        // (the prefetch registers: three float4 per thread of one team)
   a.RT = rt;
   long n_wg = (tiles + rt - 1) / rt;
   a.n_full = (int)n_wg;
