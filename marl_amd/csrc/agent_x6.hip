@@ -6,10 +6,11 @@
 // Why another decomposition: as bf16 triples the weight fragments of a hidden-unit slice no longer fit one wave
 // beside its working set (W_ih + W_hh + fc1 + fc2 slices = 204 registers), and 190 KB of pre-split weights do not fit LDS.  So the
 // two teams of the workgroup hold DIFFERENT weights instead of the same ones:
-//   team I (waves 4-7, slice s): fc1 and W_ih fragments (108 registers) - everything that depends only on a step's INPUT:
+//   team I (waves 4-7, slice s): fc1 and W_ih fragments (up to 108 registers) - what depends only on a step's INPUT:
 //          x(t+2) = relu(fc1(in(t+2))) and the input-side gate sums gi(t+1) = bias + x(t+1) W_ih, one / two steps ahead of the chain;
-//   team R (waves 0-3, slice s): W_hh and fc2 fragments (96 registers) - the recurrent part of step t: accumulators start from the
-//          handed gi(t), += h W_hh, gate math, h' (kept in fp32 registers for the blend of the next step), q(t-1) = fc2(h).
+//   team R (waves 0-3, slice s): W_hh fragments (72 registers) - the recurrent part of step t: accumulators start from the handed
+//          gi(t), += h W_hh, gate math, h' (kept in fp32 registers for the blend of the next step);
+//   q(t-1) = fc2(h), the observation prefetch and the candidate gate's x W_in go to whichever team has the time (see the kernel).
 // Products are out[row][unit] = act[row][k] W[unit][k]: activations are the MFMA A operand, read as 16 bytes per lane (row m, 8
 // consecutive k) from bf16 PLANES in LDS - every activation element is split once, where it is produced, and shared by the four
 // slice waves that consume it (5.5 vector instructions per element, once); weights are the B operand, pre-split in registers.  The
@@ -105,13 +106,16 @@ __device__ __forceinline__ long sv_off(long tile_t, int planes, int plane, int c
 // SAVE: the eval network's pass.  XS: the double-Q continuation - team I computes only the steps flagged in xmask (the last step and
 // steps at which a row has ep_len - 1 == t), the other steps' sums come from gi_in (the eval pass's step t + 1).
 //
-// The two teams run DIFFERENT loops (same barrier sequence): each keeps only its own weights and working set in registers, and
-// the memory traffic of a loop is arranged so that no wave waits for a store to complete in the steady state -
-//   team I (not XS): observation loads (4 per thread, consumed one step later) and a FIXED number of stores per step (x plane and
-//          gate sums of RTC tiles; steps past the end and row tiles past the batch recompute the last valid one and store the
-//          same values again), so the wait for the loads is a counted vmcnt, not vmcnt(0);
-//   team R (not XS): stores only (saved planes, hs, q);      team R (XS): loads only (gate sums) - fc2 / q move to team I, which
-//          is idle in that variant except for the few steps it computes in full.
+// The two teams run DIFFERENT loops (same barrier sequence): each keeps only its own weights and working set in registers.  Three
+// pieces of a step belong to neither team by nature and are dealt by variant (ALLP / FC2I / NGR below), by two rules: the longer team
+// gives work away (stamps: tools/stamps_unroll_x6.py), and no wave may end up waiting for a STORE to complete in the steady state
+// (loads and stores share one in-order counter; a wait for a load is a counted vmcnt only while the stores issued after it are a
+// fixed number):
+//   the observation prefetch (loads a step ahead, split into the input planes): team R's; team I's in the two-tile saving variant
+//          (team R's store count per step varies there) - team I then stores a FIXED number of planes per step (steps past the end and
+//          row tiles past the batch recompute the last valid one and store the same values again) - and in XS (a few steps only);
+//   fc2 / q: team I's wherever team I has no loads left (and in XS, where team R has the gate-sum loads); team R's otherwise;
+//   the candidate gate's input-side product x W_in: team R's, a step ahead and off its chain, in the variants with one action tile.
 // NK1: 32-wide k chunks of fc1 whose weight fragments the kernel holds (3: inputs up to 96 wide - 2s3z; 5: up to 160 - 3s5z; 7: up to
 // 224 - MMM2; beyond 3 one row tile per workgroup only: the input planes grow with the width).  AC: 16-wide action tiles of fc2
 template <int RTC, bool SAVE, bool XS, bool GIO = false, int NK1 = 3, int AC = 1>
