@@ -4,7 +4,7 @@
 // per step the delta pass (dh carry, gate gradients, dx) AND the weight-gradient reductions of W_ih, W_hh, W_2 and their biases.
 //
 // One workgroup = 32 rows (two 16-row tiles of the saved-activation layout) = one k block of v_mfma_f32_16x16x32_bf16 for the
-// reductions over rows; 8 waves = 2 teams x 4 hidden-unit slices (wave s of a team: units 16s .. 16s+15), two barriers per step
+// reductions over rows (NT = 2; batches of up to 256 row tiles: one tile per workgroup, NT = 1, reductions on the 16-deep MFMA); 8 waves = 2 teams x 4 hidden-unit slices (wave s of a team: units 16s .. 16s+15), two barriers per step
 // (image filled | image read):
 //   team R (waves 0-3), the dependent chain:  dh = carry + dhs + dq W_2 -> gate gradients (fp32, accumulator layout: lane (q, m) =
 //          rows 4q + r of unit 16s + m, the layout of the saved planes) -> G image in LDS | barrier |
