@@ -54,3 +54,26 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_split_kernel_capability_predicates():
+    """The *_supported entry points of the bf16x6 kernels are host functions (no GPU): which agent shapes the split unroll and the
+    split BPTT cover - the three map sizes of BASELINE's configurations - and what they leave to the fp32 kernels."""
+    from marl_amd import _lib
+    lib = _lib.load()
+    fwd = lambda B, T, N, O, A, la=1, ru=1: lib.marl_agent_unroll_x6_supported(B, T, N, O, A, la, ru)
+    bwd = lambda B, T, N, A, sparse=1: lib.marl_agent_unroll_bwd_x6_supported(B, T, N, A, sparse)
+    assert fwd(512, 120, 5, 80, 11) == 1            # 2s3z: 96 input columns, three fc1 chunks
+    assert fwd(512, 150, 8, 128, 14) == 1           # 3s5z: 150 columns, five chunks
+    assert fwd(1024, 120, 10, 176, 18) == 1         # MMM2: 204 columns, seven chunks, two action tiles
+    assert fwd(512, 3, 5, 80, 11) == 0              # T < 4: no pipeline to fill - the fp32 kernels
+    assert fwd(512, 120, 5, 80, 18) == 0            # more than 16 actions on a narrow input: one action tile only
+    assert fwd(512, 120, 10, 240, 18) == 0          # wider than 224 input columns
+    assert fwd(512, 120, 5, 84, 11) == 0            # observation width not a multiple of 8
+    assert bwd(512, 120, 5, 11) == 1 and bwd(1024, 120, 10, 18) == 1 and bwd(512, 150, 8, 14) == 1
+    assert bwd(512, 120, 5, 11, 0) == 0             # a dense dq: the fp32 kernels
+    assert bwd(512, 2, 5, 11) == 0 and bwd(512, 120, 5, 40) == 0
+    # workspace: one slab per 16 rows up to 256 row tiles, per 32 rows beyond
+    slab = 4 * (2 * 192 * 64 + 11 * 64 + 2 * 192 + 11)
+    assert lib.marl_agent_bwd_x6_workspace(512, 5, 11) == (512 * 5 // 16) * slab
+    assert lib.marl_agent_bwd_x6_workspace(4096, 5, 11) == (4096 * 5 // 32) * slab
