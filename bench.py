@@ -244,8 +244,13 @@ def load_pmc(workload):
     """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/r04_pmc_<workload>.json, written by
     tools/summarize_profiles.py) - only when the file was taken with the library that is running now (marl_hip_version() carries
     a hash of the kernel sources): numbers of an older build silently go stale when a kernel changes."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % workload)
-    if not os.path.exists(path):
+    path = None
+    for rnd in ("r05", "r04"):
+        cand = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, workload))
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         return {}, "no PMC file for this workload"
     d = json.load(open(path))
     from marl_amd import _lib
@@ -283,7 +288,7 @@ def pmc_traffic(pmc, e):
     return hit[0] if len(hit) == 1 else None
 
 
-def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16, warmup=4, ktimed=4):
+def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=12, warmup=6, ktimed=4):
     """One learner-update leg of another BASELINE configuration at its per-GPU shard size (after the contract's timed
     region; record already in HBM): updates/s, transitions/s, the whole-update fraction of the fp32 MFMA peak (SURVEY 8d
     FLOP per transition) and the executed-FLOP roofline of the kernel the update spends the most time in."""
@@ -292,6 +297,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
     from marl_amd.algorithm.q_learner import QLearner
     from marl_amd.algorithm.qtran_learner import QTRANLearner
     from marl_amd.rollout import RolloutWorker
+    from marl_amd.common.replaybuffer import ReplayBuffer
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
     # every leg starts from a device heap without the previous legs' cached blocks and workspaces.  (The 512-env bf16x6 leg is
     # bound by the HOST's launch path - its kernels add up to 1.18 ms per update, a fresh process runs it at 805-837 updates/s, this
@@ -303,40 +309,53 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
     args = make_args(alg, shape, 0)
     args.mixer_dtype = mixer_dtype
     args.gemm_mode = gemm_mode
+    args.buffer_size, args.batch_size = 2 * envs, envs
     T = args.episode_limit
     torch.manual_seed(0)
+    np.random.seed(1)
     mac = SharedMAC(args)
     learner = QTRANLearner(mac, args) if alg.startswith("qtran") else QLearner(mac, args)
     env = SyntheticSMACEnv(envs, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, T, seed=1, fixed_length=True)
     worker = RolloutWorker(env, mac, args)
+    # the update trains on replay-ring samples, as in the contract's step (the rollout plays into the ring; a sample is an episode
+    # index into it): this is the form hipGraph replay - the default for shards of at most 1536 episodes - applies to
+    buf = ReplayBuffer(args)
+    worker.record_sink = buf
     timers = KernelTimers(ops, args, envs)
+
     try:
-        ep = worker.generate_episodes(envs)[0]
+        for _ in range(2):
+            buf.store_episode(worker.generate_episodes(envs)[0])
+        ep = None
+        train = lambda i: learner.train(buf.sample(envs), i)
         for i in range(warmup):
-            learner.train(ep, i)
+            train(i)
         torch.cuda.synchronize()
         # (a generation-2 garbage collection - the previous legs' objects - costs 35-60 ms: inside eight timed updates it
         # turned 172 updates/s into 105 on some runs)
         gc.collect()
         gc.disable()
         try:
-            # rate: `updates` updates with no per-kernel events (their ~20 event records per update cost a small shard 4-15 %), the
-            # faster of two such segments (the small shards are bound by the host's launch path and a segment now and then runs 10-15 %
-            # slow with unchanged kernel times: tools/leg_seq.py) ...
-            dt = None
-            for seg in range(2):
+            # rate: `updates` updates with no per-kernel events (their ~20 event records per update cost a small shard 4-15 %), three
+            # such segments: the MEDIAN is the leg's rate and all three are on the line (the small shards are bound by the host's
+            # launch path and a segment now and then runs 10-15 % slow with unchanged kernel times: tools/leg_seq.py)
+            segs = []
+            for seg in range(3):
                 t0 = time.perf_counter()
                 for i in range(updates):
-                    learner.train(ep, warmup + seg * updates + i)
+                    train(warmup + seg * updates + i)
                 torch.cuda.synchronize()
-                d = (time.perf_counter() - t0) / updates
-                dt = d if dt is None else min(dt, d)
+                segs.append((time.perf_counter() - t0) / updates)
+            dt = sorted(segs)[1]
             # ... then the kernel table from a few updates with the HIP-event timers on
             timers.on = True
+            # (per-launch events need eager launches: the kernel table is taken with the graph replay off)
+            graphs, learner.graphs = getattr(learner, "graphs", None), None
             for i in range(ktimed):
-                learner.train(ep, warmup + 2 * updates + i)
+                train(warmup + 3 * updates + i)
             torch.cuda.synchronize()
             timers.on = False
+            learner.graphs = graphs
         finally:
             gc.enable()
         r0 = time.perf_counter()
@@ -352,8 +371,8 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
     pmc, pmc_src = load_pmc(workload)
     out = {"workload": workload, "what": label, "mixer_dtype": mixer_dtype, "gemm_mode": gemm_mode,
            "dtype": "f32 via bf16x6 split, fp32 accumulate (agent unrolls, BPTT, lambda-net heads; everything else f32)" if gemm_mode == "bf16x6" else "f32",
-           "learner_updates_per_sec": 1.0 / dt, "learner_transitions_per_sec": envs * T / dt,
-           "rollout_env_steps_per_sec": steps / t_roll,
+           "learner_updates_per_sec": 1.0 / dt, "segments_updates_per_sec": [1.0 / x for x in segs],
+           "learner_transitions_per_sec": envs * T / dt, "rollout_env_steps_per_sec": steps / t_roll,
            "roofline_update": {"bound": "mfma", "flop_per_transition": fpt, "achieved": upd_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                                "frac": upd_tf / PEAK_F32_TFLOPS},
            "kernels": [{k: e[k] for k in ("name", "launches_timed", "ms", "executed_flop", "frac")} for e in kern[:5]]}
@@ -384,7 +403,8 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=16
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": m["ms"],
                                  "bytes_per_launch": m["algorithmic_bytes"], "traffic": hit["hbm_bytes_per_launch"] if hit else None,
                                  "traffic_unit": "HBM bytes per launch of the main kernel (PMC, %s)" % pmc_src}
-    del learner, worker, env, mac, ep
+    out["hip_graph"] = bool(graphs is not None and not graphs.disabled and graphs.replays > 0)
+    del learner, worker, env, mac, ep, buf
     torch.cuda.empty_cache()
     return out
 
@@ -476,24 +496,298 @@ def cpu_baseline(alg, shape, T, envs, budget_s, threads=0):
             "batched_rollout_env_steps_per_sec": steps / t_roll, "serial_rollout_env_steps_per_sec": ssteps / t_serial}
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT touching the HIP runtime (the parent of a self-launch must stay clean: a process
+    that has initialised HIP is never replaced or forked into ranks).  From the *_VISIBLE_DEVICES lists when set, else from
+    the KFD topology (nodes with a non-zero simd_count are GPUs); None when neither says."""
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(k)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(top):
+            for line in open(os.path.join(top, d, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: run this file under torch.distributed.run as a child process
-    (N ranks on 127.0.0.1, a free port), stdout / stderr inherited, and return the child's exit code."""
-    import socket
+    (N ranks, rendezvous on 127.0.0.1 at a port torchrun picks itself: --standalone), stdout / stderr inherited, and return
+    the child's exit code."""
     import subprocess
-    have = torch.cuda.device_count()         # (counting devices does not initialise HIP in this process)
-    if have < n and os.environ.get("MARL_BENCH_ONE_DEVICE") != "1":
+    have = visible_gpus()
+    if have is not None and have < n and os.environ.get("MARL_BENCH_ONE_DEVICE") != "1":
         print("[bench] --gpus %d asked for, %d visible on this node" % (n, have), file=sys.stderr)
         return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n)]
     port = os.environ.get("MASTER_PORT")
-    if not port:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = str(s.getsockname()[1])
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    if port:
+        cmd += ["--master-addr", "127.0.0.1", "--master-port", port]
+    else:
+        cmd += ["--standalone", "--local-addr", "127.0.0.1"]     # c10d rendezvous on a free port chosen by torchrun: no bind-then-close race
+    cmd += [os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=dict(os.environ)).returncode
+
+
+DTYPE_X6 = "f32 (bf16x6 split products, fp32 accumulate)"
+LINE_LIMIT = 8000          # the driver keeps an 8 KB tail of stdout: the ONE final line must fit in it with room to spare
+
+
+def _r(x, sig=6):
+    """floats of the printed line rounded to `sig` significant digits (the full-precision line goes to bench_full.json)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """The ONE stdout line the driver parses, from the full result `out` (which goes to bench_full.json and stderr):
+    the contract's headline fields, `config`, `roofline` of the dominant kernel with at most six kernel rows,
+    `roofline_update`, `f32_mfma_twin`, `cpu_baseline`, and one short object per `configs[]` leg.  Always <= `limit` bytes:
+    optional parts are dropped (least important first) until it fits."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(out.get("config"), ("workload", "alg", "shape", "n_agents", "obs_dim", "state_dim", "n_actions", "episode_limit",
+                                               "global_envs", "envs_per_gpu", "gemm_mode", "mixer_dtype", "hip_graph", "parallelism"))
+    line.update(_pick(out, ("learner_updates_per_sec", "learner_transitions_per_sec", "rollout_env_steps_per_sec", "last_loss")))
+    roof = out.get("roofline") or {}
+    r = _pick(roof, ("bound", "kernel", "rocprof_name", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "avg_launch_ms",
+                     "launches_timed", "flop_per_launch", "bytes_per_launch"))
+    if isinstance(r.get("kernel"), str):
+        r["kernel"] = r["kernel"][:96]
+    r["kernels"] = [dict(_pick(e, ("rocprof_name", "launches_timed", "ms", "frac", "hbm_gb")), name=e["name"][:64]) for e in (roof.get("kernels") or [])[:6]]
+    if "algorithmic_rate" in roof:
+        r["algorithmic_tflops_unrolls"] = roof["algorithmic_rate"]["tflops"]
+    line["roofline"] = r
+    line["roofline_update"] = _pick(out.get("roofline_update"), ("bound", "flop_per_transition", "achieved", "peak", "unit", "frac"))
+    if out.get("f32_mfma_twin"):
+        tw = out["f32_mfma_twin"]
+        line["f32_mfma_twin"] = dict(_pick(tw, ("value", "ms_per_step", "dtype", "learner_updates_per_sec")),
+                                     roofline=_pick(tw.get("roofline"), ("rocprof_name", "frac", "avg_launch_ms", "peak")))
+    if out.get("blocking_readbacks"):
+        line["blocking_readbacks_ms_per_step"] = out["blocking_readbacks"]["ms_per_step"]
+    line["rccl"] = _pick(out.get("rccl"), ("backend", "world_seen"))
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "host_cpu_count", "cpu_model",
+                                                            "learner_updates_per_sec", "batched_rollout_env_steps_per_sec",
+                                                            "serial_rollout_env_steps_per_sec"))
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"].get("sample", "")[:200]
+    legs = []
+    for c in out.get("configs") or []:
+        ro = c.get("roofline") or {}
+        leg = {"workload": c["workload"], "gemm_mode": c["gemm_mode"], "updates_per_sec": c["learner_updates_per_sec"],
+               "segments": c.get("segments_updates_per_sec"), "roofline_update_frac": c["roofline_update"]["frac"],
+               "roofline": {"kernel": ro.get("rocprof_name"), "frac": ro.get("frac"), "traffic": ro.get("traffic")}}
+        if "roofline_mixer" in c:
+            leg["roofline_mixer"] = _pick(c["roofline_mixer"], ("rocprof_name", "frac", "traffic", "avg_launch_ms"))
+        legs.append(leg)
+    if legs:
+        line["configs"] = legs
+    line["full"] = out.get("full", "bench_full.json")
+    line = _r(line)
+    # fit: drop optional detail, least important first
+    drops = [lambda l: [c.pop("segments", None) for c in l.get("configs", [])],
+             lambda l: l["roofline"].__setitem__("kernels", l["roofline"]["kernels"][:3]),
+             lambda l: [c.pop("roofline_mixer", None) for c in l.get("configs", [])],
+             lambda l: l.pop("configs", None),
+             lambda l: l["roofline"].pop("kernels", None),
+             lambda l: l.get("cpu_baseline", {}).pop("sample", None)]
+    txt = json.dumps(line, separators=(",", ":"))
+    for d in drops:
+        if len(txt) <= limit:
+            break
+        d(line)
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) <= limit, len(txt)
+    return txt
+
+
+def emit(out):
+    """full result -> bench_full.json beside this script (and gpurun_out/ when it exists) and stderr; the compact line -> stdout, LAST"""
+    out["full"] = "bench_full.json"
+    full = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    print("[bench full] " + full, file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
+
+
+class Pipeline:
+    """The contract's step for one arithmetic mode: batched rollout of the rank's envs (T lock-steps, played straight into the
+    replay ring) -> store -> sample -> one learner.train()."""
+
+    def __init__(self, o, gemm_mode, rank, world, E):
+        from marl_amd.controller.share_params import SharedMAC
+        from marl_amd.algorithm.q_learner import QLearner
+        from marl_amd.algorithm.qtran_learner import QTRANLearner
+        from marl_amd.rollout import RolloutWorker
+        from marl_amd.common.replaybuffer import ReplayBuffer
+        from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+        self.o, self.E, self.world = o, E, world
+        args = self.args = make_args(o.alg, o.shape, o.T)
+        args.mixer_dtype = o.mixer_dtype
+        args.gemm_mode = gemm_mode
+        args.hip_graph = {"on": True, "off": False, "auto": None}[o.hip_graph]
+        args.lazy_loss = not o.blocking_loss
+        args.buffer_size = 2 * E
+        args.batch_size = E
+        torch.manual_seed(0)                     # identical random-init weights on every rank
+        self.mac = SharedMAC(args)
+        self.learner = QTRANLearner(self.mac, args) if o.alg.startswith("qtran") else QLearner(self.mac, args)
+        env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, args.episode_limit, seed=1,
+                               env0=rank * E, fixed_length=True)
+        self.worker = RolloutWorker(env, self.mac, args)
+        self.buf = ReplayBuffer(args)
+        self.worker.record_sink = self.buf          # training rollouts are played straight into the replay ring
+        np.random.seed(1 + rank)
+        self.train_steps = 0
+        self.lazy_stats = []
+
+    def one_step(self):
+        o, E = self.o, self.E
+        if o.blocking_loss:
+            episodes, _, _, steps = self.worker.generate_episodes(E)
+        else:
+            # same rollout, same device-side statistics; their copy to the host is enqueued instead of awaited (the env
+            # steps are summed from the handles after the timed region's final barrier)
+            episodes, st = self.worker.finish_episodes(self.worker.launch_episodes(), lazy=True)
+            self.lazy_stats.append(st)
+            steps = 0
+        self.buf.store_episode(episodes)
+        batch = self.buf.sample(min(self.buf.current_size, self.args.batch_size))
+        loss = self.learner.train(batch, self.train_steps)
+        self.train_steps += 1
+        return steps, loss
+
+    def barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed_region(self, timers, dev):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over ranks of the
+        time and the SUM of the env steps.  Returns (seconds, env steps, last loss)."""
+        o = self.o
+        for _ in range(o.warmup):
+            self.one_step()
+        # a full (generation-2) Python garbage collection costs ~35 ms here - three pipeline steps; collect now and
+        # keep the collector off inside the timed regions (what timeit does)
+        gc.collect()
+        gc.disable()
+        try:
+            self.barrier()
+            # HIP-event timing of the kernels on every THIRD step of the timed region: the ~16 event records of a step cost it 0.1 ms (1 %;
+            # measured with MARL_BENCH_TIMER_STRIDE=1 / 0 on one box: 9.74 / 9.63 ms per step) - the value must not pay for its own roofline
+            stride = int(os.environ.get("MARL_BENCH_TIMER_STRIDE", "3" if o.steps >= 6 else "1"))
+            # small shards replay the learner's schedule as ONE hipGraph (no per-launch events inside it): their kernel table is
+            # taken from two eager steps AFTER the timed region (kernel_table_steps below)
+            graphs = getattr(self.learner, "graphs", None)
+            self.graphed = bool(graphs is not None and not graphs.disabled and graphs.replays > 0)
+            if self.graphed:
+                stride = 0
+            first = len(self.lazy_stats)
+            t0 = time.perf_counter()
+            env_steps = 0
+            loss = None
+            for si in range(o.steps):
+                timers.on = stride > 0 and si % stride == 0
+                s, loss = self.one_step()
+                env_steps += s
+            self.barrier()
+            dt = time.perf_counter() - t0
+            timers.on = False
+        finally:
+            gc.enable()
+        env_steps += sum(st.steps() for st in self.lazy_stats[first:first + o.steps])
+        if self.graphed:
+            self.learner.graphs, keep = None, self.learner.graphs
+            timers.on = True
+            for _ in range(2):
+                self.one_step()
+            self.barrier()
+            timers.on = False
+            self.learner.graphs = keep
+        if self.world > 1:
+            tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=dev)
+            tmax = tt.clone()
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            tsum = tt.clone()
+            torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+            dt, env_steps = float(tmax[0]), float(tsum[1])
+        return dt, env_steps, loss
+
+    def close(self):
+        self.learner = self.worker = self.buf = self.mac = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def roofline_object(kern, pmc, pmc_path, steps):
+    """the roofline object of a timed region from its kernel table (KernelTimers.table): the kernel the region spent the most
+    time in; `achieved` = FLOP that kernel EXECUTES per launch / its mean launch duration (HIP events inside the timed
+    region).  Work that is avoided (the double-Q unroll reading the eval unroll's input-side sums) is a throughput gain and is
+    NOT credited here: it shows up in `algorithmic_rate` (SURVEY 8d FLOP / time) and in the end-to-end `roofline_update`."""
+    for e in kern:
+        hit = pmc_traffic(pmc, e)
+        if hit:
+            e["hbm_gb"] = hit["hbm_bytes_per_launch"] / 1e9
+            e["hbm_frac"] = hit["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+            if "SQ_INSTS_MFMA" in hit and "x6" not in e["rocprof_name"]:
+                e["mfma_flop_pmc"] = hit["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
+    roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+    if not kern:
+        return roof
+    d = kern[0]
+    roof.update(kernel=d["name"], rocprof_name=d["rocprof_name"], achieved=d["tflops"], frac=d["frac"],
+                avg_launch_ms=d["ms"], launches_timed=d["launches_timed"], flop_per_launch=d["executed_flop"],
+                traffic=(d["hbm_gb"] * 1e9 if d["hbm_gb"] else None), hbm_frac=d["hbm_frac"],
+                traffic_unit="HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)" % pmc_path,
+                what="executed FLOP (tile padding excluded) of the kernel with the largest total time in the timed region")
+    for e in kern:      # a split kernel is priced against ITS peak: six bf16 products per fp32 product
+        if "x6" in e["rocprof_name"]:
+            e["frac"] = e["tflops"] / (PEAK_BF16_TFLOPS / 6.0)
+            e["peak"] = PEAK_BF16_TFLOPS / 6.0
+    roof["kernels"] = [{k: e.get(k) for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "peak", "hbm_gb", "hbm_frac")}
+                       for e in kern[:6]]
+    if "x6" in d["rocprof_name"]:
+        roof.update(peak=PEAK_BF16_TFLOPS / 6.0, frac=d["tflops"] / (PEAK_BF16_TFLOPS / 6.0),
+                    peak_note="dense bf16 MFMA peak / 6: a bf16x6 split spends six bf16 products per fp32 product")
+    un = [e for e in kern if e["rocprof_name"] in ("agent_fwd", "agent_fwd_x6")]
+    if un:
+        t_un = sum(e["total_ms"] for e in un)
+        roof["algorithmic_rate"] = {
+            "what": "the learner's unroll launches (three per update): SURVEY 8d FLOP (B N T F_a per launch, whether computed or "
+                    "reused) / their mean duration - a throughput figure, not a pipe utilisation",
+            "tflops": sum(e["algorithmic_flop"] * e["launches_timed"] for e in un) / (t_un * 1e-3) / 1e12,
+            "executed_tflops": sum(e["executed_flop"] * e["launches_timed"] for e in un) / (t_un * 1e-3) / 1e12,
+            "avg_launch_ms": t_un / sum(e["launches_timed"] for e in un)}
+    tot_exec = sum(e["executed_flop"] * e["launches_timed"] for e in kern)
+    tot_ms = sum(e["total_ms"] for e in kern)
+    roof["all_timed_kernels"] = {"executed_tflops": tot_exec / (tot_ms * 1e-3) / 1e12, "ms_per_step": tot_ms / max(steps, 1)}
+    return roof
 
 
 def main():
@@ -506,12 +800,16 @@ def main():
     ap.add_argument("--shape", default="2s3z")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--mixer-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: mixer GEMMs on the bf16 matrix cores (config 5)")
-    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x6"], help="bf16x6: opt-in split arithmetic (fp32 products as six "
-                    "bf16 MFMA products, fp32 accumulate) for the agent unrolls / lambda-net heads of THIS run; the default line stays f32")
+    ap.add_argument("--gemm-mode", default="bf16x6", choices=["f32", "bf16x6"],
+                    help="arithmetic of the dense products.  bf16x6 (default, VERDICT r04 ruling): every fp32 operand split EXACTLY into "
+                         "three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate - fp32-accurate (same 1e-4 parity "
+                         "bounds).  f32: v_mfma_f32_16x16x4_f32 everywhere; the default run times that twin too (`f32_mfma_twin`)")
+    ap.add_argument("--no-twin", action="store_true", help="skip the f32 twin of the timed region (same steps, gemm_mode f32, same process)")
     ap.add_argument("--blocking-loss", "--blocking-readbacks", dest="blocking_loss", action="store_true",
                     help="read every update's loss and every rollout's statistics back at once (default: the copies are enqueued "
                          "and read at the end of the timed region - same device work, no host stall between steps)")
-    ap.add_argument("--hip-graph", action="store_true", help="replay the learner's forward/backward schedule as one hipGraph (opt-in)")
+    ap.add_argument("--hip-graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
+                    help="replay the learner's forward/backward schedule as one hipGraph: auto = below ~1500 envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the learner legs of the other BASELINE configurations (configs[1..4] at "
                     "their per-GPU shard sizes) that the default single-GPU run appends to the line as `configs`")
@@ -520,7 +818,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0: sweep 16 / 64 / all host CPUs, keep the fastest)")
     ap.add_argument("--leg-iters", type=int, default=5, help="iterations of the separately timed learner / rollout legs")
     ap.add_argument("--roofline-kernel", default="unroll", choices=["unroll", "mixer"],
-                    help="kernel the roofline object describes: the agent unroll (fp32 MFMA bound; headline) or the fused "
+                    help="kernel the roofline object describes: the dominant kernel of the timed region (MFMA bound; headline) or the fused "
                          "wide-state QMIX forward (config 5: HBM bound on reading the states when --mixer-dtype bf16)")
     ap.add_argument("--dry", action="store_true", help="multi-GPU pre-flight only: init RCCL, one all-reduce of the real "
                     "gradient-buffer size, print the result and exit")
@@ -530,9 +828,10 @@ def main():
         return
 
     if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: nothing in this process has touched the GPU yet (importing torch does not), so
-        # start the N ranks as a FRESH child - torch.distributed.run, one process per GPU - let it print rank 0's JSON line on
-        # our stdout and leave with its return code (a process that has initialised HIP must never be replaced by exec)
+        # plain `python bench.py --gpus N`: nothing in this process has touched the GPU yet (importing torch does not, and the
+        # GPUs are counted from the environment / the KFD topology), so start the N ranks as a FRESH child - torch.distributed.run,
+        # one process per GPU - let it print rank 0's JSON line on our stdout and leave with its return code (a process that has
+        # initialised HIP must never be replaced by exec)
         sys.exit(self_launch(o.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -580,108 +879,34 @@ def main():
             return
 
     from marl_amd import ops
-    from marl_amd.controller.share_params import SharedMAC
-    from marl_amd.algorithm.q_learner import QLearner
-    from marl_amd.algorithm.qtran_learner import QTRANLearner
-    from marl_amd.rollout import RolloutWorker
-    from marl_amd.common.replaybuffer import ReplayBuffer
-    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
-
-    args = make_args(o.alg, o.shape, o.T)
-    args.mixer_dtype = o.mixer_dtype
-    args.gemm_mode = o.gemm_mode
-    args.hip_graph = o.hip_graph
-    args.lazy_loss = not o.blocking_loss
-    T, N = args.episode_limit, args.n_agents
     E = o.envs // world                      # envs / episodes per rank
-    args.buffer_size = 2 * E
-    args.batch_size = E
-    torch.manual_seed(0)                     # identical random-init weights on every rank
-    mac = SharedMAC(args)
-    learner = QTRANLearner(mac, args) if o.alg.startswith("qtran") else QLearner(mac, args)
-    env = SyntheticSMACEnv(E, N, args.obs_shape, args.state_shape, args.n_actions, T, seed=1, env0=rank * E,
-                           fixed_length=True)
-    worker = RolloutWorker(env, mac, args)
-    buf = ReplayBuffer(args)
-    worker.record_sink = buf          # training rollouts are played straight into the replay ring
-    np.random.seed(1 + rank)
+    pipe = Pipeline(o, o.gemm_mode, rank, world, E)
+    args, learner, worker, buf = pipe.args, pipe.learner, pipe.worker, pipe.buf
+    T, N = args.episode_limit, args.n_agents
+    barrier = pipe.barrier
 
     # HIP-event timing of every heavy C-ABI call inside the timed region (on the stream it is launched on)
     timers = KernelTimers(ops, args, E)
-    timing = timers
+    dt, env_steps, loss = pipe.timed_region(timers, dev)
 
-    train_steps = [0]
-
-    lazy_stats = []
-
-    def one_step():
-        if o.blocking_loss:
-            episodes, _, _, steps = worker.generate_episodes(E)
-        else:
-            # same rollout, same device-side statistics; their copy to the host is enqueued instead of awaited (the env
-            # steps are summed from the handles after the timed region's final barrier)
-            episodes, st = worker.finish_episodes(worker.launch_episodes(), lazy=True)
-            lazy_stats.append(st)
-            steps = 0
-        buf.store_episode(episodes)
-        batch = buf.sample(min(buf.current_size, args.batch_size))
-        loss = learner.train(batch, train_steps[0])
-        train_steps[0] += 1
-        return steps, loss
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(o.warmup):
-        one_step()
-    # a full (generation-2) Python garbage collection costs ~35 ms here - three pipeline steps; collect now and
-    # keep the collector off inside the timed regions (what timeit does)
+    # separately timed legs (after the contract's timed region): learner-only and rollout-only, three passes each, the MEDIAN
+    # counts and all three are in the full result
     gc.collect()
     gc.disable()
-    barrier()
-    # HIP-event timing of the kernels on every THIRD step of the timed region: the ~16 event records of a step cost it 0.1 ms (1 %;
-    # measured with MARL_BENCH_TIMER_STRIDE=1 / 0 on one box: 9.74 / 9.63 ms per step) - the value must not pay for its own roofline
-    stride = int(os.environ.get("MARL_BENCH_TIMER_STRIDE", "3" if o.steps >= 6 else "1"))
-    t0 = time.perf_counter()
-    env_steps = 0
-    for si in range(o.steps):
-        timers.on = stride > 0 and si % stride == 0
-        ts = time.perf_counter()
-        s, loss = one_step()
-        env_steps += s
-        if os.environ.get("MARL_BENCH_DEBUG"):
-            torch.cuda.synchronize()
-            ms = torch.cuda.memory_stats()
-            print("step %.2f ms gc=%s segs=%d reserved=%.2fGB allocs=%d" % ((time.perf_counter() - ts) * 1e3, gc.get_count(),
-                  ms["segment.all.current"], ms["reserved_bytes.all.current"] / 2**30, ms["allocation.all.allocated"]), file=sys.stderr)
-    barrier()
-    dt = time.perf_counter() - t0
-    timers.on = False
-    env_steps += sum(st.steps() for st in lazy_stats[o.warmup:o.warmup + o.steps])
-    tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tt.clone()
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        tsum = tt.clone()
-        torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
-        dt, env_steps = float(tmax[0]), float(tsum[1])
-    # separately timed legs (after the contract's timed region): learner-only and rollout-only
-    # (each leg twice, the faster pass counts: one host hiccup in five iterations halved a leg's rate on a small shard)
     batch = buf.sample(E)
-    t_learn = t_roll = float("inf")
-    for rep in range(2):
+    learn_p, roll_p = [], []
+    for rep in range(3):
         barrier(); t1 = time.perf_counter()
         for i in range(o.leg_iters):
             learner.train(batch, 10 ** 6 + rep * o.leg_iters + i)
-        barrier(); t_learn = min(t_learn, (time.perf_counter() - t1) / o.leg_iters)
-    for rep in range(2):
+        barrier(); learn_p.append((time.perf_counter() - t1) / o.leg_iters)
+    for rep in range(3):
         barrier(); t1 = time.perf_counter()
         rs = 0
         for i in range(o.leg_iters):
             rs += worker.generate_episodes(E)[3]
-        barrier(); t_roll = min(t_roll, (time.perf_counter() - t1) / o.leg_iters)
+        barrier(); roll_p.append((time.perf_counter() - t1) / o.leg_iters)
+    t_learn, t_roll = sorted(learn_p)[1], sorted(roll_p)[1]
     # the same pipeline step with the REFERENCE's host semantics: every rollout's statistics and every update's loss are read
     # back at once (runner.py:85-98 uses both immediately); same device work, the host waits for it twice per step
     t_block = None
@@ -693,12 +918,46 @@ def main():
         for i in range(o.leg_iters):
             episodes, _, _, st_ = worker.generate_episodes(E)
             buf.store_episode(episodes)
-            loss_b = float(learner.train(buf.sample(min(buf.current_size, args.batch_size)), train_steps[0]))
-            train_steps[0] += 1
+            float(learner.train(buf.sample(min(buf.current_size, args.batch_size)), pipe.train_steps))
+            pipe.train_steps += 1
             blk_steps += st_
         barrier(); t_block = (time.perf_counter() - t1) / o.leg_iters
         blk_rate = blk_steps / (t_block * o.leg_iters)
     gc.enable()
+    graph_on = pipe.graphed
+    kern = timers.table()
+    timers.close()
+    del learner, worker, buf, batch
+    pipe.close()
+
+    # the f32 twin: the SAME timed region (same steps, warm-up, envs, seeds) with every product on v_mfma_f32_16x16x4_f32, in this
+    # process, so that the fp32-MFMA number stays on the line beside the split-mode headline
+    twin = None
+    if o.gemm_mode == "bf16x6" and not o.no_twin:
+        tp = Pipeline(o, "f32", rank, world, E)
+        ttimers = KernelTimers(ops, tp.args, E)
+        tdt, tsteps, tloss = tp.timed_region(ttimers, dev)
+        tkern = ttimers.table()
+        ttimers.close()
+        gc.collect(); gc.disable()
+        tb = tp.buf.sample(E)
+        tl = []
+        for rep in range(3):
+            tp.barrier(); t1 = time.perf_counter()
+            for i in range(o.leg_iters):
+                tp.learner.train(tb, 10 ** 6 + rep * o.leg_iters + i)
+            tp.barrier(); tl.append((time.perf_counter() - t1) / o.leg_iters)
+        gc.enable()
+        del tb
+        tp.close()
+        if rank == 0:
+            wl = "%s_%s_T%d_envs%d%s" % (o.alg, o.shape, T, E, "_bf16mixer" if o.mixer_dtype == "bf16" else "")
+            tpmc, tpath = load_pmc(wl) if world == 1 else ({}, "multi-GPU run: per-GPU shard")
+            twin = {"what": "the same timed region with gemm_mode f32 (every product on v_mfma_f32_16x16x4_f32), same process",
+                    "value": tsteps / tdt, "unit": "env-steps/s", "ms_per_step": tdt / o.steps * 1e3, "dtype": "f32",
+                    "last_loss": float(tloss), "learner_updates_per_sec": 1.0 / sorted(tl)[1],
+                    "learner_passes_updates_per_sec": [1.0 / x for x in tl],
+                    "roofline": roofline_object(tkern, tpmc, tpath, o.steps)}
 
     if rank == 0:
         fpt = learner_flops_per_transition(args, o.alg)
@@ -707,45 +966,8 @@ def main():
         workload = "%s_%s_T%d_envs%d%s%s" % (o.alg, o.shape, T, o.envs // world, "_bf16mixer" if o.mixer_dtype == "bf16" else "",
                                              "_bf16x6" if o.gemm_mode == "bf16x6" else "")
         pmc, pmc_path = load_pmc(workload) if world == 1 else ({}, "multi-GPU run: per-GPU shard")
-        kern = timers.table()
-        # (with --hip-graph the learner's kernels are launched from inside the replayed graph: no per-launch events)
-        for e in kern:
-            hit = pmc_traffic(pmc, e)
-            if hit:
-                e["hbm_gb"] = hit["hbm_bytes_per_launch"] / 1e9
-                e["hbm_frac"] = hit["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
-                if "SQ_INSTS_MFMA" in hit:
-                    e["mfma_flop_pmc"] = hit["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
-        roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
-        if kern:
-            # the roofline object describes the kernel the timed region spent the most time in; `achieved` = FLOP that kernel
-            # EXECUTES per launch / its mean launch duration (HIP events inside the timed region).  Work that is avoided
-            # (the double-Q unroll reading the eval unroll's input-side sums) is a throughput gain and is NOT credited here:
-            # it shows up in `algorithmic_rate` (SURVEY 8d FLOP / time) and in the end-to-end `roofline_update`.
-            d = kern[0]
-            roof.update(kernel=d["name"], rocprof_name=d["rocprof_name"], achieved=d["tflops"], frac=d["frac"],
-                        avg_launch_ms=d["ms"], launches_timed=d["launches_timed"], flop_per_launch=d["executed_flop"],
-                        traffic=(d["hbm_gb"] * 1e9 if d["hbm_gb"] else None), hbm_frac=d["hbm_frac"],
-                        traffic_unit="HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)" % pmc_path,
-                        what="executed FLOP (tile padding excluded) of the kernel with the largest total time in the timed region")
-            roof["kernels"] = [{k: e[k] for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "hbm_gb", "hbm_frac")}
-                               for e in kern[:6]]
-            if "x6" in d["rocprof_name"]:      # opt-in run on the split kernels: six bf16 products per fp32 product
-                roof.update(peak=PEAK_BF16_TFLOPS / 6.0, frac=d["tflops"] / (PEAK_BF16_TFLOPS / 6.0),
-                            peak_note="dense bf16 MFMA peak / 6: a bf16x6 split spends six bf16 products per fp32 product")
-            un = [e for e in kern if e["rocprof_name"] in ("agent_fwd", "agent_fwd_x6")]
-            if un:
-                t_un = sum(e["total_ms"] for e in un)
-                roof["algorithmic_rate"] = {
-                    "what": "the learner's unroll launches (three per update): SURVEY 8d FLOP (B N T F_a per launch, whether computed or "
-                            "reused) / their mean duration - a throughput figure, not a pipe utilisation",
-                    "tflops": sum(e["algorithmic_flop"] * e["launches_timed"] for e in un) / (t_un * 1e-3) / 1e12,
-                    "executed_tflops": sum(e["executed_flop"] * e["launches_timed"] for e in un) / (t_un * 1e-3) / 1e12,
-                    "avg_launch_ms": t_un / sum(e["launches_timed"] for e in un)}
-            tot_exec = sum(e["executed_flop"] * e["launches_timed"] for e in kern)
-            tot_ms = sum(e["total_ms"] for e in kern)
-            roof["all_timed_kernels"] = {"executed_tflops": tot_exec / (tot_ms * 1e-3) / 1e12, "frac": tot_exec / (tot_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                                         "ms_per_step": tot_ms / o.steps}
+        # (with hipGraph replay the learner's kernels are launched from inside the replayed graph: no per-launch events)
+        roof = roofline_object(kern, pmc, pmc_path, o.steps)
         if o.roofline_kernel == "mixer":
             # fused wide-state QMIX forward: one launch reads every state row once (4 S bytes), the chosen Qs (4 N) and
             # writes q_tot (4): algorithmic bytes = rows * (4 S + 4 N + 4), rows = envs per GPU * T (with bf16
@@ -767,36 +989,38 @@ def main():
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": dt / o.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if o.gemm_mode == "f32" else "f32 via bf16x6 split, fp32 accumulate (agent unrolls and BPTT of the update; the rollout and everything else f32)",
+            "dtype": "f32" if o.gemm_mode == "f32" else DTYPE_X6,
             "data": "synthetic",
             "config": {"workload": "%s_%s_T%d_envs%d" % (o.alg, o.shape, T, o.envs), "alg": o.alg, "shape": o.shape,
                        "n_agents": N, "obs_dim": args.obs_shape, "state_dim": args.state_shape,
                        "n_actions": args.n_actions, "episode_limit": T, "global_envs": o.envs, "envs_per_gpu": E,
-                       "mixer_dtype": o.mixer_dtype, "hip_graph": bool(o.hip_graph),
+                       "gemm_mode": o.gemm_mode, "mixer_dtype": o.mixer_dtype, "hip_graph": graph_on,
+                       "kernel_table": "two eager steps after the timed region (its steps replay the learner's schedule as one hipGraph)" if graph_on
+                                       else "HIP events inside the timed region",
                        "parallelism": "dp%d" % world, "numa_node": numa,
                        "step": "batched rollout (T lock-steps) + replay store/sample + 1 learner.train()"},
-            "learner_updates_per_sec": 1.0 / t_learn,
+            "learner_updates_per_sec": 1.0 / t_learn, "learner_passes_updates_per_sec": [1.0 / x for x in learn_p],
             "learner_transitions_per_sec": o.envs * T / t_learn,
             "rollout_env_steps_per_sec": rs * world / o.leg_iters / t_roll,
+            "rollout_passes_env_steps_per_sec": [rs * world / o.leg_iters / x for x in roll_p],
             "last_loss": float(loss), "loss_readback": "blocking" if o.blocking_loss else "deferred",
             "blocking_readbacks": None if t_block is None else {
                 "what": "the same step with the reference's host semantics (loss and rollout statistics read back every step); "
                         "per-rank figure of rank 0, after the timed region", "ms_per_step": t_block * 1e3,
                 "env_steps_per_sec_per_gpu": blk_rate},
             "roofline": roof, "rccl": rccl,
-            "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included)",
+            "roofline_update": {"bound": "mfma", "what": "whole learner update (all kernels, host gaps included) against the fp32 MFMA peak: "
+                                "in bf16x6 mode a throughput figure in fp32-equivalent FLOP, it may exceed 1",
                                 "flop_per_transition": fpt, "achieved": upd_tflops, "peak": PEAK_F32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": upd_tflops / PEAK_F32_TFLOPS},
+            "f32_mfma_twin": twin,
         }
         if not o.no_configs and world == 1 and (o.alg, o.shape, o.envs) == ("qmix", "2s3z", 4096):
             # the other BASELINE configurations, each at its per-GPU shard size, on this one GPU (legs after the timed region)
-            timers.close()
-            del learner, worker, buf, batch, env, mac
-            torch.cuda.empty_cache()
             out["configs"] = [config_leg(*c) for c in OTHER_CONFIGS]
         if not o.no_cpu_baseline and world == 1:      # a reported baseline of the N=1 line only
             out["cpu_baseline"] = cpu_baseline(o.alg, o.shape, T, o.cpu_envs, budget_s=20, threads=o.cpu_threads)
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

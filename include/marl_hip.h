@@ -201,8 +201,11 @@ int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, 
  * streamed against 64-row state tiles in LDS; same arithmetic, same gradient destinations.  `s`: dense segment 0 whose
  * rows start on 16-byte boundaries and hold S rounded up to 4 readable floats (EpisodeRecord pads the state row stride).
  * flags & 1: bf16 operands for the hypernet GEMM (v_mfma_f32_16x16x32_bf16, fp32 accumulate; BASELINE config 5 "bf16
- * mixer with MFMA") - the forward kernel is then bound by reading the states from HBM; mixing arithmetic, gradients and
- * the weight-gradient GEMM stay fp32.  Workspace: packed weights (+ for backward: d(hypernet output) rows x (N*E+3E)
+ * mixer with MFMA") - the forward kernel is then bound by reading the states from HBM; mixing arithmetic and gradients stay
+ * fp32.  flags & 2 (backward entry points, only together with flags & 1): the weight-gradient GEMM dW += dhy^T s also takes
+ * bf16 operands (dhy - a gradient - and the states rounded to bf16 where a 32-row chunk is staged; fp32 accumulate; the bias
+ * gradient stays an exact fp32 column sum): the four hypernet weight gradients then carry ~2e-3 relative error; without the
+ * bit that GEMM is fp32 (v_mfma_f32_16x16x4_f32).  Workspace: packed weights (+ for backward: d(hypernet output) rows x (N*E+3E)
  * and the slabs).  Supported when marl_qmix_wide_supported(N, S, E) (E == 32, N <= 10, S <= 384).
  * CONTRACT on the row padding: the kernels read the columns S .. 4 ceil(S / 4) - 1 of every state row (the 16-byte loads of the
  * last chunk) and multiply them by packed weights that are exactly zero, so these pad columns must hold FINITE values (0 * NaN
@@ -440,6 +443,16 @@ int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rs
                        int A, int last_action, int reuse_network, void* stream);
 
 const char* marl_hip_version(void);
+
+/* Experiment switches (A/B measurements, variant tests): one table per process; NO entry point reads the environment.
+ * Names and defaults: "fwd_xs" 1 (the double-Q unroll reads the eval unroll's input-side gate sums - replaces the work
+ * q_learner.py:110 repeats), "fwd_dma" 0 (LDS-DMA observation tile of the saving unroll), "fwd_w2l" 1 (six prefetch registers for
+ * wide observations), "bwd_pipe_max_rt" 4 (row tiles per workgroup up to which the one-barrier BPTT runs), "wgrad_tall" 1 (LDS-staged
+ * tall weight-gradient kernel), "wide_res" 1 / "wide_res32" 0 (resident-weights forward of the wide-state QMIX mixer, mixer.py:57-80).
+ * Results do not depend on them beyond fp32 summation order.  set: 0, or -1 for an unknown name; get: the value, or INT_MIN.
+ * marl_amd/experiments.py forwards the MARL_* environment variables of the same names once, at import. */
+int marl_experiment_set(const char* name, int value);
+int marl_experiment_get(const char* name);
 
 #ifdef __cplusplus
 }

@@ -134,6 +134,8 @@ SIGNATURES = {
     "marl_synth_rollout_supported": (I, [I, I, I]),
     "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, D, D, D, I, I, I, I, I, I, I, I, P]),
     "marl_hip_version": (C.c_char_p, []),
+    "marl_experiment_set": (I, [C.c_char_p, I]),
+    "marl_experiment_get": (I, [C.c_char_p]),
 }
 
 _lib = None
@@ -158,6 +160,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    from . import experiments
+    experiments.apply(lib)          # the MARL_* environment, read ONCE at import of marl_amd.experiments, goes into the library's table
     return lib
 
 

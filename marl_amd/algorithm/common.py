@@ -2,12 +2,11 @@
 tail, the fused clip+optimizer wrapper, the agent backward pass and data-parallel reduction."""
 from __future__ import annotations
 
-import os
 import weakref
 
 import torch
 
-from .. import ops
+from .. import ops, experiments
 from ..hostutil import FlatParams
 
 MASK_BIG = -9999999.0        # reference algorithm/q_learner.py:105,112,126 ; qtran_learner.py:106
@@ -199,9 +198,6 @@ class Scratch:
         return t
 
 
-X6_BWD_MIN_WG = int(os.environ.get("MARL_X6_BWD_MIN_WG", "1"))      # 32-row groups from which the split BPTT kernel is used (A/B switch)
-
-
 def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=None, dq_idx2=None, dq_val2=None, dq_gdiv=1):
     """BPTT of the eval unroll: the fused kernel (delta pass + W_ih/W_hh/W_2 gradients), then the
     fc1 weight gradient as one reduction over the virtual input [obs | one-hot(u_{t-1}) | agent id]
@@ -221,7 +217,7 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=
     # per 32 rows beyond) - faster than the fp32 kernels at every size measured (profiles/r04_unroll_x6_times.txt)
     from ..network import mixer as _mixer
     x6 = (getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6" and dq is None and dq_idx is not None
-          and (B * N + 31) // 32 >= X6_BWD_MIN_WG and ops.agent_unroll_bwd_x6_supported(B, T, N, A))
+          and (B * N + 31) // 32 >= experiments.get("x6_bwd_min_wg") and ops.agent_unroll_bwd_x6_supported(B, T, N, A))
     ops.agent_unroll_bwd(w, dq, dhs, saved, hs, dxp, None, grads, B, T, N, A, dq_idx=dq_idx, dq_val=dq_val,
                          dq_idx2=dq_idx2, dq_val2=dq_val2, dq_gdiv=dq_gdiv, x6=x6)
     obs, obs_bs, obs_t0 = db.o_cur if which == "cur" else db.o_next
@@ -243,13 +239,12 @@ class GradReducer:
     the GLOBAL sum(mask) happens afterwards in the optimizer kernel)."""
 
     def __init__(self, group=None):
-        import os
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         up = dist.is_available() and dist.is_initialized()
-        # MARL_FORCE_REDUCER=1: take the collective path with a single rank too (RCCL smoke test on a 1-GPU box)
-        self.enabled = up and (dist.get_world_size(group) > 1 or os.environ.get("MARL_FORCE_REDUCER") == "1")
+        # experiments.force_reducer (MARL_FORCE_REDUCER=1): take the collective path with a single rank too (RCCL smoke test on a 1-GPU box)
+        self.enabled = up and (dist.get_world_size(group) > 1 or experiments.get("force_reducer") == 1)
 
     def allreduce_(self, flat_with_stats):
         if self.enabled:
@@ -284,25 +279,13 @@ class PairedUnroll:
 
     MAX_TILES = 1024          # 128 workgroups x 8 row tiles of 16 rows (the LDS cap of the unroll kernel)
 
-    def __init__(self):
-        import os
+    def __init__(self, x6=False):
         self.side = None
-        self.enabled = os.environ.get("MARL_NO_PAIR") != "1"      # experiments: MARL_NO_PAIR=1 launches them back to back
-        self.chain = os.environ.get("MARL_NO_CHAIN") != "1"       # experiments: MARL_NO_CHAIN=1 keeps the plain pair + continuation
-        # experiments only: MARL_CHAIN_SPLIT=<CUs of the chain side>, read ONCE here; a multiple of 8 in [8, 248] (both launches
-        # need at least one XCD's worth of CUs, the library takes 1..256), 0 = never chain, anything else is ignored
-        self.forced_split = None
-        forced = os.environ.get("MARL_CHAIN_SPLIT")
-        if forced is not None:
-            try:
-                v = int(forced)
-            except ValueError:
-                v = -1
-            if v == 0 or 8 <= v <= 248:
-                self.forced_split = v
-            else:
-                import warnings
-                warnings.warn("MARL_CHAIN_SPLIT=%r ignored (want 0 or 8..248)" % forced)
+        self.x6 = bool(x6)                                          # the unrolls run on agent_fwd_x6_kernel (one or two row tiles per workgroup)
+        self.enabled = experiments.get("no_pair") != 1              # experiments: MARL_NO_PAIR=1 launches them back to back
+        self.chain = experiments.get("no_chain") != 1               # experiments: MARL_NO_CHAIN=1 keeps the plain pair + continuation
+        # experiments only: MARL_CHAIN_SPLIT=<CUs of the chain side> (marl_amd/experiments.py validates it), 0 = never chain
+        self.forced_split = experiments.get("chain_split")
 
     def applies(self, rows, T):
         return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES
@@ -327,8 +310,11 @@ class PairedUnroll:
 
     # measured step time of the unroll kernel by row tiles per workgroup (us per step, 2s3z-sized agent): one tile runs the
     # software-pipelined kernel; beyond that ~1.3 + 2.1 per tile (5.5 at 2, 7.6 at 3, 11.7 at 5)
-    @staticmethod
-    def _step_us(rt):
+    def _step_us(self, rt):
+        if self.x6:
+            # agent_fwd_x6_kernel (profiles/r04_unroll_x6_times.txt: 0.18 / 0.33 / 1.04 ms per 120 steps at 1 / 2 / 5 row tiles per CU;
+            # it holds one or two tiles per workgroup and runs more in rounds of workgroups)
+            return 1.5 if rt <= 1 else 2.75 if rt <= 2 else 1.74 * rt
         return 3.3 if rt <= 1 else 1.3 + 2.1 * rt
 
     def chain_split(self, rows, T, obs_dim):
@@ -339,7 +325,8 @@ class PairedUnroll:
         if self.forced_split is not None:                           # experiments: CUs of the chain side (the model's choice otherwise)
             return (self.forced_split, 256 - self.forced_split) if self.forced_split > 0 else None
         tiles = (rows + 15) // 16
-        cap = max(1, min(8, 2048 // (4 * max(obs_dim, 4))))          # row tiles per workgroup the unroll kernel can hold
+        # row tiles per workgroup the fp32 unroll kernel can hold (the split kernel runs further tiles in rounds of workgroups)
+        cap = 8 if self.x6 else max(1, min(8, 2048 // (4 * max(obs_dim, 4))))
         ceil = lambda a, b: -(-a // b)
         # (the continuation reads the input-side work the first unroll stored: ~0.6 of a full unroll's step time)
         plain = self._step_us(ceil(tiles, 128)) + 0.6 * self._step_us(ceil(tiles, 256))
@@ -373,27 +360,43 @@ class PairedUnroll:
 
 
 class GraphedUpdate:
-    """hipGraph replay of a learner's forward/backward schedule for replay-ring samples of a fixed shape (opt-in:
-    ``args.hip_graph = True``).  The ~25 kernel launches of ``_forward_backward`` become ONE graph launch; what varies
-    between updates (the sampled episode indices and the small per-step arrays gathered from the ring) lives in
-    persistent buffers the captured kernels point at.  Pays on small per-GPU shards, where an update is a few
-    milliseconds and the host-side launch path is exposed behind the one sync an update needs; the gradient
-    all-reduce and the optimizer stay outside the graph.  Falls back to eager launches whenever the shape differs,
-    max_episode_len is shorter than the record, or capture is not possible."""
+    """hipGraph replay of a learner's forward/backward schedule for replay-ring samples of a fixed shape.  The ~25 kernel
+    launches of ``_forward_backward`` become ONE graph launch; what varies between updates (the sampled episode indices and
+    the small per-step arrays gathered from the ring) lives in persistent buffers the captured kernels point at.  Pays on
+    small per-GPU shards - the shape of every rank of a multi-GPU run - where an update is a millisecond or two and the
+    host-side launch path is what bounds it; the gradient all-reduce and the optimizer stay outside the graph.
+    ``args.hip_graph``: True = always, False = never, absent / None / "auto" = for batches of at most AUTO_MAX_EPISODES
+    episodes.  Falls back to eager launches whenever the shape differs, max_episode_len is shorter than the record, or
+    capture is not possible.  Once the last updates all ran at the record's full length the graph is replayed BEFORE
+    max_episode_len is read back (the read-back waits only for the kernel that computes it); a shorter length redoes the
+    pass eagerly (forward / backward overwrite their outputs and zero the gradient buffer themselves)."""
 
     WARMUP = 2          # eager updates on the static buffers before capture (allocations, workspace growth)
+    AUTO_MAX_EPISODES = 1536
 
-    def __init__(self):
+    def __init__(self, auto=False):
         self.entries = {}
         self.disabled = False
+        self.auto = bool(auto)
+        self.replays = 0
+
+    @staticmethod
+    def from_args(args):
+        """the learner's GraphedUpdate (or None) for args.hip_graph"""
+        mode = getattr(args, "hip_graph", None)
+        if mode is None or mode == "auto":
+            return GraphedUpdate(auto=True)
+        return GraphedUpdate() if mode else None
 
     def run(self, learner, ring, index):
         """Returns True when the update's forward/backward was done here (static buffers + graph), else False."""
-        from ..hostutil import DeviceBatch
+        from ..hostutil import DeviceBatch, AsyncInt
         self.prepared = None
         if self.disabled:
             return False
         args = learner.args
+        if self.auto and int(index.numel()) > self.AUTO_MAX_EPISODES:
+            return False
         # static buffers alias the ring's (E, T) arrays: only full-length records of the steady-state batch size
         if ring.T != args.episode_limit or int(index.numel()) != int(args.batch_size):
             return False
@@ -408,7 +411,7 @@ class GraphedUpdate:
             idx = index.to(device=dev, dtype=torch.long).clone()
             small = ring.select_small(idx)
             db = DeviceBatch.from_record(ring, args, T=min(ring.T, args.episode_limit), index=idx, small=small)
-            e = self.entries[key] = dict(ring=weakref.ref(ring), idx=idx, small=small, db=db, calls=0, graph=None,
+            e = self.entries[key] = dict(ring=weakref.ref(ring), idx=idx, small=small, db=db, calls=0, graph=None, streak=0,
                                          avail_next=db.avail_next.clone(), u_act=db.u_act.clone())
             db.avail_next, db.u_act = e["avail_next"], e["u_act"]
             e["T"] = db.T
@@ -416,14 +419,27 @@ class GraphedUpdate:
         idx.copy_(index)
         db.o_map.copy_(idx)
         ring.select_small(idx, out=small)
-        T = DeviceBatch.first_terminated_len(small.term, args.episode_limit, reducer=learner.reducer)
-        if T != e["T"]:
-            self.prepared = (small, T)       # the eager path reuses the gathered arrays and the agreed T
-            return False
         if e["graph"] is not None and e["ws_gen"] != ops.WS.gen:
             # a workspace the captured kernels point at was reallocated (another learner / a larger request):
             # the graph would write into retired storage - drop it and capture again after a warm-up
             e["graph"], e["ws_keep"], e["calls"] = None, None, 0
+        pending = None
+        term = small.term
+        if e["graph"] is not None and e["streak"] >= 2 and term.is_cuda and term.dtype == torch.float32 and term.shape[0] > 0:
+            # speculative: launch the length kernel, start its read-back on a side stream, replay for the full length meanwhile
+            out = ops.first_terminated_len(term, args.episode_limit)
+            r = learner.reducer
+            if r is not None and r.enabled:
+                r.dist.all_reduce(out, op=r.dist.ReduceOp.MAX, group=r.group)
+            pending = AsyncInt(out)
+            T = e["T"]
+        else:
+            T = DeviceBatch.first_terminated_len(term, args.episode_limit, reducer=learner.reducer)
+            if T != e["T"]:
+                e["streak"] = 0
+                self.prepared = (small, T)       # the eager path reuses the gathered arrays and the agreed T
+                return False
+            e["streak"] += 1
         torch.clamp(small.u[:, :T], min=0, out=e["u_act"])
         e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail_next[:, :T] if small.avail is None else small.avail[:, 1:T + 1])
         db.__dict__.pop("_avail", None)
@@ -446,6 +462,14 @@ class GraphedUpdate:
                 return True
         if e["graph"] is not None:
             e["graph"].replay()
+            self.replays += 1
         else:
             learner._forward_backward(db)
+        if pending is not None:
+            m = pending.wait()
+            Tr = m if m > 0 else e["T"]
+            if Tr != e["T"]:                     # every episode of the batch ended early: redo at its own length, eagerly
+                e["streak"] = 0
+                self.prepared = (small, Tr)
+                return False
         return True

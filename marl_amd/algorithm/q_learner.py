@@ -50,9 +50,10 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         self.optimizer = FusedOptimizer(self._flat, args.optimizer, self.lr, args.grad_norm_clip)
         self._buf = Scratch()
         self.reducer = GradReducer()
-        self.pair = PairedUnroll()
+        from ..network import mixer as _mixer
+        self.pair = PairedUnroll(x6=getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6")
         self.loss_readback = LossReadback(args)
-        self.graphs = GraphedUpdate() if getattr(args, "hip_graph", False) else None
+        self.graphs = GraphedUpdate.from_args(args)
         self.last_stats = None
         self.sync_replicas()
 
@@ -117,7 +118,8 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         if a.double_q:
             shifted = on is oc and on_bs == oc_bs and on_t0 == oc_t0 + 1
             split = self.pair.chain_split(B * N, T, a.obs_shape)
-            if shifted and (self.eval_net.unroll_x6(B, T) or
+            from .. import experiments
+            if shifted and ((self.eval_net.unroll_x6(B, T) and experiments.get("fwd_xs") != 0) or
                             ops.agent_unroll_reuse_supported(B, T, N, a.obs_shape, A, split[0] if split else 256)):
                 gi = g("gi", ops.saved_shape(T, B, N, planes=3))
             cont = lambda cu: self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last,

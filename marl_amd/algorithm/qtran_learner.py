@@ -19,7 +19,7 @@ from ..hostutil import require_cuda, DeviceBatch, flatten_module
 from ..rollout import EpisodeBatch
 from ..network.mixer import QtranQBase, QtranQAlt, QtranV, QMixMixer
 from .common import (MASK_BIG, MASK_QTRAN_EVAL, LearnerParams, FlatView, FusedOptimizer, Scratch, agent_backward,
-                     GradReducer, PairedUnroll, ResumeMixin, LossReadback, SpeculativeBatchMixin)
+                     GradReducer, PairedUnroll, ResumeMixin, LossReadback, SpeculativeBatchMixin, GraphedUpdate)
 
 
 class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
@@ -50,12 +50,11 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
         self.optimizer = FusedOptimizer(self._flat, args.optimizer, self.lr, args.grad_norm_clip)
         self._buf = Scratch()
         self.reducer = GradReducer()
-        self.pair = PairedUnroll()
+        from ..network import mixer as _mixer
+        self.pair = PairedUnroll(x6=getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6")
         self.loss_readback = LossReadback(args)
+        self.graphs = GraphedUpdate.from_args(args)
         self.last_stats = None
-        if getattr(args, "hip_graph", False):
-            import warnings
-            warnings.warn("args.hip_graph is not implemented for QTRANLearner: updates run as eager launches")
         self.sync_replicas()
 
     def sync_replicas(self):
@@ -146,12 +145,20 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
                          joint_q_hat=joint_q_hat)
 
     def train(self, batch, train_step):
-        if isinstance(batch, DeviceBatch):
+        if self.graphs is not None and isinstance(batch, EpisodeBatch) and batch.ring is not None and \
+                self.graphs.run(self, batch.ring, batch.index):
+            db = None                    # forward / backward done (hipGraph replay on the static buffers)
+        elif isinstance(batch, DeviceBatch):
             db = batch
         elif isinstance(batch, EpisodeBatch) and batch.ring is not None:
             # replay sample: big arrays are read in place from the ring through the episode index
-            small = batch.ring.select_small(batch.index)
-            db = self._device_batch(batch.ring, batch.index, small)
+            prep = self.graphs.prepared if self.graphs is not None else None
+            if prep is not None:             # the graph path already gathered the small arrays and agreed on T
+                self.graphs.prepared = None
+                db = DeviceBatch.from_record(batch.ring, self.args, T=prep[1], index=batch.index, small=prep[0])
+            else:
+                small = batch.ring.select_small(batch.index)
+                db = self._device_batch(batch.ring, batch.index, small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
             db = self._device_batch(batch.record, None, None)
         else:

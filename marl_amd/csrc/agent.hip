@@ -1788,7 +1788,7 @@ inline int pick_rt(long R, size_t bytes_per_row, size_t fixed_bytes, int rt_cap,
 // (Alignment of the actual pointers is checked at launch; a launch that cannot reuse computes.)
 extern "C" int marl_agent_unroll_reuse_supported(int B, int T, int N, int O, int A, int cu_budget) {
   if (B <= 0 || T < 2 || A > 32 || A < 1 || cu_budget < 0 || cu_budget > 256 || (O % 4) != 0 || O < 4) return 0;
-  if (getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0') return 0;
+  if (!marl_switches()->fwd_xs) return 0;
   if (cu_budget == 0) cu_budget = 256;
   const long tiles = ((long)B * N + 15) / 16;
   const int want = (int)((tiles + cu_budget - 1) / cu_budget);
@@ -1822,12 +1822,12 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   a.vload = (O % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0) && O >= 4;
   int rt_cap = 8;
   bool half = false, dma = false, w2l = false;
-  static const bool xs_off = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
-  // MARL_FWD_DMA=1 (read per call): the activation-saving unroll fills its observation tile by LDS-DMA (DMA kernels).  OFF by
+  const bool xs_off = !marl_switches()->fwd_xs;      // A/B switch for measurements (common.h: MarlSwitches)
+  // switch fwd_dma = 1: the activation-saving unroll fills its observation tile by LDS-DMA (DMA kernels).  OFF by
   // default - measured slower (2s3z / 4096 envs 1.75 vs 1.62 ms; MMM2 / 1024 envs 2.98 ms at three row tiles per workgroup vs
   // 2.24 ms at two through registers): the issuing waves spend a third of every step in the nine to eleven DMA issues
   // (profiles/r03_stamps_dma.txt), although a wave alone issues such a DMA every ~100 cycles (profiles/r03_dma_probe.txt)
-  const int dma_mode = getenv("MARL_FWD_DMA") ? atoi(getenv("MARL_FWD_DMA")) : 0;
+  const int dma_mode = marl_switches()->fwd_dma;
   const bool xs_req = a.vload && gi_in && !saved && T >= 2 && !xs_off;      // the launch reads stored input-side sums
   if (a.vload && !xs_req) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW * 512 registers
     int cap2 = (NLDW * FNT) / (16 * (O / 4));
@@ -1838,7 +1838,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
     // to the rows its prefetch registers would cover (DMA kernels)
     if (saved && T > 1 && dma_mode == 1) { dma = true; cap2 = 8; }
     // activation-saving unroll, wide observations, two action tiles: six prefetch registers, fc2 fragments in LDS (W2L kernels)
-    const bool w2l_off = getenv("MARL_FWD_W2L") && getenv("MARL_FWD_W2L")[0] == '0';      // A/B switch (read per call)
+    const bool w2l_off = !marl_switches()->fwd_w2l;      // A/B switch
     // (only where it makes the launch a single round of workgroups: beside the target unroll under the pair schedule -
     // cu_budget 128 - three tiles per workgroup were SLOWER than two, 2.57 vs 2.24 ms at MMM2 / 1024 envs; alone on the chip
     // 1.25 vs 1.75 ms, profiles/r03_mmm2_schedules.txt)
@@ -1871,8 +1871,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
     const size_t lds_p = fixed + per_row_p * a.RT * 16 + 64;
     if (lds_p <= 160 * 1024) {
       const void* fp;
-      static const bool xs_off_p = getenv("MARL_FWD_XS") && getenv("MARL_FWD_XS")[0] == '0';      // A/B switch for measurements
-      const bool xs = gi_in && !saved && !xs_off_p;
+      const bool xs = gi_in && !saved && !xs_off;
       if (A <= 16) fp = saved ? (const void*)agent_fwd_pipe_kernel<1, true> : xs ? (const void*)agent_fwd_pipe_kernel<1, false, true> : (const void*)agent_fwd_pipe_kernel<1, false>;
       else fp = saved ? (const void*)agent_fwd_pipe_kernel<2, true> : xs ? (const void*)agent_fwd_pipe_kernel<2, false, true> : (const void*)agent_fwd_pipe_kernel<2, false>;
       e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
@@ -1961,7 +1960,7 @@ extern "C" int marl_agent_unroll_bwd(const marl_agent_weights_t* w, const float*
 #undef BWD_PICK
   size_t lds_used = lds;
   // few row tiles per workgroup (small shards), sparse dq: the one-barrier pipelined variant
-  static const int pipe_max_rt = getenv("MARL_BWD_PIPE_MAX_RT") ? atoi(getenv("MARL_BWD_PIPE_MAX_RT")) : 4;   // A/B switch for measurements (helps at every RT its LDS allows: +15 % per update at 1 tile, +1 % at 4)
+  const int pipe_max_rt = marl_switches()->bwd_pipe_max_rt;   // A/B switch for measurements (helps at every RT its LDS allows: +15 % per update at 1 tile, +1 % at 4)
   if (sp && a.RT <= pipe_max_rt && T >= 2) {
     const size_t lds_p = ((size_t)(2 * DGS + HS + 12) * 4 + 12) * rows + 4 * 64 * 4;
     if (lds_p <= 160 * 1024) {

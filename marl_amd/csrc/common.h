@@ -5,6 +5,17 @@
 
 #define MARL_WAVE 64
 
+// Experiment switches (A/B measurements and variant tests): ONE table per process, set through marl_experiment_set() (optim.hip;
+// marl_amd/experiments.py reads the MARL_* environment once at import and forwards it).  No launch path reads the environment.
+//   fwd_xs (1): the double-Q unroll reads the eval unroll's input-side gate sums;  fwd_dma (0): LDS-DMA observation tile of the
+//   saving unroll;  fwd_w2l (1): six prefetch registers / fc2 fragments in LDS for wide observations;  bwd_pipe_max_rt (4): row
+//   tiles up to which the pipelined BPTT runs;  wgrad_tall (1): LDS-staged tall weight-gradient kernel;  wide_res (1) / wide_res32
+//   (0): resident-weights forward of the wide-state QMIX mixer (16- / 32-row tiles)
+struct MarlSwitches {
+  int fwd_xs, fwd_dma, fwd_w2l, bwd_pipe_max_rt, wgrad_tall, wide_res, wide_res32;
+};
+extern "C" const MarlSwitches* marl_switches(void);      // optim.hip
+
 // LDS row pitches of the activation tiles, in floats beyond the tile width - the DEFAULT (+8) for files that do not choose their
 // own: rollout_fused.hip keeps it (0-1 % ahead there), agent.hip overrides it with +4 (agent.hip:16-23: +8 costs the wide MMM2
 // tiles 6 % through the LDS it takes from the row-tile count).  Why +8: a wave reads an MFMA operand fragment with one

@@ -1005,8 +1005,7 @@ __global__ __launch_bounds__(512, NX >= 7 ? 2 : 4) void wgrad_tall_kernel(WgradA
 inline int tall_xp(int K) { const int w = (K + 15) / 16 * 16; return (w % 32 == 16) ? w : w + 16; }
 // returns -1 when the shape is not covered
 inline int try_wgrad_tall(WgradArgs& a, size_t ws_bytes, hipStream_t s) {
-  static const bool off = getenv("MARL_WGRAD_TALL") && getenv("MARL_WGRAD_TALL")[0] == '0';      // A/B switch for measurements
-  if (off) return -1;
+  if (!marl_switches()->wgrad_tall) return -1;      // A/B switch for measurements (common.h: MarlSwitches)
   if (a.N != 64 || a.groups != 1 || a.Yact || !a.gvec || !a.xvec || a.M < 4096 || a.x.k1 || a.x.m0 || !a.x.p0) return -1;
   if (a.x.nhot > 1 || a.x.k0 < 16 || a.x.k0 > 224) return -1;
   if ((a.x.k0 & 3) && (a.x.nhot || a.x.nid || (a.x.ld0 & 3))) return -1;      // ragged dense width: plain dense rows padded to 16 bytes only

@@ -3,6 +3,7 @@
 // (loss numerator); 1/sum(mask) and the clip coefficient are folded into the update so the whole
 // optimizer is two launches and, on several GPUs, follows a single all-reduce.
 #include "common.h"
+#include <string.h>
 #include "../../include/marl_hip.h"
 
 namespace {
@@ -99,6 +100,31 @@ extern "C" int marl_adam_step(float* p, const float* g, float* m, float* v, long
                      beta2, eps, bc1, bc2_sqrt, clip, sumsq, den);
   MARL_CHECK_LAUNCH();
   return 0;
+}
+
+// ---- experiment switches (common.h: MarlSwitches) ----------------------------------------------------------------------------
+static MarlSwitches g_switches = {1, 0, 1, 4, 1, 1, 0};
+extern "C" const MarlSwitches* marl_switches(void) { return &g_switches; }
+static int* switch_slot(const char* name) {
+  if (!name) return nullptr;
+  struct { const char* n; int* p; } tab[] = {{"fwd_xs", &g_switches.fwd_xs}, {"fwd_dma", &g_switches.fwd_dma}, {"fwd_w2l", &g_switches.fwd_w2l},
+                                             {"bwd_pipe_max_rt", &g_switches.bwd_pipe_max_rt}, {"wgrad_tall", &g_switches.wgrad_tall},
+                                             {"wide_res", &g_switches.wide_res}, {"wide_res32", &g_switches.wide_res32}};
+  for (auto& t : tab)
+    if (!strcmp(t.n, name)) return t.p;
+  return nullptr;
+}
+// set / read one switch by name; unknown names return -1 (set) / INT_MIN (get).  Not thread-safe against concurrent launches:
+// meant for process start-up and single-threaded tests.
+extern "C" int marl_experiment_set(const char* name, int value) {
+  int* p = switch_slot(name);
+  if (!p) return -1;
+  *p = value;
+  return 0;
+}
+extern "C" int marl_experiment_get(const char* name) {
+  int* p = switch_slot(name);
+  return p ? *p : (-2147483647 - 1);
 }
 
 #ifndef MARL_SRC_HASH

@@ -15,7 +15,8 @@
 //             reduce scatter into the four weight / bias gradients.
 // BF = true: the hypernet GEMM takes bf16 operands (state tile rounded once when it is written to LDS, weights packed
 // as bf16) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation - "bf16 mixer with MFMA"; then the kernel is bound by
-// reading the states from HBM.  Everything else (mixing, gradients, the weight-gradient GEMM) stays fp32.
+// reading the states from HBM.  Mixing and the gradients stay fp32; the weight-gradient GEMM stays fp32 too unless the caller
+// also sets flags & 2 (qmix_wide_wgrad_bf16_kernel: dhy and the states rounded to bf16 where a chunk is staged).
 #include "common.h"
 #include <cstdlib>
 #include "../../include/marl_hip.h"
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_wide_wgrad_kernel(WideWgArgs 
   }
 }
 
-// The same reduction with bf16 operands (flags & 1, BASELINE config 5 "bf16 mixer with MFMA"): dhy and the states are rounded to
+// The same reduction with bf16 operands (flags & 2 beside flags & 1; BASELINE config 5 "bf16 mixer with MFMA"): dhy and the states are rounded to
 // bf16 where they are staged, a 32-row chunk is ONE k-step of v_mfma_f32_16x16x32_bf16 (21 MFMAs per wave and chunk instead of
 // 168 fp32 ones), and - the reduction index being the row - both operands come out of row-major [row][column] bf16 images
 // through ds_read_b64_tr_b16 (lane (g, i) receives column i of rows 8g .. 8g + 3: cdna_hip_programming.md T10).  The kernel is
@@ -1180,8 +1181,7 @@ extern "C" size_t marl_qmix_wide_workspace(long rows, int N, int S, int backward
 // caller that times the call can name the kernel it timed (bench.py); the same dispatch rules as below
 extern "C" const char* marl_qmix_wide_fwd_kernel(long rows, int N, int S, int flags) {
   const bool bf = (flags & 1) != 0;
-  const bool res_off = getenv("MARL_WIDE_RES") && getenv("MARL_WIDE_RES")[0] == '0';
-  const bool res32_on = getenv("MARL_WIDE_RES32") && getenv("MARL_WIDE_RES32")[0] == '1';
+  const bool res_off = !marl_switches()->wide_res, res32_on = marl_switches()->wide_res32 == 1;
   if (bf && N == 10 && (S + 15) / 16 == 21 && rows >= 128L * 16 * 16 && !res_off && res32_on) return "qmix_wide_res32_fwd_kernel";
   if (bf && N == 10 && (S + 31) / 32 == 11 && rows >= 128L * 16 * 16 && !res_off) return "qmix_wide_res_fwd_kernel";
   return "qmix_wide_kernel<false";
@@ -1195,10 +1195,10 @@ extern "C" int marl_qmix_wide_fwd(const marl_qmix_weights_t* w, const marl_src_t
   const bool bf = (flags & 1) != 0;
   hipStream_t st = (hipStream_t)stream;
   // bf16, 10 agents, 21 / 11 k-chunks (MMM2) and enough row tiles for 128 row groups: the resident-weights kernels
-  const bool res_off = getenv("MARL_WIDE_RES") && getenv("MARL_WIDE_RES")[0] == '0';      // A/B switches (read per call)
+  const bool res_off = !marl_switches()->wide_res;      // A/B switches (common.h: MarlSwitches)
   // (the 32-row-tile variant is opt-in: measured 65 us against 60 us for the 16-row one - both run their chunk loops with the
   // bf16 pipe ~75 % busy, the 32 x 32 tiles pay 8 % padding and a longer dependent chain per tile)
-  const bool res32_on = getenv("MARL_WIDE_RES32") && getenv("MARL_WIDE_RES32")[0] == '1';
+  const bool res32_on = marl_switches()->wide_res32 == 1;
   if (bf && N == 10 && (S + 15) / 16 == 21 && rows >= 128L * 16 * 16 && !res_off && res32_on) {
     Wide32Args b = {};
     b.W[0] = w->w1; b.Bv[0] = w->w1_b; b.W[1] = w->b1; b.Bv[1] = w->b1_b; b.W[2] = w->w2; b.Bv[2] = w->w2_b; b.W[3] = w->h; b.Bv[3] = w->h_b;
@@ -1275,7 +1275,7 @@ static int wide_bwd_impl(const marl_qmix_weights_t* w, const marl_src_t* s, cons
   if (rc) return rc;
   WideWgArgs g;
   g.dhy = dhy; g.s = a.s; g.ws = wslab; g.rows = rows; g.S = S; g.C = C; g.KT = KT; g.nslab = nslab;
-  if (bf) {      // bf16 operands: one k-step of the bf16 MFMA per 32-row chunk, transposed LDS reads
+  if (bf && (flags & 2)) {      // bf16 weight-gradient operands (own flag bit): one k-step of the bf16 MFMA per 32-row chunk, transposed LDS reads
     size_t lds = (size_t)2 * WCH * (wgb_gb() + wgb_xb(KT)) + 2 * WCH * sizeof(long);
     const size_t red = (size_t)WCH * 16 * WNT * sizeof(float);
     if (lds < red) lds = red;

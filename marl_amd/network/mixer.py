@@ -61,6 +61,11 @@ class _Precision:
     def _bf16(self):
         return getattr(self.args, "mixer_dtype", "fp32") == "bf16"
 
+    def _wgrad_bf16(self):
+        """with mixer_dtype "bf16" the wide-state mixer's weight-gradient GEMM takes bf16 operands too (its own flag bit of
+        the C-ABI) unless args.mixer_wgrad_dtype = "fp32" keeps that one GEMM on v_mfma_f32_16x16x4_f32"""
+        return self._bf16() and getattr(self.args, "mixer_wgrad_dtype", "bf16") != "fp32"
+
     def _lin(self, module):
         return lin_of(module, self._bf16())
 
@@ -250,7 +255,8 @@ class QMixMixer(_Precision, nn.Module):
                                     self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E)
         else:
             ops.qmix_wide_loss_bwd(self._fused_struct(), xs, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
-                                   self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E, bf16=self._bf16())
+                                   self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E, bf16=self._bf16(),
+                                   wgrad_bf16=self._wgrad_bf16())
         return dq
 
     def hip_backward(self, ctx, dq_tot, rows):
@@ -266,7 +272,7 @@ class QMixMixer(_Precision, nn.Module):
             q, s = ctx["q"], ctx["s"]
             dq = self._s.get("dq", (rows, N), q.device)
             ops.qmix_wide_bwd(self._fused_struct(), ops.src(s), q, dq_tot, dq, self._fused_struct(grad=True), rows, N,
-                              a.state_shape, E, bf16=self._bf16())
+                              a.state_shape, E, bf16=self._bf16(), wgrad_bf16=self._wgrad_bf16())
             return dq
         hy, q, s = ctx["hy"], ctx["q"], ctx["s"]
         dev = q.device
@@ -355,7 +361,8 @@ DEFAULT_GEMM_MODE = "f32"
 
 def _keep_hidden():
     """the fused head families keep their hidden activations for the backward (MARL_MLP3_KEEP=0: recompute them there)"""
-    return os.environ.get("MARL_MLP3_KEEP", "1") != "0"
+    from .. import experiments
+    return experiments.get("mlp3_keep") != 0
 
 
 def _head_stride(mods, attr):

@@ -461,13 +461,19 @@ def qmix_fused_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, g
                                        _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_loss_bwd")
 
 
-def qmix_wide_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, rows, N, S, E, bf16=False):
-    """wide-state fused QMIX backward with the TD loss folded in (include/marl_hip.h)"""
+def _wide_flags(bf16, wgrad_bf16):
+    """flags of the wide-state QMIX entry points: bit 0 = bf16 operands of the hypernet GEMM, bit 1 = bf16 operands of the
+    weight-gradient GEMM too (its own bit: a C-ABI caller that sets only bit 0 keeps fp32 weight gradients)"""
+    return (1 if bf16 else 0) | (2 if (bf16 and (wgrad_bf16 is None or wgrad_bf16)) else 0)
+
+
+def qmix_wide_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, rows, N, S, E, bf16=False, wgrad_bf16=None):
+    """wide-state fused QMIX backward with the TD loss folded in (include/marl_hip.h); wgrad_bf16: None = follow bf16"""
     lib = _lib.load()
     ws = WS.get("qmix_wide", lib.marl_qmix_wide_workspace(rows, N, S, 1), q.device)
     check(lib.marl_qmix_wide_loss_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot_tgt)), _p(_f32(r)), _p(_f32(term)),
                                       _p(_f32(padded)), float(gamma), _p(q_tot), _p(_f32(dq)), C.byref(grads), _p(_f32(loss2)),
-                                      _p(ws), ws.numel() * 4, rows, N, S, E, 1 if bf16 else 0, _stream()), "marl_qmix_wide_loss_bwd")
+                                      _p(ws), ws.numel() * 4, rows, N, S, E, _wide_flags(bf16, wgrad_bf16), _stream()), "marl_qmix_wide_loss_bwd")
 
 
 def qmix_wide_fwd_kernel(rows, N, S, bf16=False):
@@ -486,11 +492,11 @@ def qmix_wide_fwd(w, s, q, q_tot, rows, N, S, E, bf16=False):
                                  1 if bf16 else 0, _stream()), "marl_qmix_wide_fwd")
 
 
-def qmix_wide_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E, bf16=False):
+def qmix_wide_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E, bf16=False, wgrad_bf16=None):
     lib = _lib.load()
     ws = WS.get("qmix_wide", lib.marl_qmix_wide_workspace(rows, N, S, 1), q.device)
     check(lib.marl_qmix_wide_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads), _p(ws),
-                                 ws.numel() * 4, rows, N, S, E, 1 if bf16 else 0, _stream()), "marl_qmix_wide_bwd")
+                                 ws.numel() * 4, rows, N, S, E, _wide_flags(bf16, wgrad_bf16), _stream()), "marl_qmix_wide_bwd")
 
 
 def _uniform_stride(ts):

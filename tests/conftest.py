@@ -11,12 +11,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
-    # MARL_TEST_GEMM_MODE=bf16x6: the whole suite with the opt-in split kernels where they exist (same bounds; the margins
-    # table of such a run is committed beside the fp32 one)
-    mode = os.environ.get("MARL_TEST_GEMM_MODE")
-    if mode:
-        from marl_amd.network import mixer
-        mixer.DEFAULT_GEMM_MODE = mode
+
+
+GEMM_MODES = ["f32", "bf16x6"]
+
+
+@pytest.fixture(params=GEMM_MODES)
+def gemm_mode(request):
+    """Both arithmetic modes of the dense products under the SAME bounds: "f32" (v_mfma_f32_16x16x4_f32) and "bf16x6" (every fp32
+    operand split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate).  The learner-level parity
+    tests (golden cases, full-size configurations, ranks == one process) take this fixture, so the driver's `pytest -m gpu` runs and
+    prints the margins of both."""
+    return request.param
 
 
 @pytest.fixture(scope="session")

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     alg, shape = sys.argv[1], sys.argv[2]
+    gemm_mode = sys.argv[3] if len(sys.argv) > 3 else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("MARL_BENCH_BACKEND", "gloo")
     if backend == "nccl":          # RCCL: one GPU per rank
@@ -28,7 +29,7 @@ def main():
     B, T = 6, 6
     lengths = [6, 2, 3, 4, 2, 3]
     case = ("x", shape, alg, B, T, lengths, {})
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, gemm_mode)
     assert learner.reducer.enabled
     losses = []
     per = B // world

@@ -22,16 +22,45 @@ def test_self_launch_command(monkeypatch):
     assert bench.self_launch(4) == 7                          # the child's return code is ours
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    # rendezvous on 127.0.0.1 at a port torchrun picks itself (no bind-then-close race with other jobs of the node)
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
+    assert "--master-port" not in cmd
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_self_launch_honours_a_given_master_port(monkeypatch):
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **kw: seen.setdefault("cmd", cmd) and subprocess.CompletedProcess(cmd, 0))
+    monkeypatch.setenv("MARL_BENCH_ONE_DEVICE", "1")
+    monkeypatch.setenv("MASTER_PORT", "29777")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    assert bench.self_launch(2) == 0
+    cmd = seen["cmd"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777" and "--standalone" not in cmd
+
+
+def test_visible_gpus_never_touches_the_runtime(monkeypatch):
+    """the parent of a self-launch counts GPUs from the environment / the KFD topology, not through torch.cuda"""
+    import bench
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("must not ask the runtime")))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    for k in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.visible_gpus() in (None, 0) or bench.visible_gpus() > 0        # (no KFD in the build container: None)
+
+
 def test_self_launch_refuses_more_gpus_than_visible(monkeypatch):
     import bench
     monkeypatch.delenv("MARL_BENCH_ONE_DEVICE", raising=False)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not launch")))
     assert bench.self_launch(64) == 2
 

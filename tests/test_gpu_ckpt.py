@@ -114,7 +114,8 @@ args, mac, learner = build_product(case)
 assert learner.reducer.enabled
 losses = [learner.train(learners.clone_batch(seeded.make_batch(args, 4, seed=100 + i, lengths=[5, 3, -1, 4])), i) for i in range(2)]
 dist.destroy_process_group()
-os.environ.pop("MARL_FORCE_REDUCER")
+from marl_amd import experiments
+experiments.set("force_reducer", 0)          # (the environment is read once, at import: later changes go through experiments.set)
 args2, mac2, single = build_product(case)
 assert not single.reducer.enabled
 ref = [single.train(learners.clone_batch(seeded.make_batch(args2, 4, seed=100 + i, lengths=[5, 3, -1, 4])), i) for i in range(2)]

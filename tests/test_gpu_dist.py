@@ -28,16 +28,16 @@ def _run(cmd, extra_env):
     return json.loads(line)
 
 
-def _ranks_equal_one_process(alg, shape, world, backend):
+def _ranks_equal_one_process(alg, shape, world, backend, gemm_mode="f32"):
     from test_gpu_learners import build_product
     port = 29500 + (os.getpid() % 400)
     res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                "--master-addr", "127.0.0.1", "--master-port", str(port), "tests/dist_parity_worker.py", alg, shape],
+                "--master-addr", "127.0.0.1", "--master-port", str(port), "tests/dist_parity_worker.py", alg, shape, gemm_mode],
                {"MARL_BENCH_BACKEND": backend})
     B, T = 6, 6
     lengths = [6, 2, 3, 4, 2, 3]
     case = ("x", shape, alg, B, T, lengths, {})
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, gemm_mode)
     losses = []
     for i in range(3):
         losses.append(learner.train(seeded.make_batch(args, B, seed=100 + i, lengths=lengths), i))
@@ -48,9 +48,10 @@ def _ranks_equal_one_process(alg, shape, world, backend):
     np.testing.assert_allclose(res["param_abs"], np.abs(flat).sum(), rtol=1e-6)
 
 
-@pytest.mark.parametrize("alg,shape,world", [("qmix", "2s3z", 2), ("qtran_base", "3s5z", 2), ("qplex", "2s3z", 3)])
-def test_ranks_equal_one_process(alg, shape, world):
-    _ranks_equal_one_process(alg, shape, world, "gloo")
+@pytest.mark.parametrize("alg,shape,world,gemm_mode", [("qmix", "2s3z", 2, "f32"), ("qtran_base", "3s5z", 2, "f32"), ("qplex", "2s3z", 3, "f32"),
+                                                       ("qmix", "2s3z", 2, "bf16x6"), ("qplex", "2s3z", 3, "bf16x6")])
+def test_ranks_equal_one_process(alg, shape, world, gemm_mode):
+    _ranks_equal_one_process(alg, shape, world, "gloo", gemm_mode)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with two ranks needs two GPUs (the 1-GPU box runs the gloo variant)")
@@ -65,9 +66,9 @@ def test_bench_runs_under_torchrun_two_ranks():
     port = 29950 + (os.getpid() % 40)
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--envs", "64",
-              "--T", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--leg-iters", "1"],
+              "--T", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--leg-iters", "1", "--gemm-mode", "f32"],
              {"MARL_BENCH_BACKEND": "gloo", "MARL_BENCH_ONE_DEVICE": "1"})
-    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 32 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 32 and d["value"] > 0 and d["dtype"] == "f32" and "f32_mfma_twin" not in d
     # the roofline object describes the kernel with the largest total time; every timed kernel is listed with its launches
     assert d["scaling"] == "strong" and d["roofline"]["frac"] > 0 and d["roofline"]["launches_timed"] >= 2
     names = {k["name"].split("[")[0].split(" ")[0]: k["launches_timed"] for k in d["roofline"]["kernels"]}
@@ -82,6 +83,10 @@ def test_bench_launches_its_own_ranks():
               "--no-cpu-baseline", "--leg-iters", "1"],
              {"MARL_BENCH_BACKEND": "gloo", "MARL_BENCH_ONE_DEVICE": "1", "WORLD_SIZE": None})
     assert d["n_gpus"] == 2 and d["rccl"]["world_seen"] == 2 and d["config"]["envs_per_gpu"] == 32 and d["value"] > 0
+    # the default arithmetic is the split mode, with the fp32-MFMA twin of the same timed region beside it
+    assert d["config"]["gemm_mode"] == "bf16x6" and d["dtype"].startswith("f32 (bf16x6")
+    assert any("x6" in k["rocprof_name"] for k in d["roofline"]["kernels"]), d["roofline"]["kernels"]
+    assert d["f32_mfma_twin"]["value"] > 0 and d["f32_mfma_twin"]["dtype"] == "f32" and d["f32_mfma_twin"]["roofline"]["frac"] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")

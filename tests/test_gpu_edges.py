@@ -94,12 +94,13 @@ def test_first_terminated_len_kernel_matches_reference_rule():
     assert DeviceBatch.first_terminated_len(none, 9) == 9
 
 
-@pytest.mark.parametrize("alg", ["qmix", "qplex"])
-def test_hip_graph_replay_equals_eager(alg):
-    """Opt-in hipGraph replay of the learner's forward/backward (args.hip_graph): same ring, same sampled episodes ->
-    bitwise the same losses and parameters as eager launches, across the capture (update 3) and replays.  QPLEX reads
-    the current-step availability of the SAMPLED episodes through the batch's index tensor (a different sample per
-    update: the replayed gather must follow it)."""
+@pytest.mark.parametrize("alg,gemm_mode", [("qmix", "f32"), ("qplex", "f32"), ("qtran_base", "f32"), ("qmix", "bf16x6"), ("qplex", "bf16x6")])
+def test_hip_graph_replay_equals_eager(alg, gemm_mode):
+    """hipGraph replay of the learner's forward/backward (args.hip_graph: the default for small batches): same ring, same sampled
+    episodes -> bitwise the same losses and parameters as eager launches, across the capture (update 3), the replays and the
+    speculative replays (from update 5 on the graph is launched before max_episode_len is read back).  QPLEX / QTRAN read the
+    current-step availability of the SAMPLED episodes through the batch's index tensor (a different sample per update: the
+    replayed gather must follow it)."""
     import bench
     from marl_amd.controller.share_params import SharedMAC
     from marl_amd.algorithm.q_learner import QLearner
@@ -110,17 +111,18 @@ def test_hip_graph_replay_equals_eager(alg):
     for mode in (False, True):
         args = bench.make_args(alg, "2s3z", 12)
         E = 96
-        args.buffer_size, args.batch_size, args.hip_graph = 2 * E, E, mode
+        args.buffer_size, args.batch_size, args.hip_graph, args.gemm_mode = 2 * E, E, mode, gemm_mode
         torch.manual_seed(0)
         np.random.seed(7)
         mac = SharedMAC(args)
-        learner = QLearner(mac, args)
+        from marl_amd.algorithm.qtran_learner import QTRANLearner
+        learner = QTRANLearner(mac, args) if alg.startswith("qtran") else QLearner(mac, args)
         env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, 12, seed=3, fixed_length=True)
         w = RolloutWorker(env, mac, args)
         buf = ReplayBuffer(args)
         w.record_sink = buf
         losses = []
-        for i in range(6):
+        for i in range(8):
             ep = w.generate_episodes(E)[0]
             buf.store_episode(ep)
             losses.append(learner.train(buf.sample(E), i))
@@ -129,8 +131,53 @@ def test_hip_graph_replay_equals_eager(alg):
             g = learner.graphs
             assert not g.disabled, getattr(g, "error", "")
             assert any(e["graph"] is not None for e in g.entries.values()), "no graph was captured"
+            assert g.replays >= 5 and all(e["streak"] >= 2 for e in g.entries.values())
+        else:
+            assert learner.graphs is None
     assert out[False][0] == out[True][0]
     np.testing.assert_array_equal(out[False][1], out[True][1])
+
+
+def test_speculative_graph_replay_redoes_a_short_batch():
+    """the same rule on the hipGraph path: once replays run before max_episode_len is read back, a ring whose sampled episodes
+    ALL ended early gets the (already replayed) update redone eagerly at its own length - same losses, lengths and parameters
+    as a learner without graphs"""
+    import bench
+    from marl_amd.controller.share_params import SharedMAC
+    from marl_amd.algorithm.q_learner import QLearner
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd.common.replaybuffer import ReplayBuffer
+    out = {}
+    for mode in (False, True):
+        args = bench.make_args("qmix", "2s3z", 12)
+        E = 48
+        args.buffer_size, args.batch_size, args.hip_graph = E, E, mode
+        torch.manual_seed(0)
+        np.random.seed(3)
+        mac = SharedMAC(args)
+        learner = QLearner(mac, args)
+        env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, 12, seed=5, fixed_length=True)
+        w = RolloutWorker(env, mac, args)
+        buf = ReplayBuffer(args)
+        w.record_sink = buf
+        losses, lens = [], []
+        for i in range(9):
+            ep = w.generate_episodes(E)[0]
+            buf.store_episode(ep)
+            if i == 7:                          # every stored episode ends after 5 steps
+                rec = buf.record
+                rec.term[:, 4:] = 1.0
+                rec.padded[:, 5:] = 1.0
+                rec.length.fill_(5)
+            losses.append(learner.train(buf.sample(E), i))
+            lens.append(learner.max_episode_len)
+        out[mode] = (losses, lens, learner._flat.flat.detach().cpu().numpy().copy())
+        if mode:
+            assert learner.graphs.replays >= 4
+    assert out[True][1] == out[False][1] == [12] * 7 + [5, 12]
+    assert out[True][0] == out[False][0]
+    np.testing.assert_array_equal(out[True][2], out[False][2])
 
 
 def test_speculative_full_length_launch_redoes_a_short_batch():

@@ -16,18 +16,25 @@ pytestmark = pytest.mark.gpu
 E, T = 4096, 120
 
 
+MODES = ["f32", "bf16x6"]       # both arithmetic modes of the dense products, same bounds (tests/conftest.py: gemm_mode)
+
+
 @pytest.fixture(scope="module")
 def world():
     from marl_amd.rollout import RolloutWorker
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
     from test_gpu_learners import build_product
     case = ("full", "2s3z", "qmix", E, T, None, {})
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, "f32")
     args.epsilon, args.anneal_epsilon, args.seed = 0.3, 1e-4, 41
     env = SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=17)
     w = RolloutWorker(env, mac, args)
     ep, rew, wins, steps = w.generate_episodes(E)
-    return dict(case=case, args=args, mac=mac, learner=learner, ep=ep, steps=steps, eps_after=w.epsilon)
+    # the same weights behind a learner in split arithmetic (the record above is shared: the rollout's integer fields do not
+    # depend on the mode - test_gpu_rollout.py checks that - and the learner tests below read the record only)
+    _, _, learner6 = build_product(case, "bf16x6")
+    return dict(case=case, args=args, mac=mac, learner=learner, learners={"f32": learner, "bf16x6": learner6}, ep=ep, steps=steps,
+                eps_after=w.epsilon)
 
 
 def test_rollout_partition_invariance_and_oracle_samples(world):
@@ -66,10 +73,12 @@ def _grads(learner, rec, Tfix):
     return learner._flat.gradx.detach().cpu().double().numpy().copy(), {k: v.detach().cpu().numpy().copy() for k, v in learner._dbg.items()}
 
 
-def test_learner_linearity_and_oracle_samples(world):
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_learner_linearity_and_oracle_samples(world, gemm_mode):
     from marl_amd.hostutil import DeviceBatch
     from golden_cases import case_states
-    learner, rec, args = world["learner"], world["ep"].record, world["args"]
+    learner, rec = world["learners"][gemm_mode], world["ep"].record
+    args = learner.args
     Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
     full, dbg = _grads(learner, rec, Tm)
     half = E // 2
@@ -102,7 +111,8 @@ def test_learner_linearity_and_oracle_samples(world):
         np.testing.assert_allclose(a_[live], b_[live], atol=2e-4, err_msg=k)
 
 
-def test_qplex_linearity_and_oracle_samples(world):
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_qplex_linearity_and_oracle_samples(world, gemm_mode):
     """QPLEX (BASELINE config 3 shape) at the full 4096 x 120 batch: the fused lambda-net head kernels walk 30 720
     row tiles per head here.  Same properties as above: the full batch's un-normalised gradient equals the sum over
     its halves, and q_tot / target q_tot of sampled episodes equal the CPU oracle's."""
@@ -111,7 +121,7 @@ def test_qplex_linearity_and_oracle_samples(world):
     from test_gpu_learners import build_product
     from golden_cases import case_states
     case = ("fullq", "2s3z", "qplex", E, T, None, {})
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, gemm_mode)
     rec = world["ep"].record
     Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
     full, dbg = _grads(learner, rec, Tm)
@@ -136,12 +146,12 @@ def test_qplex_linearity_and_oracle_samples(world):
         np.testing.assert_allclose(a_[live], b_[live], atol=3e-4, rtol=1e-4, err_msg=k)
 
 
-def _shard_world(shape, alg, envs, T, seed, over=None):
+def _shard_world(shape, alg, envs, T, seed, over=None, gemm_mode=None):
     from marl_amd.rollout import RolloutWorker
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
     from test_gpu_learners import build_product
     case = ("shard", shape, alg, envs, T, None, over or {})
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, gemm_mode)
     args.epsilon, args.anneal_epsilon, args.seed = 0.3, 1e-4, seed
     env = SyntheticSMACEnv(envs, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, T, seed=seed + 1)
     ep, _, _, _ = RolloutWorker(env, mac, args).generate_episodes(envs)
@@ -204,7 +214,8 @@ def _linearity(learner, rec, Tm, E_, nstats, name, tol=5e-5):
     parity.close(name, "gradient full vs halves", full[:n], tot[:n], tol=tol)
 
 
-def test_config4_qtran_3s5z_shard_fullsize():
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_config4_qtran_3s5z_shard_fullsize(gemm_mode):
     """BASELINE config 4 at its per-GPU shard (QTRAN-base, 3s5z shape, 2048 envs / 4 GPUs = 512 envs x T = 150):
     614 400 agent rows through the fused joint-Q / V head kernels and the hidden-state-gradient BPTT variant.
     (a) the un-normalised [gradients | three loss numerators | sum(mask)] of the shard equal the sum over its halves;
@@ -212,28 +223,32 @@ def test_config4_qtran_3s5z_shard_fullsize():
     and every parameter gradient equal the CPU oracle's within 1e-4 of their scale."""
     from marl_amd.hostutil import DeviceBatch
     E4, T4 = 512, 150
-    case, args, learner, rec = _shard_world("3s5z", "qtran_base", E4, T4, seed=23)
+    case, args, learner, rec = _shard_world("3s5z", "qtran_base", E4, T4, seed=23, gemm_mode=gemm_mode)
     assert int(rec.padded.sum().item()) > 0
     Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
     assert Tm == T4
-    _linearity(learner, rec, Tm, E4, 4, "full:cfg4_qtran_3s5z_512x150")
-    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 255, 256, 300, 511], Tm, "full:cfg4_qtran_3s5z_512x150")
+    name = "full:cfg4_qtran_3s5z_512x150[%s]" % gemm_mode
+    _linearity(learner, rec, Tm, E4, 4, name)
+    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 255, 256, 300, 511], Tm, name)
 
 
-def test_config5_qmix_mmm2_shard_fullsize():
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_config5_qmix_mmm2_shard_fullsize(gemm_mode):
     """BASELINE config 5 at its per-GPU shard (QMIX, MMM2 shape, 8192 envs / 8 GPUs = 1024 envs x T = 120, fp32):
     S = 322 states (rows not 16-byte aligned in a dense layout), 10 agents, two action tiles in the agent kernels.
     Same two properties as config 4: shard linearity and oracle parity (forward, loss, all gradients) on samples."""
     from marl_amd.hostutil import DeviceBatch
     E5, T5 = 1024, 120
-    case, args, learner, rec = _shard_world("MMM2", "qmix", E5, T5, seed=29)
+    case, args, learner, rec = _shard_world("MMM2", "qmix", E5, T5, seed=29, gemm_mode=gemm_mode)
     Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
     assert Tm == T5
-    _linearity(learner, rec, Tm, E5, 2, "full:cfg5_qmix_MMM2_1024x120")
-    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 511, 512, 700, 1023], Tm, "full:cfg5_qmix_MMM2_1024x120")
+    name = "full:cfg5_qmix_MMM2_1024x120[%s]" % gemm_mode
+    _linearity(learner, rec, Tm, E5, 2, name)
+    _sub_batch_vs_oracle(case, args, learner, rec, [0, 1, 511, 512, 700, 1023], Tm, name)
 
 
-def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle():
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle(gemm_mode):
     """BASELINE config 5 as it is quoted ("bf16 mixer with MFMA") at its per-GPU shard, learner level: QMIX on MMM2, 1024 envs x
     T = 120, args.mixer_dtype = "bf16".  The reference has no such mode; the oracle restates it (oracle/nets.py:_LinBf16 - both
     operands of the four state-conditioned hypernet GEMMs rounded to bf16, fp32 accumulation, forward AND weight gradient), which
@@ -241,25 +256,26 @@ def test_config5_qmix_mmm2_bf16_mixer_learner_vs_oracle():
     are exact in fp32, only the accumulation order differs.  (a) what the FULL-batch launches produced (122 880 rows: the
     resident-weights bf16 forward for the target mixer, the streaming bf16 kernel with the folded loss for the eval mixer) for
     sampled episodes: q_evals, q_targets, q_tot, q_tot_target at 1e-4 of scale; (b) the sampled sub-batch with the loss numerator and
-    every parameter gradient (1e-4; the four bf16 weight-gradient GEMMs at the mode's 2e-2); (c) shard linearity."""
+    every parameter gradient (1e-4; the four bf16 weight-gradient GEMMs at 5e-3 - measured 2e-3); (c) shard linearity."""
     from marl_amd.hostutil import DeviceBatch
     from marl_amd import ops
     E5, T5 = 1024, 120
-    case, args, learner, rec = _shard_world("MMM2", "qmix", E5, T5, seed=29, over={"mixer_dtype": "bf16"})
+    case, args, learner, rec = _shard_world("MMM2", "qmix", E5, T5, seed=29, over={"mixer_dtype": "bf16"}, gemm_mode=gemm_mode)
     assert learner.mixer._bf16() and args.mixer_dtype == "bf16"
     assert ops.qmix_wide_fwd_kernel(E5 * T5, args.n_agents, args.state_shape, bf16=True) == "qmix_wide_res_fwd_kernel"
     Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
     assert Tm == T5
-    name = "full:cfg5_qmix_MMM2_1024x120_bf16mixer"
+    name = "full:cfg5_qmix_MMM2_1024x120_bf16mixer[%s]" % gemm_mode
     idx = [0, 1, 511, 512, 700, 1023]
     _, dbg = _grads(learner, rec, Tm)
     _full_batch_samples_vs_oracle(case, args, dbg, rec, idx, Tm, name)
     # the weight gradients of the four bf16 GEMMs round dhy and the states to bf16 before multiplying: a 1e-7 difference in dhy
     # between two correct evaluations can move an element across a bf16 rounding boundary (2^-8 of that term), so these four
-    # tensors are compared at the 2e-2 test_qmix_wide states for the mode (measured: 2e-3); everything else - the loss, dq and
-    # with it every agent gradient, the biases, hyper_b2.2 - at 1e-4
+    # tensors are compared at 5e-3 (measured: 2e-3); everything else - the loss, dq and
+    # with it every agent gradient, the biases, hyper_b2.2 - at 1e-4.  (The bf16 weight-gradient GEMM is its own flag bit of the C-ABI;
+    # args.mixer_wgrad_dtype = "fp32" keeps that GEMM on fp32 MFMAs: tests/test_gpu_kernels.py::test_qmix_wide[...-fwd].)
     bf_w = ("mixer.hyper_w1.weight", "mixer.hyper_b1.weight", "mixer.hyper_w2.weight", "mixer.hyper_b2.0.weight")
-    _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, grad_tol=lambda pn: 2e-2 if pn in bf_w else 1e-4)
+    _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name, grad_tol=lambda pn: 5e-3 if pn in bf_w else 1e-4)
     _linearity(learner, rec, Tm, E5, 2, name)
 
 
@@ -285,13 +301,14 @@ def _full_batch_samples_vs_oracle(case, args, dbg, rec, idx, Tm, name, tol=1e-4)
         parity.close(name, "full-batch " + k, a_[live], b_[live], tol=tol)
 
 
-def _chain_schedule_case(alg, envs, name):
+def _chain_schedule_case(alg, envs, name, gemm_mode):
     """A shard whose size selects PairedUnroll.run_chain (eval current-Q -> double-Q continuation on 160 CUs, target
     unroll beside it on 96 CUs of a side stream; reference q_learner.py:96-117, quirk Q1: the continuation starts from the
     eval pass's final hidden state and here also READS its input-side gate sums across the stream fork)."""
     from marl_amd.hostutil import DeviceBatch
     T2 = 120
-    case, args, learner, rec = _shard_world("2s3z", alg, envs, T2, seed=31)
+    name = "%s[%s]" % (name, gemm_mode)
+    case, args, learner, rec = _shard_world("2s3z", alg, envs, T2, seed=31, gemm_mode=gemm_mode)
     assert int(rec.padded.sum().item()) > 0, "ragged episodes wanted"
     Tm = DeviceBatch.first_terminated_len(rec.term, args.episode_limit)
     assert Tm == T2
@@ -316,14 +333,16 @@ def _chain_schedule_case(alg, envs, name):
     _sub_batch_vs_oracle(case, args, learner, rec, idx, Tm, name)
 
 
-def test_config2_qmix_2s3z_1024_chain_schedule():
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_config2_qmix_2s3z_1024_chain_schedule(gemm_mode):
     """BASELINE config 2 (QMIX, 2s3z, 1024 envs x T = 120 on one MI355X): its size selects the chain schedule."""
-    _chain_schedule_case("qmix", 1024, "full:cfg2_qmix_2s3z_1024x120")
+    _chain_schedule_case("qmix", 1024, "full:cfg2_qmix_2s3z_1024x120", gemm_mode)
 
 
-def test_config3_qplex_2s3z_512_shard_chain_schedule():
+@pytest.mark.parametrize("gemm_mode", MODES)
+def test_config3_qplex_2s3z_512_shard_chain_schedule(gemm_mode):
     """BASELINE config 3 at its per-GPU shard (QPLEX, 2s3z, 4096 envs / 8 GPUs = 512 envs x T = 120)."""
-    _chain_schedule_case("qplex", 512, "full:cfg3_qplex_2s3z_512x120")
+    _chain_schedule_case("qplex", 512, "full:cfg3_qplex_2s3z_512x120", gemm_mode)
 
 
 def test_qplex_mmm2_heads_run_fused_and_match_oracle():
@@ -343,8 +362,8 @@ def test_qplex_mmm2_heads_run_fused_and_match_oracle():
     xs = ops.src(s)
     xsa = ops.src(s, idx=torch.zeros(rows, args.n_agents, dtype=torch.int32, device=rec.obs.device), nhot=args.n_agents,
                   hot_w=args.n_actions)
-    import os
-    if os.environ.get("MARL_MLP3_KEEP", "1") != "0":          # (the A/B switch sends these shapes to the marl_linear composition)
+    from marl_amd import experiments
+    if experiments.get("mlp3_keep") != 0:          # (the A/B switch sends these shapes to the marl_linear composition)
         assert mx._fused_transform(xs) is not None and ops.mlp3_needs_kept(xs, args.state_shape)
         for fname, mods, nout in mx.si_weight.families():
             assert mx._fused_family(mods, xsa if fname == "ac" else xs, nout) is not None, fname

@@ -13,13 +13,16 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-def build_product(case):
+def build_product(case, gemm_mode=None):
+    """gemm_mode: "f32" / "bf16x6" (args.gemm_mode of the learner and its controller); None = the product's default"""
     from marl_amd.controller.share_params import SharedMAC
     from marl_amd.algorithm.q_learner import QLearner
     from marl_amd.algorithm.qtran_learner import QTRANLearner
     name, shape, alg, B, T, lengths, over = case
     args, agent, mixer, v, extra = case_states(case)
     args.cuda = True
+    if gemm_mode is not None:
+        args.gemm_mode = gemm_mode
     t = lambda d: {k: torch.tensor(x) for k, x in d.items()}
     mac = SharedMAC(args)
     mac.agent.load_state_dict(t(agent))
@@ -60,18 +63,18 @@ def check_pins(fix, prefix, named, tol, case, scale=1.0, none_is_zero=False):
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_forward_pieces_vs_reference(case, golden_dir):
+def test_forward_pieces_vs_reference(case, golden_dir, gemm_mode):
     """get_current/next_q_values and standalone mixer outputs vs the reference's own outputs."""
     name, shape, alg, B, T, lengths, over = case
     fix = load_fixture(golden_dir, name)
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, gemm_mode)
     batch = seeded.make_batch(args, B, seed=100, lengths=lengths)
     mac.init_hidden(B)
     q_cur, h_cur = mac.get_current_q_values(batch, T)
     q_cont, _ = mac.get_next_q_values(batch, T)            # quirk Q1: continues from the final hidden
     mac.init_hidden(B)
     q_nxt, h_nxt = mac.get_next_q_values(batch, T)
-    c = "fwd:" + name
+    c = "fwd:%s[%s]" % (name, gemm_mode)
     P = lambda key, t: parity.close(c, key, t.cpu().numpy(), fix[key])
     P("fwd/q_cur", q_cur); P("fwd/h_cur", h_cur); P("fwd/q_next", q_nxt); P("fwd/h_next", h_nxt)
     P("fwd/q_next_cont", q_cont)
@@ -93,10 +96,10 @@ def test_forward_pieces_vs_reference(case, golden_dir):
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_train_steps_vs_reference_and_oracle(case, golden_dir):
+def test_train_steps_vs_reference_and_oracle(case, golden_dir, gemm_mode):
     name, shape, alg, B, T, lengths, over = case
     fix = load_fixture(golden_dir, name)
-    args, mac, learner = build_product(case)
+    args, mac, learner = build_product(case, gemm_mode)
     _, ost = build_oracle_state(case)
     for i, ts in enumerate(TRAIN_STEPS):
         batch = seeded.make_batch(args, B, seed=100 + i, lengths=lengths)
@@ -106,7 +109,7 @@ def test_train_steps_vs_reference_and_oracle(case, golden_dir):
         # parameter whose gradient is ~0 moves by lr * g / (sqrt(v) + 1e-8) with v ~ g^2): 1e-3 for steps 1 / 200 / 201 - the
         # achieved errors are ~1e-7 of scale, so a 1e-3 regression after the target sync is caught
         rt = 1e-4 if i == 0 else 1e-3
-        c = "train:%s/step%d" % (name, ts)
+        c = "train:%s[%s]/step%d" % (name, gemm_mode, ts)
         parity.close(c, "loss vs reference", loss, fix["losses"][i], tol=rt)
         parity.close(c, "loss vs oracle", loss, oloss, tol=rt)
         assert learner.max_episode_len == ointer["T"]

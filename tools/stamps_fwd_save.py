@@ -28,7 +28,8 @@ u = torch.randint(0, A, (B, T, N), device=dev, dtype=torch.int32)
 q = torch.empty(B, T, N, A, device=dev); hl = torch.empty(B * N, 64, device=dev)
 saved = torch.empty(ops.saved_shape(T, B, N), device=dev); gi = torch.empty(ops.saved_shape(T, B, N, planes=3), device=dev)
 for mode in ("0", "1"):
-    os.environ["MARL_FWD_DMA"] = mode
+    from marl_amd import experiments
+    experiments.set("fwd_dma", int(mode))
     for _ in range(2):
         buf.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -25,7 +25,8 @@ W["b2_w"] = torch.randn(1, E, generator=g).to(dev); W["b2_b"] = torch.randn(1, g
 sd = torch.zeros(R, 324, device=dev); sd[:, :S] = torch.randn(R, S, device=dev)
 q = torch.randn(R, N, device=dev); out = torch.empty(R, device=dev)
 if len(sys.argv) > 2:
-    os.environ["MARL_WIDE_RES32"] = sys.argv[2]
+    from marl_amd import experiments
+    experiments.set("wide_res32", int(sys.argv[2]))
 for _ in range(3):
     buf.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
