@@ -194,7 +194,8 @@ class KernelTimers:
         self._orig[name] = orig
 
         def timed(*a, **k):
-            m = model(a, k) if self.on else None
+            # (never inside a hipGraph capture: an event recorded there belongs to the graph and cannot be timed)
+            m = model(a, k) if (self.on and not torch.cuda.is_current_stream_capturing()) else None
             if m is None:
                 return orig(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -44,6 +44,8 @@ struct BX6Args {
   float* ws;               // [n_wg][slab]
   int B, T, N, A;
   long R;
+  long tile_base;          // first row tile of this launch (a batch may run as two launches: full rounds of two-tile workgroups, then
+  int slab_base;           // one round of one-tile workgroups) and its first slab
 };
 
 __host__ __device__ inline long slab_floats(int A) { return 2L * 192 * 64 + (long)A * 64 + 2 * 192 + A; }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   float* BS = reinterpret_cast<float*>(XM + 512);               // [4][256]: team R's bias sums, one slot per thread
 
   const long NTILES = (a.R + 15) >> 4;
-  const long tile0 = (long)NT * blockIdx.x;
+  const long tile0 = (long)NT * blockIdx.x + a.tile_base;
   const long tl[2] = {tile0, tile0 + 1 < NTILES ? tile0 + 1 : tile0};      // (a missing second tile reads the first: its gradients are zero)
   if (tid < 16 * NT) {
     const long rho = tile0 * 16 + tid;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
           if (rho >= 0) a.dh0[(long)rho * H + u] = carry[tt][r];
         }
     }
-    float* slab = a.ws + (long)blockIdx.x * slab_floats(a.A);
+    float* slab = a.ws + ((long)blockIdx.x + a.slab_base) * slab_floats(a.A);
     float bs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -416,54 +418,51 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     for (int t = T - 1; t >= 0; --t) {
       const int par = t & 1;
       const char* img = Gt;
-      WG_BARRIER();
+      WG_BARRIER();                                  // first barrier of the step: the image holds the gate gradients of step t
       ST_MARK(0);
-      int rb, tb0, tb1;
-      lane_parts(rb, tb0, tb1);
-      if (t > 0) publish(t - 1);                     // (loaded during the previous step; the buffers were last read before this barrier)
-      if (t > 1) xhload(t - 2);
-      __builtin_amdgcn_sched_barrier(0);
-      // dW_ih[this wave's 16 columns of r | z | n][all 64] += [drp | dzp | dnp]^T x ;  dW_hh[...] += [drp | dzp | dhn]^T h_prev
-      {
-        const FWT ar = g_colsn<NT>(img, rb, 0 * 64 + 16 * s), az = g_colsn<NT>(img, rb, 1 * 64 + 16 * s);
-        {
-          const FWT an = g_colsn<NT>(img, rb, 2 * 64 + 16 * s);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const FWT xb = fr_getn<NT>(XB + par * FRB, c, lane);
-#define OP(p_, q_) accI[0][c] = mmx(ar.p_, xb.q_, accI[0][c]); accI[1][c] = mmx(az.p_, xb.q_, accI[1][c]); accI[2][c] = mmx(an.p_, xb.q_, accI[2][c]);
-            X6_TERMS(OP)
-#undef OP
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        ST_MARK(1);
-        {
-          const FWT an = g_colsn<NT>(img, rb, 3 * 64 + 16 * s);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const FWT hb = fr_getn<NT>(HB + par * FRB, c, lane);
-#define OP(p_, q_) accH[0][c] = mmx(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mmx(az.p_, hb.q_, accH[1][c]); accH[2][c] = mmx(an.p_, hb.q_, accH[2][c]);
-            X6_TERMS(OP)
-#undef OP
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      ST_MARK(2);
-      // dW_2[action][this wave's 16 columns] += dq(t-1)^T h(t-1): h(t-1) = h_prev of THIS step (HB[par], stable until the next barrier).
-      // Lane (g, i): action i, k slots = rows 4g .. 4g+3 of tile 0, then of tile 1
-      if (t > 0) dw2(QT + ((t - 1) % 3) * 32, fr_getn<NT>(HB + par * FRB, s, lane));
-      WG_BARRIER();                                  // second barrier of the step (the image has been read)
-      // the steps to come: the dq pairs of step t-2 handed over
+      // the steps to come: the dq pairs of step t-2 handed over (their slot's previous content - step t+1 - was last read before
+      // this barrier: team R's gate gradients of step t+1 and this team's dW_2 product of step t+2)
       if (ti < 16 * NT) {
         if (t >= 2) QT[((t - 2) % 3) * 32 + ti] = qn;
         qn = qload(ti, t - 3);
       }
+      int rb, tb0, tb1;
+      lane_parts(rb, tb0, tb1);
+      // ALL of this step's image fragments go to registers first (48 at NT = 2), so that the second barrier - "the image has been
+      // read" - can come BEFORE this team's 150 products: they then run while team R computes the gate gradients of step t-1 (vector
+      // work that used to leave the matrix pipe idle with this team parked at the barrier) and refills the image
+      const FWT ar = g_colsn<NT>(img, rb, 0 * 64 + 16 * s), az = g_colsn<NT>(img, rb, 1 * 64 + 16 * s);
+      const FWT ani = g_colsn<NT>(img, rb, 2 * 64 + 16 * s), anh = g_colsn<NT>(img, rb, 3 * 64 + 16 * s);
+      if (t > 0) publish(t - 1);                     // (loaded during the previous step; the buffers were last read before this barrier)
+      if (t > 1) xhload(t - 2);
+      WG_BARRIER();                                  // second barrier of the step (waits for the LDS reads above: the image may be refilled)
+      ST_MARK(1);
+      __builtin_amdgcn_sched_barrier(0);
+      // dW_ih[this wave's 16 columns of r | z | n][all 64] += [drp | dzp | dnp]^T x ;  dW_hh[...] += [drp | dzp | dhn]^T h_prev
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const FWT xb = fr_getn<NT>(XB + par * FRB, c, lane);
+#define OP(p_, q_) accI[0][c] = mmx(ar.p_, xb.q_, accI[0][c]); accI[1][c] = mmx(az.p_, xb.q_, accI[1][c]); accI[2][c] = mmx(ani.p_, xb.q_, accI[2][c]);
+        X6_TERMS(OP)
+#undef OP
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ST_MARK(2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const FWT hb = fr_getn<NT>(HB + par * FRB, c, lane);
+#define OP(p_, q_) accH[0][c] = mmx(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mmx(az.p_, hb.q_, accH[1][c]); accH[2][c] = mmx(anh.p_, hb.q_, accH[2][c]);
+        X6_TERMS(OP)
+#undef OP
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // dW_2[action][this wave's 16 columns] += dq(t-1)^T h(t-1): h(t-1) = h_prev of THIS step (HB[par], stable until the barrier after
+      // the next).  Lane (g, i): action i, k slots = rows 4g .. 4g+3 of tile 0, then of tile 1
+      if (t > 0) dw2(QT + ((t - 1) % 3) * 32, fr_getn<NT>(HB + par * FRB, s, lane));
       ST_MARK(3);
     }
     ST_DUMP(4);
-    float* slab = a.ws + (long)blockIdx.x * slab_floats(a.A);
+    float* slab = a.ws + ((long)blockIdx.x + a.slab_base) * slab_floats(a.A);
 #pragma unroll
     for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -526,13 +525,23 @@ extern "C" int marl_agent_unroll_bwd_x6_supported(int B, int T, int N, int A, in
   return 1;
 }
 
-// row tiles per workgroup: one while that fills at most one round of workgroups (the small shards), two beyond
-static int bx6_nt(long R) { return (R + 15) / 16 <= 256 ? 1 : 2; }
+// Workgroups of a batch of R rows: up to 256 row tiles run one tile per workgroup (the small shards: one round of workgroups);
+// beyond that two tiles per workgroup in FULL rounds of 256 workgroups, and when what is left fits one round of one-tile workgroups
+// (at most 256 tiles) it runs as such - a second launch of the one-tile instantiation, whose step is ~0.65 of the two-tile one's
+// (4096 envs x 5 agents = 1280 tiles: 512 two-tile workgroups + 256 one-tile ones instead of 640 = 2.5 rounds of two-tile ones)
+static void bx6_plan(long R, long& n2, long& n1) {
+  const long tiles = (R + 15) / 16;
+  if (tiles <= 256) { n2 = 0; n1 = tiles; return; }
+  n2 = tiles / 512 * 256;
+  const long rem = tiles - 2 * n2;
+  if (n2 > 0 && rem > 0 && rem <= 256) { n1 = rem; return; }
+  n2 = (tiles + 1) / 2; n1 = 0;
+}
 
 extern "C" size_t marl_agent_bwd_x6_workspace(int B, int N, int A) {
-  const long R = (long)B * N;
-  const int nt = bx6_nt(R);
-  return (size_t)((R + 16 * nt - 1) / (16 * nt)) * slab_floats(A) * sizeof(float);
+  long n2, n1;
+  bx6_plan((long)B * N, n2, n1);
+  return (size_t)(n2 + n1) * slab_floats(A) * sizeof(float);
 }
 
 extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int* dq_idx, const float* dq_val, const int* dq_idx2,
@@ -548,22 +557,28 @@ extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int
   a.dq_idx = dq_idx; a.dq_val = dq_val; a.dq_idx2 = dq_idx2; a.dq_val2 = dq_val2; a.dq_gdiv = dq_gdiv > 1 ? dq_gdiv : 1;
   a.dhs = dhs; a.saved = saved; a.dxp = dxp; a.dh0 = dh0; a.ws = ws;
   a.B = B; a.T = T; a.N = N; a.A = A; a.R = (long)B * N;
-  const int nt = bx6_nt(a.R);
-  const unsigned nwg = (unsigned)((a.R + 16 * nt - 1) / (16 * nt));
+  long n2, n1;
+  bx6_plan(a.R, n2, n1);
   const size_t lds = (size_t)GBUF + 8 * FRB + 32 * H * 4 + 3 * 32 * 16 + 2 * 32 * 4 + 2 * 256 * 4 + 4 * 256 * 4;
 #define BX6_PICK(NT_) (dhs ? (dq_idx2 ? (const void*)agent_bwd_x6_kernel<true, true, NT_> : (const void*)agent_bwd_x6_kernel<true, false, NT_>) \
                            : (dq_idx2 ? (const void*)agent_bwd_x6_kernel<false, true, NT_> : (const void*)agent_bwd_x6_kernel<false, false, NT_>))
-  const void* fn = nt == 1 ? BX6_PICK(1) : BX6_PICK(2);
-#undef BX6_PICK
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
   hipStream_t st = (hipStream_t)stream;
-  void* kargs[] = {(void*)&a};
-  e = hipLaunchKernel(fn, dim3(nwg), dim3(BNT), kargs, lds, st);
-  if (e != hipSuccess) return (int)e;
-  MARL_CHECK_LAUNCH();
+  for (int pass = 0; pass < 2; ++pass) {
+    const long nwg = pass == 0 ? n2 : n1;
+    if (nwg == 0) continue;
+    const void* fn = pass == 0 ? BX6_PICK(2) : BX6_PICK(1);
+    a.tile_base = pass == 0 ? 0 : 2 * n2;
+    a.slab_base = pass == 0 ? 0 : (int)n2;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    void* kargs[] = {(void*)&a};
+    e = hipLaunchKernel(fn, dim3((unsigned)nwg), dim3(BNT), kargs, lds, st);
+    if (e != hipSuccess) return (int)e;
+    MARL_CHECK_LAUNCH();
+  }
+#undef BX6_PICK
   RedArgs r;
-  r.ws = ws; r.nwg = (int)nwg; r.A = A;
+  r.ws = ws; r.nwg = (int)(n2 + n1); r.A = A;
   r.dWih = g->w_ih; r.dWhh = g->w_hh; r.dW2 = g->fc2_w; r.dbih = g->b_ih; r.dbhh = g->b_hh; r.db2 = g->fc2_b;
   const long slab = slab_floats(A);
   hipLaunchKernelGGL(agent_bwd_x6_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, st, r);

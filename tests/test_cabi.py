@@ -73,7 +73,11 @@ def test_split_kernel_capability_predicates():
     assert bwd(512, 120, 5, 11) == 1 and bwd(1024, 120, 10, 18) == 1 and bwd(512, 150, 8, 14) == 1
     assert bwd(512, 120, 5, 11, 0) == 0             # a dense dq: the fp32 kernels
     assert bwd(512, 2, 5, 11) == 0 and bwd(512, 120, 5, 40) == 0
-    # workspace: one slab per 16 rows up to 256 row tiles, per 32 rows beyond
+    # workspace: one slab per workgroup - one row tile (16 rows) per workgroup up to 256 tiles; beyond that two-tile workgroups in
+    # full rounds of 256, and what is left as one-tile workgroups when that is at most one round, else two-tile workgroups throughout
     slab = 4 * (2 * 192 * 64 + 11 * 64 + 2 * 192 + 11)
     assert lib.marl_agent_bwd_x6_workspace(512, 5, 11) == (512 * 5 // 16) * slab
-    assert lib.marl_agent_bwd_x6_workspace(4096, 5, 11) == (4096 * 5 // 32) * slab
+    assert lib.marl_agent_bwd_x6_workspace(4096, 5, 11) == (512 + 256) * slab          # 1280 tiles = 2 x 512 + 256
+    assert lib.marl_agent_bwd_x6_workspace(2048, 5, 11) == (256 + 128) * slab          # 640 tiles = 512 + 128
+    assert lib.marl_agent_bwd_x6_workspace(3000, 5, 11) == 469 * slab                  # 938 tiles = 512 + 426: two-tile workgroups throughout
+    assert lib.marl_agent_bwd_x6_workspace(1024, 5, 11) == 160 * slab                  # 320 tiles: less than one full round of two-tile workgroups
