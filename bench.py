@@ -125,10 +125,13 @@ class KernelTimers:
             f = 2.0 * M * Nn * K
             return ("linear M=%d N=%d K=%d (generic GEMM)" % (M, Nn, K), "linear_kernel", f, f, 4.0 * M * (Nn + K))
 
-        def qmix(mult, label, roc):
+        def qmix(mult, label, roc, loss=False):
             def m(ar, kw):
                 rows, N_, S_, E_ = ar[-4], ar[-3], ar[-2], ar[-1]
                 f = 2.0 * rows * S_ * (N_ * E_ + 3 * E_) * mult
+                if kw.get("x6"):      # the split variant: template arguments <BWD, 8 waves, LOSS, X6 = true>
+                    name = "qmix_fused_kernel<%s, 8, %s, true>" % ("true" if mult > 1 else "false", "true" if loss else "false")
+                    return (label + ", fp32 products as six bf16 MFMA products", name, f, f, 4.0 * rows * (S_ + N_ + 1), True)
                 return (label, roc, f, f, 4.0 * rows * (S_ + N_ + 1))
             return m
 
@@ -175,7 +178,7 @@ class KernelTimers:
         self.models = {"agent_unroll_fwd": fwd, "agent_unroll_fwd_x6": fwd_x6, "agent_unroll_bwd": bwd, "linear_wgrad": wgrad, "linear": lin,
                        "qmix_fused_fwd": qmix(1, "qmix_fused_kernel forward (target mixer)", "qmix_fused_kernel<false"),
                        "qmix_fused_bwd": qmix(2, "qmix_fused_kernel backward", "qmix_fused_kernel<true"),
-                       "qmix_fused_loss_bwd": qmix(2, "qmix_fused_kernel forward + TD loss + backward", "qmix_fused_kernel<true"),
+                       "qmix_fused_loss_bwd": qmix(2, "qmix_fused_kernel forward + TD loss + backward", "qmix_fused_kernel<true", loss=True),
                        "qmix_wide_fwd": wide_fwd,
                        "qmix_wide_bwd": qmix_kw(2, "qmix_wide backward (recompute + d(out)) + weight-gradient GEMM", "qmix_wide", 6),
                        "qmix_wide_loss_bwd": qmix_kw(2, "qmix_wide forward + TD loss + backward + weight-gradient GEMM", "qmix_wide", 12),
@@ -202,7 +205,8 @@ class KernelTimers:
             e0.record()
             r = orig(*a, **k)
             e1.record()
-            self.rec.setdefault(m[0], {"roc": m[1], "ev": [], "exec": m[2], "alg": m[3], "bytes": m[4], "call": name})["ev"].append((e0, e1))
+            self.rec.setdefault(m[0], {"roc": m[1], "ev": [], "exec": m[2], "alg": m[3], "bytes": m[4], "call": name,
+                                       "x6": ("x6" in m[1]) or (len(m) > 5 and bool(m[5]))})["ev"].append((e0, e1))
             return r
         setattr(self.ops, name, timed)
 
@@ -214,7 +218,7 @@ class KernelTimers:
             ms = [a.elapsed_time(b) for a, b in r["ev"]]
             avg = float(np.mean(ms))
             tf = r["exec"] / (avg * 1e-3) / 1e12
-            e = {"name": label, "rocprof_name": r["roc"], "call": r["call"], "launches_timed": len(ms), "ms": avg, "total_ms": float(np.sum(ms)),
+            e = {"name": label, "rocprof_name": r["roc"], "call": r["call"], "x6": r["x6"], "launches_timed": len(ms), "ms": avg, "total_ms": float(np.sum(ms)),
                  "executed_flop": r["exec"], "algorithmic_flop": r["alg"], "tflops": tf, "frac": tf / PEAK_F32_TFLOPS,
                  "algorithmic_bytes": r["bytes"], "hbm_gb": None, "hbm_frac": None}
             rows.append(e)
@@ -379,7 +383,7 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=12
            "kernels": [{k: e[k] for k in ("name", "launches_timed", "ms", "executed_flop", "frac")} for e in kern[:5]]}
     if kern:
         d = kern[0]
-        x6k = "x6" in d["rocprof_name"]
+        x6k = d["x6"]
         peak = PEAK_BF16_TFLOPS / 6.0 if x6k else PEAK_F32_TFLOPS
         hit = pmc_traffic(pmc, d)
         out["roofline"] = {"bound": "mfma", "kernel": d["name"], "rocprof_name": d["rocprof_name"], "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s",
@@ -756,7 +760,7 @@ def roofline_object(kern, pmc, pmc_path, steps):
         if hit:
             e["hbm_gb"] = hit["hbm_bytes_per_launch"] / 1e9
             e["hbm_frac"] = hit["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
-            if "SQ_INSTS_MFMA" in hit and "x6" not in e["rocprof_name"]:
+            if "SQ_INSTS_MFMA" in hit and not e["x6"]:
                 e["mfma_flop_pmc"] = hit["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
     roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
     if not kern:
@@ -768,12 +772,12 @@ def roofline_object(kern, pmc, pmc_path, steps):
                 traffic_unit="HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes; %s)" % pmc_path,
                 what="executed FLOP (tile padding excluded) of the kernel with the largest total time in the timed region")
     for e in kern:      # a split kernel is priced against ITS peak: six bf16 products per fp32 product
-        if "x6" in e["rocprof_name"]:
+        if e["x6"]:
             e["frac"] = e["tflops"] / (PEAK_BF16_TFLOPS / 6.0)
             e["peak"] = PEAK_BF16_TFLOPS / 6.0
     roof["kernels"] = [{k: e.get(k) for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "peak", "hbm_gb", "hbm_frac")}
                        for e in kern[:6]]
-    if "x6" in d["rocprof_name"]:
+    if d["x6"]:
         roof.update(peak=PEAK_BF16_TFLOPS / 6.0, frac=d["tflops"] / (PEAK_BF16_TFLOPS / 6.0),
                     peak_note="dense bf16 MFMA peak / 6: a bf16x6 split spends six bf16 products per fp32 product")
     un = [e for e in kern if e["rocprof_name"] in ("agent_fwd", "agent_fwd_x6")]

@@ -195,6 +195,20 @@ int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, 
                              const float* r, const float* term, const float* padded, float gamma, float* q_tot,
                              float* dq, const marl_qmix_weights_t* grads, float* loss2, float* ws, size_t ws_bytes,
                              long rows, int N, int S, int E, void* stream);
+/* The same three entry points with the two GEMMs of a tile - hypernet output (network/mixer.py:60-77) and the hypernet weight
+ * gradient - as bf16x6 split products (args.gemm_mode = "bf16x6"; see the agent_x6 / mlp3_x6 blocks for the arithmetic: every fp32
+ * operand split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate).  Same arguments, same
+ * workspace, same supported shapes, same epilogue arithmetic; results differ from the fp32-MFMA entry points by summation order
+ * and the dropped <= 2^-24 terms only. */
+int marl_qmix_fused_fwd_x6(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
+                           long rows, int N, int S, int E, void* stream);
+int marl_qmix_fused_bwd_x6(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot,
+                           float* dq, const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows,
+                           int N, int S, int E, void* stream);
+int marl_qmix_fused_loss_bwd_x6(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* q_tot_tgt,
+                                const float* r, const float* term, const float* padded, float gamma, float* q_tot,
+                                float* dq, const marl_qmix_weights_t* grads, float* loss2, float* ws, size_t ws_bytes,
+                                long rows, int N, int S, int E, void* stream);
 
 /* Fused QMIX for WIDE states (qmix_wide.hip; MMM2: S = 322, N = 10 -> a 416 x 322 concatenated hypernet that does not fit
  * the registers-resident design above): the weights are packed per call into MFMA-fragment order (L2 resident) and

@@ -95,6 +95,9 @@ SIGNATURES = {
     "marl_qmix_fused_fwd": (I, [QW, SRC, P, P, L, I, I, I, P]),
     "marl_qmix_fused_bwd": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, P]),
     "marl_qmix_fused_loss_bwd": (I, [QW, SRC, P, P, P, P, P, F, P, P, QW, P, P, SZ, L, I, I, I, P]),
+    "marl_qmix_fused_fwd_x6": (I, [QW, SRC, P, P, L, I, I, I, P]),
+    "marl_qmix_fused_bwd_x6": (I, [QW, SRC, P, P, P, QW, P, SZ, L, I, I, I, P]),
+    "marl_qmix_fused_loss_bwd_x6": (I, [QW, SRC, P, P, P, P, P, F, P, P, QW, P, P, SZ, L, I, I, I, P]),
     "marl_qmix_wide_supported": (I, [I, I, I]),
     "marl_qmix_wide_workspace": (SZ, [L, I, I, I]),
     "marl_qmix_wide_fwd_kernel": (C.c_char_p, [L, I, I, I]),

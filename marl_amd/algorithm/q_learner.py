@@ -119,7 +119,7 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
             shifted = on is oc and on_bs == oc_bs and on_t0 == oc_t0 + 1
             split = self.pair.chain_split(B * N, T, a.obs_shape)
             from .. import experiments
-            if shifted and ((self.eval_net.unroll_x6(B, T) and experiments.get("fwd_xs") != 0) or
+            if shifted and ((self.eval_net.unroll_x6(B, T, oc) and experiments.get("fwd_xs") != 0) or
                             ops.agent_unroll_reuse_supported(B, T, N, a.obs_shape, A, split[0] if split else 256)):
                 gi = g("gi", ops.saved_shape(T, B, N, planes=3))
             cont = lambda cu: self.eval_net.unroll(on, on_bs, on_t0, db.u_fed, db.u_bs, 0, B, T, q_en, None, h_scr, None, h0=h_last,

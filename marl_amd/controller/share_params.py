@@ -106,11 +106,13 @@ class SharedMAC:
         return torch.argmax(q_value)
 
     # ------------------------------------------------------------------ batched primitives
-    def unroll_x6(self, B, T):
-        """True when a T-step unroll over B episodes runs on the bf16x6 split kernel (args.gemm_mode = "bf16x6" and a shape
-        csrc/agent_x6.hip covers)."""
+    def unroll_x6(self, B, T, obs=None):
+        """True when a T-step unroll over B episodes runs on the bf16x6 split kernel (args.gemm_mode = "bf16x6", a shape
+        csrc/agent_x6.hip covers and - when given - an observation tensor on a 16-byte boundary: a misaligned view takes the
+        fp32 kernels instead of failing in the entry point)."""
         from ..network import mixer as _mixer
         return (T >= 4 and getattr(self.args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6"
+                and (obs is None or obs.data_ptr() % 16 == 0)
                 and ops.agent_unroll_x6_supported(B, T, self.n_agents, self.obs_shape, self.n_actions, self.args.last_action,
                                                   self.args.reuse_network))
 
@@ -121,7 +123,7 @@ class SharedMAC:
         N, A, O = self.n_agents, self.n_actions, self.obs_shape
         if h0 == "state":
             h0 = None if self.hidden_states is None else self.hidden_states.reshape(B * N, -1).contiguous()
-        if self.unroll_x6(B, T):
+        if self.unroll_x6(B, T, obs):
             # opt-in: every product of the unroll as six bf16 MFMA products (csrc/agent_x6.hip); same `saved` layout, so the
             # fp32 BPTT kernel runs from it; gi_out / gi_in pair up because every unroll of these dimensions comes here
             ops.agent_unroll_fwd_x6(self.agent.weights(), obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved,

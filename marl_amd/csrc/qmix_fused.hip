@@ -18,7 +18,13 @@
 // tile is its MFMA cycles PLUS the issue cycles of everything else: the point of this deal is the instruction count
 // (the by-segment deal it replaces needed ~3x the VALU instructions, LDS round trips for a_e and a second barrier).
 // Supported when E == 32, N <= 5 and S <= 128 (QMIX on 2s3z / matrix game); wide states: qmix_wide.hip.
-#include "common.h"
+// X6 (the *_x6 entry points, args.gemm_mode = "bf16x6"): the two GEMMs of a tile - hypernet output and dW - with every fp32 product as
+// six bf16 MFMA products (x6.h).  Same column deal, same epilogue, same accumulator layouts: the state tile lives in LDS as three
+// bf16 planes (each element split once, where the tile is stashed), the weights are pre-split B fragments in registers
+// (v_mfma_f32_16x16x32_bf16, four 32-wide k chunks), and the weight gradient contracts over the tile's 16 rows on
+// v_mfma_f32_16x16x16_bf16: its A operand IS split4(d(out)) of the accumulator layout, its B operand comes from the row-major
+// state planes through transposed LDS reads (ds_read_b64_tr_b16: rows 4g .. 4g+3 of a column per lane).
+#include "x6.h"
 #include "../../include/marl_hip.h"
 
 namespace {
@@ -27,6 +33,7 @@ constexpr int E = 32;
 constexpr int KCQ = 8;            // k-chunks of 16 (S padded to 128)
 constexpr int SS = 128 + 4;       // LDS row stride of the state tile
 constexpr int NAG = 5;            // agent groups (N <= 5); groups 5, 6, 7 = b1, w2, h
+constexpr int PP = 136;           // X6: pitch (bf16 elements) of the state planes: 272-byte rows spread the 16-byte fragment reads of a 16-lane group over all banks
 
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -87,11 +94,22 @@ __device__ __forceinline__ float sign_clamp(float x, float lo) { return __builti
 //     target = r + gamma q_tot_target (1 - terminated),  td = mask (target - q_tot),  dL/dq_tot = -2 mask td
 // with mask = 1 - padded (un-normalised: the division by the global sum(mask) is folded into the optimizer step); the loss
 // numerator and sum(mask) go through the slab like the weight gradients (fixed summation order).
-template <bool BWD, int NW, bool LOSS = false>
+template <bool BWD, int NW, bool LOSS = false, bool X6 = false>
 __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
   static_assert(!LOSS || BWD, "the loss is folded into the backward kernel");
+  static_assert(!X6 || NW == 8, "the split variant runs eight waves (two column tiles per wave: 96 registers of pre-split weights)");
   constexpr int QNT = 64 * NW, EW = 32 / NW, GPT = 16 / EW, TPW = 8 / GPT, LT = TPW - 1;
-  __shared__ __attribute__((aligned(16))) float Ss[2][16 * SS];   // state tile, double buffered
+  // state tile, double buffered: fp32 rows, or (X6) three bf16 planes [buffer][plane][16 rows][PP]
+  constexpr int SRAW = X6 ? 2 * 3 * 16 * PP * 2 : 2 * 16 * SS * 4;
+  __shared__ __attribute__((aligned(16))) char Sraw[SRAW];
+  float (*Ss)[16 * SS] = reinterpret_cast<float (*)[16 * SS]>(Sraw);
+  short* const Sp = reinterpret_cast<short*>(Sraw);
+  constexpr int PLN = 16 * PP, PBUF = 3 * PLN;                    // elements per plane / per buffer
+  // X6 backward: the weight fragments of the last k chunk as ready fragments in LDS (the wave runs at the 256-register ceiling:
+  // 72 instead of 96 registers of weights beside 64 of dW accumulators and the epilogue's working set - no spills)
+  constexpr int KR = (X6 && BWD) ? (LOSS ? 2 : 3) : 4;            // k chunks whose fragments stay in registers
+  constexpr int KL = 4 - KR;                                      // ... and in LDS: [wave][tile][chunk][plane][lane]
+  __shared__ __attribute__((aligned(16))) i32x4 WL[KL ? NW * TPW * KL * 3 * 64 : 1];
   __shared__ __attribute__((aligned(16))) float Qt2[2][8][16];    // q tile, transposed: rows 0..4 agents, 5 = ones (b1), 6, 7 = zeros
   __shared__ __attribute__((aligned(16))) float QT[NW][16];       // per-wave partial q_tot
   __shared__ __attribute__((aligned(16))) float DQP[NW][NAG][16]; // per-wave partial dq (backward)
@@ -104,7 +122,8 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
   const bool ones = S < 128;                    // room for the ones column -> bias gradients from the dW MFMAs
 
   // ---- this lane's column in each tile: group g = GPT c + gl, mixing element e
-  f32x4 wq[TPW][KCQ];
+  f32x4 wq[X6 ? 1 : TPW][X6 ? 1 : KCQ];
+  F3 wq6[X6 ? TPW : 1][X6 ? KR : 1];      // X6: B fragments, lane (g, column of lane m): W[column][32 kc + 8g .. + 7], split once
   float bias[TPW];
   int grp[TPW];
 #pragma unroll
@@ -115,13 +134,28 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
     if (g < NAG) { if (g < N) { Wp = a.W[0] + (long)(g * E + e) * S; Bp = a.Bv[0] + g * E + e; } }
     else { Wp = a.W[g - NAG + 1] + (long)e * S; Bp = a.Bv[g - NAG + 1] + e; }
     bias[c] = Bp ? *Bp : 0.f;
+    if (X6) {
 #pragma unroll
-    for (int kc = 0; kc < KCQ; ++kc)
+      for (int kc = 0; kc < 4; ++kc) {
+        float v[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = 16 * kc + 4 * q4 + i;
-        wq[c][kc][i] = (Wp && kk < S) ? Wp[kk] : 0.f;
+        for (int jj = 0; jj < 8; ++jj) {
+          const int kk = 32 * kc + 8 * q4 + jj;
+          v[jj] = (Wp && kk < S) ? Wp[kk] : 0.f;
+        }
+        const F3 f = split8((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4], v[5], v[6], v[7]});
+        if (kc < KR) wq6[c][kc < KR ? kc : 0] = f;
+        else { i32x4* wl = WL + (((wave * TPW + c) * (KL ? KL : 1) + (kc - KR)) * 3) * 64 + lane; wl[0] = f.h; wl[64] = f.m; wl[128] = f.l; }
       }
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < KCQ; ++kc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = 16 * kc + 4 * q4 + i;
+          wq[c][kc][i] = (Wp && kk < S) ? Wp[kk] : 0.f;
+        }
+    }
   }
   const bool is6 = grp[LT] == 6, is7 = grp[LT] == 7;
   const float wb2e = a.wb2[e];
@@ -198,8 +232,15 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NPF; ++i)
-      *reinterpret_cast<f32x4*>(&Ss[buf][(fr + (QNT / 32) * i) * SS + fc4]) = pf[i];
+    for (int i = 0; i < NPF; ++i) {
+      if (X6) {                                           // split once, here: 8 bytes per plane
+        const F3h f = split4(pf[i]);
+        short* p = Sp + buf * PBUF + (fr + (QNT / 32) * i) * PP + fc4;
+        *reinterpret_cast<i32x2*>(p) = f.h;
+        *reinterpret_cast<i32x2*>(p + PLN) = f.m;
+        *reinterpret_cast<i32x2*>(p + 2 * PLN) = f.l;
+      } else *reinterpret_cast<f32x4*>(&Ss[buf][(fr + (QNT / 32) * i) * SS + fc4]) = pf[i];
+    }
   };
   // q / g elements of this thread, also one tile ahead (threads 0..16N-1: q, threads 192..207: g)
   float pq = 0.f, pg = 0.f, pl[4] = {0.f, 0.f, 0.f, 0.f};
@@ -261,15 +302,42 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
     f32x4 acc[TPW];
 #pragma unroll
     for (int c = 0; c < TPW; ++c) acc[c] = (f32x4){bias[c], bias[c], bias[c], bias[c]};
-    const float* sr = &Ss[buf][m * SS + 4 * q4];
+    if (X6) {
+      // A fragments: row m, columns 32 kc + 8g .. + 7 of each plane (one 16-byte read per plane); even / odd k chunks on
+      // separate accumulators: four independent chains for the wave's two column tiles
+      f32x4 accb[TPW];
 #pragma unroll
-    for (int kc = 0; kc < KCQ; ++kc) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(sr + 16 * kc);
-      // round robin over the wave's column tiles: back-to-back MFMAs on ONE accumulator run at 80 % of the pipe (common.h)
+      for (int c = 0; c < TPW; ++c) accb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const short* sp = Sp + buf * PBUF + m * PP + 8 * q4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int kc = 0; kc < 4; ++kc) {
+        F3 xa;
+        xa.h = *reinterpret_cast<const i32x4*>(sp + 32 * kc);
+        xa.m = *reinterpret_cast<const i32x4*>(sp + PLN + 32 * kc);
+        xa.l = *reinterpret_cast<const i32x4*>(sp + 2 * PLN + 32 * kc);
+        F3 wk[TPW];
 #pragma unroll
-        for (int c = 0; c < TPW; ++c) acc[c] = mfma16(a4[i], wq[c][kc][i], acc[c]);
+        for (int c = 0; c < TPW; ++c) {
+          if (kc < KR) wk[c] = wq6[c][kc < KR ? kc : 0];
+          else { const i32x4* wl = WL + (((wave * TPW + c) * (KL ? KL : 1) + (kc - KR)) * 3) * 64 + lane; wk[c].h = wl[0]; wk[c].m = wl[64]; wk[c].l = wl[128]; }
+        }
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < TPW; ++c) { if (kc & 1) accb[c] = mm(xa.p_, wk[c].q_, accb[c]); else acc[c] = mm(xa.p_, wk[c].q_, acc[c]); }
+        OP(m, m) OP(h, l) OP(l, h) OP(h, m) OP(m, h) OP(h, h)
+#undef OP
+      }
+#pragma unroll
+      for (int c = 0; c < TPW; ++c) acc[c] += accb[c];
+    } else {
+      const float* sr = &Ss[buf][m * SS + 4 * q4];
+#pragma unroll
+      for (int kc = 0; kc < KCQ; ++kc) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sr + 16 * kc);
+        // round robin over the wave's column tiles: back-to-back MFMAs on ONE accumulator run at 80 % of the pipe (common.h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < TPW; ++c) acc[c] = mfma16(a4[i], wq[c][kc][i], acc[c]);
+      }
     }
     ST_MARK(2);
     __builtin_amdgcn_sched_barrier(0);             // the MFMA run first, the epilogue after it (no fine interleaving)
@@ -371,16 +439,37 @@ __global__ __launch_bounds__(64 * NW, 2) void qmix_fused_kernel(QmixArgs a) {
       ST_MARK(5);
       __builtin_amdgcn_sched_barrier(0);
       // ---- dW += d(out)^T [s | 1]
-      const float* sd = &Ss[buf][(4 * q4) * SS + m];
+      if (X6) {
+        // contraction over the tile's 16 rows on v_mfma_f32_16x16x16_bf16 (k slot j of lane (g, .) = row 4g + j): the A operand is
+        // split4 of d(out) as it sits in the accumulator layout; the B operand (rows 4g .. 4g+3 of state column 16 kc + lane) comes
+        // from the row-major planes by transposed reads: lane (g, i = 4 qq + p) passes &plane[4g + qq][16 kc + 4p]
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        F3h dA[TPW];
 #pragma unroll
-      for (int kc = 0; kc < KCQ; ++kc) {
-        f32x4 sD;
+        for (int c = 0; c < TPW; ++c) dA[c] = split4(dhy[c]);
+        const short* tb = Sp + buf * PBUF + (4 * q4 + (m >> 2)) * PP + 4 * (m & 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sD[i] = sd[i * SS + 16 * kc];
+        for (int kc = 0; kc < KCQ; ++kc) {
+          F3h sb;
+          sb.h = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 16 * kc)));
+          sb.m = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + PLN + 16 * kc)));
+          sb.l = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 2 * PLN + 16 * kc)));
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < TPW; ++c) accW[c][kc] = mmh(dA[c].p_, sb.q_, accW[c][kc]);
+          OP(m, m) OP(h, l) OP(l, h) OP(h, m) OP(m, h) OP(h, h)
+#undef OP
+        }
+      } else {
+        const float* sd = &Ss[buf][(4 * q4) * SS + m];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int kc = 0; kc < KCQ; ++kc) {
+          f32x4 sD;
 #pragma unroll
-          for (int c = 0; c < TPW; ++c) accW[c][kc] = mfma16(dhy[c][i], sD[i], accW[c][kc]);
+          for (int i = 0; i < 4; ++i) sD[i] = sd[i * SS + 16 * kc];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) accW[c][kc] = mfma16(dhy[c][i], sD[i], accW[c][kc]);
+        }
       }
       prow0 = row0;
     }
@@ -513,24 +602,35 @@ extern "C" size_t marl_qmix_fused_workspace(long rows, int N, int S) {
   return (size_t)grid_for(rows) * qmix_slab_floats(N * E + 3 * E, S) * sizeof(float);
 }
 
-extern "C" int marl_qmix_fused_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
-                                   long rows, int N, int S, int Eq, void* stream) {
+static int qmix_fwd_impl(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
+                         long rows, int N, int S, int Eq, bool x6, void* stream) {
   if (rows <= 0) return 0;
   if (!supported(N, S, Eq)) return (int)hipErrorInvalidValue;
   QmixArgs a;
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
   a.g = nullptr; a.q_tot = q_tot; a.dq = nullptr; a.ws = nullptr;
   a.lr = a.lterm = a.lpadded = a.lq_tgt = nullptr; a.gamma = 0.f;
-  hipLaunchKernelGGL((qmix_fused_kernel<false, 4>), dim3(grid_for(rows, 2)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (x6) hipLaunchKernelGGL((qmix_fused_kernel<false, 8, false, true>), dim3(grid_for(rows, 1)), dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((qmix_fused_kernel<false, 4>), dim3(grid_for(rows, 2)), dim3(256), 0, (hipStream_t)stream, a);
   MARL_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int marl_qmix_fused_fwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
+                                   long rows, int N, int S, int Eq, void* stream) {
+  return qmix_fwd_impl(w, s, q, q_tot, rows, N, S, Eq, false, stream);
+}
+extern "C" int marl_qmix_fused_fwd_x6(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, float* q_tot,
+                                      long rows, int N, int S, int Eq, void* stream) {
+  return qmix_fwd_impl(w, s, q, q_tot, rows, N, S, Eq, true, stream);
+}
 
 static int qmix_bwd_launch(QmixArgs& a, const marl_qmix_weights_t* grads, float* loss2, float* ws, long rows, int N, int S,
-                           bool loss, hipStream_t st) {
+                           bool loss, bool x6, hipStream_t st) {
   const unsigned nwg = grid_for(rows);
-  if (loss) hipLaunchKernelGGL((qmix_fused_kernel<true, 8, true>), dim3(nwg), dim3(512), 0, st, a);
+  if (x6) {
+    if (loss) hipLaunchKernelGGL((qmix_fused_kernel<true, 8, true, true>), dim3(nwg), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((qmix_fused_kernel<true, 8, false, true>), dim3(nwg), dim3(512), 0, st, a);
+  } else if (loss) hipLaunchKernelGGL((qmix_fused_kernel<true, 8, true>), dim3(nwg), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((qmix_fused_kernel<true, 8, false>), dim3(nwg), dim3(512), 0, st, a);
   MARL_CHECK_LAUNCH();
   QmixRedArgs r;
@@ -546,9 +646,9 @@ static int qmix_bwd_launch(QmixArgs& a, const marl_qmix_weights_t* grads, float*
   return 0;
 }
 
-extern "C" int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
-                                   const float* dq_tot, float* dq, const marl_qmix_weights_t* grads, float* ws,
-                                   size_t ws_bytes, long rows, int N, int S, int Eq, void* stream) {
+static int qmix_bwd_impl(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q, const float* dq_tot, float* dq,
+                         const marl_qmix_weights_t* grads, float* ws, size_t ws_bytes, long rows, int N, int S, int Eq, bool x6,
+                         void* stream) {
   if (rows <= 0) return 0;
   if (!supported(N, S, Eq)) return (int)hipErrorInvalidValue;
   if (ws_bytes < marl_qmix_fused_workspace(rows, N, S)) return (int)hipErrorInvalidValue;
@@ -556,14 +656,24 @@ extern "C" int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
   a.g = dq_tot; a.q_tot = nullptr; a.dq = dq; a.ws = ws;
   a.lr = a.lterm = a.lpadded = a.lq_tgt = nullptr; a.gamma = 0.f;
-  return qmix_bwd_launch(a, grads, nullptr, ws, rows, N, S, false, (hipStream_t)stream);
+  return qmix_bwd_launch(a, grads, nullptr, ws, rows, N, S, false, x6, (hipStream_t)stream);
+}
+extern "C" int marl_qmix_fused_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
+                                   const float* dq_tot, float* dq, const marl_qmix_weights_t* grads, float* ws,
+                                   size_t ws_bytes, long rows, int N, int S, int Eq, void* stream) {
+  return qmix_bwd_impl(w, s, q, dq_tot, dq, grads, ws, ws_bytes, rows, N, S, Eq, false, stream);
+}
+extern "C" int marl_qmix_fused_bwd_x6(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
+                                      const float* dq_tot, float* dq, const marl_qmix_weights_t* grads, float* ws,
+                                      size_t ws_bytes, long rows, int N, int S, int Eq, void* stream) {
+  return qmix_bwd_impl(w, s, q, dq_tot, dq, grads, ws, ws_bytes, rows, N, S, Eq, true, stream);
 }
 
-extern "C" int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
-                                        const float* q_tot_tgt, const float* r, const float* term, const float* padded,
-                                        float gamma, float* q_tot, float* dq, const marl_qmix_weights_t* grads,
-                                        float* loss2, float* ws, size_t ws_bytes, long rows, int N, int S, int Eq,
-                                        void* stream) {
+static int qmix_loss_bwd_impl(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
+                              const float* q_tot_tgt, const float* r, const float* term, const float* padded,
+                              float gamma, float* q_tot, float* dq, const marl_qmix_weights_t* grads,
+                              float* loss2, float* ws, size_t ws_bytes, long rows, int N, int S, int Eq, bool x6,
+                              void* stream) {
   if (rows <= 0) return 0;
   if (!supported(N, S, Eq) || !q_tot_tgt || !r || !term || !padded || !loss2) return (int)hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(q_tot) & 15) return (int)hipErrorInvalidValue;       // written 16 bytes per lane
@@ -572,5 +682,19 @@ extern "C" int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl
   if (fill(a, w, s, q, rows, N, S)) return (int)hipErrorInvalidValue;
   a.g = nullptr; a.q_tot = q_tot; a.dq = dq; a.ws = ws;
   a.lr = r; a.lterm = term; a.lpadded = padded; a.lq_tgt = q_tot_tgt; a.gamma = gamma;
-  return qmix_bwd_launch(a, grads, loss2, ws, rows, N, S, true, (hipStream_t)stream);
+  return qmix_bwd_launch(a, grads, loss2, ws, rows, N, S, true, x6, (hipStream_t)stream);
+}
+extern "C" int marl_qmix_fused_loss_bwd(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
+                                        const float* q_tot_tgt, const float* r, const float* term, const float* padded,
+                                        float gamma, float* q_tot, float* dq, const marl_qmix_weights_t* grads,
+                                        float* loss2, float* ws, size_t ws_bytes, long rows, int N, int S, int Eq,
+                                        void* stream) {
+  return qmix_loss_bwd_impl(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, ws, ws_bytes, rows, N, S, Eq, false, stream);
+}
+extern "C" int marl_qmix_fused_loss_bwd_x6(const marl_qmix_weights_t* w, const marl_src_t* s, const float* q,
+                                           const float* q_tot_tgt, const float* r, const float* term, const float* padded,
+                                           float gamma, float* q_tot, float* dq, const marl_qmix_weights_t* grads,
+                                           float* loss2, float* ws, size_t ws_bytes, long rows, int N, int S, int Eq,
+                                           void* stream) {
+  return qmix_loss_bwd_impl(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, ws, ws_bytes, rows, N, S, Eq, true, stream);
 }

@@ -61,6 +61,10 @@ class _Precision:
     def _bf16(self):
         return getattr(self.args, "mixer_dtype", "fp32") == "bf16"
 
+    def _x6mode(self):
+        """args.gemm_mode = "bf16x6": the mixer's dense products as bf16x6 splits where a split kernel exists"""
+        return getattr(self.args, "gemm_mode", DEFAULT_GEMM_MODE) == "bf16x6"
+
     def _wgrad_bf16(self):
         """with mixer_dtype "bf16" the wide-state mixer's weight-gradient GEMM takes bf16 operands too (its own flag bit of
         the C-ABI) unless args.mixer_wgrad_dtype = "fp32" keeps that one GEMM on v_mfma_f32_16x16x4_f32"""
@@ -191,7 +195,7 @@ class QMixMixer(_Precision, nn.Module):
         if self._fused_ok(xs):
             # one kernel: hypernet GEMMs (weights in registers) + mixing; nothing 256-wide touches HBM
             qtot = self._s.get("qtot" + tag, (rows,), dev)
-            ops.qmix_fused_fwd(self._fused_struct(), xs, q, qtot, rows, N, a.state_shape, E)
+            ops.qmix_fused_fwd(self._fused_struct(), xs, q, qtot, rows, N, a.state_shape, E, x6=self._x6mode())
             if ctx is not None:
                 ctx.update(q=q, s=s, fused=True)
             return qtot
@@ -252,7 +256,7 @@ class QMixMixer(_Precision, nn.Module):
         xs = ops.src(s)
         if self._fused_ok(xs):
             ops.qmix_fused_loss_bwd(self._fused_struct(), xs, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
-                                    self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E)
+                                    self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E, x6=self._x6mode())
         else:
             ops.qmix_wide_loss_bwd(self._fused_struct(), xs, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq,
                                    self._fused_struct(grad=True), loss2, rows, N, a.state_shape, E, bf16=self._bf16(),
@@ -266,7 +270,7 @@ class QMixMixer(_Precision, nn.Module):
             q, s = ctx["q"], ctx["s"]
             dq = self._s.get("dq", (rows, N), q.device)
             ops.qmix_fused_bwd(self._fused_struct(), ops.src(s), q, dq_tot, dq,
-                               self._fused_struct(grad=True), rows, N, a.state_shape, E)
+                               self._fused_struct(grad=True), rows, N, a.state_shape, E, x6=self._x6mode())
             return dq
         if ctx.get("wide"):
             q, s = ctx["q"], ctx["s"]

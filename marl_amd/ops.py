@@ -440,23 +440,26 @@ def qmix_weights(t):
     return w
 
 
-def qmix_fused_fwd(w, s, q, q_tot, rows, N, S, E):
-    check(_lib.load().marl_qmix_fused_fwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot)), rows, N, S, E, _stream()),
-          "marl_qmix_fused_fwd")
+def qmix_fused_fwd(w, s, q, q_tot, rows, N, S, E, x6=False):
+    """x6: the bf16x6 split variant of the kernel (args.gemm_mode = "bf16x6"; same arguments)"""
+    lib = _lib.load()
+    fn = lib.marl_qmix_fused_fwd_x6 if x6 else lib.marl_qmix_fused_fwd
+    check(fn(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot)), rows, N, S, E, _stream()), "marl_qmix_fused_fwd")
 
 
-def qmix_fused_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E):
+def qmix_fused_bwd(w, s, q, dq_tot, dq, grads, rows, N, S, E, x6=False):
     lib = _lib.load()
     ws = WS.get("qmix_fused", lib.marl_qmix_fused_workspace(rows, N, S), q.device)
-    check(lib.marl_qmix_fused_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads),
-                                  _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_bwd")
+    fn = lib.marl_qmix_fused_bwd_x6 if x6 else lib.marl_qmix_fused_bwd
+    check(fn(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dq)), C.byref(grads),
+             _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_bwd")
 
 
-def qmix_fused_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, rows, N, S, E):
+def qmix_fused_loss_bwd(w, s, q, q_tot_tgt, r, term, padded, gamma, q_tot, dq, grads, loss2, rows, N, S, E, x6=False):
     """fused QMIX backward with the TD loss folded in (include/marl_hip.h); loss2: 2-element device view accumulated into"""
     lib = _lib.load()
     ws = WS.get("qmix_fused", lib.marl_qmix_fused_workspace(rows, N, S), q.device)
-    check(lib.marl_qmix_fused_loss_bwd(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot_tgt)), _p(_f32(r)), _p(_f32(term)),
+    check((lib.marl_qmix_fused_loss_bwd_x6 if x6 else lib.marl_qmix_fused_loss_bwd)(C.byref(w), C.byref(s), _p(_f32(q)), _p(_f32(q_tot_tgt)), _p(_f32(r)), _p(_f32(term)),
                                        _p(_f32(padded)), float(gamma), _p(q_tot), _p(_f32(dq)), C.byref(grads), _p(_f32(loss2)),
                                        _p(ws), ws.numel() * 4, rows, N, S, E, _stream()), "marl_qmix_fused_loss_bwd")
 

@@ -1029,11 +1029,12 @@ def test_qmix_mix(dev):
     close(dq, q.grad, 1e-4)
 
 
+@pytest.mark.parametrize("x6", [False, True], ids=["f32", "bf16x6"])
 @pytest.mark.parametrize("R,N,S", [(333, 5, 120), (16, 5, 120), (4099, 3, 48), (50, 2, 4), (1000, 5, 126), (257, 4, 128), (100, 1, 128),
                                    (8200, 5, 124)])
-def test_qmix_fused(dev, R, N, S):
-    """fused hypernet + mixing kernels (forward, dq, hypernet weight gradients) vs torch-CPU autograd of
-    the restated QMixMixer.forward (reference network/mixer.py:57-80); S not a multiple of 4 falls back."""
+def test_qmix_fused(dev, R, N, S, x6):
+    """fused hypernet + mixing kernels (forward, dq, hypernet weight gradients; fp32 MFMA and the bf16x6 split variant) vs torch-CPU
+    autograd of the restated QMixMixer.forward (reference network/mixer.py:57-80); S not a multiple of 4 falls back."""
     from marl_amd import ops
     E = 32
     assert ops.qmix_fused_supported(N, S, E)
@@ -1065,10 +1066,10 @@ def test_qmix_fused(dev, R, N, S):
     xs = ops.src(sd[:, :S])
     out = torch.full((R,), 9.0, device=dev)
     qd = cu(q.detach(), dev)
-    ops.qmix_fused_fwd(ops.qmix_weights(Wd), xs, qd, out, R, N, S, E)
+    ops.qmix_fused_fwd(ops.qmix_weights(Wd), xs, qd, out, R, N, S, E, x6=x6)
     close(out, qt, 1e-4)
     dq = torch.full((R, N), 9.0, device=dev)
-    ops.qmix_fused_bwd(ops.qmix_weights(Wd), xs, qd, cu(gq, dev), dq, ops.qmix_weights(Gd), R, N, S, E)
+    ops.qmix_fused_bwd(ops.qmix_weights(Wd), xs, qd, cu(gq, dev), dq, ops.qmix_weights(Gd), R, N, S, E, x6=x6)
     close(dq, q.grad, 1e-4)
     scale = max(1.0, (R / 64.0) ** 0.5)
     for k, v in P.items():
