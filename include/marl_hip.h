@@ -292,9 +292,11 @@ int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const
  * Same arguments, same meaning: `saved` (the six activation planes per row-step the fp32 BPTT kernel marl_agent_unroll_bwd reads,
  * same tile layout), `gi_out` / `gi_in` (the input-side gate sums one unroll stores and the double-Q continuation reads; these
  * hold PLAIN sums here - a pair of launches that shares them must both be this entry), `cu_budget` (two row tiles per workgroup
- * once there are more tiles than that many CUs).  marl_agent_unroll_x6_supported(): H = 64, A <= 16, O a multiple of 8,
- * O + A + N <= 224, T >= 4, A <= 16 (A <= 32 when the input is wider than 160 columns): 2s3z-, 3s5z- and MMM2-sized agents;
- * beyond 96 input columns one row tile per workgroup.  The caller uses marl_agent_unroll_fwd otherwise. */
+ * once there are more tiles than that many CUs).  marl_agent_unroll_x6_supported(), exactly: H = 64; 8 <= O <= 192 and O a multiple
+ * of 8 (a row tile's observations fit three 16-byte prefetch registers per thread of one team); input width
+ * I = O + (last_action ? A : 0) + (reuse_network ? N : 0) <= 224; 1 <= A <= 16, or <= 32 when I > 160 (two action tiles only in the
+ * widest instantiation); T >= 4; B T N 256 < 2^32 (32-bit offsets): 2s3z-, 3s5z- and MMM2-sized agents; beyond 96 input columns one row
+ * tile per workgroup.  The entry point also wants obs on a 16-byte boundary.  The caller uses marl_agent_unroll_fwd otherwise. */
 int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A, int last_action, int reuse_network);
 int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                              const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
@@ -319,8 +321,10 @@ int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int* dq_idx, c
  * exactly into three bf16 terms (hi + mid + lo) and a product is the six bf16 products hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid
  * accumulated in fp32 by v_mfma_f32_16x16x32_bf16: the error against fp64 is that of the fp32 MFMA path (dropped terms <= 2^-24 of a
  * product), at 0.4 of its matrix-pipe time.  Same math as marl_mlp3_fwd_save / marl_mlp3_bwd_saved (network/mixer.py:117-145,
- * :149-171) for THREE-layer heads with N3 <= 16 outputs and up to 192 input columns whose width is not a multiple of 16 (the first
- * free column carries the ones that produce the layer-1 bias gradient).  `hsave`: marl_mlp3_save_floats(M, 1, groups) floats in the
+ * :149-171) for THREE-layer heads (w2 != NULL, H1 = H2 = 64) with N3 <= 16 outputs that marl_mlp3_supported() covers, whose virtual input
+ * width KV = K1 + (the kernels' own padding of a dense segment 0 that is not a multiple of 4) satisfies KV < 16 KC with
+ * KC = 4 ceil(KV / 64) <= 12: at most 191 columns, and the last 64-column block must leave a free column (KV = 112 is accepted, 64 /
+ * 128 / 192 are not) - the first free column carries the ones that produce the layer-1 bias gradient.  `hsave`: marl_mlp3_save_floats(M, 1, groups) floats in the
  * layout of the fp32 pair (the kept fp32 activations; the backward splits them).  hsave == NULL in the forward: nothing is kept
  * (target mixer).  Workspace: marl_mlp3_bwd_workspace(). */
 int marl_mlp3_x6_supported(const marl_src_t* x, int K1, int H1, int H2, int N3, int groups);

@@ -56,6 +56,14 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
 
 
+def _src_cpu(k):
+    """a marl_src_t describing a dense (rows, k) input with 16-byte aligned rows (widths only: no device memory is touched)"""
+    from marl_amd._lib import MarlSrc
+    s = MarlSrc()
+    s.p0, s.ld0, s.k0 = 4096, (k + 3) // 4 * 4, k
+    return s
+
+
 def test_split_kernel_capability_predicates():
     """The *_supported entry points of the bf16x6 kernels are host functions (no GPU): which agent shapes the split unroll and the
     split BPTT cover - the three map sizes of BASELINE's configurations - and what they leave to the fp32 kernels."""
@@ -70,6 +78,14 @@ def test_split_kernel_capability_predicates():
     assert fwd(512, 120, 5, 80, 18) == 0            # more than 16 actions on a narrow input: one action tile only
     assert fwd(512, 120, 10, 240, 18) == 0          # wider than 224 input columns
     assert fwd(512, 120, 5, 84, 11) == 0            # observation width not a multiple of 8
+    assert fwd(512, 120, 5, 192, 11) == 1 and fwd(512, 120, 5, 200, 11) == 0      # O <= 192: three prefetch registers per thread of one team
+    assert fwd(512, 120, 8, 128, 16) == 1 and fwd(512, 120, 8, 128, 17) == 0      # 152 / 153 input columns: one action tile up to 160 columns
+    assert fwd(512, 120, 10, 176, 32) == 1 and fwd(512, 120, 10, 176, 33) == 0    # wider than 160: two action tiles, 32 actions at most
+    # the fused-head split pair: the padded input width must leave a free column in its last 64-column block
+    m3 = lambda k, n3=1: lib.marl_mlp3_x6_supported(__import__("ctypes").byref(_src_cpu(k)), k, 64, 64, n3, 10)
+    assert m3(112) == 1 and m3(120) == 1 and m3(175) == 1 and m3(188) == 1
+    assert m3(191) == 0                             # a dense input of 191 columns is padded to 192 by the kernels: no free column
+    assert m3(128) == 0 and m3(192) == 0 and m3(64) == 0 and m3(120, 17) == 0
     assert bwd(512, 120, 5, 11) == 1 and bwd(1024, 120, 10, 18) == 1 and bwd(512, 150, 8, 14) == 1
     assert bwd(512, 120, 5, 11, 0) == 0             # a dense dq: the fp32 kernels
     assert bwd(512, 2, 5, 11) == 0 and bwd(512, 120, 5, 40) == 0
