@@ -290,6 +290,14 @@ def pmc_traffic(pmc, e):
         rest = by[:-1]
         key = lambda v: v.get("SQ_INSTS_MFMA", v.get("hbm_bytes_per_launch", 0))
         hit = [by[-1]] if tag == "save" else ([min(rest, key=key)] if tag == "reus" else [max(rest, key=key)]) if rest else []
+    if e["rocprof_name"] == "agent_bwd_x6_kernel" and len(hit) > 1:
+        # one call = up to two launches (full rounds of two-tile workgroups, then one round of one-tile ones: the <.., 2> and <.., 1>
+        # instantiations of the same variant): the call's traffic is their sum
+        tot = dict(hit[0])
+        for k in ("hbm_bytes_per_launch", "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA"):
+            if all(k in h for h in hit):
+                tot[k] = sum(h[k] for h in hit)
+        return tot
     return hit[0] if len(hit) == 1 else None
 
 

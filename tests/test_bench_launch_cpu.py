@@ -104,3 +104,7 @@ def test_pmc_traffic_picks_the_instantiation_a_timed_call_launched():
     assert bench.pmc_traffic(pmc, e("mlp3x6_fwd_kernel (fused 64-wide heads, 10 heads, K1=175)", "mlp3x6_fwd"))["hbm_bytes_per_launch"] == 1.9e9
     assert bench.pmc_traffic(pmc, e("mlp3x6_fwd_kernel (fused 64-wide heads, 10 heads, K1=120)", "mlp3x6_fwd"))["hbm_bytes_per_launch"] == 1.5e9
     assert bench.pmc_traffic({}, e("agent_bwd_kernel (BPTT ...)", "agent_bwd_kernel")) is None
+    # the split BPTT call is two launches at large batches (two-tile workgroups in full rounds + a round of one-tile ones): summed
+    pmc2 = dict(pmc)
+    pmc2["agent_bwd_x6_kernel<false, false, 1>"] = k(0.9e9)
+    assert bench.pmc_traffic(pmc2, e("agent_bwd_x6_kernel (BPTT ...)", "agent_bwd_x6_kernel"))["hbm_bytes_per_launch"] == 5.4e9

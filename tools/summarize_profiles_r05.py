@@ -21,7 +21,7 @@ for sub in ("qplex_f32", "qplex_bf16x6", "qmix_bf16x6", "qtran", "mmm2_bf16"):
 for name in ("_bench_line.json", "_bench_full.json", "_bench_profiled_line.json"):
     src = os.path.join(G, tag + name)
     if os.path.exists(src) and os.path.getsize(src) > 0:
-        line = open(src).read().strip()
+        line = [l for l in open(src).read().splitlines() if l.startswith("{")][-1].strip()      # (stdout also carries the host classes' prints)
         json.loads(line)
         open(os.path.join(P, tag + name), "w").write(line + "\n")
 for name in ("_mlp3_times.txt", "_unroll_x6_times.txt", "_bptt_x6_ab.txt", "_learner_rates.txt", "_shard_steps.txt", "_soak.txt", "_qmix_times.txt"):
