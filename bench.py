@@ -173,7 +173,10 @@ class KernelTimers:
         def roll(ar, kw):
             E_, T_, N_ = ar[9], ar[10], ar[11]
             f = float(Fa) * E_ * T_ * N_
-            return ("synth_rollout_kernel (whole rollout, T lock-steps)", "synth_rollout", f, f, 4.0 * E_ * (T_ + 1) * (N_ * O + S + N_ * A))
+            by = 4.0 * E_ * (T_ + 1) * (N_ * O + S + N_ * A)
+            if kw.get("x6"):      # csrc/rollout_x6.hip: the agent step as bf16x6 split products
+                return ("synth_rollout_x6_kernel (whole rollout, T lock-steps; fp32 products as six bf16 MFMA products)", "synth_rollout_x6_kernel", f, f, by, True)
+            return ("synth_rollout_kernel (whole rollout, T lock-steps)", "synth_rollout_kernel", f, f, by)
 
         self.models = {"agent_unroll_fwd": fwd, "agent_unroll_fwd_x6": fwd_x6, "agent_unroll_bwd": bwd, "linear_wgrad": wgrad, "linear": lin,
                        "qmix_fused_fwd": qmix(1, "qmix_fused_kernel forward (target mixer)", "qmix_fused_kernel<false"),

@@ -460,6 +460,18 @@ int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rs
                        float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N, int O, int S,
                        int A, int last_action, int reuse_network, void* stream);
 
+/* The same whole rollout with the agent step (network/q_network.py:16-21) as bf16x6 split products (rollout_x6.hip; args.gemm_mode =
+ * "bf16x6"): same arguments, same environment, same epsilon-greedy choice, same record - the integer fields agree with
+ * marl_synth_rollout wherever no two available actions' Q values lie within fp32 rounding of each other (the choice is an argmax).
+ * fc1 is evaluated as (bias + W1[:, obs | id] in) + W1[:, O + last action]: the observation part on the matrix cores a step ahead,
+ * the chosen action's column added in fp32.  Supported: H = 64, 1 <= A <= 16, O a multiple of 4, O + A + N <= 160, N <= 48. */
+int marl_synth_rollout_x6_supported(int N, int O, int A);
+int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
+                          int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
+                          float* r, float* term, float* padded, int* length, int* won, float* h_out,
+                          float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N, int O, int S,
+                          int A, int last_action, int reuse_network, void* stream);
+
 const char* marl_hip_version(void);
 
 /* Experiment switches (A/B measurements, variant tests): one table per process; NO entry point reads the environment.

@@ -411,13 +411,18 @@ def synth_rollout_supported(N, O, A):
     return bool(_lib.load().marl_synth_rollout_supported(N, O, A))
 
 
+def synth_rollout_x6_supported(N, O, A):
+    return bool(_lib.load().marl_synth_rollout_x6_supported(N, O, A))
+
+
 def synth_rollout(w, seed, rseed, env0, episode, fixed_len, eps, rec, h_out, E, T, N, O, S, A, last_action, reuse_network,
-                  stats=None, eps_sched=None):
+                  stats=None, eps_sched=None, x6=False):
     """eps: device (T,) epsilon per lock-step, or None with eps_sched = (eps0, anneal, eps_min): the per-step anneal of
     rollout.py:100-101 is then evaluated inside the kernel (fp64, like the host loop) and no schedule crosses PCIe."""
     e0, ea, em = (0.0, 0.0, 0.0) if eps_sched is None else eps_sched
     assert (eps is None) != (eps_sched is None)
-    check(_lib.load().marl_synth_rollout(C.byref(w), int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode,
+    fn = _lib.load().marl_synth_rollout_x6 if x6 else _lib.load().marl_synth_rollout       # x6: the agent step as bf16x6 split products
+    check(fn(C.byref(w), int(seed) & 0xFFFFFFFF, int(rseed) & 0xFFFFFFFF, env0, episode,
                                          1 if fixed_len else 0, _p(_f32(eps)) if eps is not None else None, _p(_f32(rec.obs)), _p(_f32(rec.state)),
                                          rec.state.stride(-2), _p(_f32(rec.avail)), _p(_i32(rec.u)), _p(_f32(rec.r)), _p(_f32(rec.term)),
                                          _p(_f32(rec.padded)), _p(_i32(rec.length)), _p(_i32(rec.won)), _p(h_out),

@@ -224,8 +224,10 @@ class RolloutWorker:
             for t in range(T):
                 epsilon = epsilon - self.anneal_epsilon if epsilon > self.min_epsilon else epsilon
         mac.init_hidden(E)
+        from .network import mixer as _mixer
+        x6 = getattr(a, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6"      # the agent step as split products (csrc/rollout_x6.hip)
         env.whole_rollout(mac.agent.weights(), None, self.rseed, rec, a.last_action, a.reuse_network,
-                          h_out=mac.hidden_states.view(E * N, H), eps_sched=sched)
+                          h_out=mac.hidden_states.view(E * N, H), eps_sched=sched, x6=x6)
         if not evaluate:
             self.epsilon = epsilon
         return rec, evaluate

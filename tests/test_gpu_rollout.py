@@ -20,12 +20,18 @@ def _mac(args, scale=3.0):
 
 
 @pytest.mark.parametrize("eps,evaluate", [(0.0, True), (0.5, False), (1.0, False)])
-def test_batched_rollout_matches_oracle(eps, evaluate):
+def test_batched_rollout_matches_oracle(eps, evaluate, gemm_mode):
+    """(gemm_mode "bf16x6": the whole-rollout kernel is csrc/rollout_x6.hip - the agent step as split products; the per-step paths
+    it is compared with run the fp32 kernels: the integer fields agree because no two available actions' Q values of these cases
+    lie within rounding of each other)"""
     from marl_amd.rollout import RolloutWorker
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd import ops
     T, E = 8, 37
     args = seeded.make_args("2s3z", "qmix", episode_limit=T, epsilon=eps, seed=77)
     args.anneal_epsilon = 0.01
+    args.gemm_mode = gemm_mode
+    assert ops.synth_rollout_x6_supported(5, 80, 11)
     mac, agent = _mac(args)
     env = SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=5, env0=2)
     w = RolloutWorker(env, mac, args)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Where a lock-step of the split rollout kernel (csrc/rollout_x6.hip) goes, per wave of workgroup 0 (diagnostic build
+`make -C marl_amd/csrc stamps`):  python tools/stamps_rollout_x6.py [envs]
+team R (waves 0-3): P1 recurrence | B1 | P2 fc1 | B2 | P3 x | B3 | P4 state + availability | B4
+team I (waves 4-7): P1 observations | B1 | P2 fc2 + choice | B2 | P3 env step, uniforms | B3 | P4 gate sums | B4"""
+import os, sys, ctypes
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MARL_HIP_LIB"] = os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so")
+sys.path.insert(0, HERE)
+import torch  # noqa: E402
+from marl_amd import _lib  # noqa: E402
+from stamps import show  # noqa: E402
+import bench  # noqa: E402
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+lib = _lib.load()
+buf = torch.zeros(16 * 16, dtype=torch.int64, device="cuda")
+fn = lib.marl_debug_stamps_rollout_x6
+fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
+assert fn(buf.data_ptr()) == 0
+from marl_amd.controller.share_params import SharedMAC
+from marl_amd.rollout import RolloutWorker
+from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+args = bench.make_args("qmix", "2s3z", 0)
+args.gemm_mode = "bf16x6"
+mac = SharedMAC(args); mac.cuda()
+env = SyntheticSMACEnv(E, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, args.episode_limit, seed=1, fixed_length=True)
+w = RolloutWorker(env, mac, args)
+for _ in range(2):
+    buf.zero_()
+    w.generate_episodes(E)
+    torch.cuda.synchronize()
+show(buf.cpu().view(16, 16).numpy(), ["P1", "B1", "P2", "B2", "P3", "B3", "P4", "B4"], "split rollout", E, args.episode_limit)
