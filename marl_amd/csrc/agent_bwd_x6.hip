@@ -489,19 +489,23 @@ struct RedArgs {
   const float* ws; int nwg; int A;
   float *dWih, *dWhh, *dW2, *dbih, *dbhh, *db2;
 };
-// fixed-order sum of the workgroups' slabs into the gradient tensors (accumulated into)
-__global__ __launch_bounds__(256) void agent_bwd_x6_reduce_kernel(RedArgs a) {
-  __shared__ float part[4][64];
+// fixed-order sum of the workgroups' slabs into the gradient tensors (accumulated into): 16 partial sums per element (768 slabs of
+// 100 KB at the headline shape: four partial sums per element left the reduction latency-bound, 73 us)
+constexpr int BRSG = 16;
+__global__ __launch_bounds__(64 * BRSG) void agent_bwd_x6_reduce_kernel(RedArgs a) {
+  __shared__ float part[BRSG][64];
   const long slab = slab_floats(a.A);
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + el;
   float s = 0.f;
   if (e < slab)
-    for (int w = sg; w < a.nwg; w += 4) s += a.ws[(long)w * slab + e];
+    for (int w = sg; w < a.nwg; w += BRSG) s += a.ws[(long)w * slab + e];
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0 || e >= slab) return;
-  s = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+  s = 0.f;
+#pragma unroll
+  for (int g = 0; g < BRSG; ++g) s += part[g][el];
   long k = e;
   if (k < 192 * 64) { a.dWih[k] += s; return; }
   k -= 192 * 64;
@@ -581,7 +585,7 @@ extern "C" int marl_agent_unroll_bwd_x6(const marl_agent_weights_t* w, const int
   r.ws = ws; r.nwg = (int)(n2 + n1); r.A = A;
   r.dWih = g->w_ih; r.dWhh = g->w_hh; r.dW2 = g->fc2_w; r.dbih = g->b_ih; r.dbhh = g->b_hh; r.db2 = g->fc2_b;
   const long slab = slab_floats(A);
-  hipLaunchKernelGGL(agent_bwd_x6_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(agent_bwd_x6_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(64 * BRSG), 0, st, r);
   MARL_CHECK_LAUNCH();
   return 0;
 }
