@@ -435,10 +435,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       const FWT ani = g_colsn<NT>(img, rb, 2 * 64 + 16 * s), anh = g_colsn<NT>(img, rb, 3 * 64 + 16 * s);
       if (t > 0) publish(t - 1);                     // (loaded during the previous step; the buffers were last read before this barrier)
       if (t > 1) xhload(t - 2);
-      WG_BARRIER();                                  // second barrier of the step (waits for the LDS reads above: the image may be refilled)
-      ST_MARK(1);
       __builtin_amdgcn_sched_barrier(0);
-      // dW_ih[this wave's 16 columns of r | z | n][all 64] += [drp | dzp | dnp]^T x ;  dW_hh[...] += [drp | dzp | dhn]^T h_prev
+      // dW_ih[this wave's 16 columns of r | z | n][all 64] += [drp | dzp | dnp]^T x - BEFORE the second barrier: these products fill
+      // the matrix pipe's bubbles while team R (the other wave of this SIMD) waits for its transposed image reads
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const FWT xb = fr_getn<NT>(XB + par * FRB, c, lane);
@@ -447,7 +446,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
 #undef OP
       }
       __builtin_amdgcn_sched_barrier(0);
+      ST_MARK(1);
+      WG_BARRIER();                                  // second barrier of the step (the image fragments are in registers: the image may be refilled)
       ST_MARK(2);
+      // dW_hh[...] += [drp | dzp | dhn]^T h_prev - behind the barrier, beside team R's gate gradients of the next step
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const FWT hb = fr_getn<NT>(HB + par * FRB, c, lane);
