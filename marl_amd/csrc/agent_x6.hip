@@ -334,12 +334,8 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         f32x4* gp = reinterpret_cast<f32x4*>(GI0) + ((bg * RTC + rr) * 4 + s) * 192 + lane;
         gp[0] = ag[0]; gp[64] = ag[1];
         if (!NGR) gp[128] = ag[2];
-        if (GIO) {
-          float* const go = a.gi_out + sv_off((long)ts * NTILES + tile0 + rr, 3, 0, s, lane);
-          *reinterpret_cast<f32x4*>(go) = ag[0];
-          *reinterpret_cast<f32x4*>(go + 1024) = ag[1];
-          if (!NGR) *reinterpret_cast<f32x4*>(go + 2048) = ag[2];
-        }
+        // (GIO: the sums are stored to gi_out by the team R wave that consumes them - this team is the longer one in the saving
+        // variants, by the stamps: gate sums + their stores 4 400 of 8 900 cycles per two-tile step)
       }
     };
     // XS: q(ts) = fc2(h) of row tile rt from planes Hp[bh]
@@ -492,6 +488,12 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
         ah[2] = splat(bias_hn);
         if (fl) { ah[0] = gp[0]; ah[1] = gp[64]; an = NGR ? anx[rt] : gp[128]; }
         else { ah[0] = gB[0]; ah[1] = gB[1]; an = gB[2]; }
+        if (GIO) {                                   // the input-side gate sums of step t for a later XS launch (the n plane of the NGR variants: nin())
+          float* const go = a.gi_out + sv_off((long)t * NTILES + tile0 + rt, 3, 0, s, lane);
+          *reinterpret_cast<f32x4*>(go) = ah[0];
+          *reinterpret_cast<f32x4*>(go + 1024) = ah[1];
+          if (!NGR) *reinterpret_cast<f32x4*>(go + 2048) = an;
+        }
         if (XS) {                                    // the next tile: this step's, or tile 0 of the next step (stored step + 1)
           const bool same = rt + 1 < RTW;
           const int nts = same ? t + 1 : t + 2;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   int* elen = rown + rows;                                                 // [rows] episode length of the local env
   unsigned* pfxO = reinterpret_cast<unsigned*>(elen + rows);               // [rows] hash prefix of the observations of the slot to generate
   unsigned* pfxA = pfxO + rows;                                            // [rows] ... of its availability
-  unsigned* pfxS = pfxA + rows;                                            // [rows] ... of its state (per env)
+  unsigned* pfxS = pfxA + rows;                                            // [rows] ... of its state (per env: entries 0 .. EPW-1); entries rows/2 .. : the reward hash prefix of the NEXT step, per env
   float* uex = reinterpret_cast<float*>(pfxS + rows);                      // [2 step parities][2][rows] explore / pick uniforms of a step's choice
   int4* rmeta = reinterpret_cast<int4*>(uex + 4 * rows);                   // [rows] {obs offset of (b,0,n,0), avail offset, episode length, n}
   int4* emeta = rmeta + rows;                                              // [rows] {state offset of (b,0,0), episode length, env in range, -}
@@ -325,6 +325,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       a.u[c_uoff[rt] + t * N] = arg;
     }
   };
+  // (the reward prefixes live in the upper half of pfxS, double-buffered by step parity: EPW <= rows / 4 - always, unless N < 4)
+  const bool pre_r = 4 * nenv_wg <= rows;
   // the uniforms of step t+1's choice and the hash prefixes of slot t+2, ONE hash per thread of a 256-thread team (index ti)
   auto hashes = [&](int t, int ti) __attribute__((always_inline)) {
     const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
@@ -337,6 +339,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       else if (kind == 2) pfxO[r] = hprefix(a.seed, ST_OBS, env, tg + 2u);
       else if (kind == 3) pfxA[r] = hprefix(a.seed, ST_AVAIL, env, tg + 2u);
       else if (r < nenv_wg) pfxS[r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg + 2u);
+      else if (pre_r && r >= rows / 2 && r - rows / 2 < nenv_wg)      // the reward prefix of step t+1 (off the env step's dependent chain)
+        pfxS[rows / 2 + ((t + 1) & 1) * (rows / 4) + (r - rows / 2)] = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + r - rows / 2), tg + 1u);
     }
   };
   // epsilon of step t: a device vector, or the reference's per-step anneal (rollout.py:100-101) evaluated here in fp64
@@ -547,7 +551,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         const bool live = t < L;
         float term = 0.f;
         if (live) {
-          const unsigned pre_ = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
+          const unsigned pre_ = (pre_r && t > 0) ? pfxS[rows / 2 + (t & 1) * (rows / 4) + es_el]
+                                                 : hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
           term = u01(hfin(pre_, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
         }
         float acc = 0.f;
