@@ -274,7 +274,7 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         }
         const float s0 = (drp[0] + drp[1]) + (drp[2] + drp[3]), s1 = (dzp[0] + dzp[1]) + (dzp[2] + dzp[3]);
         const float s2 = (dnp[0] + dnp[1]) + (dnp[2] + dnp[3]), s3 = (dhn[0] + dhn[1]) + (dhn[2] + dhn[3]);
-        if (BSL) { bsl[0] += s0; bsl[256] += s1; bsl[512] += s2; bsl[768] += s3; }
+        if (BSL) { bsl[0] += s0; bsl[256] += s1; bsl[512] += s2; bsl[768] += s3; }      // (ds_add_f32 without return was measured: 0.40 -> 0.55 ms at 512 envs - LDS float atomics serialise)
         else { bsr[0] += s0; bsr[1] += s1; bsr[2] += s2; bsr[3] += s3; }
         g_put(img, wb, 0 * 64 + 16 * s, tt, split4(drp));
         g_put(img, wb, 1 * 64 + 16 * s, tt, split4(dzp));
