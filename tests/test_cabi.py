@@ -81,6 +81,11 @@ def test_split_kernel_capability_predicates():
     assert fwd(512, 120, 5, 192, 11) == 1 and fwd(512, 120, 5, 200, 11) == 0      # O <= 192: three prefetch registers per thread of one team
     assert fwd(512, 120, 8, 128, 16) == 1 and fwd(512, 120, 8, 128, 17) == 0      # 152 / 153 input columns: one action tile up to 160 columns
     assert fwd(512, 120, 10, 176, 32) == 1 and fwd(512, 120, 10, 176, 33) == 0    # wider than 160: two action tiles, 32 actions at most
+    # the split whole-rollout kernel: 2s3z- and 3s5z-sized agents (<= 160 input columns, <= 16 actions, whole environments in at most
+    # three - wide inputs: two - row tiles of 16 rows)
+    rx6 = lib.marl_synth_rollout_x6_supported
+    assert rx6(5, 80, 11) == 1 and rx6(8, 128, 14) == 1 and rx6(2, 4, 3) == 1
+    assert rx6(10, 176, 18) == 0 and rx6(5, 80, 17) == 0 and rx6(5, 82, 11) == 0 and rx6(49, 40, 5) == 0 and rx6(33, 100, 5) == 0
     # the fused-head split pair: the padded input width must leave a free column in its last 64-column block
     m3 = lambda k, n3=1: lib.marl_mlp3_x6_supported(__import__("ctypes").byref(_src_cpu(k)), k, 64, 64, n3, 10)
     assert m3(112) == 1 and m3(120) == 1 and m3(175) == 1 and m3(188) == 1
