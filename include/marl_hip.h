@@ -364,6 +364,29 @@ int marl_qtran_head_bwd(const marl_qtran_weights_t* w, const float* hidden, cons
                         int accumulate, float* d_enc0_w, float* d_enc0_b, float* d_enc2_b, float* ws, size_t ws_bytes,
                         long BT, int N, int A, int AE, void* stream);
 
+/* State parts of the heads' first layers: sp_k (BT, 64) = W_k[:, :S] s + b_k for k < nsets (1 or 2) - the `sp` argument of
+ * marl_qtran_head_fwd.  The joint-Q head and the V head of one update read the same states (qtran_learner.py:116-118):
+ * nsets = 2 serves both from one pass over s.  W_k: q.0 / v.0 weight (64, ldw_k), ldw_k >= S; s: BT rows of S columns as
+ * one dense segment (p0, ld0 % 4 == 0, 16-byte aligned; the row remap and the episode map of marl_src_t are honoured -
+ * the learner reads s and s_next in place from the (T+1)-slot storage).  Use when marl_qtran_state_parts_supported(S)
+ * (S % 4 == 0, S <= 384); otherwise marl_linear. */
+int marl_qtran_state_parts_supported(int S);
+int marl_qtran_state_parts(const marl_src_t* s, long BT, int S, int nsets, const float* W0, long ldw0, const float* b0, float* sp0,
+                           const float* W1, long ldw1, const float* b1, float* sp1, void* stream);
+/* Every weight gradient of one head that is a reduction over the BT rows, in one pass (network/mixer.py:381,386-387 /
+ * :412,416-417; replaces five marl_linear_wgrad calls on tensors marl_qtran_head_fwd / _bwd have written):
+ *   d_q0_w (64, ld_q0) += dy1^T [s | e2[:, :AE]]   d_q0_b += colsum(dy1)   d_q2_w (64,64) += dy2^T y1   d_q2_b += colsum(dy2)
+ *   d_q4_w (64) += d_out^T y2   d_q4_b (1) += sum(d_out)   d_enc2_w (AE, AE) += de2[:, :AE]^T s1[:, :AE]
+ * s as in marl_qtran_state_parts; s1, e2, de2 (BT, AEP); y1, y2, dy1, dy2 (BT, 64); d_out (BT).  ws: marl_qtran_wgrad_rows_workspace(S, AE)
+ * bytes.  Slabs + fixed-order reduce: bitwise reproducible.  Use when marl_qtran_wgrad_rows_supported(S, AE)
+ * (S % 4 == 0, S <= 384, AE = 64 + A with A <= 16). */
+int marl_qtran_wgrad_rows_supported(int S, int AE);
+size_t marl_qtran_wgrad_rows_workspace(int S, int AE);
+int marl_qtran_wgrad_rows(const marl_src_t* s, const float* s1, const float* e2, const float* y1, const float* y2,
+                          const float* d_out, const float* dy1, const float* dy2, const float* de2, float* d_q0_w, long ld_q0,
+                          float* d_q0_b, float* d_q2_w, float* d_q2_b, float* d_q4_w, float* d_q4_b, float* d_enc2_w, float* ws,
+                          size_t ws_bytes, long BT, int S, int AE, void* stream);
+
 /* QPLEX (DMAQer.forward + calc_v/calc_adv, mixer.py:211-288; DMAQ_SI_Weight tail :158-169).
  *  wv row = [w_raw (N) | v (N)] (outputs of hyper_w_final.2 / V.2);
  *  heads = key (rows,K,1) | agents (rows,K,N) | action (rows,K,N) raw extractor outputs.

@@ -118,6 +118,11 @@ SIGNATURES = {
     "marl_qtran_supported": (I, [I, I, I]),
     "marl_qtran_head_fwd": (I, [QT, P, P, P, P, P, P, P, P, L, I, I, I, P]),
     "marl_qtran_bwd_workspace": (SZ, [L, I]),
+    "marl_qtran_state_parts_supported": (I, [I]),
+    "marl_qtran_state_parts": (I, [SRC, L, I, I, P, L, P, P, P, L, P, P, P]),
+    "marl_qtran_wgrad_rows_supported": (I, [I, I]),
+    "marl_qtran_wgrad_rows_workspace": (SZ, [I, I]),
+    "marl_qtran_wgrad_rows": (I, [SRC] + [P] * 8 + [P, L, P, P, P, P, P, P, P, SZ, L, I, I, P]),
     "marl_qtran_head_bwd": (I, [QT, P, P, P, P, P, P, P, P, P, I, P, P, P, P, SZ, L, I, I, I, P]),
     "marl_qplex_mix_fwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "marl_qplex_mix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),

@@ -114,10 +114,16 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
         hs2, hst2 = hs.view(R, H), hs_tgt.view(R, H)
         ctx_q, ctx_v = {}, {}
         # the state columns of the joint-Q head's first layer are shared by the two evaluations of the eval mixer
-        sp_e = self.mixer.state_part(db.s, BT, "e") if self.mixer._qt_ok(hs2) else None
+        # and the V head reads the same states: both state parts come from one pass over s
+        sp_e = sp_v = None
+        if self.mixer._qt_ok(hs2):
+            if self.v._qt_ok(hs2):
+                sp_e, sp_v = self.mixer.state_part(db.s, BT, "e", other=self.v)
+            else:
+                sp_e = self.mixer.state_part(db.s, BT, "e")
         joint_q = self.mixer.hip_forward(db.s, hs2, u_taken, BT, ctx=ctx_q, tag="e", sp=sp_e)
         joint_q_tgt = self.target_mixer.hip_forward(db.s_next, hst2, opt_tgt, BT, tag="t")
-        v = self.v.hip_forward(db.s, hs2, BT, ctx=ctx_v)
+        v = self.v.hip_forward(db.s, hs2, BT, ctx=ctx_v, sp=sp_v)
         joint_q_hat = self.mixer.hip_forward(db.s, hs2, opt_eval, BT, tag="h", sp=sp_e)      # detached in the loss
 
         q_sum_opt, q_sum_nopt, q_ind = g("q_sum_opt", (BT,)), g("q_sum_nopt", (BT,)), g("q_ind", (R,))

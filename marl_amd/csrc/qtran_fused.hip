@@ -469,6 +469,359 @@ __global__ __launch_bounds__(64 * NW, 2) void qtran_bwd_agents_kernel(QtArgs a) 
   for (int e = tid; e < AEP * KW; e += 64 * NW) slab[e] = (e % KW) <= HD + 16 ? red[e] : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------- state parts
+// sp_k = W_k[:, :S] s + b_k  (k < NSETS), (BT, 64) each: the state columns of the heads' first layers (:386, :416).
+// The joint-Q head and the V head of one update read the SAME states, so NSETS = 2 serves both from one pass over s.
+// A workgroup stages 64 contiguous rows of s (one contiguous 64*S*4-byte block, 16-byte loads) in LDS; wave (t, g) keeps
+// the fragments of feature tile t of its weight set in registers (KC chunks of 16 columns) and multiplies them with the
+// row tiles of the block: NSETS = 2: set g, all four row tiles; NSETS = 1: row tiles 2g, 2g + 1.  Two workgroups per CU
+// cover each other's loads.  fp32 on v_mfma_f32_16x16x4_f32, the accumulators of the row tiles interleaved.
+struct SpArgs {
+  ConcatSrc s; long BT; int S, kc;
+  const float* W[2]; long ldw[2]; const float* b[2]; float* sp[2];
+};
+constexpr int SPR = 64;           // rows per block
+
+// row `row` of the states (remap + episode map of ConcatSrc) as an element offset into p0, in two steps so that callers can
+// issue the episode-map reads of several rows together before the first dependent row read: (e, w) first, then the offset
+__device__ __forceinline__ void state_row_ew(const ConcatSrc& s, long row, unsigned& e, long& w) {
+  if (s.rpe0 == 0) { e = 0; w = row; return; }
+  e = fastdiv((unsigned)row, s.fd0);
+  w = (long)((unsigned)row - e * (unsigned)s.rpe0) + s.off0;
+}
+__device__ __forceinline__ long state_row_off(const ConcatSrc& s, unsigned e, long w, int ev) {
+  return (s.rpe0 == 0 ? w : (long)(s.emap0 ? ev : (int)e) * s.bs0 + w) * s.ld0;
+}
+
+template <int KC, int NSETS>
+__global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RT = NSETS == 2 ? 4 : 2;          // row tiles per wave and block
+  constexpr int CW = KC <= 16 ? 1 : 2;            // 16-byte column slots per lane and row (S <= 256: one)
+  constexpr int RW = SPR / NW;                    // rows a wave stages per block
+  constexpr int XR = 16 * KC + 4;                 // LDS row stride; the columns S..16 KC stay zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, m = lane & 15;
+  const int t = wave & 3, g = wave >> 2;
+  const int set = NSETS == 2 ? g : 0, rt0 = NSETS == 2 ? 0 : 2 * g;
+  const int S = a.S;
+  const float* W = a.W[set] + (long)(16 * t + m) * a.ldw[set];
+  f32x4 wf[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k0 = 16 * c + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = W[k0 + i < S ? k0 + i : S - 1];
+      wf[c][i] = k0 + i < S ? v : 0.f;
+    }
+  }
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b[set] + 16 * t + 4 * q);
+  float* sp = a.sp[set];
+  for (int e = tid; e < SPR * (XR - S); e += 64 * NW) {
+    const int r = e / (XR - S), c = e - r * (XR - S);
+    smem[r * XR + S + c] = 0.f;
+  }
+  const int S4 = S >> 2;
+  // the next block's rows travel in registers while this one multiplies: wave w stages rows w, w + 8, .. (one contiguous
+  // 4*S-byte read per row; the row's place in s - remap, episode map - is wave-uniform).  Rows past BT re-read row BT - 1
+  // (their results are not stored), lanes past the row its last 16 bytes (not staged): no branches around the loads.
+  f32x4 ps[RW][CW];
+  auto fetch = [&](long blk) {
+    const long row0 = blk * SPR;
+    unsigned e[RW]; long w[RW]; int ev[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      long row = row0 + wave + NW * j;
+      row = row < a.BT ? row : a.BT - 1;
+      state_row_ew(a.s, row, e[j], w[j]);
+      ev[j] = a.s.emap0 ? a.s.emap0[e[j]] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      const bool ok = w[j] >= 0 || a.s.rpe0 == 0;
+      const float* src = a.s.p0 + state_row_off(a.s, e[j], ok ? w[j] : 0, ev[j]);
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        int c4 = lane + 64 * k;
+        c4 = c4 < S4 ? c4 : S4 - 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * c4);
+        ps[j][k] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  const long nblk = (a.BT + SPR - 1) / SPR;
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+    const long row0 = blk * SPR;
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 < S4) *reinterpret_cast<f32x4*>(smem + (wave + NW * j) * XR + 4 * c4) = ps[j][k];
+      }
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+    f32x4 acc[RT];
+    const float* xb = smem + (16 * rt0 + m) * XR + 4 * q;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = bv;
+    f32x4 xn[RT];                                          // fragments of chunk c + 1 are read while chunk c multiplies
+#pragma unroll
+    for (int i = 0; i < RT; ++i) xn[i] = *reinterpret_cast<const f32x4*>(xb + i * 16 * XR);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      f32x4 x[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) x[i] = xn[i];
+      if (c + 1 < KC) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) xn[i] = *reinterpret_cast<const f32x4*>(xb + i * 16 * XR + 16 * (c + 1));
+      }
+      if (RT == 4) mfma16x4_il4(wf[c], x[0], acc[0], wf[c], x[1], acc[1], wf[c], x[2], acc[2], wf[c], x[3], acc[3]);
+      else mfma16x4_il2(wf[c], x[0], acc[0], wf[c], x[1], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const long row = row0 + 16 * (rt0 + i) + m;
+      if (row < a.BT) *reinterpret_cast<f32x4*>(sp + row * HD + 16 * t + 4 * q) = acc[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- row-level weight gradients
+// One pass over the B*T rows for every weight gradient that is a reduction over rows (:386-387, :416-417, the second
+// encoder layer :381, :412):
+//   dW_q1 += dy1^T [s | e2]   db_q1 += colsum(dy1)      dW_q2 += dy2^T y1   db_q2 += colsum(dy2)
+//   dw_q3 += d_out^T y2       db_q3 += sum(d_out)       dW_e2 += de2^T s1
+// (five marl_linear_wgrad launches and their reduces before).  A workgroup stages WR = 32 rows of all nine tensors side by
+// side in ONE LDS matrix Z[32][ZW]: a single compile-time row stride = 4 mod 16, so the column-wise fragment reads below
+// are conflict-free and their row offsets are instruction immediates; the next block's rows travel in registers while
+// this one multiplies.  Every product is out[j][k] = sum_r Z[r][acol + j] Z[r][bcol + k]: 16x16 output tiles dealt
+// round-robin to the 8 waves (tile ids: dy1^T s k-tile-major, dy1^T e2, dy2^T y1, de2^T s1), accumulated in registers
+// over the workgroup's blocks, written to a slab per workgroup and summed in a fixed order by
+// qtran_wgrad_reduce_kernel: bitwise reproducible.
+constexpr int WR = 32;
+
+struct WgArgs {
+  ConcatSrc s;
+  const float *e2, *y1, *s1, *dy1, *dy2, *de2, *y2, *d_out;
+  float* slab;                    // [grid][slab_elems]
+  long BT; int S, AE, TS, ntiles;
+};
+struct WgRedArgs {
+  const float* slab;
+  float *dWq1, *dbq1, *dWq2, *dbq2, *dwq3, *dbq3, *dWe2;
+  long ldq1; int nwg, S, AE, AEP, TS;
+};
+// slab of one workgroup: [64][16 TS] dy1^T s | [64][AEP] dy1^T e2 | [64][64] dy2^T y1 | [AEP][AEP] de2^T s1 | 256 vector sums
+__host__ __device__ inline int wg_slab_elems(int TS, int AEP) { return 64 * 16 * TS + 64 * AEP + 64 * 64 + AEP * AEP + 256; }
+
+template <int W4>
+__device__ __forceinline__ void wg_slot(int e, int& r, int& c4) { r = e / W4; c4 = e - r * W4; }
+
+// FT: feature tiles of the encoder (5: joint-Q, 4: V); SMAX: columns reserved for s (224: 4 register slots, 16 tiles per
+// wave; 384: 6 slots, 20 tiles)
+template <int FT, int SMAX>
+__global__ __launch_bounds__(64 * NW, 1) void qtran_wgrad_rows_kernel(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Z[];
+  constexpr int AEP = 16 * FT, E4 = AEP / 4, ESL = (WR * E4 + 64 * NW - 1) / (64 * NW);
+  constexpr int SSL = (WR * (SMAX / 4) + 64 * NW - 1) / (64 * NW), MAXT = SMAX <= 224 ? 16 : 20;
+  constexpr int cE2 = 0, cY1 = AEP, cS1 = cY1 + 64, cD1 = cS1 + AEP, cD2 = cD1 + 64, cDE = cD2 + 64, cY2 = cDE + AEP, cDO = cY2 + 64,
+                cS = cDO + 4, ZW = cS + SMAX;
+  static_assert(ZW % 16 == 4 || ZW % 16 == 12, "row stride");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, m = lane & 15;
+  const int S = a.S, S4 = S >> 2, TS = a.TS;
+  const int NS = 4 * TS, XW = 16 * TS;
+  const int OFF1 = 64 * XW, OFF2 = OFF1 + 64 * AEP, OFF3 = OFF2 + 64 * 64, OFFB = OFF3 + AEP * AEP;
+
+  // tile id -> fragment columns in Z (ac, bc) and the slab position (so, ld)
+  auto tile_of = [&](int id, int& ac, int& bc, int& so, int& ld) {
+    ac = cD1; bc = cY1; so = -1; ld = 0;
+    if (id < NS) { const int tj = id & 3, tk = id >> 2; ac = cD1 + 16 * tj; bc = cS + 16 * tk; so = 16 * tj * XW + 16 * tk; ld = XW; return; }
+    id -= NS;
+    if (id < 4 * FT) { const int tj = id & 3, tk = id >> 2; ac = cD1 + 16 * tj; bc = cE2 + 16 * tk; so = OFF1 + 16 * tj * AEP + 16 * tk; ld = AEP; return; }
+    id -= 4 * FT;
+    if (id < 16) { const int tj = id & 3, tk = id >> 2; ac = cD2 + 16 * tj; bc = cY1 + 16 * tk; so = OFF2 + 16 * tj * 64 + 16 * tk; ld = 64; return; }
+    id -= 16;
+    if (id < FT * FT) { const int tk = id / FT, tj = id - tk * FT; ac = cDE + 16 * tj; bc = cS1 + 16 * tk; so = OFF3 + 16 * tj * AEP + 16 * tk; ld = AEP; }
+  };
+  const float* zl = Z + 4 * q * ZW + m;
+  f32x4 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float vsum = 0.f;               // threads 0..63: db_q1[tid]; 64..127: db_q2; 128..191: dw_q3; 192: db_q3
+
+  // the columns of the last s tile past S are read by its products (their results are never used): keep them finite
+  for (int e = tid; e < WR * (XW - S); e += 64 * NW) {
+    const int r = e / (XW - S), c = e - r * (XW - S);
+    if (S + c < SMAX) Z[r * ZW + cS + S + c] = 0.f;
+  }
+  // staging slots (block-invariant): slot j of a segment is its float4 number j*512 + tid -> (row, column/4)
+  int srow[SSL], sc4[SSL];
+#pragma unroll
+  for (int j = 0; j < SSL; ++j) { const int e = j * 64 * NW + tid; srow[j] = e / S4; sc4[j] = e - srow[j] * S4; }
+  f32x4 ps[SSL], pe2[ESL], ps1[ESL], pde[ESL], py1, pd1, pd2, py2;
+  float pdo = 0.f;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](long blk) {
+    const long row0 = blk * WR;
+    const int nrows = (int)(a.BT - row0 < WR ? a.BT - row0 : WR);
+    unsigned se[SSL]; long sw[SSL]; int sev[SSL];
+#pragma unroll
+    for (int j = 0; j < SSL; ++j) {                     // (rows past the block re-read its first row; selected away below)
+      state_row_ew(a.s, row0 + (srow[j] < nrows ? srow[j] : 0), se[j], sw[j]);
+      sev[j] = a.s.emap0 ? a.s.emap0[se[j]] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < SSL; ++j) {
+      const bool ok = srow[j] < nrows && (sw[j] >= 0 || a.s.rpe0 == 0);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.s.p0 + state_row_off(a.s, se[j], sw[j] >= 0 ? sw[j] : 0, sev[j]) + 4 * sc4[j]);
+      ps[j] = ok ? v : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < ESL; ++j) {
+      int r, c4; wg_slot<E4>(j * 64 * NW + tid, r, c4);
+      const bool ok = r < nrows;
+      const long o = (row0 + r) * AEP + 4 * c4;
+      pe2[j] = ok ? *reinterpret_cast<const f32x4*>(a.e2 + o) : zero4;
+      ps1[j] = ok ? *reinterpret_cast<const f32x4*>(a.s1 + o) : zero4;
+      pde[j] = ok ? *reinterpret_cast<const f32x4*>(a.de2 + o) : zero4;
+    }
+    {
+      int r, c4; wg_slot<16>(tid, r, c4);
+      const bool ok = r < nrows;
+      const long o = (row0 + r) * 64 + 4 * c4;
+      py1 = ok ? *reinterpret_cast<const f32x4*>(a.y1 + o) : zero4;
+      pd1 = ok ? *reinterpret_cast<const f32x4*>(a.dy1 + o) : zero4;
+      pd2 = ok ? *reinterpret_cast<const f32x4*>(a.dy2 + o) : zero4;
+      py2 = ok ? *reinterpret_cast<const f32x4*>(a.y2 + o) : zero4;
+    }
+    if (tid < WR) pdo = tid < nrows ? a.d_out[row0 + tid] : 0.f;
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < SSL; ++j)
+      if (srow[j] < WR) *reinterpret_cast<f32x4*>(Z + srow[j] * ZW + cS + 4 * sc4[j]) = ps[j];
+#pragma unroll
+    for (int j = 0; j < ESL; ++j) {
+      int r, c4; wg_slot<E4>(j * 64 * NW + tid, r, c4);
+      if (r < WR) {
+        *reinterpret_cast<f32x4*>(Z + r * ZW + cE2 + 4 * c4) = pe2[j];
+        *reinterpret_cast<f32x4*>(Z + r * ZW + cS1 + 4 * c4) = ps1[j];
+        *reinterpret_cast<f32x4*>(Z + r * ZW + cDE + 4 * c4) = pde[j];
+      }
+    }
+    {
+      int r, c4; wg_slot<16>(tid, r, c4);
+      *reinterpret_cast<f32x4*>(Z + r * ZW + cY1 + 4 * c4) = py1;
+      *reinterpret_cast<f32x4*>(Z + r * ZW + cD1 + 4 * c4) = pd1;
+      *reinterpret_cast<f32x4*>(Z + r * ZW + cD2 + 4 * c4) = pd2;
+      *reinterpret_cast<f32x4*>(Z + r * ZW + cY2 + 4 * c4) = py2;
+    }
+    if (tid < WR) Z[tid * ZW + cDO] = pdo;
+  };
+
+  const long nblk = (a.BT + WR - 1) / WR;
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+    stage();
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+    // tile pairs (i, i + 1) x two 16-row chunks, software-pipelined: the 16 fragment reads of the next step are issued
+    // before the 8 MFMAs of this one (tiles past ntiles read valid columns; their products are skipped)
+    auto frags = [&](int i, int c, f32x4& fa0, f32x4& fb0, f32x4& fa1, f32x4& fb1) {
+      int ac0, bc0, ac1, bc1, so, ld;
+      tile_of(wave + NW * i, ac0, bc0, so, ld);
+      tile_of(wave + NW * (i + 1), ac1, bc1, so, ld);
+      const float *pa0 = zl + ac0, *pb0 = zl + bc0, *pa1 = zl + ac1, *pb1 = zl + bc1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fa0[k] = pa0[(16 * c + k) * ZW]; fb0[k] = pb0[(16 * c + k) * ZW];
+        fa1[k] = pa1[(16 * c + k) * ZW]; fb1[k] = pb1[(16 * c + k) * ZW];
+      }
+    };
+    f32x4 na0, nb0, na1, nb1;
+    frags(0, 0, na0, nb0, na1, nb1);
+#pragma unroll
+    for (int i = 0; i < MAXT; i += 2) {
+#pragma unroll
+      for (int c = 0; c < WR / 16; ++c) {
+        const f32x4 fa0 = na0, fb0 = nb0, fa1 = na1, fb1 = nb1;
+        if (c + 1 < WR / 16) frags(i, c + 1, na0, nb0, na1, nb1);
+        else if (i + 2 < MAXT) frags(i + 2, 0, na0, nb0, na1, nb1);
+        if (wave + NW * i < a.ntiles) mfma16x4_il2(fa0, fb0, acc[i], fa1, fb1, acc[i + 1]);      // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // bias / last-layer sums on the vector unit (4 waves, one column each)
+    if (tid < 193) {
+      const int col = tid < 64 ? cD1 + tid : tid < 128 ? cD2 + tid - 64 : tid < 192 ? cY2 + tid - 128 : cDO;
+      const bool wd = tid >= 128 && tid < 192;
+      float v = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < WR; ++r) v += wd ? Z[r * ZW + col] * Z[r * ZW + cDO] : Z[r * ZW + col];
+      vsum += v;
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + (long)blockIdx.x * wg_slab_elems(TS, AEP);
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    int ac, bc, so, ld;
+    tile_of(wave + NW * i, ac, bc, so, ld);
+    if (so >= 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) slab[so + (4 * q + k) * ld + m] = acc[i][k];
+    }
+  }
+  if (tid < 256) slab[OFFB + tid] = tid < 193 ? vsum : 0.f;
+}
+
+// s += base[(w0 + 4i) * stride] for i = 0, 1, .. while w0 + 4i < nwg, in that order; eight reads in flight (the plain loop
+// waits for every read before it issues the next: 64 dependent HBM latencies for 256 slabs)
+__device__ __forceinline__ float slab_sum4(const float* base, long stride, int w0, int nwg) {
+  float s = 0.f;
+  int w = w0;
+  for (; w + 28 < nwg; w += 32) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = base[(long)(w + 4 * k) * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; w < nwg; w += 4) s += base[(long)w * stride];
+  return s;
+}
+
+// gradients += slabs (fixed order: 4 interleaved partial sums per element, as qtran_reduce_kernel)
+__global__ __launch_bounds__(256) void qtran_wgrad_reduce_kernel(WgRedArgs a) {
+  __shared__ float part[4][64];
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int XW = 16 * a.TS, OFF1 = 64 * XW, OFF2 = OFF1 + 64 * a.AEP, OFF3 = OFF2 + 64 * 64, OFFB = OFF3 + a.AEP * a.AEP, n = OFFB + 256;
+  // which destination (if any) this element feeds: the pad elements are skipped without being read
+  float* dst = nullptr;
+  if (e < OFF1) { const int j = e / XW, k = e - j * XW; if (k < a.S) dst = a.dWq1 + (long)j * a.ldq1 + k; }
+  else if (e < OFF2) { const int i1 = e - OFF1, j = i1 / a.AEP, k = i1 - j * a.AEP; if (k < a.AE) dst = a.dWq1 + (long)j * a.ldq1 + a.S + k; }
+  else if (e < OFF3) dst = a.dWq2 + (e - OFF2);
+  else if (e < OFFB) { const int i3 = e - OFF3, j = i3 / a.AEP, k = i3 - j * a.AEP; if (j < a.AE && k < a.AE) dst = a.dWe2 + (long)j * a.AE + k; }
+  else if (e < n) { const int b = e - OFFB; dst = b < 64 ? a.dbq1 + b : b < 128 ? a.dbq2 + (b - 64) : b < 192 ? a.dwq3 + (b - 128) : b == 192 ? a.dbq3 : nullptr; }
+  float s = 0.f;
+  if (dst) s = slab_sum4(a.slab + e, n, sg, a.nwg);
+  part[sg][el] = s;
+  __syncthreads();
+  if (sg != 0 || !dst) return;
+  *dst += ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+}
+
 struct QtRedArgs {
   const float *slab1, *slab2;
   float *dWe1, *dbe1, *dbe2;
@@ -482,11 +835,8 @@ __global__ __launch_bounds__(256) void qtran_reduce_kernel(QtRedArgs a) {
   const int e = blockIdx.x * 64 + el;
   const int n2 = a.AEP * KW;
   float s = 0.f;
-  if (e < n2) {
-    for (int w = sg; w < a.nwg; w += 4) s += a.slab2[(long)w * n2 + e];
-  } else if (e < n2 + a.AEP) {
-    for (int w = sg; w < a.nwg; w += 4) s += a.slab1[(long)w * a.AEP + (e - n2)];
-  }
+  if (e < n2) s = slab_sum4(a.slab2 + e, n2, sg, a.nwg);
+  else if (e < n2 + a.AEP) s = slab_sum4(a.slab1 + (e - n2), a.AEP, sg, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0) return;
@@ -504,6 +854,20 @@ __global__ __launch_bounds__(256) void qtran_reduce_kernel(QtRedArgs a) {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// the states as the callers hold them: dense (BT, S) or rows of the (T+1)-slot episode storage through a row remap and an
+// optional episode map (replay samples read in place); one dense segment, rows 16-byte aligned
+inline bool state_src_ok(const marl_src_t* s, int S) {
+  return s && s->p0 && s->k0 == S && !s->k1 && !s->nhot && !s->nid && !s->m0 && s->ld0 % 4 == 0 && aligned16(s->p0);
+}
+inline ConcatSrc state_src(const marl_src_t* s) {
+  ConcatSrc c = {};
+  c.p0 = s->p0; c.ld0 = s->ld0; c.k0 = s->k0;
+  c.rpe0 = s->rpe0; c.bs0 = s->bs0; c.off0 = s->off0;
+  c.fd0 = make_fastdiv((unsigned)(s->rpe0 > 0 ? s->rpe0 : 1));
+  c.fdi = make_fastdiv(1); c.fdn = make_fastdiv(1);
+  c.emap0 = s->emap0;
+  return c;
+}
 inline int ft_of(int AE) { return (AE + 15) / 16; }
 inline size_t fwd_lds(int FT, bool hot) {
   const int AEP = 16 * FT;
@@ -561,6 +925,88 @@ extern "C" int marl_qtran_head_fwd(const marl_qtran_weights_t* w, const float* h
   const unsigned grid = grid_for(BT);
   if (A > 0) return launch(qtran_fwd_kernel<5, true>, a, grid, fwd_lds(5, true), s);
   return launch(qtran_fwd_kernel<4, false>, a, grid, fwd_lds(4, false), s);
+}
+
+extern "C" int marl_qtran_state_parts_supported(int S) { return (S >= 4 && S % 4 == 0 && S <= 384) ? 1 : 0; }
+
+extern "C" int marl_qtran_state_parts(const marl_src_t* s, long BT, int S, int nsets, const float* W0, long ldw0, const float* b0,
+                                      float* sp0, const float* W1, long ldw1, const float* b1, float* sp1, void* stream) {
+  if (BT <= 0) return 0;
+  if (!marl_qtran_state_parts_supported(S) || nsets < 1 || nsets > 2 || !s || !W0 || !b0 || !sp0) return (int)hipErrorInvalidValue;
+  if (nsets == 2 && (!W1 || !b1 || !sp1)) return (int)hipErrorInvalidValue;
+  if (!state_src_ok(s, S) || !aligned16(sp0) || !aligned16(b0) || (nsets == 2 && (!aligned16(sp1) || !aligned16(b1)))) return (int)hipErrorInvalidValue;
+  SpArgs a = {};
+  a.s = state_src(s); a.BT = BT; a.S = S; a.kc = (S + 15) / 16;
+  a.W[0] = W0; a.ldw[0] = ldw0; a.b[0] = b0; a.sp[0] = sp0;
+  a.W[1] = W1; a.ldw[1] = ldw1; a.b[1] = b1; a.sp[1] = sp1;
+  const long nblk = (BT + SPR - 1) / SPR;
+  static const int buckets[] = {4, 8, 12, 14, 16, 20, 24};
+  int KCT = 24;
+  for (int b : buckets) if (a.kc <= b) { KCT = b; break; }
+  const size_t lds = (size_t)SPR * (16 * KCT + 4) * sizeof(float);
+  const long cap = 256;                                   // workgroups resident on the chip
+  // equal shares: every workgroup walks ceil(nblk / cap) blocks (a grid of cap would leave a partial last round)
+  const long rounds = (nblk + cap - 1) / cap;
+  const unsigned grid = (unsigned)((nblk + rounds - 1) / rounds);
+  const void* fn = nullptr;
+#define SP_CASE(K) case K: fn = nsets == 2 ? (const void*)qtran_state_parts_kernel<K, 2> : (const void*)qtran_state_parts_kernel<K, 1>; break;
+  switch (KCT) { SP_CASE(4) SP_CASE(8) SP_CASE(12) SP_CASE(14) SP_CASE(16) SP_CASE(20) SP_CASE(24) }
+#undef SP_CASE
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3(grid), dim3(64 * NW), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  MARL_CHECK_LAUNCH();
+  return 0;
+}
+
+namespace {
+inline int wg_ts(int S) { return (S + 15) / 16; }
+inline int wg_zw(int FT, int smax) { return 3 * 16 * FT + 4 * 64 + 4 + smax; }
+}  // namespace
+
+extern "C" int marl_qtran_wgrad_rows_supported(int S, int AE) {
+  const int FT = ft_of(AE);
+  return (S >= 4 && S % 4 == 0 && S <= 384 && (FT == 4 || FT == 5)) ? 1 : 0;
+}
+extern "C" size_t marl_qtran_wgrad_rows_workspace(int S, int AE) {
+  return (size_t)256 * wg_slab_elems(wg_ts(S), 16 * ft_of(AE)) * sizeof(float);
+}
+
+extern "C" int marl_qtran_wgrad_rows(const marl_src_t* s, const float* s1, const float* e2, const float* y1, const float* y2,
+                                     const float* d_out, const float* dy1, const float* dy2, const float* de2,
+                                     float* d_q0_w, long ld_q0, float* d_q0_b, float* d_q2_w, float* d_q2_b, float* d_q4_w,
+                                     float* d_q4_b, float* d_enc2_w, float* ws, size_t ws_bytes, long BT, int S, int AE,
+                                     void* stream) {
+  if (BT <= 0) return 0;
+  if (!marl_qtran_wgrad_rows_supported(S, AE) || ws_bytes < marl_qtran_wgrad_rows_workspace(S, AE)) return (int)hipErrorInvalidValue;
+  if (!state_src_ok(s, S) || !aligned16(s1) || !aligned16(e2) || !aligned16(y1) || !aligned16(y2) || !aligned16(dy1) || !aligned16(dy2) ||
+      !aligned16(de2) || !aligned16(ws)) return (int)hipErrorInvalidValue;
+  const int FT = ft_of(AE), AEP = 16 * FT;
+  WgArgs a = {};
+  a.s = state_src(s); a.e2 = e2; a.y1 = y1; a.s1 = s1; a.dy1 = dy1; a.dy2 = dy2; a.de2 = de2; a.y2 = y2; a.d_out = d_out;
+  a.slab = ws; a.BT = BT; a.S = S; a.AE = AE; a.TS = wg_ts(S);
+  a.ntiles = 4 * a.TS + 4 * FT + 16 + FT * FT;
+  const long nblk = (BT + WR - 1) / WR;
+  const unsigned grid = (unsigned)(nblk < 256 ? nblk : 256);
+  const bool big = S > 224;
+  const size_t lds = (size_t)WR * wg_zw(FT, big ? 384 : 224) * sizeof(float);
+  const void* fn = FT == 5 ? (big ? (const void*)qtran_wgrad_rows_kernel<5, 384> : (const void*)qtran_wgrad_rows_kernel<5, 224>)
+                           : (big ? (const void*)qtran_wgrad_rows_kernel<4, 384> : (const void*)qtran_wgrad_rows_kernel<4, 224>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3(grid), dim3(64 * NW), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  MARL_CHECK_LAUNCH();
+  WgRedArgs r = {};
+  r.slab = ws; r.dWq1 = d_q0_w; r.ldq1 = ld_q0; r.dbq1 = d_q0_b; r.dWq2 = d_q2_w; r.dbq2 = d_q2_b; r.dwq3 = d_q4_w; r.dbq3 = d_q4_b;
+  r.dWe2 = d_enc2_w; r.nwg = (int)grid; r.S = S; r.AE = AE; r.AEP = AEP; r.TS = a.TS;
+  const int total = wg_slab_elems(a.TS, AEP);
+  hipLaunchKernelGGL(qtran_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, r);
+  MARL_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" size_t marl_qtran_bwd_workspace(long BT, int AE) {

@@ -646,14 +646,28 @@ class _QtranFusedHead:
                 new.__dict__[k] = _copy.deepcopy(v, memo)
         return new
 
-    def state_part(self, s, BT, tag="e"):
+    def state_part(self, s, BT, tag="e", other=None):
         """sp = W_0[:, :S] s + b_0 (BT, 64): the state columns of the head's first layer.  Independent of hidden
-        states and actions, so one call serves every evaluation of this network on the same states."""
+        states and actions, so one call serves every evaluation of this network on the same states.  ``other``: a second
+        head (the V network beside the joint-Q network) evaluated on the same rows in the same pass over s; returns
+        (sp, sp_other) then."""
         q0 = self._qt_layers()[2]
         S = self.args.state_shape
         sp = self._s.get("sp" + tag, (BT, q0.out_features), s.device)
-        Lin(q0.weight.data[:, :S], q0.bias, self._bf16()).fwd(ops.src(s), sp, BT)
-        return sp
+        heads = [(self, sp)]
+        if other is not None:
+            heads.append((other, other._s.get("sp" + tag, (BT, q0.out_features), s.device)))
+        if ops.qtran_state_parts_supported(S, s) and not self._bf16():
+            sets = []
+            for net, out in heads:
+                l0 = net._qt_layers()[2]
+                sets.append((l0.weight.data, l0.bias.data, out))
+            ops.qtran_state_parts(s, BT, S, sets)
+        else:
+            for net, out in heads:
+                l0 = net._qt_layers()[2]
+                Lin(l0.weight.data[:, :S], l0.bias, net._bf16()).fwd(ops.src(s), out, BT)
+        return sp if other is None else (sp, heads[1][1])
 
     def _qt_forward(self, s, hidden, u_idx, BT, ctx, tag, sp):
         N, A, AE, AEP, S = self._qt_dims()
@@ -690,11 +704,16 @@ class _QtranFusedHead:
         ops.qtran_head_bwd(self._qt_struct(), ctx["hidden"], ctx["u_idx"] if A else None, d_out, ctx["y1"], ctx["y2"],
                            dy1, dy2, de2, dhidden, accumulate, e0.weight.grad, e0.bias.grad, e2l.bias.grad, BT, N, A, AE)
         # row-level weight gradients: reductions over BT rows of tensors the kernel above has just written
+        s = ctx["s"]
+        if ops.qtran_wgrad_rows_supported(S, AE, s) and not self._bf16():
+            ops.qtran_wgrad_rows(s, ctx["s1"], ctx["e2"], ctx["y1"], ctx["y2"], d_out, dy1, dy2, de2, q0.weight.grad, q0.bias.grad,
+                                 q2.weight.grad, q2.bias.grad, q4.weight.grad, q4.bias.grad, e2l.weight.grad, BT, S, AE)
+            return
         self._lin(q4).wgrad(d_out.view(BT, 1), ops.src(ctx["y2"]), BT)
         self._lin(q2).wgrad(dy2, ops.src(ctx["y1"]), BT)
         # first head layer, [s | esum] -> 64: the state columns and the encoder columns as two reductions - the state part
         # (216 columns on 3s5z) runs on the LDS-staged tall kernel, which the virtual concat of two dense segments does not
-        self._wgrad_split(q0, dy1, ctx["s"], ctx["e2"][:, :AE], BT, S)
+        self._wgrad_split(q0, dy1, s, ctx["e2"][:, :AE], BT, S)
         Lin(e2l.weight, None, self._bf16()).wgrad(de2[:, :AE], ops.src(ctx["s1"][:, :AE]), BT)
 
 

@@ -635,6 +635,42 @@ def qtran_head_fwd(w, hidden, u, sp, out, s1, e2, y1, y2, BT, N, A, AE):
                                           _p(y1), _p(y2), BT, N, A, AE, _stream()), "marl_qtran_head_fwd")
 
 
+def _state_rows_ok(s):
+    t = s.t if isinstance(s, Rows) else s
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.dtype == torch.float32
+
+
+def qtran_state_parts_supported(S, s=None):
+    return bool(_lib.load().marl_qtran_state_parts_supported(S)) and (s is None or _state_rows_ok(s))
+
+
+def qtran_state_parts(s, BT, S, sets):
+    """sets: one or two (weight (64, >= S) row-major, bias (64), out (BT, 64)) triples evaluated on the same rows of s"""
+    (W0, b0, o0), (W1, b1, o1) = sets[0], (sets[1] if len(sets) > 1 else (None, None, None))
+    for W in (W0, W1):
+        assert W is None or (W.stride(1) == 1 and W.dtype == torch.float32)
+    x = src(s)
+    check(_lib.load().marl_qtran_state_parts(C.byref(x), BT, S, len(sets), _p(W0), W0.stride(0), _p(_f32(b0)), _p(_f32(o0)),
+                                             _p(W1), W1.stride(0) if W1 is not None else 0, _p(b1), _p(o1), _stream()),
+          "marl_qtran_state_parts")
+
+
+def qtran_wgrad_rows_supported(S, AE, s=None):
+    return bool(_lib.load().marl_qtran_wgrad_rows_supported(S, AE)) and (s is None or _state_rows_ok(s))
+
+
+def qtran_wgrad_rows(s, s1, e2, y1, y2, d_out, dy1, dy2, de2, d_q0_w, d_q0_b, d_q2_w, d_q2_b, d_q4_w, d_q4_b, d_enc2_w,
+                     BT, S, AE):
+    lib = _lib.load()
+    ws = WS.get("qtran_wg", lib.marl_qtran_wgrad_rows_workspace(S, AE), s.device)
+    assert d_q0_w.stride(1) == 1 and d_q2_w.is_contiguous() and d_enc2_w.is_contiguous()
+    x = src(s)
+    check(lib.marl_qtran_wgrad_rows(C.byref(x), _p(_f32(s1)), _p(_f32(e2)), _p(_f32(y1)), _p(_f32(y2)), _p(_f32(d_out)),
+                                    _p(_f32(dy1)), _p(_f32(dy2)), _p(_f32(de2)), _p(d_q0_w), d_q0_w.stride(0), _p(_f32(d_q0_b)),
+                                    _p(_f32(d_q2_w)), _p(_f32(d_q2_b)), _p(_f32(d_q4_w)), _p(_f32(d_q4_b)), _p(_f32(d_enc2_w)),
+                                    _p(ws), ws.numel() * 4, BT, S, AE, _stream()), "marl_qtran_wgrad_rows")
+
+
 def qtran_head_bwd(w, hidden, u, d_out, y1, y2, dy1, dy2, de2, dhidden, accumulate, d_enc0_w, d_enc0_b, d_enc2_b,
                    BT, N, A, AE):
     lib = _lib.load()

@@ -1209,7 +1209,8 @@ def test_rollout_kernels_match_numpy_env(dev):
 
 
 @pytest.mark.parametrize("kind,BT,N,A,S", [("q", 37, 8, 14, 216), ("q", 16, 5, 11, 120), ("q", 1, 2, 3, 1), ("q", 300, 3, 16, 40),
-                                            ("v", 37, 8, 14, 216), ("v", 129, 5, 11, 120), ("q", 4100, 8, 14, 216)])
+                                            ("v", 37, 8, 14, 216), ("v", 129, 5, 11, 120), ("q", 4100, 8, 14, 216),
+                                            ("q", 700, 3, 9, 320), ("v", 333, 4, 5, 228), ("v", 9000, 2, 5, 224), ("q", 64, 2, 16, 384)])
 def test_qtran_fused_heads(dev, kind, BT, N, A, S):
     """Fused QtranQBase / QtranV kernels (csrc/qtran_fused.hip) behind the mixer classes: forward, gradient on the
     hidden states and every parameter gradient vs torch-CPU autograd of the reference forward (network/mixer.py:378-388,
@@ -1292,6 +1293,70 @@ def test_qtran_fused_heads(dev, kind, BT, N, A, S):
     else:
         pub = mod(s.view(1, BT, S), h.detach().view(1, BT, N, 64))
     close(pub.view(-1), out_ref, 2e-5, 1e-4, msg="public forward")
+
+
+@pytest.mark.parametrize("BT,S", [(37, 216), (4100, 216), (64, 4), (1000, 384), (129, 120)])
+def test_qtran_state_parts(dev, BT, S):
+    """marl_qtran_state_parts behind _QtranFusedHead.state_part: the state columns of q.0 / v.0 (network/mixer.py:386, :416)
+    for one head and for the joint-Q / V pair in one pass, vs torch fp64."""
+    import types
+    from marl_amd.network.mixer import QtranQBase, QtranV
+    from marl_amd import ops
+    assert ops.qtran_state_parts_supported(S)
+    args = types.SimpleNamespace(n_agents=3, n_actions=7, state_shape=S, rnn_hidden_dim=64, qtran_hidden_dim=64)
+    torch.manual_seed(BT + S)
+    qn, vn = QtranQBase(args).to(dev), QtranV(args).to(dev)
+    s = torch.randn(BT, S, generator=torch.Generator().manual_seed(S)).to(dev)
+
+    def want(net):
+        l0 = net._qt_layers()[2]
+        return (s.double() @ l0.weight.data[:, :S].double().t() + l0.bias.data.double()).float()
+    one = qn.state_part(s, BT, "x").clone()
+    close(one, want(qn), 2e-5, 1e-4, msg="single")
+    a, b = qn.state_part(s, BT, "y", other=vn)
+    close(a, want(qn), 2e-5, 1e-4, msg="pair/q")
+    close(b, want(vn), 2e-5, 1e-4, msg="pair/v")
+    assert torch.equal(a, one)                                # the pair kernel multiplies in the same order
+
+
+@pytest.mark.parametrize("kind,BT,S", [("q", 37, 216), ("q", 8229, 216), ("v", 2500, 384)])
+def test_qtran_row_kernels_reproducible_and_remapped(dev, kind, BT, S):
+    """The row-level kernels (state parts, weight gradients) on states read in place from (T+1)-slot storage through a row
+    remap and an episode map give the bits of the dense call, and repeated calls give the same bits (slabs, fixed-order
+    reduce)."""
+    import types
+    from marl_amd.network.mixer import QtranQBase, QtranV
+    from marl_amd.hostutil import FlatParams
+    from marl_amd import ops
+    N, A, T = 3, 6, 11
+    B = (BT + T - 1) // T
+    BT = B * T
+    args = types.SimpleNamespace(n_agents=N, n_actions=A, state_shape=S, rnn_hidden_dim=64, qtran_hidden_dim=64)
+    torch.manual_seed(BT)
+    mod = (QtranQBase if kind == "q" else QtranV)(args).to(dev)
+    fp = FlatParams(list(mod.parameters()), dev, with_grad=True)
+    g = torch.Generator().manual_seed(BT + 1)
+    store = torch.randn(B + 5, T + 1, S, generator=g).to(dev)              # episode storage, T + 1 slots
+    emap = torch.randperm(B + 5, generator=g)[:B].int().to(dev)
+    rows = ops.Rows(store.view(-1, S), (T, T + 1, 1), emap)                 # s_next of the sampled episodes
+    dense = store[emap.long(), 1:].reshape(BT, S).contiguous()
+    h = (torch.randn(BT * N, 64, generator=g) * 0.7).to(dev)
+    u = torch.randint(0, A, (BT * N,), generator=g).int().to(dev)
+    d = torch.randn(BT, generator=g).to(dev)
+    got = []
+    for src in (dense, rows, rows, dense, rows):
+        fp.grad.zero_()
+        ctx = {}
+        sp = mod.state_part(src, BT, "e").clone()
+        out = (mod.hip_forward(src, h, u, BT, ctx=ctx, sp=sp) if kind == "q" else mod.hip_forward(src, h, BT, ctx=ctx, sp=sp)).clone()
+        assert ctx.get("fused")
+        dh = torch.zeros(BT * N, 64, device=dev)
+        mod.hip_backward(ctx, d, BT, dh, accumulate=False)
+        got.append((sp, out, fp.grad.clone()))
+    for other in got[1:]:
+        for a_, b_ in zip(got[0], other):
+            assert torch.equal(a_, b_)
+    assert float(got[0][2].abs().max()) > 0
 
 
 def _qmix_reference(P, s, q, gq, N, E, bf16, wgrad_fp32=False):

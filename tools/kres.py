@@ -19,7 +19,9 @@ for line in err.splitlines():
         rows.append(cur)
     elif cur is not None:
         cur[k] = v
-names = subprocess.run(["/usr/bin/c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+if not rows:                      # compile error: c++filt without arguments would wait on stdin
+    sys.exit("no kernels reported - compile output:\n" + err[-3000:])
+names = subprocess.run(["/usr/bin/c++filt"] + [r["name"] for r in rows], capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
 print("%-90s %5s %5s %6s %6s %8s %4s" % ("kernel", "VGPR", "AGPR", "vspill", "sspill", "scratch", "occ"))
 for r, n in zip(rows, names):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
