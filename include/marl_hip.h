@@ -410,11 +410,13 @@ int marl_first_terminated_len(const float* term, long ld, int E, int T, int* out
  * episodes idx[b] (int64) in one launch.  Sources are the ring's arrays: u (E,T,N) int32, r / terminated / padded (E,T)
  * fp32, length / won (E) int32, avail (E,T+1,N,A) fp32 ((T+1)-slot storage).  Outputs: o_map (B) = idx as int32 (the
  * episode map the unroll / mixer kernels read obs and state through), u and u_act = max(u, 0) (B,T,N), r / term / padded
- * (B,T), length / won (B), avail_next (B,T,N,A) = avail slots 1..T.  obs and state are NOT copied. */
+ * (B,T), length / won (B), avail_next (B,T,N,A) = avail slots 1..T; avail_cur (B,T,N,A) or NULL = avail slots 0..T-1 with
+ * zeros from each episode's end on - the availability QPLEX / QTRAN mask the current-step greedy action with
+ * (q_learner.py:135-140, qtran_learner.py:103-108).  obs and state are NOT copied. */
 int marl_replay_gather(const long long* idx, int B, int T, int N, int A, const int* u_src, const float* r_src,
                        const float* term_src, const float* padded_src, const int* length_src, const int* won_src,
                        const float* avail_src, int* o_map, int* u, int* u_act, float* r, float* term, float* padded,
-                       int* length, int* won, float* avail_next, void* stream);
+                       int* length, int* won, float* avail_next, float* avail_cur, void* stream);
 
 /* TD target + masked squared error (q_learner.py:165-168).  Writes the UN-normalised gradient
  * dq_tot = -2 mask^2 td and out2 = {sum (mask td)^2, sum mask}; the 1/sum(mask) factor is applied

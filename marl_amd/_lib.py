@@ -80,7 +80,7 @@ SIGNATURES = {
     "marl_agent_bwd_x6_workspace": (SZ, [I, I, I]),
     "marl_agent_unroll_bwd_x6": (I, [AW, P, P, P, P, I, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
     "marl_agent_unroll_bwd": (I, [AW, P, P, P, P, P, I, P, P, P, P, P, AG, P, SZ, I, I, I, I, P]),
-    "marl_replay_gather": (I, [P, I, I, I, I] + [P] * 16 + [P]),
+    "marl_replay_gather": (I, [P, I, I, I, I] + [P] * 17 + [P]),
     "marl_q_gather": (I, [P, P, P, F, P, L, I, P]),
     "marl_q_masked_max": (I, [P, P, F, P, P, L, I, P]),
     "marl_q_double_select": (I, [P, P, P, F, P, P, L, I, P]),

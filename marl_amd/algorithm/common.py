@@ -409,11 +409,16 @@ class GraphedUpdate:
             # ONE persistent index tensor: the batch keeps a reference to it (the lazy `avail` gather of QPLEX reads the
             # ring through it), so refreshing it below is what every later warm-up, capture and replay sees
             idx = index.to(device=dev, dtype=torch.long).clone()
-            small = ring.select_small(idx)
+            small = ring.select_small(idx, avail_cur=getattr(learner, "needs_avail", False))
             db = DeviceBatch.from_record(ring, args, T=min(ring.T, args.episode_limit), index=idx, small=small)
+            # a device gather (one launch) wrote u_act / avail_next / avail_cur itself and the batch holds full-length VIEWS of
+            # them (T = ring.T here): refreshing `small` in place below refreshes the batch.  Other records get static copies.
+            fused = getattr(small, "avail_next", None) is not None and db.T == ring.T
             e = self.entries[key] = dict(ring=weakref.ref(ring), idx=idx, small=small, db=db, calls=0, graph=None, streak=0,
-                                         avail_next=db.avail_next.clone(), u_act=db.u_act.clone())
-            db.avail_next, db.u_act = e["avail_next"], e["u_act"]
+                                         fused=fused, avail_next=None if fused else db.avail_next.clone(),
+                                         u_act=None if fused else db.u_act.clone())
+            if not fused:
+                db.avail_next, db.u_act = e["avail_next"], e["u_act"]
             e["T"] = db.T
         idx, small, db = e["idx"], e["small"], e["db"]
         idx.copy_(index)
@@ -440,9 +445,11 @@ class GraphedUpdate:
                 self.prepared = (small, T)       # the eager path reuses the gathered arrays and the agreed T
                 return False
             e["streak"] += 1
-        torch.clamp(small.u[:, :T], min=0, out=e["u_act"])
-        e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail_next[:, :T] if small.avail is None else small.avail[:, 1:T + 1])
-        db.__dict__.pop("_avail", None)
+        if not e["fused"]:
+            torch.clamp(small.u[:, :T], min=0, out=e["u_act"])
+            e["avail_next"].view(small.E, T, small.N, small.A).copy_(small.avail_next[:, :T] if small.avail is None else small.avail[:, 1:T + 1])
+        if getattr(small, "avail_cur", None) is None:
+            db.__dict__.pop("_avail", None)
         learner.max_episode_len = T
         e["calls"] += 1
         if e["graph"] is None and e["calls"] > self.WARMUP:

@@ -54,6 +54,7 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
         self.pair = PairedUnroll(x6=getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6")
         self.loss_readback = LossReadback(args)
         self.graphs = GraphedUpdate.from_args(args)
+        self.needs_avail = args.alg == 'qplex'       # the current-step availability masks the greedy action (:135-140)
         self.last_stats = None
         self.sync_replicas()
 
@@ -190,7 +191,7 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
                 self.graphs.prepared = None
                 db = DeviceBatch.from_record(batch.ring, self.args, T=prep[1], index=batch.index, small=prep[0])
             else:
-                small = batch.ring.select_small(batch.index)
+                small = batch.ring.select_small(batch.index, avail_cur=self.needs_avail)
                 db = self._device_batch(batch.ring, batch.index, small)
                 if db is None:
                     return self._finish_update(train_step)

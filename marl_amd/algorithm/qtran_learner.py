@@ -54,6 +54,7 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
         self.pair = PairedUnroll(x6=getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6")
         self.loss_readback = LossReadback(args)
         self.graphs = GraphedUpdate.from_args(args)
+        self.needs_avail = True                      # local greedy actions are masked with the current availability (:103-108)
         self.last_stats = None
         self.sync_replicas()
 
@@ -163,7 +164,7 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
                 self.graphs.prepared = None
                 db = DeviceBatch.from_record(batch.ring, self.args, T=prep[1], index=batch.index, small=prep[0])
             else:
-                small = batch.ring.select_small(batch.index)
+                small = batch.ring.select_small(batch.index, avail_cur=self.needs_avail)
                 db = self._device_batch(batch.ring, batch.index, small)
         elif isinstance(batch, EpisodeBatch) and batch.record is not None:
             db = self._device_batch(batch.record, None, None)

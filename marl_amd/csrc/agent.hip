@@ -1738,8 +1738,7 @@ __global__ __launch_bounds__(256) void agent_bwd_reduce_kernel(BwdRedArgs a) {
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + el;
   float s = 0.f;
-  if (e < slab)
-    for (int w = sg; w < a.nwg; w += 4) s += a.ws[(long)w * slab + e];
+  if (e < slab) s = slab_sum(a.ws + e, slab, sg, 4, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0 || e >= slab) return;

@@ -500,8 +500,7 @@ __global__ __launch_bounds__(64 * BRSG) void agent_bwd_x6_reduce_kernel(RedArgs 
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + el;
   float s = 0.f;
-  if (e < slab)
-    for (int w = sg; w < a.nwg; w += BRSG) s += a.ws[(long)w * slab + e];
+  if (e < slab) s = slab_sum(a.ws + e, slab, sg, BRSG, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0 || e >= slab) return;

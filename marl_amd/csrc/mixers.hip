@@ -690,7 +690,7 @@ struct GatherArgs {
   const int *u_src, *length_src, *won_src;
   const float *r_src, *term_src, *padded_src, *avail_src;
   int *o_map, *u, *u_act, *length, *won;
-  float *r, *term, *padded, *avail_next;
+  float *r, *term, *padded, *avail_next, *avail_cur;
   int B, T, N, A;
 };
 __global__ __launch_bounds__(TPB) void replay_gather_kernel(GatherArgs a) {
@@ -700,6 +700,13 @@ __global__ __launch_bounds__(TPB) void replay_gather_kernel(GatherArgs a) {
   const float* av = a.avail_src + (e * (a.T + 1) + 1) * (long)a.N * a.A;
   float* ao = a.avail_next + (long)b * TNA;
   for (int i = blockIdx.y * 1024 + threadIdx.x; i < TNA && i < (blockIdx.y + 1) * 1024; i += TPB) ao[i] = av[i];
+  if (a.avail_cur) {                 // slots 0..T-1, zeros from the episode's end on (the learners' `avail`: hostutil.DeviceBatch)
+    const int NA = a.N * a.A;
+    const long live = (long)a.length_src[e] * NA;
+    const float* ac = av - NA;
+    float* co = a.avail_cur + (long)b * TNA;
+    for (int i = blockIdx.y * 1024 + threadIdx.x; i < TNA && i < (blockIdx.y + 1) * 1024; i += TPB) co[i] = i < live ? ac[i] : 0.f;
+  }
   if (blockIdx.y != 0) return;
   const int TN = a.T * a.N;
   for (int i = threadIdx.x; i < TN; i += TPB) {
@@ -723,13 +730,14 @@ __global__ __launch_bounds__(TPB) void replay_gather_kernel(GatherArgs a) {
 extern "C" int marl_replay_gather(const long long* idx, int B, int T, int N, int A, const int* u_src, const float* r_src,
                                   const float* term_src, const float* padded_src, const int* length_src,
                                   const int* won_src, const float* avail_src, int* o_map, int* u, int* u_act, float* r,
-                                  float* term, float* padded, int* length, int* won, float* avail_next, void* stream) {
+                                  float* term, float* padded, int* length, int* won, float* avail_next, float* avail_cur,
+                                  void* stream) {
   if (B <= 0 || T <= 0) return 0;
   GatherArgs a;
   a.idx = idx; a.u_src = u_src; a.length_src = length_src; a.won_src = won_src;
   a.r_src = r_src; a.term_src = term_src; a.padded_src = padded_src; a.avail_src = avail_src;
   a.o_map = o_map; a.u = u; a.u_act = u_act; a.length = length; a.won = won;
-  a.r = r; a.term = term; a.padded = padded; a.avail_next = avail_next;
+  a.r = r; a.term = term; a.padded = padded; a.avail_next = avail_next; a.avail_cur = avail_cur;
   a.B = B; a.T = T; a.N = N; a.A = A;
   const int chunks = (T * N * A + 1023) / 1024;
   hipLaunchKernelGGL(replay_gather_kernel, dim3((unsigned)B, (unsigned)(chunks > 0 ? chunks : 1)), dim3(TPB), 0, (hipStream_t)stream, a);

@@ -536,8 +536,7 @@ __global__ __launch_bounds__(64 * RSG) void qmix_fused_reduce_kernel(QmixRedArgs
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + el;
   float s = 0.f;
-  if (e < slab)
-    for (int w = sg; w < a.nwg; w += RSG) s += a.ws[(long)w * slab + e];
+  if (e < slab) s = slab_sum(a.ws + e, slab, sg, RSG, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0 || e >= slab) return;

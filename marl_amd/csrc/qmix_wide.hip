@@ -1077,11 +1077,8 @@ __global__ __launch_bounds__(64 * RSG) void qmix_wide_reduce_kernel(WideRedArgs 
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long e = (long)blockIdx.x * 64 + el;
   float s = 0.f;
-  if (e < n1) {
-    for (int w = sg; w < a.nslab; w += RSG) s += a.ws[(long)w * n1 + e];
-  } else if (e < n1 + E + 3) {
-    for (int w = sg; w < a.nwg; w += RSG) s += a.slab2[(long)w * (E + 3) + (e - n1)];
-  }
+  if (e < n1) s = slab_sum(a.ws + e, n1, sg, RSG, a.nslab);
+  else if (e < n1 + E + 3) s = slab_sum(a.slab2 + (e - n1), E + 3, sg, RSG, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0) return;

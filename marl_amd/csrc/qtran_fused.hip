@@ -785,22 +785,6 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_wgrad_rows_kernel(WgArgs a) 
   if (tid < 256) slab[OFFB + tid] = tid < 193 ? vsum : 0.f;
 }
 
-// s += base[(w0 + 4i) * stride] for i = 0, 1, .. while w0 + 4i < nwg, in that order; eight reads in flight (the plain loop
-// waits for every read before it issues the next: 64 dependent HBM latencies for 256 slabs)
-__device__ __forceinline__ float slab_sum4(const float* base, long stride, int w0, int nwg) {
-  float s = 0.f;
-  int w = w0;
-  for (; w + 28 < nwg; w += 32) {
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = base[(long)(w + 4 * k) * stride];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += v[k];
-  }
-  for (; w < nwg; w += 4) s += base[(long)w * stride];
-  return s;
-}
-
 // gradients += slabs (fixed order: 4 interleaved partial sums per element, as qtran_reduce_kernel)
 __global__ __launch_bounds__(256) void qtran_wgrad_reduce_kernel(WgRedArgs a) {
   __shared__ float part[4][64];
@@ -815,7 +799,7 @@ __global__ __launch_bounds__(256) void qtran_wgrad_reduce_kernel(WgRedArgs a) {
   else if (e < OFFB) { const int i3 = e - OFF3, j = i3 / a.AEP, k = i3 - j * a.AEP; if (j < a.AE && k < a.AE) dst = a.dWe2 + (long)j * a.AE + k; }
   else if (e < n) { const int b = e - OFFB; dst = b < 64 ? a.dbq1 + b : b < 128 ? a.dbq2 + (b - 64) : b < 192 ? a.dwq3 + (b - 128) : b == 192 ? a.dbq3 : nullptr; }
   float s = 0.f;
-  if (dst) s = slab_sum4(a.slab + e, n, sg, a.nwg);
+  if (dst) s = slab_sum(a.slab + e, n, sg, 4, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0 || !dst) return;
@@ -835,8 +819,8 @@ __global__ __launch_bounds__(256) void qtran_reduce_kernel(QtRedArgs a) {
   const int e = blockIdx.x * 64 + el;
   const int n2 = a.AEP * KW;
   float s = 0.f;
-  if (e < n2) s = slab_sum4(a.slab2 + e, n2, sg, a.nwg);
-  else if (e < n2 + a.AEP) s = slab_sum4(a.slab1 + (e - n2), a.AEP, sg, a.nwg);
+  if (e < n2) s = slab_sum(a.slab2 + e, n2, sg, 4, a.nwg);
+  else if (e < n2 + a.AEP) s = slab_sum(a.slab1 + (e - n2), a.AEP, sg, 4, a.nwg);
   part[sg][el] = s;
   __syncthreads();
   if (sg != 0) return;

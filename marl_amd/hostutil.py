@@ -304,7 +304,10 @@ class DeviceBatch:
         fused = getattr(rec, "avail_next", None) is not None       # select_small on the device (one launch) made these
         self.u_act = cutc(rec.u_act) if fused else self.u_taken.clamp(min=0)
         self.r, self.term, self.padded = cutc(rec.r).view(-1), cutc(rec.term).view(-1), cutc(rec.padded).view(-1)
-        # `avail` (current-step availability, QPLEX / QTRAN only) is built lazily; a fused gather did not copy it
+        # `avail` (current-step availability, QPLEX / QTRAN only): gathered with the small arrays when the learner asked for
+        # it (select_small(avail_cur=True)), else built lazily; a fused gather did not copy the full array
+        if fused and getattr(rec, "avail_cur", None) is not None:
+            self._avail = rec.avail_cur[:, :T].reshape(E * T * N, A)
         self._avail_src = (rec, T) if rec.avail is not None else (big, T, idx, rec.length)
         self.avail_next = (rec.avail_next[:, :T] if fused else rec.avail[:, 1:T + 1]).reshape(E * T * N, A)
         return self

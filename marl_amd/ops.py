@@ -314,7 +314,8 @@ _FT_OUT = {}
 
 
 def replay_gather(idx, src, out):
-    """src / out: objects with u, r, term, padded, length, won (+ src.avail, out.o_map, out.u_act, out.avail_next)."""
+    """src / out: objects with u, r, term, padded, length, won (+ src.avail, out.o_map, out.u_act, out.avail_next and, when the
+    learner masks current-step actions, out.avail_cur)."""
     assert idx.dtype == torch.int64 and idx.is_cuda and idx.is_contiguous()
     B, T, N, A = int(idx.numel()), src.T, src.N, src.A
     for t in (src.u, src.r, src.term, src.padded, src.length, src.won, src.avail, out.u, out.u_act, out.r, out.term, out.padded,
@@ -324,7 +325,8 @@ def replay_gather(idx, src, out):
     check(_lib.load().marl_replay_gather(_p(idx), B, T, N, A, _p(src.u), _p(_f32(src.r)), _p(_f32(src.term)), _p(_f32(src.padded)),
                                          _p(src.length), _p(src.won), _p(_f32(src.avail)), _p(_i32(out.o_map)), _p(_i32(out.u)),
                                          _p(_i32(out.u_act)), _p(_f32(out.r)), _p(_f32(out.term)), _p(_f32(out.padded)),
-                                         _p(_i32(out.length)), _p(_i32(out.won)), _p(_f32(out.avail_next)), _stream()),
+                                         _p(_i32(out.length)), _p(_i32(out.won)), _p(_f32(out.avail_next)),
+                                         _p(getattr(out, "avail_cur", None)), _stream()),
           "marl_replay_gather")
 
 
