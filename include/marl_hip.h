@@ -358,6 +358,12 @@ typedef struct {
 int marl_qtran_supported(int N, int A, int AE);
 int marl_qtran_head_fwd(const marl_qtran_weights_t* w, const float* hidden, const int* u, const float* sp, float* out,
                         float* s1, float* e2, float* y1, float* y2, long BT, int N, int A, int AE, void* stream);
+/* The joint-Q head on the same states and hidden states for two action sets in one launch: out <- u (activations saved as in
+ * marl_qtran_head_fwd), out2 <- u2 (nothing saved): the taken and the greedy actions of the eval mixer, qtran_learner.py:116
+ * and :133.  The encoder's first-layer product is computed once.  A > 0 only. */
+int marl_qtran_head_fwd2(const marl_qtran_weights_t* w, const float* hidden, const int* u, const int* u2, const float* sp,
+                         float* out, float* out2, float* s1, float* e2, float* y1, float* y2, long BT, int N, int A, int AE,
+                         void* stream);
 size_t marl_qtran_bwd_workspace(long BT, int AE);
 int marl_qtran_head_bwd(const marl_qtran_weights_t* w, const float* hidden, const int* u, const float* d_out,
                         const float* y1, const float* y2, float* dy1, float* dy2, float* de2, float* dhidden,

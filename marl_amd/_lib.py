@@ -117,6 +117,7 @@ SIGNATURES = {
     "marl_mlp3_x6_bwd_saved": (I, [M3, SRC, P, L, L, M3, P, SZ, P, SZ, L, I, I, I, P]),
     "marl_qtran_supported": (I, [I, I, I]),
     "marl_qtran_head_fwd": (I, [QT, P, P, P, P, P, P, P, P, L, I, I, I, P]),
+    "marl_qtran_head_fwd2": (I, [QT, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P]),
     "marl_qtran_bwd_workspace": (SZ, [L, I]),
     "marl_qtran_state_parts_supported": (I, [I]),
     "marl_qtran_state_parts": (I, [SRC, L, I, I, P, L, P, P, P, L, P, P, P]),

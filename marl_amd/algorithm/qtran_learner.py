@@ -122,10 +122,10 @@ class QTRANLearner(ResumeMixin, SpeculativeBatchMixin):
                 sp_e, sp_v = self.mixer.state_part(db.s, BT, "e", other=self.v)
             else:
                 sp_e = self.mixer.state_part(db.s, BT, "e")
-        joint_q = self.mixer.hip_forward(db.s, hs2, u_taken, BT, ctx=ctx_q, tag="e", sp=sp_e)
+        # the taken and the greedy actions of the eval mixer (:116, :133; the latter detached in the loss) in one launch
+        joint_q, joint_q_hat = self.mixer.hip_forward(db.s, hs2, u_taken, BT, ctx=ctx_q, tag="e", sp=sp_e, u_idx2=opt_eval)
         joint_q_tgt = self.target_mixer.hip_forward(db.s_next, hst2, opt_tgt, BT, tag="t")
         v = self.v.hip_forward(db.s, hs2, BT, ctx=ctx_v, sp=sp_v)
-        joint_q_hat = self.mixer.hip_forward(db.s, hs2, opt_eval, BT, tag="h", sp=sp_e)      # detached in the loss
 
         q_sum_opt, q_sum_nopt, q_ind = g("q_sum_opt", (BT,)), g("q_sum_nopt", (BT,)), g("q_ind", (R,))
         ops.agent_sum(q_max_eval, q_sum_opt, BT, N, 1)

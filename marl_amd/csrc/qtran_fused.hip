@@ -40,6 +40,7 @@ struct QtArgs {
   // per-row inputs
   const float* hidden;                      // (BT*N, 64)
   const int* u;                             // (BT*N) action index (< 0: none) or null
+  const int* u2; float* out2;               // forward, DUAL: a second set of actions on the same rows -> out2 (BT)
   const float* sp;                          // (BT, 64) = W_q1[:, :S] s + b_q1
   const float* d_out;                       // (BT)            backward
   // outputs / saved activations
@@ -136,7 +137,11 @@ __device__ __forceinline__ long first_tile(int wave) { return (long)wave * gridD
 __device__ __forceinline__ long tile_step() { return (long)NW * gridDim.x; }
 
 // ------------------------------------------------------------------------------------------------- forward
-template <int FT, bool HOT>
+// DUAL: the joint-Q head on the same states and hidden states for TWO action sets (the taken actions, whose activations are
+// saved for the backward pass, and the greedy ones: qtran_learner.py:116 / :133) - the encoder's first-layer product W_e1h h,
+// 72 % of the multiply-adds of one evaluation at 8 agents, is shared; the second set's pre-activation is the first's plus the
+// difference of the two one-hot table rows.
+template <int FT, bool HOT, bool DUAL = false>
 __global__ __launch_bounds__(64 * NW, 2) void qtran_fwd_kernel(QtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int AEP = 16 * FT, TS = AEP + 4;
@@ -167,14 +172,17 @@ __global__ __launch_bounds__(64 * NW, 2) void qtran_fwd_kernel(QtArgs a) {
     const long bt = live ? tile * 16 + m : a.BT - 1;
     const float* hrow = a.hidden + bt * N * HD + 4 * q;
     const int* urow = HOT ? a.u + bt * N : nullptr;
+    const int* urow2 = DUAL ? a.u2 + bt * N : nullptr;
     f32x4 spv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) spv[t] = *reinterpret_cast<const f32x4*>(a.sp + bt * HD + 16 * t + 4 * q);
-    f32x4 s1[FT];
+    f32x4 s1[FT], s1d[DUAL ? FT : 1];
 #pragma unroll
     for (int t = 0; t < FT; ++t) s1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (DUAL ? FT : 1); ++t) s1d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one agent: e1 = W_e1h h + (b_e1 + W_e1[:, 64 + u]);  s1 += relu(e1)
-    auto step = [&](const f32x4 (&xv)[4], int uu) __attribute__((always_inline)) {
+    auto step = [&](const f32x4 (&xv)[4], int uu, int uu2) __attribute__((always_inline)) {
       f32x4 acc[FT];
       const int tr = HOT ? ((uu >= 0 && uu < 16) ? uu : 16) : 0;
       const float* tp = tab + tr * TS + 4 * q;
@@ -183,23 +191,54 @@ __global__ __launch_bounds__(64 * NW, 2) void qtran_fwd_kernel(QtArgs a) {
       layer<FT, 4>(acc, W1s, xv, lane);
 #pragma unroll
       for (int t = 0; t < FT; ++t) s1[t] += relu4(acc[t]);
+      if constexpr (DUAL) {
+        const float* tp2 = tab + ((uu2 >= 0 && uu2 < 16) ? uu2 : 16) * TS + 4 * q;
+#pragma unroll
+        for (int t = 0; t < FT; ++t) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(tp2 + 16 * t) - *reinterpret_cast<const f32x4*>(tp + 16 * t);
+          s1d[t] += relu4(acc[t] + d);
+        }
+      }
     };
-    auto load = [&](f32x4 (&xv)[4], int& uu, int n) __attribute__((always_inline)) {
+    auto load = [&](f32x4 (&xv)[4], int& uu, int& uu2, int n) __attribute__((always_inline)) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) xv[c] = *reinterpret_cast<const f32x4*>(hrow + (long)n * HD + 16 * c);
       uu = HOT ? urow[n] : -1;
+      uu2 = DUAL ? urow2[n] : -1;
     };
     // two named register sets (no set-to-set copies: the next agent's loads are in flight while this one computes)
     f32x4 xA[4], xB[4];
-    int uA, uB;
-    load(xA, uA, 0);
+    int uA, uB, vA, vB;
+    load(xA, uA, vA, 0);
     for (int n = 0; n < N; n += 2) {
-      load(xB, uB, n + 1 < N ? n + 1 : N - 1);
-      step(xA, uA);
+      load(xB, uB, vB, n + 1 < N ? n + 1 : N - 1);
+      step(xA, uA, vA);
       if (n + 1 < N) {
-        load(xA, uA, n + 2 < N ? n + 2 : N - 1);
-        step(xB, uB);
+        load(xA, uA, vA, n + 2 < N ? n + 2 : N - 1);
+        step(xB, uB, vB);
       }
+    }
+    if constexpr (DUAL) {            // the tail for the second action set (nothing saved)
+      f32x4 e2d[FT], y1d[4], y2d[4];
+#pragma unroll
+      for (int t = 0; t < FT; ++t) e2d[t] = *reinterpret_cast<const f32x4*>(nb2 + 16 * t + 4 * q);
+      layer<FT, FT>(e2d, W2s, s1d, lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y1d[t] = spv[t];
+      layer<4, FT>(y1d, Q1s, e2d, lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { y1d[t] = relu4(y1d[t]); y2d[t] = *reinterpret_cast<const f32x4*>(bq2s + 16 * t + 4 * q); }
+      layer<4, 4>(y2d, Q2s, y1d, lane);
+      float o = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        y2d[t] = relu4(y2d[t]);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(w3s + 16 * t + 4 * q);
+        o += (w[0] * y2d[t][0] + w[1] * y2d[t][1]) + (w[2] * y2d[t][2] + w[3] * y2d[t][3]);
+      }
+      o += __shfl_xor(o, 16, 64);
+      o += __shfl_xor(o, 32, 64);
+      if (live && q == 0) a.out2[bt] = o + bq3;
     }
     // esum = W_e2 s1 + N b_e2
     f32x4 e2[FT];
@@ -580,7 +619,7 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a)
 #pragma unroll
         for (int i = 0; i < RT; ++i) xn[i] = *reinterpret_cast<const f32x4*>(xb + i * 16 * XR + 16 * (c + 1));
       }
-      if (RT == 4) mfma16x4_il4(wf[c], x[0], acc[0], wf[c], x[1], acc[1], wf[c], x[2], acc[2], wf[c], x[3], acc[3]);
+      if constexpr (RT == 4) mfma16x4_il4(wf[c], x[0], acc[0], wf[c], x[1], acc[1], wf[c], x[2], acc[2], wf[c], x[3], acc[3]);
       else mfma16x4_il2(wf[c], x[0], acc[0], wf[c], x[1], acc[1]);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -909,6 +948,21 @@ extern "C" int marl_qtran_head_fwd(const marl_qtran_weights_t* w, const float* h
   const unsigned grid = grid_for(BT);
   if (A > 0) return launch(qtran_fwd_kernel<5, true>, a, grid, fwd_lds(5, true), s);
   return launch(qtran_fwd_kernel<4, false>, a, grid, fwd_lds(4, false), s);
+}
+
+extern "C" int marl_qtran_head_fwd2(const marl_qtran_weights_t* w, const float* hidden, const int* u, const int* u2, const float* sp,
+                                    float* out, float* out2, float* s1, float* e2, float* y1, float* y2, long BT, int N, int A,
+                                    int AE, void* stream) {
+  if (BT <= 0) return 0;
+  if (!supported(N, A, AE) || A <= 0 || !u || !u2 || !out2) return (int)hipErrorInvalidValue;
+  if (!aligned16(hidden) || !aligned16(sp)) return (int)hipErrorInvalidValue;
+  const bool save = s1 != nullptr;
+  if (save && (!e2 || !y1 || !y2 || !aligned16(s1) || !aligned16(e2) || !aligned16(y1) || !aligned16(y2))) return (int)hipErrorInvalidValue;
+  QtArgs a = {};
+  fill_w(a, w);
+  a.hidden = hidden; a.u = u; a.u2 = u2; a.sp = sp; a.out = out; a.out2 = out2; a.s1 = s1; a.e2 = e2; a.y1 = y1; a.y2 = y2;
+  a.BT = BT; a.N = N; a.A = A; a.AE = AE;
+  return launch(qtran_fwd_kernel<5, true, true>, a, grid_for(BT), fwd_lds(5, true), (hipStream_t)stream);
 }
 
 extern "C" int marl_qtran_state_parts_supported(int S) { return (S >= 4 && S % 4 == 0 && S <= 384) ? 1 : 0; }

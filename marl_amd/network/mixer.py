@@ -669,7 +669,7 @@ class _QtranFusedHead:
                 Lin(l0.weight.data[:, :S], l0.bias, net._bf16()).fwd(ops.src(s), out, BT)
         return sp if other is None else (sp, heads[1][1])
 
-    def _qt_forward(self, s, hidden, u_idx, BT, ctx, tag, sp):
+    def _qt_forward(self, s, hidden, u_idx, BT, ctx, tag, sp, u_idx2=None):
         N, A, AE, AEP, S = self._qt_dims()
         dev = hidden.device
         if sp is None:
@@ -679,10 +679,15 @@ class _QtranFusedHead:
         if ctx is not None:
             s1, e2 = self._s.get("s1" + tag, (BT, AEP), dev), self._s.get("e2" + tag, (BT, AEP), dev)
             y1, y2 = self._s.get("y1" + tag, (BT, 64), dev), self._s.get("y2" + tag, (BT, 64), dev)
-        ops.qtran_head_fwd(self._qt_struct(), hidden, u_idx if A else None, sp, out, s1, e2, y1, y2, BT, N, A, AE)
+        out2 = None
+        if u_idx2 is not None:          # a second action set on the same rows: the first encoder product is shared
+            out2 = self._s.get("out2" + tag, (BT,), dev)
+            ops.qtran_head_fwd2(self._qt_struct(), hidden, u_idx, u_idx2, sp, out, out2, s1, e2, y1, y2, BT, N, A, AE)
+        else:
+            ops.qtran_head_fwd(self._qt_struct(), hidden, u_idx if A else None, sp, out, s1, e2, y1, y2, BT, N, A, AE)
         if ctx is not None:
             ctx.update(fused=True, s=s, hidden=hidden, u_idx=u_idx, s1=s1, e2=e2, y1=y1, y2=y2)
-        return out
+        return out if u_idx2 is None else (out, out2)
 
     def _wgrad_split(self, lin, dY, s, e, BT, S):
         """lin.weight.grad += dY^T [s | e], lin.bias.grad += colsum(dY): column blocks [0, S) and [S, S + width(e))"""
@@ -735,10 +740,14 @@ class QtranQBase(_QtranFusedHead, _Precision, nn.Module):
     def _qt_actions(self):
         return self.args.n_actions
 
-    def hip_forward(self, s, hidden, u_idx, BT, ctx=None, tag="e", sp=None):
-        """s (BT,S); hidden (BT*N,H); u_idx (BT*N) int32 -> joint q (BT).  sp: optional result of state_part(s)."""
+    def hip_forward(self, s, hidden, u_idx, BT, ctx=None, tag="e", sp=None, u_idx2=None):
+        """s (BT,S); hidden (BT*N,H); u_idx (BT*N) int32 -> joint q (BT).  sp: optional result of state_part(s).
+        u_idx2: a second set of actions evaluated on the same states and hidden states -> (q, q2); ctx belongs to the first."""
         if self._qt_ok(hidden):
-            return self._qt_forward(s, hidden, u_idx, BT, ctx, tag, sp)
+            return self._qt_forward(s, hidden, u_idx, BT, ctx, tag, sp, u_idx2)
+        if u_idx2 is not None:
+            q1 = self.hip_forward(s, hidden, u_idx, BT, ctx=ctx, tag=tag, sp=sp)
+            return q1, self.hip_forward(s, hidden, u_idx2, BT, tag=tag + "2", sp=sp)
         a = self.args
         N, H, A, Q = a.n_agents, a.rnn_hidden_dim, a.n_actions, a.qtran_hidden_dim
         R, ae = BT * N, H + A

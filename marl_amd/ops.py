@@ -673,6 +673,12 @@ def qtran_wgrad_rows(s, s1, e2, y1, y2, d_out, dy1, dy2, de2, d_q0_w, d_q0_b, d_
                                     _p(ws), ws.numel() * 4, BT, S, AE, _stream()), "marl_qtran_wgrad_rows")
 
 
+def qtran_head_fwd2(w, hidden, u, u2, sp, out, out2, s1, e2, y1, y2, BT, N, A, AE):
+    check(_lib.load().marl_qtran_head_fwd2(C.byref(w), _p(_f32(hidden)), _p(_i32(u)), _p(_i32(u2)), _p(_f32(sp)), _p(_f32(out)),
+                                           _p(_f32(out2)), _p(s1), _p(e2), _p(y1), _p(y2), BT, N, A, AE, _stream()),
+          "marl_qtran_head_fwd2")
+
+
 def qtran_head_bwd(w, hidden, u, d_out, y1, y2, dy1, dy2, de2, dhidden, accumulate, d_enc0_w, d_enc0_b, d_enc2_b,
                    BT, N, A, AE):
     lib = _lib.load()

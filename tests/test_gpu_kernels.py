@@ -1319,6 +1319,35 @@ def test_qtran_state_parts(dev, BT, S):
     assert torch.equal(a, one)                                # the pair kernel multiplies in the same order
 
 
+@pytest.mark.parametrize("BT,N,A,S", [(37, 8, 14, 216), (4100, 3, 16, 40), (1, 2, 3, 1)])
+def test_qtran_two_action_sets(dev, BT, N, A, S):
+    """QtranQBase.hip_forward(u_idx2=...): the joint-Q head for the taken and the greedy actions in one launch
+    (qtran_learner.py:116, :133).  The first set's outputs and saved activations are the bits of the single call; the second
+    set's value matches its own single call within fp32 rounding (its pre-activation is formed as first + table difference)."""
+    import types
+    from marl_amd.network.mixer import QtranQBase
+    args = types.SimpleNamespace(n_agents=N, n_actions=A, state_shape=S, rnn_hidden_dim=64, qtran_hidden_dim=64)
+    torch.manual_seed(BT + A)
+    mod = QtranQBase(args).to(dev)
+    g = torch.Generator().manual_seed(BT)
+    s = torch.randn(BT, S, generator=g).to(dev)
+    h = (torch.randn(BT * N, 64, generator=g) * 0.7).to(dev)
+    u1 = torch.randint(0, A, (BT * N,), generator=g).int()
+    u1[::5] = -1
+    u2 = torch.randint(0, A, (BT * N,), generator=g).int()
+    u1, u2 = u1.to(dev), u2.to(dev)
+    assert mod._qt_ok(h)
+    c1, c2 = {}, {}
+    a1 = mod.hip_forward(s, h, u1, BT, ctx=c1, tag="a").clone()
+    saved1 = {k: c1[k].clone() for k in ("s1", "e2", "y1", "y2")}
+    b1 = mod.hip_forward(s, h, u2, BT, tag="b").clone()
+    a2, b2 = mod.hip_forward(s, h, u1, BT, ctx=c2, tag="c", u_idx2=u2)
+    assert torch.equal(a1, a2)
+    for k, v in saved1.items():
+        assert torch.equal(v, c2[k]), k
+    close(b2, b1, 2e-5, 1e-4, msg="second action set")
+
+
 @pytest.mark.parametrize("kind,BT,S", [("q", 37, 216), ("q", 8229, 216), ("v", 2500, 384)])
 def test_qtran_row_kernels_reproducible_and_remapped(dev, kind, BT, S):
     """The row-level kernels (state parts, weight gradients) on states read in place from (T+1)-slot storage through a row
