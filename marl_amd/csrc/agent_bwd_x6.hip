@@ -176,19 +176,32 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
   __syncthreads();
   const int T = a.T;
   // (idx, val, idx2, val2) of row r at step t
-  auto qload = [&](int r, int t) {
-    int4 e = make_int4(0, 0, 0, 0);                   // an absent pair is (column 0, value 0): no branches where it is used
+  // The pairs are READ a step before they are handed over (qraw: index and value unconditionally, nothing looks at them) and
+  // range-checked when they are written to the table (qfix): no global round trip inside a step of the weight-gradient team
+  // (stamps at one tile: the wave that does this was 1 600 cycles behind the other three at the second barrier, 21 % of the step).
+  // Raw: (idx, val bits, idx2, val2 bits), idx = -1 where the row / step does not exist.
+  auto qraw = [&](int r, int t) {
+    int4 e = make_int4(-1, 0, -1, 0);
     const int ri = rowidx[r];
     if (ri >= 0 && t >= 0) {
-      const long k = (long)ri + (long)t * a.N;
-      const int i1 = a.dq_idx[k];
-      if (i1 >= 0 && i1 < a.A) { e.x = i1; e.y = __float_as_int(a.dq_val[k / a.dq_gdiv]); }
-      if (a.dq_idx2) {
-        const int i2 = a.dq_idx2[k];
-        if (i2 >= 0 && i2 < a.A) { e.z = i2; e.w = __float_as_int(a.dq_val2[k / a.dq_gdiv]); }
-      }
+      const unsigned k = (unsigned)ri + (unsigned)t * (unsigned)a.N;      // (B T N < 2^24: the host checks B T N H 4 < 2^32)
+      const unsigned kv = a.dq_gdiv == 1 ? k : k / (unsigned)a.dq_gdiv;    // (a 64-bit '/' is a few hundred instructions here)
+      e.x = a.dq_idx[k];
+      e.y = __float_as_int(a.dq_val[kv]);
+      if (a.dq_idx2) { e.z = a.dq_idx2[k]; e.w = __float_as_int(a.dq_val2[kv]); }
     }
     return e;
+  };
+  // an absent pair is (column 0, value 0): no branches where it is used
+  // Who hands the pairs of step t - 2 over during step t (slot (t - 2) % 3 = (t + 1) % 3 was last read by team R's gate gradients of
+  // step t + 1 and by the dW_2 product of step t + 2, both before the first barrier of step t + 1).  One tile: team R's wave 0, at
+  // the END of its gate phase - it waits ~700 cycles at the first barrier for the weight-gradient team, whose wave that did this
+  // was the last at the second barrier by ~950 cycles (stamps; moving the duty to another wave of that team moved the lag with
+  // it).  Two tiles: team R runs at the register ceiling, the weight-gradient team's first wave keeps the duty behind the barrier.
+  constexpr bool QDR = NT == 1;
+  auto qfix = [&](int4 e) {
+    const bool ok1 = e.x >= 0 && e.x < a.A, ok2 = e.z >= 0 && e.z < a.A;
+    return make_int4(ok1 ? e.x : 0, ok1 ? e.y : 0, ok2 ? e.z : 0, ok2 ? e.w : 0);
   };
   // per-lane address parts of the image - worked out again in every step from the lane number (a dozen integer instructions) rather
   // than kept in registers across the loop: both teams run at the 256-register ceiling
@@ -243,7 +256,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     };
     svload(T - 1, 0);
     if (NT == 2) svload(T - 1, NT - 1);
-    if (tid < 16 * NT) { QT[((T - 1) % 3) * 32 + tid] = qload(tid, T - 1); QT[((T - 2 + 3) % 3) * 32 + tid] = qload(tid, T - 2); }
+    if (tid < 16 * NT) { QT[((T - 1) % 3) * 32 + tid] = qfix(qraw(tid, T - 1)); QT[((T - 2 + 3) % 3) * 32 + tid] = qfix(qraw(tid, T - 2)); }
+    int4 qnR = make_int4(-1, 0, -1, 0);
+    if (QDR && tid < 16 * NT) qnR = qraw(tid, T - 3);
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
       const int par = t & 1;
@@ -280,6 +295,10 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         g_put(img, wb, 1 * 64 + 16 * s, tt, split4(dzp));
         g_put(img, wb, 2 * 64 + 16 * s, tt, split4(dnp));
         g_put(img, wb, 3 * 64 + 16 * s, tt, split4(dhn));
+      }
+      if (QDR && tid < 16 * NT) {                    // the dq pairs of the steps to come (see QDR)
+        if (t >= 2) QT[((t - 2) % 3) * 32 + tid] = qfix(qnR);
+        qnR = qraw(tid, t - 3);
       }
       ST_MARK(0);
       WG_BARRIER();
@@ -406,8 +425,8 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
     xhload(T - 1);
     publish(T - 1);
     xhload(T - 2);
-    int4 qn = make_int4(0, 0, 0, 0);
-    if (ti < 16 * NT) qn = qload(ti, T - 3);
+    int4 qn = make_int4(-1, 0, -1, 0);
+    if (!QDR && ti < 16 * NT) qn = qraw(ti, T - 3);
     __syncthreads();
     {      // the last step's dq meets h(T-1), the hidden state after the last step (plane 0 of step T)
       f32x4 hT[NT];
@@ -422,9 +441,9 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
       ST_MARK(0);
       // the steps to come: the dq pairs of step t-2 handed over (their slot's previous content - step t+1 - was last read before
       // this barrier: team R's gate gradients of step t+1 and this team's dW_2 product of step t+2)
-      if (ti < 16 * NT) {
-        if (t >= 2) QT[((t - 2) % 3) * 32 + ti] = qn;
-        qn = qload(ti, t - 3);
+      if (!QDR && ti < 16 * NT) {
+        if (t >= 2) QT[((t - 2) % 3) * 32 + ti] = qfix(qn);
+        qn = qraw(ti, t - 3);
       }
       int rb, tb0, tb1;
       lane_parts(rb, tb0, tb1);

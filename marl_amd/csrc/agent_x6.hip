@@ -193,6 +193,8 @@ __global__ __launch_bounds__(XNT, 2) void agent_fwd_x6_kernel(X6Args a) {
   constexpr bool ALLP = !XS && !(SAVE && RTC == 2);
   // FC2I: fc2 / q in team I - in XS (team R then has loads only) and wherever team I has no loads to count stores against (ALLP): the
   // one wave per row tile that carries fc2 would otherwise be team R's longest, on the chain
+  // (round 5, again: fc2 of the plain unroll in team R - stamps at one tile show team I's fc2 wave 450 cycles behind its three
+  // partners and team R waiting a third of the step - measured 0.183 -> 0.200 ms at 512 envs, 1.018 -> 1.039 at 4096: not kept)
   constexpr bool FC2I = XS || (ALLP && AC == 1);
   constexpr int NLDK = ALLP ? 3 : NLD;
   constexpr int PT = 256;                          // participating threads: one team

@@ -5,7 +5,7 @@ team R (waves 0-3): h W_hh products | gate math + h planes | stores + fc2 | barr
 mode bwd (csrc/agent_bwd_x6.hip): team R: gate gradients + image | barrier | carry chain | dW_hh;  team I: barrier | dx | dW_ih | dW_2 + hand-offs"""
 import os, sys, ctypes
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MARL_HIP_LIB"] = os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so")
+os.environ.setdefault("MARL_HIP_LIB", os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so"))
 sys.path.insert(0, HERE)
 import torch  # noqa: E402
 from marl_amd import _lib, ops  # noqa: E402
@@ -19,7 +19,7 @@ buf = torch.zeros(16 * 16, dtype=torch.int64, device=dev)
 for fn in (lib.marl_debug_stamps_agent_x6, lib.marl_debug_stamps_agent_bwd_x6):
     fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
     assert fn(buf.data_ptr()) == 0
-N, O, S, A, T = bench.SHAPES["2s3z"]
+N, O, S, A, T = bench.SHAPES[os.environ.get("SHAPE", "2s3z")]
 g = torch.Generator().manual_seed(0)
 P = {"fc1.weight": torch.randn(64, O + A + N, generator=g) * 0.1, "fc1.bias": torch.randn(64, generator=g) * 0.1,
      "rnn.weight_ih": torch.randn(192, 64, generator=g) * 0.1, "rnn.weight_hh": torch.randn(192, 64, generator=g) * 0.1,
