@@ -24,6 +24,9 @@
 #include <cstdlib>
 #include "../../include/marl_hip.h"
 
+#ifndef DWHH_HEAD
+#define DWHH_HEAD -1      // A/B builds: chunks of dW_hh before the second barrier (-1: by tile count)
+#endif
 namespace {
 
 constexpr int H = 64;
@@ -464,13 +467,24 @@ __global__ __launch_bounds__(BNT, 2) void agent_bwd_x6_kernel(BX6Args a) {
         X6_TERMS(OP)
 #undef OP
       }
+      // dW_hh[...] += [drp | dzp | dhn]^T h_prev: HEAD of its four column chunks before the second barrier, the rest behind it
+      // beside team R's gate gradients of the next step.  Two tiles (stamps, 3s5z 1024 envs): the interval before the barrier is
+      // bound by team R's products (6 070 cycles against this team's 5 100), the one behind it by THIS team (4 030 against 3 320)
+      // -> one chunk moves forward.  One tile: the interval before the barrier is the longer one for this team already.
+      constexpr int HEAD = DWHH_HEAD >= 0 ? DWHH_HEAD : (NT == 2 ? 1 : 0);
+#pragma unroll
+      for (int c = 0; c < HEAD; ++c) {
+        const FWT hb = fr_getn<NT>(HB + par * FRB, c, lane);
+#define OP(p_, q_) accH[0][c] = mmx(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mmx(az.p_, hb.q_, accH[1][c]); accH[2][c] = mmx(anh.p_, hb.q_, accH[2][c]);
+        X6_TERMS(OP)
+#undef OP
+      }
       __builtin_amdgcn_sched_barrier(0);
       ST_MARK(1);
       WG_BARRIER();                                  // second barrier of the step (the image fragments are in registers: the image may be refilled)
       ST_MARK(2);
-      // dW_hh[...] += [drp | dzp | dhn]^T h_prev - behind the barrier, beside team R's gate gradients of the next step
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = HEAD; c < 4; ++c) {
         const FWT hb = fr_getn<NT>(HB + par * FRB, c, lane);
 #define OP(p_, q_) accH[0][c] = mmx(ar.p_, hb.q_, accH[0][c]); accH[1][c] = mmx(az.p_, hb.q_, accH[1][c]); accH[2][c] = mmx(anh.p_, hb.q_, accH[2][c]);
         X6_TERMS(OP)
