@@ -161,12 +161,20 @@ int marl_agent_bcast(const float* in, long ld_in, float* out, long ld_out, long 
                      void* stream);
 
 /* QMixMixer.forward after the hypernet layers (mixer.py:64-80).  hy row = [w1raw (N*E, agent-major)
- * | b1 (E) | w2raw (E) | relu(hyper_b2.0) (E)], b2 = hyper_b2.2 output. */
-int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* q, float* q_tot,
-                      long rows, int N, int E, void* stream);
-/* its autograd: fills dhy[w1raw|b1|w2raw] (the 4th block is written by the caller), db2, dq */
-int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
+ * | b1 (E) | w2raw (E) | relu(hyper_b2.0) (E)].  b2 (rows) = hyper_b2.2 output, or NULL: then it is formed in the kernel from the
+ * fourth block, b2 = w22 . hb + b22 (w22 (E), b22 (1): hyper_b2.2's weight and bias, mixer.py:46-47). */
+int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* w22, const float* b22, const float* q,
+                      float* q_tot, long rows, int N, int E, void* stream);
+/* its autograd: fills dhy[w1raw|b1|w2raw], db2 (= dq_tot), dq; the 4th block of dhy is written by the caller, or here when w22 is
+ * given: d hb = dq_tot w22 (hb > 0) - the backward of hyper_b2.2 and its relu */
+int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, const float* w22, float* dhy,
                       float* db2, float* dq, long rows, int N, int E, void* stream);
+/* The state-conditioned bias layers of QMixMixer in one pass over s, written into hy (rows, ldhy):
+ * hy[:, c_b1 : c_b1 + 32] = hyper_b1(s), hy[:, c_h : c_h + 32] = relu(hyper_b2.0(s)) (mixer.py:44-47; E = 32).  Wb1, Wh: (32, S)
+ * weights with the same row stride; s as in marl_qtran_state_parts.  With marl_qmix_mix_fwd(b2 = NULL) the generic mixer path
+ * (two_hyper_layers, mixer.py:36-43) launches no marl_linear. */
+int marl_qmix_tail_fwd(const marl_src_t* s, long rows, int S, const float* Wb1, long ldb1, const float* bb1, const float* Wh,
+                       long ldwh, const float* bh, float* hy, long ldhy, int c_b1, int c_h, void* stream);
 
 /* Fused QMIX (qmix_fused.hip): hypernet GEMMs + mixing in one kernel; the backward recomputes the
  * hypernet tile and accumulates the hypernet weight gradients in registers.  Supported when
@@ -374,8 +382,8 @@ int marl_qtran_head_bwd(const marl_qtran_weights_t* w, const float* hidden, cons
  * marl_qtran_head_fwd.  The joint-Q head and the V head of one update read the same states (qtran_learner.py:116-118):
  * nsets = 2 serves both from one pass over s.  W_k: q.0 / v.0 weight (64, ldw_k), ldw_k >= S; s: BT rows of S columns as
  * one dense segment (p0, ld0 % 4 == 0, 16-byte aligned; the row remap and the episode map of marl_src_t are honoured -
- * the learner reads s and s_next in place from the (T+1)-slot storage).  Use when marl_qtran_state_parts_supported(S)
- * (S % 4 == 0, S <= 384); otherwise marl_linear. */
+ * the learner reads s and s_next in place from the (T+1)-slot storage; S % 4 != 0 reads the row's last 16 bytes, whose pad
+ * must be finite).  Use when marl_qtran_state_parts_supported(S) (S <= 384); otherwise marl_linear. */
 int marl_qtran_state_parts_supported(int S);
 int marl_qtran_state_parts(const marl_src_t* s, long BT, int S, int nsets, const float* W0, long ldw0, const float* b0, float* sp0,
                            const float* W1, long ldw1, const float* b1, float* sp1, void* stream);

@@ -88,8 +88,9 @@ SIGNATURES = {
     "marl_vec_add": (I, [P, P, P, L, P]),
     "marl_agent_sum": (I, [P, L, P, L, L, I, I, P]),
     "marl_agent_bcast": (I, [P, L, P, L, L, I, I, I, P]),
-    "marl_qmix_mix_fwd": (I, [P, L, P, P, P, L, I, I, P]),
-    "marl_qmix_mix_bwd": (I, [P, L, P, P, P, P, P, L, I, I, P]),
+    "marl_qmix_mix_fwd": (I, [P, L, P, P, P, P, P, L, I, I, P]),
+    "marl_qmix_mix_bwd": (I, [P, L, P, P, P, P, P, P, L, I, I, P]),
+    "marl_qmix_tail_fwd": (I, [SRC, L, I, P, L, P, P, L, P, P, L, I, I, P]),
     "marl_qmix_fused_supported": (I, [I, I, I]),
     "marl_qmix_fused_workspace": (SZ, [L, I, I]),
     "marl_qmix_fused_fwd": (I, [QW, SRC, P, P, L, I, I, I, P]),

@@ -168,8 +168,10 @@ __global__ void agent_bcast_kernel(const float* in, long ld_in, float* out, long
 }
 
 // ---- QMIX: 32 lanes per row (lane = embed unit e), two rows per wave ---------------------------
-__global__ void qmix_mix_fwd_kernel(const float* hy, long ldh, const float* b2, const float* q, float* q_tot,
-                                    long rows, int N, int E) {
+// b2 == nullptr: the state-conditioned scalar bias is formed here from the relu'd hidden layer in hy's last E columns,
+// b2 = w22 . hb + b22 (hyper_b2.2, network/mixer.py:46-47)
+__global__ void qmix_mix_fwd_kernel(const float* hy, long ldh, const float* b2, const float* w22, const float* b22, const float* q,
+                                    float* q_tot, long rows, int N, int E) {
   const int half = (threadIdx.x & 63) >> 5, l = threadIdx.x & 31;
   const long wave_id = ((long)blockIdx.x * TPB + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * TPB) >> 6;
@@ -183,15 +185,17 @@ __global__ void qmix_mix_fwd_kernel(const float* hy, long ldh, const float* b2, 
         for (int n = 0; n < N; ++n) a += q[r * N + n] * fabsf(h[n * E + e]);
         const float hid = a > 0.f ? a : (__expf(a) - 1.f);       // elu, alpha = 1
         part += hid * fabsf(h[N * E + E + e]);
+        if (!b2) part += w22[e] * h[N * E + 2 * E + e];
       }
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (r < rows && l == 0) q_tot[r] = part + b2[r];
+    if (r < rows && l == 0) q_tot[r] = part + (b2 ? b2[r] : b22[0]);
   }
 }
 
-__global__ void qmix_mix_bwd_kernel(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
+// w22 != nullptr: also d hb = dq_tot w22 (hb > 0) into dhy's last E columns (the backward of hyper_b2.2 and its relu)
+__global__ void qmix_mix_bwd_kernel(const float* hy, long ldh, const float* q, const float* dq_tot, const float* w22, float* dhy,
                                     float* db2, float* dq, long rows, int N, int E) {
   const int half = (threadIdx.x & 63) >> 5, l = threadIdx.x & 31;
   const long wave_id = ((long)blockIdx.x * TPB + threadIdx.x) >> 6;
@@ -216,6 +220,7 @@ __global__ void qmix_mix_bwd_kernel(const float* hy, long ldh, const float* q, c
         dh[N * E + E + e] = g * hid * sgn2;                       // d w2raw
         const float dpre = g * fabsf(w2r) * (a > 0.f ? 1.f : ex);
         dh[N * E + e] = dpre;                                     // d b1
+        if (w22) dh[N * E + 2 * E + e] = h[N * E + 2 * E + e] > 0.f ? g * w22[e] : 0.f;
         for (int n = 0; n < N; ++n) {
           const float w1r = h[n * E + e];
           const float sgn1 = w1r > 0.f ? 1.f : (w1r < 0.f ? -1.f : 0.f);
@@ -581,21 +586,22 @@ extern "C" int marl_agent_bcast(const float* in, long ld_in, float* out, long ld
   return 0;
 }
 
-extern "C" int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* q, float* q_tot, long rows,
-                                 int N, int E, void* stream) {
+extern "C" int marl_qmix_mix_fwd(const float* hy, long ldh, const float* b2, const float* w22, const float* b22, const float* q,
+                                 float* q_tot, long rows, int N, int E, void* stream) {
   if (rows <= 0) return 0;
+  if (!b2 && (!w22 || !b22)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(qmix_mix_fwd_kernel, dim3(nblk((rows + 1) / 2 * 64, 8192)), dim3(TPB), 0, (hipStream_t)stream,
-                     hy, ldh, b2, q, q_tot, rows, N, E);
+                     hy, ldh, b2, w22, b22, q, q_tot, rows, N, E);
   MARL_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, float* dhy,
+extern "C" int marl_qmix_mix_bwd(const float* hy, long ldh, const float* q, const float* dq_tot, const float* w22, float* dhy,
                                  float* db2, float* dq, long rows, int N, int E, void* stream) {
   if (rows <= 0) return 0;
   if (N > 16) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(qmix_mix_bwd_kernel, dim3(nblk((rows + 1) / 2 * 64, 8192)), dim3(TPB), 0, (hipStream_t)stream,
-                     hy, ldh, q, dq_tot, dhy, db2, dq, rows, N, E);
+                     hy, ldh, q, dq_tot, w22, dhy, db2, dq, rows, N, E);
   MARL_CHECK_LAUNCH();
   return 0;
 }

@@ -517,7 +517,8 @@ __global__ __launch_bounds__(64 * NW, 2) void qtran_bwd_agents_kernel(QtArgs a) 
 // cover each other's loads.  fp32 on v_mfma_f32_16x16x4_f32, the accumulators of the row tiles interleaved.
 struct SpArgs {
   ConcatSrc s; long BT; int S, kc;
-  const float* W[2]; long ldw[2]; const float* b[2]; float* sp[2];
+  // per (set, 16-feature tile): first weight row (S columns used, row stride ldw), bias, first output column, relu?
+  const float* W[2][4]; long ldw[2]; const float* b[2][4]; float* out[2][4]; long ldo[2]; int relu[2][4];
 };
 constexpr int SPR = 64;           // rows per block
 
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a)
   const int t = wave & 3, g = wave >> 2;
   const int set = NSETS == 2 ? g : 0, rt0 = NSETS == 2 ? 0 : 2 * g;
   const int S = a.S;
-  const float* W = a.W[set] + (long)(16 * t + m) * a.ldw[set];
+  const float* W = a.W[set][t] + (long)m * a.ldw[set];
   f32x4 wf[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
@@ -555,13 +556,15 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a)
       wf[c][i] = k0 + i < S ? v : 0.f;
     }
   }
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b[set] + 16 * t + 4 * q);
-  float* sp = a.sp[set];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b[set][t] + 4 * q);
+  float* sp = a.out[set][t];
+  const long ldo = a.ldo[set];
+  const bool relu = a.relu[set][t] != 0;
   for (int e = tid; e < SPR * (XR - S); e += 64 * NW) {
     const int r = e / (XR - S), c = e - r * (XR - S);
     smem[r * XR + S + c] = 0.f;
   }
-  const int S4 = S >> 2;
+  const int S4 = (S + 3) >> 2;         // (S % 4 != 0: the row stride covers the last 16 bytes, whose pad meets zero weights)
   // the next block's rows travel in registers while this one multiplies: wave w stages rows w, w + 8, .. (one contiguous
   // 4*S-byte read per row; the row's place in s - remap, episode map - is wave-uniform).  Rows past BT re-read row BT - 1
   // (their results are not stored), lanes past the row its last 16 bytes (not staged): no branches around the loads.
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a)
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const long row = row0 + 16 * (rt0 + i) + m;
-      if (row < a.BT) *reinterpret_cast<f32x4*>(sp + row * HD + 16 * t + 4 * q) = acc[i];
+      if (row < a.BT) *reinterpret_cast<f32x4*>(sp + row * ldo + 4 * q) = relu ? relu4(acc[i]) : acc[i];
     }
     __syncthreads();
   }
@@ -965,19 +968,11 @@ extern "C" int marl_qtran_head_fwd2(const marl_qtran_weights_t* w, const float* 
   return launch(qtran_fwd_kernel<5, true, true>, a, grid_for(BT), fwd_lds(5, true), (hipStream_t)stream);
 }
 
-extern "C" int marl_qtran_state_parts_supported(int S) { return (S >= 4 && S % 4 == 0 && S <= 384) ? 1 : 0; }
-
-extern "C" int marl_qtran_state_parts(const marl_src_t* s, long BT, int S, int nsets, const float* W0, long ldw0, const float* b0,
-                                      float* sp0, const float* W1, long ldw1, const float* b1, float* sp1, void* stream) {
-  if (BT <= 0) return 0;
-  if (!marl_qtran_state_parts_supported(S) || nsets < 1 || nsets > 2 || !s || !W0 || !b0 || !sp0) return (int)hipErrorInvalidValue;
-  if (nsets == 2 && (!W1 || !b1 || !sp1)) return (int)hipErrorInvalidValue;
-  if (!state_src_ok(s, S) || !aligned16(sp0) || !aligned16(b0) || (nsets == 2 && (!aligned16(sp1) || !aligned16(b1)))) return (int)hipErrorInvalidValue;
-  SpArgs a = {};
-  a.s = state_src(s); a.BT = BT; a.S = S; a.kc = (S + 15) / 16;
-  a.W[0] = W0; a.ldw[0] = ldw0; a.b[0] = b0; a.sp[0] = sp0;
-  a.W[1] = W1; a.ldw[1] = ldw1; a.b[1] = b1; a.sp[1] = sp1;
-  const long nblk = (BT + SPR - 1) / SPR;
+namespace {
+// launch of the row GEMM [BT, S] x [S, 64 per set] -> 16-feature tiles written where the descriptors say
+int sp_launch(SpArgs& a, int nsets, hipStream_t stream) {
+  a.kc = (a.S + 15) / 16;
+  const long nblk = (a.BT + SPR - 1) / SPR;
   static const int buckets[] = {4, 8, 12, 14, 16, 20, 24};
   int KCT = 24;
   for (int b : buckets) if (a.kc <= b) { KCT = b; break; }
@@ -993,10 +988,49 @@ extern "C" int marl_qtran_state_parts(const marl_src_t* s, long BT, int S, int n
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   void* kargs[] = {(void*)&a};
-  e = hipLaunchKernel(fn, dim3(grid), dim3(64 * NW), kargs, lds, (hipStream_t)stream);
+  e = hipLaunchKernel(fn, dim3(grid), dim3(64 * NW), kargs, lds, stream);
   if (e != hipSuccess) return (int)e;
   MARL_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+// (S % 4 != 0 is covered when the rows are padded to 16 bytes - ld0 % 4 == 0, as the episode storage is - and the pad is finite)
+extern "C" int marl_qtran_state_parts_supported(int S) { return (S >= 1 && S <= 384) ? 1 : 0; }
+
+extern "C" int marl_qtran_state_parts(const marl_src_t* s, long BT, int S, int nsets, const float* W0, long ldw0, const float* b0,
+                                      float* sp0, const float* W1, long ldw1, const float* b1, float* sp1, void* stream) {
+  if (BT <= 0) return 0;
+  if (!marl_qtran_state_parts_supported(S) || nsets < 1 || nsets > 2 || !s || !W0 || !b0 || !sp0) return (int)hipErrorInvalidValue;
+  if (nsets == 2 && (!W1 || !b1 || !sp1)) return (int)hipErrorInvalidValue;
+  if (!state_src_ok(s, S) || !aligned16(sp0) || !aligned16(b0) || (nsets == 2 && (!aligned16(sp1) || !aligned16(b1)))) return (int)hipErrorInvalidValue;
+  SpArgs a = {};
+  a.s = state_src(s); a.BT = BT; a.S = S;
+  const float* W[2] = {W0, W1}; const long ldw[2] = {ldw0, ldw1}; const float* b[2] = {b0, b1}; float* sp[2] = {sp0, sp1};
+  for (int k = 0; k < nsets; ++k) {
+    a.ldw[k] = ldw[k]; a.ldo[k] = HD;
+    for (int t = 0; t < 4; ++t) { a.W[k][t] = W[k] + 16 * t * ldw[k]; a.b[k][t] = b[k] + 16 * t; a.out[k][t] = sp[k] + 16 * t; a.relu[k][t] = 0; }
+  }
+  return sp_launch(a, nsets, (hipStream_t)stream);
+}
+
+// The state-conditioned bias path of QMixMixer (network/mixer.py:44-47, :69-77) in one pass over s, written straight into the
+// hypernet output matrix hy (rows, ldhy) the mixing kernels read:  hy[:, c_b1 : c_b1 + 32] = hyper_b1(s),
+// hy[:, c_h : c_h + 32] = relu(hyper_b2.0(s)).  E = qmix_hidden_dim = 32 (two feature tiles each).
+extern "C" int marl_qmix_tail_fwd(const marl_src_t* s, long rows, int S, const float* Wb1, long ldb1, const float* bb1,
+                                  const float* Wh, long ldwh, const float* bh, float* hy, long ldhy, int c_b1, int c_h,
+                                  void* stream) {
+  if (rows <= 0) return 0;
+  if (!marl_qtran_state_parts_supported(S) || !state_src_ok(s, S) || !Wb1 || !bb1 || !Wh || !bh || !hy) return (int)hipErrorInvalidValue;
+  if (ldb1 != ldwh || !aligned16(bb1) || !aligned16(bh) || !aligned16(hy) || ldhy % 4 || c_b1 % 4 || c_h % 4) return (int)hipErrorInvalidValue;
+  SpArgs a = {};
+  a.s = state_src(s); a.BT = rows; a.S = S;
+  a.ldw[0] = ldb1; a.ldo[0] = ldhy;
+  for (int t = 0; t < 2; ++t) {
+    a.W[0][t] = Wb1 + 16 * t * ldb1; a.b[0][t] = bb1 + 16 * t; a.out[0][t] = hy + c_b1 + 16 * t; a.relu[0][t] = 0;
+    a.W[0][2 + t] = Wh + 16 * t * ldwh; a.b[0][2 + t] = bh + 16 * t; a.out[0][2 + t] = hy + c_h + 16 * t; a.relu[0][2 + t] = 1;
+  }
+  return sp_launch(a, 1, (hipStream_t)stream);
 }
 
 namespace {

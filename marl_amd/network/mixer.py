@@ -231,14 +231,28 @@ class QMixMixer(_Precision, nn.Module):
         else:
             self._lin(self.hyper_w1).fwd(xs, hy[:, :N * E], rows)
             self._lin(self.hyper_w2).fwd(xs, hy[:, N * E + E:N * E + 2 * E], rows)
-        self._lin(self.hyper_b1).fwd(xs, hy[:, N * E:N * E + E], rows)
         b20, b22 = _linears(self.hyper_b2)
-        self._lin(b20).fwd(xs, hy[:, N * E + 2 * E:], rows, act=1)
-        self._lin(b22).fwd(ops.src(hy[:, N * E + 2 * E:]), b2, rows)
-        ops.qmix_mix_fwd(hy, b2, q, qtot, rows, N, E)
+        tail = self._tail_ok(s)
+        if tail:
+            # hyper_b1 and hyper_b2.0 in one pass over s, straight into hy; hyper_b2.2 inside the mixing kernel: no marl_linear
+            ops.qmix_tail_fwd(s, rows, a.state_shape, self.hyper_b1.weight.data, self.hyper_b1.bias.data, b20.weight.data,
+                              b20.bias.data, hy, N * E, N * E + 2 * E)
+            ops.qmix_mix_fwd(hy, None, q, qtot, rows, N, E, w22=b22.weight.data, b22=b22.bias.data)
+        else:
+            self._lin(self.hyper_b1).fwd(xs, hy[:, N * E:N * E + E], rows)
+            self._lin(b20).fwd(xs, hy[:, N * E + 2 * E:], rows, act=1)
+            self._lin(b22).fwd(ops.src(hy[:, N * E + 2 * E:]), b2, rows)
+            ops.qmix_mix_fwd(hy, b2, q, qtot, rows, N, E)
         if ctx is not None:
-            ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2, kept=kept if a.two_hyper_layers else {})
+            ctx.update(hy=hy, q=q, s=s, hw1=hw1, hw2=hw2, kept=kept if a.two_hyper_layers else {}, tail=tail)
         return qtot
+
+    def _tail_ok(self, s):
+        """the bias layers hyper_b1 / hyper_b2 on the row kernel (csrc/qtran_fused.hip: marl_qmix_tail_fwd) - fp32 only"""
+        a = self.args
+        return (not self._bf16() and not getattr(self, "no_fused", False)
+                and ops.qmix_tail_supported(a.state_shape, a.qmix_hidden_dim, s)
+                and self.hyper_b1.weight.data.data_ptr() % 4 == 0)
 
     def loss_backward_fused(self, s):
         """True when hip_loss_backward covers this shape (one of the two fused kernel families)."""
@@ -283,12 +297,13 @@ class QMixMixer(_Precision, nn.Module):
         dhy = self._s.get("dhy", hy.shape, dev)
         db2 = self._s.get("db2", (rows, 1), dev)
         dq = self._s.get("dq", (rows, N), dev)
-        ops.qmix_mix_bwd(hy, q, dq_tot, dhy, db2, dq, rows, N, E)
+        b20, b22 = _linears(self.hyper_b2)
+        ops.qmix_mix_bwd(hy, q, dq_tot, dhy, db2, dq, rows, N, E, w22=b22.weight.data if ctx.get("tail") else None)
         xs = ops.src(s)
         hb, dhb = hy[:, N * E + 2 * E:], dhy[:, N * E + 2 * E:]
-        b20, b22 = _linears(self.hyper_b2)
         self._lin(b22).wgrad(db2, ops.src(hb), rows)
-        self._lin(b22).bwd_x(db2, dhb, rows)
+        if not ctx.get("tail"):
+            self._lin(b22).bwd_x(db2, dhb, rows)
         self._lin(b20).wgrad(dhb, xs, rows, Yact=hb)
         self._lin(self.hyper_b1).wgrad(dhy[:, N * E:N * E + E], xs, rows)
         if a.two_hyper_layers:

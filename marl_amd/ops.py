@@ -287,15 +287,30 @@ def agent_bcast(inp, out, rows, N, D, accumulate=False):
                                        1 if accumulate else 0, _stream()), "marl_agent_bcast")
 
 
-def qmix_mix_fwd(hy, b2, q, q_tot, rows, N, E):
-    check(_lib.load().marl_qmix_mix_fwd(_p(_f32(hy)), hy.stride(0), _p(_f32(b2)), _p(_f32(q)), _p(_f32(q_tot)), rows,
+def qmix_mix_fwd(hy, b2, q, q_tot, rows, N, E, w22=None, b22=None):
+    """b2 None: formed in the kernel from hy's relu'd fourth block with hyper_b2.2's weight w22 (E) and bias b22 (1)"""
+    check(_lib.load().marl_qmix_mix_fwd(_p(_f32(hy)), hy.stride(0), _p(b2), _p(w22), _p(b22), _p(_f32(q)), _p(_f32(q_tot)), rows,
                                         N, E, _stream()), "marl_qmix_mix_fwd")
 
 
-def qmix_mix_bwd(hy, q, dq_tot, dhy, db2, dq, rows, N, E):
+def qmix_mix_bwd(hy, q, dq_tot, dhy, db2, dq, rows, N, E, w22=None):
+    """w22 given: the fourth block of dhy (d hb through hyper_b2.2 and the relu) is written here too"""
     assert dhy.stride(0) == hy.stride(0)
-    check(_lib.load().marl_qmix_mix_bwd(_p(_f32(hy)), hy.stride(0), _p(_f32(q)), _p(_f32(dq_tot)), _p(_f32(dhy)),
+    check(_lib.load().marl_qmix_mix_bwd(_p(_f32(hy)), hy.stride(0), _p(_f32(q)), _p(_f32(dq_tot)), _p(w22), _p(_f32(dhy)),
                                         _p(_f32(db2)), _p(_f32(dq)), rows, N, E, _stream()), "marl_qmix_mix_bwd")
+
+
+def qmix_tail_supported(S, E, s):
+    return E == 32 and qtran_state_parts_supported(S, s)
+
+
+def qmix_tail_fwd(s, rows, S, b1_w, b1_b, h_w, h_b, hy, c_b1, c_h):
+    """hy[:, c_b1:c_b1+32] = hyper_b1(s), hy[:, c_h:c_h+32] = relu(hyper_b2.0(s)) in one pass over s (Rows or dense)"""
+    assert b1_w.stride(1) == 1 and h_w.stride(1) == 1 and b1_w.stride(0) == h_w.stride(0) and hy.stride(1) == 1
+    x = src(s)
+    check(_lib.load().marl_qmix_tail_fwd(C.byref(x), rows, S, _p(_f32(b1_w)), b1_w.stride(0), _p(_f32(b1_b)), _p(_f32(h_w)),
+                                         h_w.stride(0), _p(_f32(h_b)), _p(_f32(hy)), hy.stride(0), c_b1, c_h, _stream()),
+          "marl_qmix_tail_fwd")
 
 
 def qplex_mix_fwd(w_raw, v, q, max_q, key, ag, ac, v_tot, a_tot, lam_out, rows, N, K, weighted, minus_one):

@@ -1319,6 +1319,56 @@ def test_qtran_state_parts(dev, BT, S):
     assert torch.equal(a, one)                                # the pair kernel multiplies in the same order
 
 
+@pytest.mark.parametrize("rows,N,S,padded", [(37, 5, 120, False), (2500, 10, 322, True), (130, 3, 48, True)])
+def test_qmix_two_hyper_tail(dev, rows, N, S, padded):
+    """QMixMixer(two_hyper_layers) generic path: hyper_b1 / hyper_b2.0 from one pass over s (marl_qmix_tail_fwd) and hyper_b2.2 inside
+    the mixing kernels (network/mixer.py:44-47, :69-77) vs the marl_linear composition and vs torch autograd of the reference
+    forward; `padded`: the states are rows of 16-byte padded storage (S % 4 != 0 on MMM2: S = 322 in 324-float rows)."""
+    import types
+    from marl_amd.network.mixer import QMixMixer
+    from marl_amd.hostutil import FlatParams
+    from marl_amd import ops
+    args = types.SimpleNamespace(n_agents=N, state_shape=S, qmix_hidden_dim=32, hyper_hidden_dim=64, two_hyper_layers=True)
+    torch.manual_seed(rows + S)
+    mod, ref = QMixMixer(args), QMixMixer(args)
+    ref.load_state_dict(mod.state_dict())
+    g = torch.Generator().manual_seed(rows)
+    s = torch.randn(rows, S, generator=g)
+    q = torch.randn(rows, N, generator=g).requires_grad_()
+    gq = torch.randn(rows, generator=g)
+    # torch reference (mixer.py:57-80)
+    w1 = torch.abs(ref.hyper_w1(s)).view(rows, N, 32)
+    b1 = ref.hyper_b1(s).view(rows, 1, 32)
+    hid = F.elu(torch.bmm(q.view(rows, 1, N), w1) + b1)
+    w2 = torch.abs(ref.hyper_w2(s)).view(rows, 32, 1)
+    want = (torch.bmm(hid, w2) + ref.hyper_b2(s).view(rows, 1, 1)).view(rows)
+    (want * gq).sum().backward()
+    mod.to(dev)
+    fp = FlatParams(list(mod.parameters()), dev, with_grad=True)
+    if padded:
+        ld = (S + 3) // 4 * 4
+        store = torch.zeros(rows, ld, device=dev)
+        store[:, :S] = s.to(dev)
+        sd = store[:, :S]                                        # unit inner stride, 16-byte aligned rows
+    else:
+        sd = s.to(dev)
+    qd, gd = q.detach().to(dev), gq.to(dev)
+    outs = {}
+    for tail in (True, False):
+        mod.no_fused = not tail
+        fp.grad.zero_()
+        ctx = {}
+        qt = mod.hip_forward(qd, sd, rows, ctx=ctx).clone()
+        assert bool(ctx.get("tail")) == tail
+        dq = mod.hip_backward(ctx, gd, rows).clone()
+        outs[tail] = (qt, dq, fp.grad.clone())
+        close(qt, want, 2e-5, 1e-4, msg="q_tot tail=%s" % tail)
+        close(dq, q.grad, 2e-5, 1e-4, msg="dq tail=%s" % tail)
+        scale = max(1.0, (rows / 64.0) ** 0.5)
+        for (name, p_), pr in zip(mod.named_parameters(), ref.parameters()):
+            close(p_.grad, pr.grad, 3e-5 * scale * max(1.0, float(pr.grad.abs().max())), 1e-4, msg="%s tail=%s" % (name, tail))
+
+
 @pytest.mark.parametrize("BT,N,A,S", [(37, 8, 14, 216), (4100, 3, 16, 40), (1, 2, 3, 1)])
 def test_qtran_two_action_sets(dev, BT, N, A, S):
     """QtranQBase.hip_forward(u_idx2=...): the joint-Q head for the taken and the greedy actions in one launch
