@@ -102,3 +102,18 @@ def test_split_kernel_capability_predicates():
     assert lib.marl_agent_bwd_x6_workspace(2048, 5, 11) == (256 + 128) * slab          # 640 tiles = 512 + 128
     assert lib.marl_agent_bwd_x6_workspace(3000, 5, 11) == 469 * slab                  # 938 tiles = 512 + 426: two-tile workgroups throughout
     assert lib.marl_agent_bwd_x6_workspace(1024, 5, 11) == 160 * slab                  # 320 tiles: less than one full round of two-tile workgroups
+
+
+def test_qtran_row_kernel_predicates_and_workspace():
+    """Host functions of the QTRAN row-level kernels (no GPU): which state widths / encoder widths they cover, and the slab
+    workspace the row-gradient kernel asks for (256 workgroups x [64 x 16 ceil(S/16) | 64 x AEP | 64 x 64 | AEP x AEP | 256])."""
+    from marl_amd import _lib
+    lib = _lib.load()
+    sp, wg, ws = lib.marl_qtran_state_parts_supported, lib.marl_qtran_wgrad_rows_supported, lib.marl_qtran_wgrad_rows_workspace
+    assert sp(216) and sp(120) and sp(322) and sp(1) and sp(384)          # (S % 4 != 0: padded rows, checked per call)
+    assert not sp(0) and not sp(385)
+    assert wg(216, 78) and wg(120, 64) and wg(384, 80) and wg(4, 64)
+    assert not wg(322, 74) and not wg(388, 78) and not wg(216, 81) and not wg(216, 48)
+    for S, AE in ((216, 78), (120, 64), (384, 80)):
+        aep, ts = (AE + 15) // 16 * 16, (S + 15) // 16
+        assert ws(S, AE) == 256 * (64 * 16 * ts + 64 * aep + 64 * 64 + aep * aep + 256) * 4
