@@ -163,8 +163,7 @@ __device__ __forceinline__ void gru_point(float ar, float az, float ain, float a
 // s = p[w0 * stride] + p[(w0 + step) * stride] + .. (w < n), added in that order, eight reads in flight.  The slab reduce kernels
 // sum hundreds of slabs per element: written as `for (..) s += p[..]` every read waits for the previous one (the add keeps the
 // order), and the kernel runs at one HBM latency per slab - 26 us for a 7 MB reduce (round 5, qtran_reduce_kernel: 27 -> 7 us).
-__device__ __forceinline__ float slab_sum(const float* p, long stride, int w0, int step, int n) {
-  float s = 0.f;
+__device__ __forceinline__ float slab_acc(float s, const float* p, long stride, int w0, int step, int n) {
   int w = w0;
   for (; w + 7 * step < n; w += 8 * step) {
     float v[8];
@@ -176,6 +175,7 @@ __device__ __forceinline__ float slab_sum(const float* p, long stride, int w0, i
   for (; w < n; w += step) s += p[(long)w * stride];
   return s;
 }
+__device__ __forceinline__ float slab_sum(const float* p, long stride, int w0, int step, int n) { return slab_acc(0.f, p, stride, w0, step, n); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void mlp3_reduce_kernel(Mlp3RedArgs a) {
   const bool shared = a.groups > 1 && ((first && a.gs_w1 == 0 && a.gs_b1 == 0) || (second && a.gs_w2 == 0 && a.gs_b2 == 0));
   if (shared && g != 0) return;
   float s = 0.f;
-  for (int gg = g; gg < (shared ? a.groups : g + 1); ++gg)
-    for (int sl = 0; sl < a.nst; ++sl) s += a.ws[((long)sl * a.groups + gg) * SZ + r];
+  for (int gg = g; gg < (shared ? a.groups : g + 1); ++gg)      // (same order of additions; eight reads in flight: common.h)
+    s = slab_acc(s, a.ws + (long)gg * SZ + r, (long)a.groups * SZ, 0, 1, a.nst);
   if (first) {
     const int n = (int)(r / K1x), k = (int)(r - (long)n * K1x);
     if (k < a.K1) a.dW1[g * a.gs_w1 + (long)n * a.K1 + k] += s;
