@@ -249,17 +249,15 @@ OTHER_CONFIGS = [("cfg2 QMIX 2s3z 1024 envs (1 GPU)", "qmix", "2s3z", 1024, "fp3
 
 
 def load_pmc(workload):
-    """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/r04_pmc_<workload>.json, written by
-    tools/summarize_profiles.py) - only when the file was taken with the library that is running now (marl_hip_version() carries
-    a hash of the kernel sources): numbers of an older build silently go stale when a kernel changes."""
-    path = None
-    for rnd in ("r05", "r04"):
-        cand = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, workload))
-        if os.path.exists(cand):
-            path = cand
-            break
-    if path is None:
+    """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/<round>_pmc_<workload>.json of the newest
+    round that has one, written by tools/summarize_profiles.py) - only when the file was taken with the library that is running
+    now (marl_hip_version() carries a hash of the kernel sources): numbers of an older build silently go stale when a kernel
+    changes."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % workload)))
+    if not cands:
         return {}, "no PMC file for this workload"
+    path = cands[-1]
     d = json.load(open(path))
     from marl_amd import _lib
     ver = _lib.load().marl_hip_version().decode()
@@ -514,12 +512,13 @@ def cpu_baseline(alg, shape, T, envs, budget_s, threads=0):
 
 def visible_gpus():
     """GPUs this process would see, WITHOUT touching the HIP runtime (the parent of a self-launch must stay clean: a process
-    that has initialised HIP is never replaced or forked into ranks).  From the *_VISIBLE_DEVICES lists when set, else from
-    the KFD topology (nodes with a non-zero simd_count are GPUs); None when neither says."""
-    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(k)
-        if v is not None:
-            return len([x for x in v.split(",") if x.strip() != ""])
+    that has initialised HIP is never replaced or forked into ranks).  From the *_VISIBLE_DEVICES lists when set - the
+    SMALLEST of them: HIP_ / CUDA_VISIBLE_DEVICES index into the set ROCR_VISIBLE_DEVICES leaves, so every list bounds the
+    count - else from the KFD topology (nodes with a non-zero simd_count are GPUs); None when neither says."""
+    counts = [len([x for x in os.environ[k].split(",") if x.strip() != ""])
+              for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(k) is not None]
+    if counts:
+        return min(counts)
     top = "/sys/class/kfd/kfd/topology/nodes"
     try:
         n = 0

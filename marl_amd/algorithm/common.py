@@ -2,6 +2,7 @@
 tail, the fused clip+optimizer wrapper, the agent backward pass and data-parallel reduction."""
 from __future__ import annotations
 
+import warnings
 import weakref
 
 import torch
@@ -388,6 +389,16 @@ class GraphedUpdate:
             return GraphedUpdate(auto=True)
         return GraphedUpdate() if mode else None
 
+    SCHEDULE_ARGS = ("gemm_mode", "mixer_dtype", "mixer_wgrad_dtype", "double_q", "no_loss_fold", "lazy_loss", "gamma",
+                     "two_hyper_layers", "last_action", "reuse_network")
+
+    @staticmethod
+    def _schedule_key(args):
+        """what a captured schedule froze besides shapes and pointers: the generation of the experiments table (every
+        experiments.set() bumps it) and the args fields the launch sequence reads"""
+        from .. import experiments
+        return (experiments.generation,) + tuple(repr(getattr(args, k, None)) for k in GraphedUpdate.SCHEDULE_ARGS)
+
     def run(self, learner, ring, index):
         """Returns True when the update's forward/backward was done here (static buffers + graph), else False."""
         from ..hostutil import DeviceBatch, AsyncInt
@@ -424,9 +435,10 @@ class GraphedUpdate:
         idx.copy_(index)
         db.o_map.copy_(idx)
         ring.select_small(idx, out=small)
-        if e["graph"] is not None and e["ws_gen"] != ops.WS.gen:
-            # a workspace the captured kernels point at was reallocated (another learner / a larger request):
-            # the graph would write into retired storage - drop it and capture again after a warm-up
+        if e["graph"] is not None and (e["ws_gen"] != ops.WS.gen or e["sched_key"] != self._schedule_key(args)):
+            # a workspace the captured kernels point at was reallocated (another learner / a larger request): the graph would
+            # write into retired storage; or a host-side decision frozen at capture (an experiments switch, an args field the
+            # schedule reads) changed on the live learner - drop it and capture again after a warm-up
             e["graph"], e["ws_keep"], e["calls"] = None, None, 0
         pending = None
         term = small.term
@@ -461,9 +473,11 @@ class GraphedUpdate:
                     learner._forward_backward(db)
                 e["graph"] = g
                 e["ws_gen"], e["ws_keep"] = ops.WS.gen, ops.WS.snapshot()
+                e["sched_key"] = self._schedule_key(args)
             except Exception as ex:      # capture not possible on this stack: stay eager for good
                 self.disabled = True
                 self.error = repr(ex)
+                warnings.warn("hipGraph capture of the learner update failed (%s): updates stay on eager launches" % self.error)
                 torch.cuda.synchronize()
                 learner._forward_backward(db)
                 return True

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a)
     const int r = e / (XR - S), c = e - r * (XR - S);
     smem[r * XR + S + c] = 0.f;
   }
-  const int S4 = (S + 3) >> 2;         // (S % 4 != 0: the row stride covers the last 16 bytes, whose pad meets zero weights)
+  const int S4 = (S + 3) >> 2;         // (S % 4 != 0: the row stride covers the last 16 bytes; the elements past S are zeroed at the LDS store)
   // the next block's rows travel in registers while this one multiplies: wave w stages rows w, w + 8, .. (one contiguous
   // 4*S-byte read per row; the row's place in s - remap, episode map - is wave-uniform).  Rows past BT re-read row BT - 1
   // (their results are not stored), lanes past the row its last 16 bytes (not staged): no branches around the loads.
@@ -602,7 +602,13 @@ __global__ __launch_bounds__(64 * NW, 1) void qtran_state_parts_kernel(SpArgs a)
 #pragma unroll
       for (int k = 0; k < CW; ++k) {
         const int c4 = lane + 64 * k;
-        if (c4 < S4) *reinterpret_cast<f32x4*>(smem + (wave + NW * j) * XR + 4 * c4) = ps[j][k];
+        f32x4 v = ps[j][k];
+        if ((S & 3) && c4 == S4 - 1) {      // the row's last 16 bytes reach past S: whatever the neighbour holds there (a
+#pragma unroll                            // column slice of a wider buffer) must not meet the zero weights as NaN / Inf
+          for (int i = 1; i < 4; ++i)
+            if (i >= (S & 3)) v[i] = 0.f;
+        }
+        if (c4 < S4) *reinterpret_cast<f32x4*>(smem + (wave + NW * j) * XR + 4 * c4) = v;
       }
     __syncthreads();
     if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);

@@ -30,8 +30,32 @@ def install(script_dir=None):
         shim = os.path.join(HERE, "smac_shim")
         if shim not in sys.path:
             sys.path.insert(1, shim)
+    else:
+        vectorise_real_smac(int(os.environ.get("MARL_N_ENVS", "1")))
     if script_dir and script_dir not in sys.path:
         sys.path.append(script_dir)
+
+
+def vectorise_real_smac(n_envs, n_threads=None):
+    """A REAL `smac` is importable: `StarCraft2Env(**kw)` of reference main.py:16-20 then builds ``n_envs`` of them
+    behind marl_amd.env.host_vector.HostVectorEnv (lock-step rollout, one H2D + one D2H per step) when MARL_N_ENVS > 1;
+    with MARL_N_ENVS <= 1 the script gets the plain environment and the reference's serial loop."""
+    if n_envs <= 1:
+        return False
+    import smac.env as smac_env
+    real = smac_env.StarCraft2Env
+    if getattr(real, "_marl_vectorised", False):
+        return True
+
+    def StarCraft2Env(*a, **kw):
+        from marl_amd.env.host_vector import HostVectorEnv
+        threads = n_threads if n_threads is not None else int(os.environ.get("MARL_ENV_THREADS", str(min(n_envs, 16))))
+        return HostVectorEnv((lambda: real(*a, **kw), n_envs), seed=kw.get("seed", 1) or 1, n_threads=threads)
+
+    StarCraft2Env._marl_vectorised = True
+    StarCraft2Env._marl_real = real
+    smac_env.StarCraft2Env = StarCraft2Env
+    return True
 
 
 def main(argv):

@@ -47,6 +47,7 @@ if _host_values["chain_split"] is not None and not (_host_values["chain_split"] 
     warnings.warn("MARL_CHAIN_SPLIT=%r ignored (want 0 or a multiple of 8 in 8..248)" % _host_values["chain_split"])
     _host_values["chain_split"] = None
 _applied = None
+generation = 0          # bumped by every set(): schedules captured as hipGraphs (algorithm/common.py:GraphedUpdate) are dropped when it moves
 
 
 def apply(lib):
@@ -55,19 +56,26 @@ def apply(lib):
     _applied = lib
     for k, v in _lib_values.items():
         if v != LIB_DEFAULTS[k]:
-            lib.marl_experiment_set(k.encode(), int(v))
+            rc = lib.marl_experiment_set(k.encode(), int(v))
+            assert rc == 0, "marl_experiment_set(%s) failed" % k
 
 
 def get(name):
+    """host switches from this module; library switches from the LIBRARY's table once it is loaded (a C-ABI caller may have
+    set them through marl_experiment_set directly - the kernels read that table, so the host decisions must too)"""
     if name in _host_values:
         return _host_values[name]
     if name in _lib_values:
+        if _applied is not None:
+            _lib_values[name] = int(_applied.marl_experiment_get(name.encode()))
         return _lib_values[name]
     raise KeyError(name)
 
 
 def set(name, value):      # noqa: A001 - mirrors marl_experiment_set
     """set one switch for the rest of the process (tests, A/B tools); library switches go to the library at once"""
+    global generation
+    generation += 1
     if name in _host_values:
         _host_values[name] = value
         return

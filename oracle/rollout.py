@@ -104,36 +104,42 @@ class SynthSMAC:
 class SerialSynthEnv:
     """SMAC-style serial API (rollout.py:37-166 / main.py:16-29) over SynthSMAC.
     The k-th ``reset()`` plays env id k, episode 0 - so n serial episodes equal the
-    n parallel env slots of a batched rollout."""
+    n parallel env slots of a batched rollout.  With ``env_id`` the object IS env slot ``env_id``
+    and its k-th ``reset()`` plays that slot's episode k (n such objects = one batched env)."""
 
-    def __init__(self, synth: SynthSMAC):
+    def __init__(self, synth: SynthSMAC, env_id=None):
         self.sy = synth
-        self.c = -1
+        self.fixed = env_id is not None
+        self.c = env_id if self.fixed else -1
+        self.e = -1 if self.fixed else 0
         self.t = 0
 
     def reset(self):
-        self.c += 1
+        if self.fixed:
+            self.e += 1
+        else:
+            self.c += 1
         self.t = 0
-        self.L = int(self.sy.length([self.c], [0])[0])
+        self.L = int(self.sy.length([self.c], [self.e])[0])
 
     def get_obs(self):
-        return list(self.sy.obs([self.c], [0], self.t)[0].astype(np.float64))
+        return list(self.sy.obs([self.c], [self.e], self.t)[0].astype(np.float64))
 
     def get_state(self):
-        return self.sy.state([self.c], [0], self.t)[0].astype(np.float64)
+        return self.sy.state([self.c], [self.e], self.t)[0].astype(np.float64)
 
     def get_avail_actions(self):
-        return list(self.sy.avail([self.c], [0], self.t)[0].astype(np.int64))
+        return list(self.sy.avail([self.c], [self.e], self.t)[0].astype(np.int64))
 
     def get_avail_agent_actions(self, i):
         return self.get_avail_actions()[i]
 
     def step(self, actions):
         a = np.asarray([int(x) for x in actions])[None]
-        r = float(self.sy.reward([self.c], [0], self.t, a)[0])
+        r = float(self.sy.reward([self.c], [self.e], self.t, a)[0])
         self.t += 1
         done = self.t >= self.L
-        info = {"battle_won": bool(self.sy.won([self.c], [0])[0])} if done else {}
+        info = {"battle_won": bool(self.sy.won([self.c], [self.e])[0])} if done else {}
         return r, done, info
 
     def get_env_info(self):

@@ -49,6 +49,9 @@ def test_visible_gpus_never_touches_the_runtime(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("must not ask the runtime")))
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
     assert bench.visible_gpus() == 3
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")          # HIP_ indexes into the ROCR_ set: both lists bound the count
+    assert bench.visible_gpus() == 1
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     assert bench.visible_gpus() == 0
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")

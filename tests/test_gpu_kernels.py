@@ -1319,6 +1319,31 @@ def test_qtran_state_parts(dev, BT, S):
     assert torch.equal(a, one)                                # the pair kernel multiplies in the same order
 
 
+@pytest.mark.parametrize("BT,S", [(100, 322), (70, 50), (33, 121)])
+def test_qtran_state_parts_ignores_what_follows_a_row(dev, BT, S):
+    """S % 4 != 0: the kernel reads a row's last 16 bytes, which reach past S into whatever the storage holds there - a column
+    slice of a wider buffer may carry NaN / Inf neighbours.  They are zeroed before the multiply."""
+    import types
+    from marl_amd.network.mixer import QtranQBase
+    from marl_amd import ops
+    if not ops.qtran_state_parts_supported(S):
+        pytest.skip("state width not covered by the row kernel")
+    args = types.SimpleNamespace(n_agents=3, n_actions=7, state_shape=S, rnn_hidden_dim=64, qtran_hidden_dim=64)
+    torch.manual_seed(BT + S)
+    qn = QtranQBase(args).to(dev)
+    SP = (S + 3) // 4 * 4
+    wide = torch.randn(BT, SP, generator=torch.Generator().manual_seed(S)).to(dev)
+    wide[:, S:] = float("nan")
+    wide[::2, S:] = float("inf")
+    s = wide[:, :S]
+    assert ops.qtran_state_parts_supported(S, s)
+    l0 = qn._qt_layers()[2]
+    want = (s.double() @ l0.weight.data[:, :S].double().t() + l0.bias.data.double()).float()
+    got = qn.state_part(s, BT, "x").clone()
+    assert torch.isfinite(got).all()
+    close(got, want, 2e-5, 1e-4, msg="slice with non-finite neighbours")
+
+
 @pytest.mark.parametrize("rows,N,S,padded", [(37, 5, 120, False), (2500, 10, 322, True), (130, 3, 48, True)])
 def test_qmix_two_hyper_tail(dev, rows, N, S, padded):
     """QMixMixer(two_hyper_layers) generic path: hyper_b1 / hyper_b2.0 from one pass over s (marl_qmix_tail_fwd) and hyper_b2.2 inside

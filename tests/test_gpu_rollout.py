@@ -262,3 +262,57 @@ def test_replay_sample_is_read_in_place(alg, shape):
     # generic consumers still get the reference's 11-key dict
     d = batch.numpy()
     assert d["o"].shape == (40, T, sh["n_agents"], sh["obs_shape"])
+
+
+@pytest.mark.parametrize("eps,evaluate,threads", [(0.0, True, 0), (0.5, False, 0), (0.5, False, 4)])
+def test_host_vector_env_matches_device_env(eps, evaluate, threads):
+    """R6 for HOST environments: n objects with the reference's serial env API (rollout.py:42,61-64,86-88) behind
+    HostVectorEnv give the record of the device synthetic env bit for bit (same lock-step protocol, same batched agent
+    step / epsilon-greedy kernels), with ONE H2D and ONE D2H copy per lock-step."""
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd.env.host_vector import HostVectorEnv
+    T, E, env0 = 8, 13, 2
+    args = seeded.make_args("2s3z", "qmix", episode_limit=T, epsilon=eps, seed=77)
+    args.anneal_epsilon = 0.01
+    mac, agent = _mac(args)
+    sy = orl.SynthSMAC(5, 80, 120, 11, T, seed=5)
+    henv = HostVectorEnv([orl.SerialSynthEnv(sy, env_id=env0 + i) for i in range(E)], seed=5, env0=env0, n_threads=threads)
+    assert henv.get_env_info() == sy.get_env_info()
+    wh = RolloutWorker(henv, mac, args)
+    wd = RolloutWorker(SyntheticSMACEnv(E, 5, 80, 120, 11, T, seed=5, env0=env0), mac, args)
+    wd.rollout_mode = "unfused"
+    for rollout in range(2):        # the second one continues the episode counters and the epsilon schedule
+        eh, rh, winh, sh = wh.generate_episodes(E, evaluate=evaluate)
+        ed, rd, wind, sd = wd.generate_episodes(E, evaluate=evaluate)
+        for f in ("obs", "state", "avail", "u", "r", "term", "padded", "length", "won"):
+            assert torch.equal(getattr(eh.record, f), getattr(ed.record, f)), (rollout, f)
+        assert sh == sd and winh == wind and rh == rd
+        np.testing.assert_allclose(wh.epsilon, wd.epsilon, rtol=1e-12)
+        # one bundle up (+ the first observation) and one action vector down per lock-step
+        assert henv.d2h_copies == (rollout + 1) * T and henv.h2d_copies == (rollout + 1) * (T + 1)
+    # ... and the oracle's batched restatement of the second rollout
+    oep, _, _, osteps, _ = orl.batched_rollout(agent, args, sy, E, eps if evaluate else eps - T * 0.01 if eps > args.min_epsilon else eps,
+                                               evaluate=evaluate, rseed=77, env0=env0, episode=1)
+    assert sh == osteps
+    np.testing.assert_array_equal(eh.numpy()["u"], oep["u"])
+
+
+def test_host_vector_env_matches_reference_greedy_fixture(golden_dir):
+    """the reference RolloutWorker's own greedy record on six serial episodes (tests/golden/rollout.npz: smac_greedy, written
+    by the reference's rollout.py) == six host environments stepped in lock-step through the adapter"""
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.host_vector import HostVectorEnv
+    fix = np.load(golden_dir + "/rollout.npz")
+    args = seeded.make_args("2s3z", "qmix", episode_limit=8)
+    args.epsilon = 0.0
+    mac, _ = _mac(args)
+    sy = orl.SynthSMAC(5, 80, 120, 11, 8, seed=5)
+    w = RolloutWorker(HostVectorEnv([orl.SerialSynthEnv(sy, env_id=i) for i in range(6)], seed=5), mac, args)
+    ep, rew, wins, steps = w.generate_episodes(6, evaluate=True)
+    got = ep.numpy()
+    for k in ("u", "r", "padded", "terminated", "avail_u", "avail_u_next"):
+        np.testing.assert_allclose(got[k], fix["smac_greedy/%s" % k], atol=1e-6, err_msg=k)
+    chk = seeded.checksum([got["o"], got["o_next"], got["s"], got["s_next"]])
+    np.testing.assert_allclose(chk, float(fix["smac_greedy/o_checksum"]), rtol=1e-6)
+    assert steps == int(fix["smac_greedy/steps"]) and list(wins) == list(fix["smac_greedy/wins"])

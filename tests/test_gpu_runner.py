@@ -123,3 +123,31 @@ def test_reference_style_main_flow_on_dropin(tmp_path):
                        cwd=str(tmp_path), capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, PYTHONPATH=root, MARL_N_ENVS="16", MPLBACKEND="Agg"))
     assert p.returncode == 0 and "MAIN_FLOW_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_main_flow_vectorises_a_real_smac_install(tmp_path):
+    """A `smac` package that IS importable (here: a stand-in whose StarCraft2Env is a serial host environment with the
+    reference's env API) + MARL_N_ENVS > 1: the launcher wraps it in HostVectorEnv, and main.py's flow trains on the lock-step
+    rollout over host environments (reference main.py:16-29, rollout.py:42,61-64,86-88)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = tmp_path / "site" / "smac"
+    pkg.mkdir(parents=True)
+    (pkg / "__init__.py").write_text("")
+    (pkg / "env.py").write_text(
+        "import itertools\n"
+        "from oracle.rollout import SynthSMAC, SerialSynthEnv\n"
+        "_ids = itertools.count()\n"
+        "class StarCraft2Env(SerialSynthEnv):\n"
+        "    def __init__(self, map_name='2s3z', **kw):\n"
+        "        assert map_name == '2s3z'\n"
+        "        super().__init__(SynthSMAC(5, 80, 120, 11, 24, seed=3), env_id=next(_ids))\n")
+    p = subprocess.run([sys.executable, "-m", "marl_amd.dropin", os.path.join(root, "tests", "dropin_main_flow.py"),
+                        "--alg", "qmix", "--map", "2s3z", "--result_dir", str(tmp_path / "res"), "--model_dir", str(tmp_path / "m")],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=root + os.pathsep + str(tmp_path / "site"), MARL_N_ENVS="6",
+                                MARL_ENV_THREADS="3", MPLBACKEND="Agg"))
+    assert p.returncode == 0 and "MAIN_FLOW_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "marl_amd.env.host_vector" in p.stdout

@@ -170,3 +170,22 @@ def test_state_dicts_match_reference_checkpoints(golden_dir):
         assert got == ref, path
         checked += 1
     assert checked >= 20
+
+
+def test_launcher_vectorises_an_importable_smac(tmp_path, monkeypatch):
+    """`python -m marl_amd.dropin` with a real `smac` on the path: MARL_N_ENVS > 1 swaps smac.env.StarCraft2Env for a
+    factory of HostVectorEnv over that many real environments (not called here - it needs the GPU); <= 1 leaves it alone."""
+    pkg = tmp_path / "smac"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "env.py").write_text("class StarCraft2Env:\n    pass\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    _forget_dropin_modules()
+    from marl_amd.dropin.__main__ import vectorise_real_smac
+    import smac.env as se
+    real = se.StarCraft2Env
+    assert vectorise_real_smac(1) is False and se.StarCraft2Env is real
+    assert vectorise_real_smac(8) is True
+    assert se.StarCraft2Env is not real and se.StarCraft2Env._marl_real is real
+    assert vectorise_real_smac(8) is True and se.StarCraft2Env._marl_real is real      # idempotent
+    _forget_dropin_modules()

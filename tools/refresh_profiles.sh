@@ -1,30 +1,82 @@
 #!/bin/bash
-# Regenerates the evidence under profiles/ (run ON THE GPU BOX from the repo root through gpurun):
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r01'
-# 1. rocprofv3 --kernel-trace --stats of the default bench command           -> gpurun_out/<tag>_bench/
-# 2. PMC passes (own runs, --kernel-trace only) of the learner               -> gpurun_out/<tag>_pmc/pass{1..4}
-# 3. in-kernel stamp shares of the three persistent kernels (diagnostic .so) -> gpurun_out/<tag>_stamps.txt
-# Then, in the container: python tools/summarize_profiles.py <tag>   (writes profiles/<tag>_*)
-TAG=${1:-r01}
+# Evidence of one round, ON THE GPU BOX from the repo root:   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r06'
+# then in the container:   python tools/summarize_profiles.py r06     (writes profiles/r06_*)
+#  1. rocprofv3 --kernel-trace --stats of the default bench command (headline only)           -> gpurun_out/<round>_bench/
+#  2. PMC passes (own runs, --kernel-trace only; FETCH_SIZE and WRITE_SIZE in separate passes) of the learner at the headline
+#     workload AND at every configs[] leg of bench.py - gpurun_out/<round>_pmc_<workload>/pass*/; SQ group (MFMA busy, VALU) for the
+#     4096-env workloads
+#  3. the full default bench line, soak runs (2000 steps at 4096 and 512 envs), shard steps, learner rates, the fused-head timings
+# PARTS (second argument, default "all"): any of  bench pmc stats times rates shards soak line
+TAG=${1:?usage: refresh_profiles.sh <round tag, e.g. r06> [parts]}
+PARTS=${2:-all}
+want() { [ "$PARTS" = all ] || [[ " $PARTS " == *" $1 "* ]]; }
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
-rm -rf $OUT/${TAG}_bench $OUT/${TAG}_pmc
-# (headline workload only: the legs of the other configurations would mix their launches into the per-kernel averages)
+python3 -c "from marl_amd import _lib; print(_lib.load().marl_hip_version().decode())" > $OUT/${TAG}_lib_version.txt
+if want bench; then rm -rf $OUT/${TAG}_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -o p -- python3 bench.py --no-cpu-baseline --no-configs > $OUT/${TAG}_bench.log 2>&1
-grep '^{"metric"' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench_line.json
-P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU"
-P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU GRBM_GUI_ACTIVE"
-i=0
-for P in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/${TAG}_pmc/pass$i -o p -- python3 tools/prof_learner.py --updates 3 --rollouts 2 > $OUT/${TAG}_pmc.pass$i.log 2>&1 || true
+grep '^{"metric"' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench_profiled_line.json
+fi
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+pmc() {   # workload-name  full(0/1)  prof_learner args...
+  local W=$1 FULL=$2; shift 2
+  local i=0
+  for P in "FETCH_SIZE" "WRITE_SIZE" "$P1"; do
+    i=$((i+1))
+    if [ $i = 3 ] && [ $FULL = 0 ]; then break; fi
+    rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$W/pass$i -o p -- python3 tools/prof_learner.py --updates 3 --warmup 1 "$@" > $OUT/${TAG}_pmc_$W.pass$i.log 2>&1 || true
+  done
+}
+if want pmc; then rm -rf $OUT/${TAG}_pmc_*
+pmc qmix_2s3z_T120_envs4096 1 --rollouts 2
+pmc qmix_2s3z_T120_envs1024 0 --envs 1024
+pmc qplex_2s3z_T120_envs512 0 --alg qplex --envs 512
+pmc qtran_base_3s5z_T150_envs512 0 --alg qtran_base --shape 3s5z --envs 512
+pmc qmix_MMM2_T120_envs1024_bf16mixer 0 --shape MMM2 --envs 1024 --mixer-dtype bf16
+pmc qplex_2s3z_T120_envs512_bf16x6 0 --alg qplex --envs 512 --gemm-mode bf16x6
+pmc qplex_2s3z_T120_envs4096 0 --alg qplex --envs 4096
+pmc qplex_2s3z_T120_envs4096_bf16x6 1 --alg qplex --envs 4096 --gemm-mode bf16x6
+pmc qmix_2s3z_T120_envs4096_bf16x6 1 --gemm-mode bf16x6
+pmc qmix_2s3z_T120_envs1024_bf16x6 0 --envs 1024 --gemm-mode bf16x6
+pmc qmix_2s3z_T120_envs512 0 --envs 512
+pmc qmix_2s3z_T120_envs512_bf16x6 0 --envs 512 --gemm-mode bf16x6
+pmc qtran_base_3s5z_T150_envs512_bf16x6 0 --alg qtran_base --shape 3s5z --envs 512 --gemm-mode bf16x6
+pmc qmix_MMM2_T120_envs1024_bf16mixer_bf16x6 0 --shape MMM2 --envs 1024 --mixer-dtype bf16 --gemm-mode bf16x6
+fi
+if want stats; then
+# kernel stats of the QMIX / QPLEX updates in both modes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qmix_bf16x6 -o p -- python3 tools/prof_learner.py --alg qmix --envs 4096 --updates 6 --warmup 2 --gemm-mode bf16x6 > $OUT/${TAG}_qmix_bf16x6.log 2>&1
+for M in f32 bf16x6; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qplex_$M -o p -- python3 tools/prof_learner.py --alg qplex --envs 4096 --updates 6 --warmup 2 --gemm-mode $M > $OUT/${TAG}_qplex_$M.log 2>&1
 done
-make -C marl_amd/csrc stamps > /dev/null 2>&1
-( for k in rollout fwd bwd wgrad qmix mlp3; do python3 tools/stamps.py $k 4096 2>/dev/null | grep -v amdgpu.ids; echo; done
-  for k in fwd_pipe bwd_pipe rollout; do python3 tools/stamps.py $k 512 2>/dev/null | grep -v amdgpu.ids; echo; done ) > $OUT/${TAG}_stamps.txt
-timeout 900 python3 bench.py > $OUT/${TAG}_bench_full.log 2>&1
-grep '^{"metric"' $OUT/${TAG}_bench_full.log | tail -1 > $OUT/${TAG}_bench_full_line.json
-# 4. QPLEX learner (config 3 shape, 4096 envs): kernel stats + standalone timings of the fused head kernels
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qplex -o p -- python3 tools/prof_learner.py --alg qplex --shape 2s3z --envs 4096 --updates 6 > $OUT/${TAG}_qplex.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_qtran -o p -- python3 tools/prof_learner.py --alg qtran_base --shape 3s5z --envs 512 --updates 12 --warmup 3 > $OUT/${TAG}_qtran.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_mmm2_bf16 -o p -- python3 tools/prof_learner.py --shape MMM2 --envs 1024 --mixer-dtype bf16 --updates 8 --warmup 3 > $OUT/${TAG}_mmm2_bf16.log 2>&1
+fi
+if want times; then
+# timings
 python3 tools/time_mlp3.py 4096 > $OUT/${TAG}_mlp3_times.txt 2>&1
-ls $OUT/${TAG}_bench $OUT/${TAG}_pmc/* | head -40
+python3 tools/time_unroll_x6.py 4096 1024 512 256 > $OUT/${TAG}_unroll_x6_times.txt 2>&1
+SHAPE=3s5z python3 tools/time_unroll_x6.py 512 2048 >> $OUT/${TAG}_unroll_x6_times.txt 2>&1
+SHAPE=MMM2 python3 tools/time_unroll_x6.py 1024 >> $OUT/${TAG}_unroll_x6_times.txt 2>&1
+python3 tools/time_qmix.py 4096 1024 512 > $OUT/${TAG}_qmix_times.txt 2>&1
+python3 tools/time_rollout.py > $OUT/${TAG}_rollout_times.txt 2>&1
+fi
+if want rates; then
+( for a in "--alg qmix --envs 512" "--alg qmix --envs 4096" "--alg qplex --envs 512" "--alg qplex --envs 4096"; do for w in 1 100000; do
+    echo -n "$a --gemm-mode bf16x6, split BPTT $([ $w = 1 ] && echo on || echo off) : "; MARL_X6_BWD_MIN_WG=$w python3 tools/prof_learner.py $a --gemm-mode bf16x6 --warmup 5 --updates 30 2>/dev/null | tail -1; done; done ) > $OUT/${TAG}_bptt_x6_ab.txt
+( for a in "--alg qmix --envs 1024" "--alg qmix --envs 4096" "--alg vdn --envs 4096" "--alg qplex --envs 512" "--alg qplex --envs 512 --gemm-mode bf16x6" "--alg qplex --envs 4096" \
+           "--alg qplex --envs 4096 --gemm-mode bf16x6" "--alg qmix --envs 512" "--alg qmix --envs 512 --gemm-mode bf16x6" "--alg qmix --envs 1024 --gemm-mode bf16x6" "--alg qmix --envs 4096 --gemm-mode bf16x6" "--alg qtran_base --shape 3s5z --envs 512" "--alg qtran_base --shape 3s5z --envs 512 --gemm-mode bf16x6" "--alg qtran_base --shape 3s5z --envs 2048" "--shape MMM2 --envs 1024" "--shape MMM2 --envs 1024 --mixer-dtype bf16" "--shape MMM2 --envs 1024 --mixer-dtype bf16 --gemm-mode bf16x6" "--alg qmix --shape 3s5z --envs 1024" "--alg qmix --shape 3s5z --envs 1024 --gemm-mode bf16x6"; do
+    echo -n "$a : "; python3 tools/prof_learner.py $a --warmup 5 --updates 20 2>/dev/null | tail -1; done ) > $OUT/${TAG}_learner_rates.txt
+fi
+if want shards; then
+for e in 512 1024 2048 4096; do python3 bench.py --envs $e --gemm-mode f32 --no-cpu-baseline --no-configs --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('envs_per_gpu=%d gemm_mode=f32 hip_graph=%s : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['envs_per_gpu'], d['config']['hip_graph'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"; done > $OUT/${TAG}_shard_steps.txt
+for e in 512 1024 2048 4096; do python3 bench.py --envs $e --gemm-mode bf16x6 --no-twin --no-cpu-baseline --no-configs --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('envs_per_gpu=%d gemm_mode=bf16x6 hip_graph=%s : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['envs_per_gpu'], d['config']['hip_graph'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"; done >> $OUT/${TAG}_shard_steps.txt
+fi
+if want soak; then
+for e in 4096 512; do python3 bench.py --envs $e --no-twin --no-cpu-baseline --no-configs --steps 2000 --warmup 20 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('soak: envs=%d steps=%d ms_per_step %.3f env-steps/s %.2f M (timed %.1f s)' % (d['config']['global_envs'], d['steps'], d['ms_per_step'], d['value']/1e6, d['ms_per_step']*d['steps']/1e3))"; done > $OUT/${TAG}_soak.txt
+fi
+if want line; then
+timeout 1200 python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_full.log
+cp bench_full.json $OUT/${TAG}_bench_full.json
+fi
+ls $OUT | grep ${TAG}_ | head -60
