@@ -287,6 +287,7 @@ class PairedUnroll:
         self.chain = experiments.get("no_chain") != 1               # experiments: MARL_NO_CHAIN=1 keeps the plain pair + continuation
         # experiments only: MARL_CHAIN_SPLIT=<CUs of the chain side> (marl_amd/experiments.py validates it), 0 = never chain
         self.forced_split = experiments.get("chain_split")
+        self.big_pair = experiments.get("big_pair") == 1            # experiments: MARL_BIG_PAIR=1 (see run_chain)
 
     def applies(self, rows, T):
         return self.enabled and T >= 8 and 32 <= (rows + 15) // 16 <= self.MAX_TILES
@@ -351,6 +352,14 @@ class PairedUnroll:
         it on the rest with more tiles per workgroup; nothing waits for a launch gap in the middle.  Larger shards keep
         the plain schedule (pair first/second, then cont over the whole chip)."""
         split = self.chain_split(rows, T, obs_dim) if cont is not None else None
+        if split is None and self.big_pair and self.enabled and not self.applies(rows, T) and T >= 8:
+            # batches beyond the pair's tile cap: the HBM-bound saving unroll and the issue-bound target unroll in flight
+            # together, every launch over the whole chip - the dispatcher mixes their workgroups over the CUs
+            if cont is not None:
+                self._fork(lambda: (first(256), cont(256)), lambda: second(256))
+            else:
+                self._fork(lambda: first(256), lambda: second(256))
+            return
         if split is None:
             self.run(rows, T, first, second)
             if cont is not None:

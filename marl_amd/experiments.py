@@ -12,6 +12,7 @@ library switches (environment variable -> name, default):
     MARL_WGRAD_TALL -> wgrad_tall 1   LDS-staged tall weight-gradient kernel
     MARL_WIDE_RES -> wide_res 1, MARL_WIDE_RES32 -> wide_res32 0    resident-weights forward of the wide-state QMIX mixer
 host switches:
+    MARL_BIG_PAIR -> big_pair 0       batches beyond the pair's tile cap: eval chain and target unroll in flight together (two streams)
     MARL_NO_PAIR -> no_pair 0         the eval and target unrolls back to back instead of side by side on two streams
     MARL_NO_CHAIN -> no_chain 0       never the chain schedule (eval -> double-Q continuation beside the target unroll)
     MARL_CHAIN_SPLIT -> chain_split None    CUs of the chain side (0 = never chain, else a multiple of 8 in [8, 248])
@@ -26,7 +27,7 @@ import os
 import warnings
 
 LIB_DEFAULTS = {"fwd_xs": 1, "fwd_dma": 0, "fwd_w2l": 1, "bwd_pipe_max_rt": 4, "wgrad_tall": 1, "wide_res": 1, "wide_res32": 0}
-HOST_DEFAULTS = {"no_pair": 0, "no_chain": 0, "chain_split": None, "mlp3_keep": 1, "x6_bwd_min_wg": 1, "force_reducer": 0}
+HOST_DEFAULTS = {"big_pair": 0, "no_pair": 0, "no_chain": 0, "chain_split": None, "mlp3_keep": 1, "x6_bwd_min_wg": 1, "force_reducer": 0}
 
 
 def _env_int(name, default):

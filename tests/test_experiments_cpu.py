@@ -45,9 +45,9 @@ def test_no_getenv_in_kernel_sources_and_one_reader_in_the_host_package():
     readers = []
     for dp, _, fs in os.walk(os.path.join(ROOT, "marl_amd")):
         for f in fs:
-            if f.endswith(".py") and re.search(r"os\.environ\.get\(\s*[\"']MARL_(?!HIP_LIB|N_ENVS)", open(os.path.join(dp, f)).read()):
+            if f.endswith(".py") and re.search(r"os\.environ\.get\(\s*[\"']MARL_(?!HIP_LIB|N_ENVS|ENV_THREADS)", open(os.path.join(dp, f)).read()):
                 readers.append(os.path.relpath(os.path.join(dp, f), ROOT))
-    assert readers == ["marl_amd/experiments.py"], readers           # (MARL_HIP_LIB / MARL_N_ENVS are not switches)
+    assert readers == ["marl_amd/experiments.py"], readers           # (MARL_HIP_LIB / MARL_N_ENVS / MARL_ENV_THREADS are not switches)
 
 
 def test_graph_policy_from_args_and_split_step_model():
