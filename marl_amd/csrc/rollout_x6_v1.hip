@@ -1,35 +1,28 @@
+// THE FIRST DECOMPOSITION of the split whole-rollout kernel (round 5), kept behind marl_experiment_set("rollout_v1", 1) as the
+// bitwise twin of rollout_x6.hip (same arithmetic, another division of labour: tests/test_gpu_rollout.py compares the two records).
 // Whole-rollout persistent kernel with the agent step as bf16x6 split products (x6.h; args.gemm_mode = "bf16x6"): ONE launch plays all
 // T lock-steps of E synthetic SMAC-shaped environments (reference rollout.py:60-101 + controller/share_params.py:37-72, vectorised).
 // Same environment (synth_hash.h), same epsilon-greedy choice, same episode record as rollout_fused.hip (the fp32 MFMA kernel); the
 // agent's products (network/q_network.py:16-21) are six bf16 MFMA products each, fp32 accumulate.
 //
-// Round 6 decomposition (the round-5 one lives on in rollout_x6_v1.hip as this kernel's bitwise twin).  What bounded the first one:
-// its input-side gate sums travelled team I -> LDS (12 KB of fp32 per row tile) -> team R, which capped a workgroup at three row
-// tiles (4096 envs x 5 agents = five tiles per CU -> TWO rounds of three-tile workgroups, one tile-slot in six empty) and cost a
-// fourth barrier per lock-step.  Here the recurrent team holds BOTH gate matrices and runs x W_ih and h W_hh down ONE accumulator
-// chain (bias, the x chunks, then the h chunks: the very order of additions the hand-over had, so the two kernels agree bit for bit):
-//   team R (waves 0-3, hidden-unit slice s): W_ih and W_hh fragments (144 registers), the hidden state in fp32 registers
-//   team I (waves 4-7, slice s):             fc1 (observation part) and fc2 fragments, the epsilon-greedy choice, the env step
-// No gate-sum buffer: 30 KB of LDS per row tile -> up to FIVE tiles per workgroup, the whole share of a CU in one round.
-// A lock-step, three LDS-only barriers; the dependent chain is  rec (R) | choice (I) | x (I), everything else rides beside it:
-//   A  R: gates(t) = bias + x(t) W_ih + h(t-1) W_hh, gate math, h(t) -> planes        I: pre(t+1) = fc1 of the slot-(t+1) planes; the hashes
-//                                                                                        of the steps to come (uniforms, slot prefixes)
-//   B  I: q(t) = fc2(h(t)) and the epsilon-greedy choice IN REGISTERS                  R: generate the observations of slot t+2 (record +
-//         (a row's 16 actions on a DPP row: max + three ballots)                          planes), first part
-//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step (reward / terminated / padded)
-//                                                                                     R: rest of the observations; state + availability of slot t+2
-// fc1 = (bias + W1[:, obs | id] in) - on the matrix cores, a step ahead - + W1[:, O + u], one column of fp32 weights added per row
-// once u is known (a table in LDS).  Availability lives in LDS as one bit mask per row and slot (four slots deep: no hazards).
+// Why it is another decomposition and not a variant of rollout_fused.hip: pre-split, a hidden-unit slice's weights are 204 registers,
+// so the two teams of the workgroup hold DIFFERENT weights (as in agent_x6.hip) - and a rollout cannot run its input side ahead of
+// the recurrence, because step t + 1's input contains the action chosen at step t.  What can run ahead is the OBSERVATION part of fc1
+// (the environment's observations do not depend on the actions): fc1 = (bias + W1[:, obs | id] in) - on the matrix cores, a step
+// ahead - + W1[:, O + u], one column of fp32 weights added per row once u is known (a table in LDS).
+//   team R (waves 0-3, hidden-unit slice s): W_hh and fc1 fragments (72 + 12 NK1 registers), the hidden state in fp32 registers
+//   team I (waves 4-7, slice s):             W_ih and fc2 fragments (72 + 24)
+// A lock-step, four LDS-only barriers:
+//   P1  R: gates(t) = GI(t) + h(t-1) W_hh, gate math, h(t) -> planes          I: generate the observations of slot t+1 (record + planes)
+//   P2  R: pre(t+1) = fc1 of the slot-(t+1) planes                            I: q(t) = fc2(h(t)) and the epsilon-greedy choice IN REGISTERS
+//                                                                                (a wave holds a row tile's 16 actions on 16 lanes: DPP max + ballots)
+//   P3  R: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes                     I: env step (reward / terminated / padded), next uniforms, hash prefixes
+//   P4  R: generate state + availability of slot t+2                         I: GI(t+1) = bias + x(t+1) W_ih -> LDS
+// A workgroup holds whole environments in RTC <= 3 row tiles of 16 (episode, agent) rows (~45 KB of LDS per tile); larger batches
+// run in rounds of workgroups (4096 envs x 5 agents: 512 workgroups of 8 environments = two full rounds).
 #include "x6.h"
 #include "synth_hash.h"
 #include "../../include/marl_hip.h"
-
-// the round-5 kernel (rollout_x6_v1.hip)
-int marl_rollout_x6_v1_supported(int N, int O, int A);
-int marl_rollout_x6_v1(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode, int fixed_len, const float* eps,
-                       float* obs, float* state, long state_ld, float* avail, int* u, float* r, float* term, float* padded, int* length,
-                       int* won, float* h_out, float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N, int O,
-                       int S, int A, int last_action, int reuse_network, void* stream);
 
 namespace {
 
@@ -118,18 +111,19 @@ template <int RTC, int NK1>
 __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int team = wave >> 2, s = wave & 3;      // team 0 = R (the recurrence; off the chain: slot generation), team 1 = I (fc1, fc2 + choice, x, env step)
+  const int team = wave >> 2, s = wave & 3;      // team 0 = R (recurrent + fc1), team 1 = I (W_ih + fc2 + choice)
   const int q = lane >> 4, m = lane & 15, u = 16 * s + m;
   constexpr int rows = 16 * RTC;
   const int T = a.T, N = a.N, O = a.O, S = a.S, A = a.A;
   const int IP = a.KI + 8;
   const int IN_E = 3 * rows * IP, XP_E = 3 * rows * HP;
-  short* In0 = reinterpret_cast<short*>(smem);                             // [3][rows][IP]   input planes of the slot fc1 reads next
+  short* In0 = reinterpret_cast<short*>(smem);                             // [3][rows][IP]   input planes of the slot to come
   short* Xp0 = In0 + IN_E;                                                 // [3][rows][HP]   x(t+1)
   short* Hp0 = Xp0 + XP_E;                                                 // [2][3][rows][HP] h by step parity
-  float* W1a = reinterpret_cast<float*>(Hp0 + 2 * XP_E);                   // [A + 1][64]: fc1 columns of the one-hot(last action) block; row A = zeros
-  unsigned* avm = reinterpret_cast<unsigned*>(W1a + (A + 1) * H);          // [4 slots][rows] availability bit masks (bit k = action k)
-  int* act = reinterpret_cast<int*>(avm + 4 * rows);                       // [rows]
+  float* GI0 = reinterpret_cast<float*>(Hp0 + 2 * XP_E);                   // [RTC][4][3][64] f32x4
+  float* Av0 = GI0 + RTC * 4 * 3 * 256;                                    // [2][rows][A] availability by slot parity
+  float* W1a = Av0 + 2 * rows * A;                                         // [A + 1][64]: fc1 columns of the one-hot(last action) block; row A = zeros
+  int* act = reinterpret_cast<int*>(W1a + (A + 1) * H);                    // [rows]
   int* rowe = act + rows;                                                  // [rows] local env of the row
   int* rown = rowe + rows;                                                 // [rows] agent
   int* elen = rown + rows;                                                 // [rows] episode length of the local env
@@ -138,7 +132,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   unsigned* pfxS = pfxA + rows;                                            // [rows] ... of its state (per env: entries 0 .. EPW-1); entries rows/2 .. : the reward hash prefix of the NEXT step, per env
   float* uex = reinterpret_cast<float*>(pfxS + rows);                      // [2 step parities][2][rows] explore / pick uniforms of a step's choice
   int4* rmeta = reinterpret_cast<int4*>(uex + 4 * rows);                   // [rows] {obs offset of (b,0,n,0), avail offset, episode length, n}
-  int4* emeta = rmeta + rows;                                              // [EPW] {state offset of (b,0,0), episode length, env in range, -}
+  int4* emeta = rmeta + rows;                                              // [rows] {state offset of (b,0,0), episode length, env in range, -}
+  i32x4* W2f = reinterpret_cast<i32x4*>(emeta + rows);                     // [2 k chunks][3 planes][64 lanes]: the fc2 fragments (the same for every wave)
   auto hpp = [&](int b) { return Hp0 + b * XP_E; };
 
   const int nenv_wg = a.EPW;
@@ -153,7 +148,6 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     rown[r] = (int)(rho % N);
     act[r] = -1;
   }
-  for (int r = tid; r < 4 * rows; r += RNT) avm[r] = 0u;
   const int lmin = T / 2 > 1 ? T / 2 : 1;
   for (int e = tid; e < nenv_wg; e += RNT) {
     int b = b0 + e; if (b > a.E - 1) b = a.E - 1;
@@ -182,8 +176,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   for (int el = tid; el < nenv_wg; el += RNT)
     emeta[el] = make_int4((b0 + el) * (T + 1) * (int)a.SL, elen[el], b0 + el < a.E ? 1 : 0, 0);
 
-  // ---- the environment's slot t -> record (+ input planes / availability masks); flattened over (row, 4-column group) items,
-  // branch-free (rollout_fused.hip: gen_slot); `tl` / `nthr`: the threads that share the work
+  // ---- the environment's slot t -> record (+ input planes / availability); flattened over (row, 4-column group) items, branch-free
+  // (rollout_fused.hip: gen_slot); `first` / `nthr`: the threads that share the work
   const int O4 = O >> 2, S4 = (S + 3) >> 2;
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1), invA = 1.0f / (float)A;
   const float invS4 = 1.0f / (float)(S4 > 0 ? S4 : 1), invS = 1.0f / (float)S;
@@ -199,10 +193,12 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     pfxA[r] = hprefix(a.seed, ST_AVAIL, (unsigned)(a.env0 + b0 + rowe[r]), tg);
     if (r < nenv_wg) pfxS[r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg);
   };
-  // observation items e_lo <= e < e_hi of slot t (item = (row, 4-column group)), thread tl of nthr
-  auto gen_obs = [&](int t, bool to_lds, int e_lo, int e_hi, int tl, int nthr) __attribute__((always_inline)) {
+  // the (row, 4-column group) items of a thread are the same at every step: their metadata is resolved once (gen_obs_items) and
+  // kept in registers by the team that generates the observations inside the loop - a step reads only the slot's hash prefix
+  constexpr int NOI = NK1 == 3 ? 5 : 8;                    // items per thread of a 256-thread team: rows (<= 48) x O / 4 (<= 8 NK1) <= 256 NOI
+  auto gen_obs = [&](int t, bool to_lds, int tl, int nthr) {
     const int tNO = t * N * O;
-    for (int e = e_lo + tl; e < e_hi; e += nthr) {
+    for (int e = tl; e < vrows * O4; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invO4);
       const int k = 4 * (e - r * O4);
       const int4 mt = rmeta[r];
@@ -225,20 +221,17 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       }
     }
   };
-  // state + availability of slot t: record, and the availability bit masks of the slot (ring entry t & 3: zero when this starts - the
-  // entry of slot t + 1 is cleared here for the next call)
-  auto gen_rest = [&](int t, int tl, int nthr) __attribute__((always_inline)) {
+  auto gen_rest = [&](int t, float* Av, int tl, int nthr) {
     const int tNA = t * N * A, tS = t * (int)a.SL;
-    unsigned* am = avm + (t & 3) * rows;
-    for (int r = tl; r < rows; r += nthr) avm[((t + 1) & 3) * rows + r] = 0u;
     for (int e = tl; e < vrows * A; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invA);
       const int k = e - r * A;
       const int4 mt = rmeta[r];
       const float uu = u01(hfin(pfxA[r], (unsigned)(mt.w * A + k)));
       const bool on = (t <= mt.z) & ((k == 0) | (uu < 0.7f));
-      a.avail[(long)mt.y + tNA + k] = on ? 1.f : 0.f;
-      if (on) atomicOr(am + r, 1u << k);
+      const float v = on ? 1.f : 0.f;
+      a.avail[(long)mt.y + tNA + k] = v;
+      Av[r * A + k] = v;
     }
     if (svec) {
       for (int e = tl; e < nenv_wg * S4; e += nthr) {
@@ -263,13 +256,11 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       }
     }
   };
-  const int n_oi = vrows * O4;                   // observation items of a slot
-  // ---- prologue: slot 0 (record, planes, masks) -> x(0) (team I); then slot 1 takes the input planes' place
   __syncthreads();
   if (tid < rows) { gen_prefix_obs(0, tid); gen_prefix_rest(0, tid); }
   __syncthreads();
-  gen_obs(0, true, 0, n_oi, tid, RNT);
-  gen_rest(0, tid, RNT);
+  gen_obs(0, true, tid, RNT);
+  gen_rest(0, Av0, tid, RNT);
   __syncthreads();
   if (tid < rows) {       // prefixes of slot 1; uniforms of the first choice
     gen_prefix_obs(1, tid); gen_prefix_rest(1, tid);
@@ -278,99 +269,99 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     uex[rows + tid] = u01(hkey(a.rseed, ST_PICK, env, tg0, (unsigned)rown[tid]));
   }
   const int KC1 = a.KI >> 5;
+
+  // ---- q = fc2(h) and the epsilon-greedy choice (share_params.py:66-70) of a row tile, in registers: lane (q, m) of the accumulator
+  // tile holds rows 4q + r of action m - a row's 16 actions sit on the 16 lanes of a DPP row.  A wave computes q of the tile (12
+  // products) and makes the choice of its rows 4q + s (four rows in ONE pass of ballots); the four slice waves of a team cover a
+  // tile.  Both teams hold the fc2 fragments: row tiles 0 .. RTI-1 are team I's, the last of three is team R's (it waits otherwise).
+  constexpr int RTI = RTC == 3 ? 2 : RTC;
+  // (ready fragments in LDS, read back per use: the teams need their registers for their own weights - keeping them in team I's
+  // registers was measured: 41 spilled registers in the three-tile instantiation, slower)
+  if (wave < 2) {
+    const F3 f = wfrag(a.W2, H, 0, A, H, wave, lane);
+    W2f[(wave * 3 + 0) * 64 + lane] = f.h; W2f[(wave * 3 + 1) * 64 + lane] = f.m; W2f[(wave * 3 + 2) * 64 + lane] = f.l;
+  }
+  const float bias_2 = m < A ? a.b2[m] : 0.f;
+  int c_rr[RTC], c_len[RTC], c_uoff[RTC], c_av[RTC];      // this lane's row of each tile: its index (clamped), episode length (-1: not a row), offsets
+#pragma unroll
+  for (int rt = 0; rt < RTC; ++rt) {
+    const int row = rt * 16 + 4 * q + s;
+    const bool valid = row < vrows;
+    const int rr = valid ? row : vrows - 1;
+    const int4 mt = rmeta[rr];
+    c_rr[rt] = rr; c_len[rt] = valid ? mt.z : -1;
+    c_uoff[rt] = (b0 + rowe[rr]) * T * N + mt.w;
+    c_av[rt] = rr * A + (m < A ? m : 0);
+  }
+  auto choose = [&](int rt, int t, float eps) __attribute__((always_inline)) {
+    const int par = t & 1;
+    F3 hb[2], w2[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      hb[c] = bfrag(hpp(par ^ 1) + rt * 16 * HP, HP, rows * HP, c, lane);
+      w2[c].h = W2f[(c * 3 + 0) * 64 + lane]; w2[c].m = W2f[(c * 3 + 1) * 64 + lane]; w2[c].l = W2f[(c * 3 + 2) * 64 + lane];
+    }
+    f32x4 ac[2] = {splat(bias_2), splat(0.f)};
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
+    X6_TERMS(OP)
+#undef OP
+    const f32x4 qv = ac[0] + ac[1];
+    const float qs = s == 0 ? qv[0] : s == 1 ? qv[1] : s == 2 ? qv[2] : qv[3];
+    const int rr = c_rr[rt], sh = 16 * q;
+    const bool on = m < A && Av0[par * rows * A + c_av[rt]] != 0.f;
+    const float v = on ? qs : -3.0e38f;
+    const float mx = group_max16(v);
+    const unsigned am = (unsigned)(__ballot(on) >> sh) & 0xffffu;
+    const unsigned em = (unsigned)(__ballot(on && v == mx) >> sh) & 0xffffu;
+    const int navail = __popc(am);
+    int arg = em ? __ffs(em) - 1 : (am ? __ffs(am) - 1 : 0);
+    const bool explore = uex[par * 2 * rows + rr] < eps;
+    int kk = (int)floorf(uex[par * 2 * rows + rows + rr] * (float)navail);
+    if (kk > navail - 1) kk = navail - 1;
+    const bool sel = explore && on && __popc(am & ((1u << m) - 1u)) == kk;
+    const unsigned sm = (unsigned)(__ballot(sel) >> sh) & 0xffffu;
+    if (sm) arg = __ffs(sm) - 1;
+    if (!(t < c_len[rt])) arg = -1;
+    if (c_len[rt] >= 0 && m == 0) {
+      act[rt * 16 + 4 * q + s] = arg;
+      a.u[c_uoff[rt] + t * N] = arg;
+    }
+  };
   // (the reward prefixes live in the upper half of pfxS, double-buffered by step parity: EPW <= rows / 4 - always, unless N < 4)
   const bool pre_r = 4 * nenv_wg <= rows;
+  // the uniforms of step t+1's choice and the hash prefixes of slot t+2, ONE hash per thread of a 256-thread team (index ti)
+  auto hashes = [&](int t, int ti) __attribute__((always_inline)) {
+    const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
+    const int kind = ti / rows, r = ti - kind * rows;
+    if (kind < 5) {
+      const unsigned env = (unsigned)(a.env0 + b0 + rowe[r]), nn_ = (unsigned)rown[r];
+      float* ux = uex + ((t + 1) & 1) * 2 * rows;
+      if (kind == 0) ux[r] = u01(hkey(a.rseed, ST_EXPLORE, env, tg + 1u, nn_));
+      else if (kind == 1) ux[rows + r] = u01(hkey(a.rseed, ST_PICK, env, tg + 1u, nn_));
+      else if (kind == 2) pfxO[r] = hprefix(a.seed, ST_OBS, env, tg + 2u);
+      else if (kind == 3) pfxA[r] = hprefix(a.seed, ST_AVAIL, env, tg + 2u);
+      else if (r < nenv_wg) pfxS[r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg + 2u);
+      else if (pre_r && r >= rows / 2 && r - rows / 2 < nenv_wg)      // the reward prefix of step t+1 (off the env step's dependent chain)
+        pfxS[rows / 2 + ((t + 1) & 1) * (rows / 4) + (r - rows / 2)] = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + r - rows / 2), tg + 1u);
+    }
+  };
   // epsilon of step t: a device vector, or the reference's per-step anneal (rollout.py:100-101) evaluated here in fp64
   float eps_next = a.eps ? a.eps[0] : (float)a.eps0;
   double eps_d = a.eps0;
 
   if (team == 0) {
-    // =============================== team R: the recurrence; beside the chain: the slots to come ===============================
-    F3 wi[6], wh[6];
+    // =============================== team R: fc1 (observation part), the recurrence, x ===============================
+    F3 wh[6], w1[NK1];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        wi[2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
-        wh[2 * g + c] = wfrag(a.Whh, H, g * H + 16 * s, 3 * H, H, c, lane);
-      }
-    const float bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u], bias_hn = a.bhh[2 * H + u];
-    f32x4 hreg[RTC];
-#pragma unroll
-    for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
-    // R's share of a slot's observation items before the choice barrier (team I needs ~the choice's time to get there)
-    const int oi_cut = (n_oi * 5) >> 3;
-    WG_BARRIER();                                  // P0: slot 0 in the planes, tables (team I: fc1, x(0))
-    WG_BARRIER();                                  // P1: x(0), pre(0) taken: the input planes are free
-    gen_obs(1, 1 < T, 0, n_oi, tid, RNT / 2);      // slot 1 (team I: its hashes ran before P0)
-    gen_rest(1, tid, RNT / 2);
-    WG_BARRIER();                                  // P2
-    ST_DECL(6);
-    for (int t = 0; t < T; ++t) {
-      const int par = t & 1;
-      // ---- A: gates(t) = bias + x(t) W_ih + h(t-1) W_hh (one accumulator chain per gate: bias, x chunks, h chunks), gate math, h(t)
-#pragma unroll
-      for (int rt = 0; rt < RTC; ++rt) {
-        f32x4 ag[3] = {splat(bias_r), splat(bias_z), splat(bias_n)};
-        f32x4 ahn = splat(bias_hn);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const F3 xb = bfrag(Xp0 + rt * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ag[g] = mm(xb.p_, wi[2 * g + c].q_, ag[g]);
-          X6_TERMS(OP)
-#undef OP
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const F3 hb = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) ag[0] = mm(hb.p_, wh[c].q_, ag[0]); ag[1] = mm(hb.p_, wh[2 + c].q_, ag[1]); ahn = mm(hb.p_, wh[4 + c].q_, ahn);
-          X6_TERMS(OP)
-#undef OP
-        }
-        f32x4 hn;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hn[r] = gru_h_x6(ag[0][r], ag[1][r], ag[2][r], ahn[r], hreg[rt][r]);
-        put4(hpp(par ^ 1), HP, rows * HP, rt * 16 + 4 * q, u, hn);
-        hreg[rt] = hn;
-      }
-      ST_MARK(0);
-      WG_BARRIER();                                // B1: h(t) planes | pre(t+1) taken: the input planes are free; prefixes of slot t+2
-      ST_MARK(1);
-      // ---- B, C: slot t+2 (its observations feed fc1 in A of step t+1; its availability the choice of step t+2)
-      if (t + 2 <= T) gen_obs(t + 2, t + 2 < T, 0, oi_cut, tid, RNT / 2);
-      ST_MARK(2);
-      WG_BARRIER();                                // B2: act(t)
-      ST_MARK(3);
-      if (t + 2 <= T) {
-        gen_obs(t + 2, t + 2 < T, oi_cut, n_oi, tid, RNT / 2);
-        gen_rest(t + 2, tid, RNT / 2);
-      }
-      ST_MARK(4);
-      WG_BARRIER();                                // B3: x(t+1) planes | slot t+2
-      ST_MARK(5);
-    }
-    ST_DUMP(6);
-    if (a.h_out) {
-#pragma unroll
-      for (int rt = 0; rt < RTC; ++rt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * q + r;
-          const long rho = row0 + row;
-          if (row < vrows && rho < a.R) a.h_out[rho * H + u] = hreg[rt][r];
-        }
-      }
-    }
-  } else {
-    // =============================== team I: fc1, fc2 + the choice, x, the environment's bookkeeping ===============================
-    const int ti = tid - RNT / 2;
-    F3 w1[NK1], w2[2];
+      for (int c = 0; c < 2; ++c) wh[2 * g + c] = wfrag(a.Whh, H, g * H + 16 * s, 3 * H, H, c, lane);
 #pragma unroll
     for (int c = 0; c < NK1; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
+    const float bias_1 = a.b1[u], bias_hn = a.bhh[2 * H + u];
+    f32x4 hreg[RTC], pre[RTC];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) w2[c] = wfrag(a.W2, H, 0, A, H, c, lane);
-    const float bias_1 = a.b1[u], bias_2 = m < A ? a.b2[m] : 0.f;
-    f32x4 pre[RTC];
+    for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
     // pre = bias + W1[:, obs | id] in  of every row tile from the input planes (three accumulator chains, chunk c on chain c % 3)
     auto fc1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -402,64 +393,94 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         put4(Xp0, HP, rows * HP, rt * 16 + 4 * q, u, x);
       }
     };
-    // ---- q = fc2(h) and the epsilon-greedy choice (share_params.py:66-70) of a row tile, in registers: lane (q, m) of the accumulator
-    // tile holds rows 4q + r of action m - a row's 16 actions sit on the 16 lanes of a DPP row.  Every wave of the team computes q of
-    // the tile (12 products) and makes the choice of its rows 4q + s (four rows in ONE pass of ballots).
-    int c_rr[RTC], c_len[RTC], c_uoff[RTC];      // this lane's row of each tile: its index (clamped), episode length (-1: not a row), u offset
-#pragma unroll
-    for (int rt = 0; rt < RTC; ++rt) {
-      const int row = rt * 16 + 4 * q + s;
-      const bool valid = row < vrows;
-      const int rr = valid ? row : vrows - 1;
-      const int4 mt = rmeta[rr];
-      c_rr[rt] = rr; c_len[rt] = valid ? mt.z : -1;
-      c_uoff[rt] = (b0 + rowe[rr]) * T * N + mt.w;
-    }
-    auto choose = [&](int rt, int t, float eps) __attribute__((always_inline)) {
+    WG_BARRIER();                                  // slot 0 in the planes, tables
+    fc1();
+    xput();                                        // x(0): no last action
+    WG_BARRIER();                                  // x(0) | (team I: GI(0))
+    gen_rest(1, Av0 + rows * A, tid, RNT / 2);     // state + availability of slot 1
+    WG_BARRIER();
+    ST_DECL(8);
+    for (int t = 0; t < T; ++t) {
       const int par = t & 1;
-      F3 hb[2];
+      // ---- P1: gates(t) on top of the handed input-side sums, gate math, h(t)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(par ^ 1) + rt * 16 * HP, HP, rows * HP, c, lane);
-      f32x4 ac[2] = {splat(bias_2), splat(0.f)};
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
-      X6_TERMS(OP)
+      for (int rt = 0; rt < RTC; ++rt) {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(GI0) + (rt * 4 + s) * 192 + lane;
+        f32x4 ah[3] = {gp[0], gp[64], splat(bias_hn)};
+        const f32x4 an = gp[128];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const F3 hb = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, c, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ah[g] = mm(hb.p_, wh[2 * g + c].q_, ah[g]);
+          X6_TERMS(OP)
 #undef OP
-      const f32x4 qv = ac[0] + ac[1];
-      const float qs = s == 0 ? qv[0] : s == 1 ? qv[1] : s == 2 ? qv[2] : qv[3];
-      const int rr = c_rr[rt], sh = 16 * q;
-      const bool on = m < A && ((avm[(t & 3) * rows + rr] >> m) & 1u) != 0u;
-      const float v = on ? qs : -3.0e38f;
-      const float mx = group_max16(v);
-      const unsigned am = (unsigned)(__ballot(on) >> sh) & 0xffffu;
-      const unsigned em = (unsigned)(__ballot(on && v == mx) >> sh) & 0xffffu;
-      const int navail = __popc(am);
-      int arg = em ? __ffs(em) - 1 : (am ? __ffs(am) - 1 : 0);
-      const bool explore = uex[par * 2 * rows + rr] < eps;
-      int kk = (int)floorf(uex[par * 2 * rows + rows + rr] * (float)navail);
-      if (kk > navail - 1) kk = navail - 1;
-      const bool sel = explore && on && __popc(am & ((1u << m) - 1u)) == kk;
-      const unsigned sm = (unsigned)(__ballot(sel) >> sh) & 0xffffu;
-      if (sm) arg = __ffs(sm) - 1;
-      if (!(t < c_len[rt])) arg = -1;
-      if (c_len[rt] >= 0 && m == 0) {
-        act[rt * 16 + 4 * q + s] = arg;
-        a.u[c_uoff[rt] + t * N] = arg;
+        }
+        f32x4 hn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hn[r] = gru_h_x6(ah[0][r], ah[1][r], an[r], ah[2][r], hreg[rt][r]);
+        put4(hpp(par ^ 1), HP, rows * HP, rt * 16 + 4 * q, u, hn);
+        hreg[rt] = hn;
       }
-    };
-    // the uniforms of step t+1's choice and the hash prefixes of slot t+2 (+ the reward prefix of step t+1): items (kind, row), kind-major
-    auto hashes = [&](int t) __attribute__((always_inline)) {
-      const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-      for (int x = ti; x < 5 * rows; x += RNT / 2) {
-        const int kind = x / rows, r = x - kind * rows;
-        const unsigned env = (unsigned)(a.env0 + b0 + rowe[r]), nn_ = (unsigned)rown[r];
-        float* ux = uex + ((t + 1) & 1) * 2 * rows;
-        if (kind == 0) ux[r] = u01(hkey(a.rseed, ST_EXPLORE, env, tg + 1u, nn_));
-        else if (kind == 1) ux[rows + r] = u01(hkey(a.rseed, ST_PICK, env, tg + 1u, nn_));
-        else if (kind == 2) pfxO[r] = hprefix(a.seed, ST_OBS, env, tg + 2u);
-        else if (kind == 3) pfxA[r] = hprefix(a.seed, ST_AVAIL, env, tg + 2u);
-        else if (r < nenv_wg) pfxS[r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg + 2u);
-        else if (pre_r && r >= rows / 2 && r - rows / 2 < nenv_wg)      // the reward prefix of step t+1 (off the env step's dependent chain)
-          pfxS[rows / 2 + ((t + 1) & 1) * (rows / 4) + (r - rows / 2)] = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + r - rows / 2), tg + 1u);
+      ST_MARK(0);
+      WG_BARRIER();                                // B1: h(t) planes | obs planes of slot t+1
+      ST_MARK(1);
+      // ---- P2: pre(t+1) from the planes team I filled during P1; the hashes of the steps to come (they depend on nothing of this
+      // step; the uniforms go to the other parity's buffer - team I reads this step's now); the choice of the third row tile
+      const float eps = eps_next;
+      if (a.eps) { if (t + 1 < T) eps_next = a.eps[t + 1]; }
+      else { eps_d = eps_d > a.eps_min ? eps_d - a.eps_anneal : eps_d; eps_next = (float)eps_d; }
+      if (RTC == 3) choose(RTC - 1, t, eps);
+      if (t + 1 < T) fc1();
+      hashes(t, tid);
+      ST_MARK(2);
+      WG_BARRIER();                                // B2: act(t)
+      ST_MARK(3);
+      // ---- P3: x(t+1)
+      if (t + 1 < T) xput();
+      ST_MARK(4);
+      WG_BARRIER();                                // B3: x(t+1) planes | prefixes of slot t+2
+      ST_MARK(5);
+      // ---- P4: state + availability of slot t+2 (its availability buffer held slot t's, last read before B2)
+      if (t + 2 <= T) gen_rest(t + 2, Av0 + par * rows * A, tid, RNT / 2);
+      ST_MARK(6);
+      WG_BARRIER();                                // B4: GI(t+1)
+      ST_MARK(7);
+    }
+    ST_DUMP(8);
+    if (a.h_out) {
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * q + r;
+          const long rho = row0 + row;
+          if (row < vrows && rho < a.R) a.h_out[rho * H + u] = hreg[rt][r];
+        }
+      }
+    }
+  } else {
+    // =============================== team I: W_ih, fc2 + the choice, the environment's bookkeeping ===============================
+    const int ti = tid - RNT / 2;
+    F3 wi[6];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wi[2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
+    const float bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u];
+    // GI = bias + x W_ih of every row tile from the x planes -> LDS (for the R wave of this slice)
+    auto gih = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+        f32x4 ag[3] = {splat(bias_r), splat(bias_z), splat(bias_n)};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const F3 xb = bfrag(Xp0 + rt * 16 * HP, HP, rows * HP, c, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ag[g] = mm(xb.p_, wi[2 * g + c].q_, ag[g]);
+          X6_TERMS(OP)
+#undef OP
+        }
+        f32x4* gp = reinterpret_cast<f32x4*>(GI0) + (rt * 4 + s) * 192 + lane;
+        gp[0] = ag[0]; gp[64] = ag[1]; gp[128] = ag[2];
       }
     };
     // env step: lane -> (env, agent); the N rows of an environment sit in ONE wave, environments dealt to the four waves in turn
@@ -467,33 +488,66 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     const int es_n = lane - es_er * N, es_l0 = es_er * N;
     const int es_el = 4 * es_er + s;
     const bool es_has = es_er < es_epw && es_el < nenv_wg && b0 + es_el < a.E;
+    // this thread's observation items (row, 4-column group): item j = ti + 256 j, the same at every step
+    int oi_off[NOI], oi_len[NOI], oi_idx[NOI], oi_lds[NOI], oi_row[NOI];
+#pragma unroll
+    for (int j = 0; j < NOI; ++j) {
+      int e = ti + (RNT / 2) * j;
+      const bool has = e < vrows * O4;
+      if (!has) e = 0;
+      const int r = (int)(((float)e + 0.5f) * invO4);
+      const int k = 4 * (e - r * O4);
+      const int4 mt = rmeta[r];
+      oi_off[j] = mt.x + k; oi_len[j] = has ? mt.z : -2;      // (no item: never live, nothing stored)
+      oi_idx[j] = mt.w * O + k; oi_lds[j] = r * IP + k; oi_row[j] = r;
+    }
+    auto gen_obs_items = [&](int t, bool to_lds) __attribute__((always_inline)) {
+      const int tNO = t * N * O;
+#pragma unroll
+      for (int j = 0; j < NOI; ++j) {
+        if (oi_len[j] == -2) continue;
+        const unsigned po = pfxO[oi_row[j]];
+        const unsigned lm = t <= oi_len[j] ? 0xffffffffu : 0u, fm = t < oi_len[j] ? 0xffffffffu : 0u;
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = bits(2.0f * u01(hfin(po, (unsigned)(oi_idx[j] + i))) - 1.0f) & lm;
+        *reinterpret_cast<u32x4*>(a.obs + (long)oi_off[j] + tNO) = v;
+        if (to_lds) {
+          f32x4 w;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(float, v[i] & fm);
+          const F3h f = split4(w);
+          short* p = In0 + oi_lds[j];
+          *reinterpret_cast<i32x2*>(p) = f.h;
+          *reinterpret_cast<i32x2*>(p + rows * IP) = f.m;
+          *reinterpret_cast<i32x2*>(p + 2 * rows * IP) = f.l;
+        }
+      }
+    };
     float ep_r = 0.f;
-    WG_BARRIER();                                  // P0: slot 0 in the planes, tables
-    fc1();
-    xput();                                        // x(0): no last action
-    WG_BARRIER();                                  // P1: (team R: slot 1 -> the input planes)
-    WG_BARRIER();                                  // P2
-    ST_DECL(6);
+    WG_BARRIER();                                  // (team R: slot 0 planes -> fc1, x(0))
+    WG_BARRIER();                                  // x(0)
+    gih();                                         // GI(0)
+    WG_BARRIER();
+    ST_DECL(8);
     for (int t = 0; t < T; ++t) {
+      const int par = t & 1;
       const float eps = eps_next;
       if (a.eps) { if (t + 1 < T) eps_next = a.eps[t + 1]; }
       else { eps_d = eps_d > a.eps_min ? eps_d - a.eps_anneal : eps_d; eps_next = (float)eps_d; }
       const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-      // ---- A: pre(t+1) from the planes of slot t+1; the hashes of the steps to come (they depend on nothing of this step; the uniforms
-      // go to the other parity's buffer, the slot prefixes were last read before B3 of step t-1)
-      if (t + 1 < T) fc1();
-      hashes(t);
+      // ---- P1: the observations of slot t+1 -> record, and (steps that feed the network) -> input planes
+      gen_obs_items(t + 1, t + 1 < T);
       ST_MARK(0);
-      WG_BARRIER();                                // B1: h(t)
+      WG_BARRIER();                                // B1
       ST_MARK(1);
-      // ---- B: q(t) and the choice
+      // ---- P2: q(t) and the choice of this team's row tiles
 #pragma unroll
-      for (int rt = 0; rt < RTC; ++rt) choose(rt, t, eps);
+      for (int rt = 0; rt < RTI; ++rt) choose(rt, t, eps);
       ST_MARK(2);
       WG_BARRIER();                                // B2: act(t)
       ST_MARK(3);
-      // ---- C: x(t+1); env step (reward / terminated / padded; fixed-order fp32 sum over agents)
-      if (t + 1 < T) xput();
+      // ---- P3: env step (reward / terminated / padded; fixed-order fp32 sum over agents)
       if (es_has) {
         const int L = elen[es_el];
         const bool live = t < L;
@@ -523,48 +577,46 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       ST_MARK(4);
       WG_BARRIER();                                // B3: x(t+1)
       ST_MARK(5);
+      // ---- P4: GI(t+1)
+      if (t + 1 < T) gih();
+      ST_MARK(6);
+      WG_BARRIER();                                // B4
+      ST_MARK(7);
     }
-    ST_DUMP(6);
+    ST_DUMP(8);
     if (a.stats && es_has && es_n == 0) a.stats[b0 + es_el] = ep_r;
   }
 }
 
-// LDS bytes of a workgroup of RTC row tiles holding EPW environments
-static size_t rx6_lds(int rtc, int KI, int A, int epw) {
+// LDS bytes of a workgroup of RTC row tiles
+static size_t rx6_lds(int rtc, int KI, int A) {
   const size_t rows = 16 * (size_t)rtc, IP = KI + 8;
-  return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)(A + 1) * H * 4 + 4 * rows * 4 /* avm */ + rows * (4 * 4 /* act rowe rown elen */ + 3 * 4 /* pfx */ + 4 * 4 /* uex */) +
-         rows * 16 /* rmeta */ + (size_t)epw * 16 /* emeta */;
+  return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)rtc * 4 * 3 * 1024 + 2 * rows * A * 4 + (size_t)(A + 1) * H * 4 +
+         rows * (4 * 4 + 3 * 4 + 4 * 4) + 2 * rows * 16 + 6 * 64 * 16;
 }
-// row tiles a workgroup may hold: five fc1 chunks (wide inputs) cost registers and LDS
-static int rx6_max_tiles(int KI) { return KI > 96 ? 4 : 5; }
 
 }  // namespace
 
-ST_DEFINE_SETTER(marl_debug_stamps_rollout_x6)
+ST_DEFINE_SETTER(marl_debug_stamps_rollout_x6_v1)
 
 // shapes the split rollout covers: H = 64, <= 16 actions, observation width a multiple of 4, input width <= 160 (three / five fc1
-// chunks: 2s3z- and 3s5z-sized agents), whole environments in at most five (wide inputs: four) row tiles; an environment's agents in
-// one wave
-extern "C" int marl_synth_rollout_x6_supported(int N, int O, int A) {
+// chunks: 2s3z- and 3s5z-sized agents), whole environments in at most three row tiles (N <= 48; an environment's agents in one wave)
+__attribute__((visibility("hidden"))) int marl_rollout_x6_v1_supported(int N, int O, int A) {
   if (A < 1 || A > 16 || N < 1 || O < 4 || (O & 3)) return 0;
   const int I = O + A + N;
   if (I > 160) return 0;
   const int KI = (I + 31) / 32 * 32;
-  const int mt = rx6_max_tiles(KI);
-  if (N > 16 * mt || N > 64) return 0;                   // a whole environment in one workgroup; its agents on one wave (env step)
-  return rx6_lds((N + 15) / 16, KI, A, 1) <= 160 * 1024 ? 1 : 0;
+  if (N > (KI > 96 ? 32 : 48)) return 0;                   // whole environments in at most three (wide inputs: two) row tiles
+  return rx6_lds(KI > 96 ? 2 : 3, KI, A) <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
+__attribute__((visibility("hidden"))) int marl_rollout_x6_v1(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
                                      int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                                      float* r, float* term, float* padded, int* length, int* won, float* h_out,
                                      float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N,
                                      int O, int S, int A, int last_action, int reuse_network, void* stream) {
-  if (marl_switches()->rollout_v1 && marl_rollout_x6_v1_supported(N, O, A))
-    return marl_rollout_x6_v1(w, seed, rseed, env0, episode, fixed_len, eps, obs, state, state_ld, avail, u, r, term, padded, length, won,
-                              h_out, stats, eps0, eps_anneal, eps_min, E, T, N, O, S, A, last_action, reuse_network, stream);
   if (E <= 0 || T <= 0) return 0;
-  if (w->H != H || state_ld < S || !marl_synth_rollout_x6_supported(N, O, A)) return (int)hipErrorInvalidValue;
+  if (w->H != H || state_ld < S || !marl_rollout_x6_v1_supported(N, O, A)) return (int)hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(obs) & 15) return (int)hipErrorInvalidValue;
   RX6Args a;
   a.W1 = w->fc1_w; a.b1 = w->fc1_b; a.Wih = w->w_ih; a.Whh = w->w_hh; a.bih = w->b_ih; a.bhh = w->b_hh;
@@ -581,10 +633,9 @@ extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned see
   if ((double)E * (T + 1) * N * (O > A ? O : A) >= 2147483648.0 || (double)E * (T + 1) * state_ld >= 2147483648.0)
     return (int)hipErrorInvalidValue;
   // environments per workgroup: one workgroup per CU while the batch fits one round (small batches spread over all CUs with partly
-  // filled tiles); beyond that as few FULL rounds of 256 workgroups as five row tiles per workgroup allow, evenly filled
+  // filled tiles); beyond that as few FULL rounds of 256 workgroups as three row tiles per workgroup allow, evenly filled
   const int nk1 = a.KI > 96 ? 5 : 3;
-  int epw_max = 16 * rx6_max_tiles(a.KI) / N;
-  while (epw_max > 1 && rx6_lds((epw_max * N + 15) / 16, a.KI, A, epw_max) > 160 * 1024) --epw_max;
+  const int epw_max = (nk1 == 3 ? 48 : 32) / N;            // (five fc1 chunks: two row tiles per workgroup - registers)
   if (epw_max < 1) return (int)hipErrorInvalidValue;
   int epw = (E + 255) / 256;
   if (epw > epw_max) {
@@ -594,15 +645,12 @@ extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned see
   }
   a.EPW = epw;
   const int rtc = (epw * N + 15) / 16;
-  const size_t lds = rx6_lds(rtc, a.KI, A, epw);
+  const size_t lds = rx6_lds(rtc, a.KI, A);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   dim3 grid((unsigned)((E + epw - 1) / epw)), block(RNT);
-  const void* fn = nullptr;
-#define RX6_PICK(NK_) (rtc == 1 ? (const void*)synth_rollout_x6_kernel<1, NK_> : rtc == 2 ? (const void*)synth_rollout_x6_kernel<2, NK_> \
-                       : rtc == 3 ? (const void*)synth_rollout_x6_kernel<3, NK_> : (const void*)synth_rollout_x6_kernel<4, NK_>)
-  if (nk1 == 3) fn = rtc == 5 ? (const void*)synth_rollout_x6_kernel<5, 3> : RX6_PICK(3);
-  else fn = RX6_PICK(5);
-#undef RX6_PICK
+  const void* fn;
+  if (nk1 == 3) fn = rtc == 1 ? (const void*)synth_rollout_x6_kernel<1, 3> : rtc == 2 ? (const void*)synth_rollout_x6_kernel<2, 3> : (const void*)synth_rollout_x6_kernel<3, 3>;
+  else fn = rtc == 1 ? (const void*)synth_rollout_x6_kernel<1, 5> : (const void*)synth_rollout_x6_kernel<2, 5>;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   void* kargs[] = {(void*)&a};

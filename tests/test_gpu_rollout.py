@@ -316,3 +316,34 @@ def test_host_vector_env_matches_reference_greedy_fixture(golden_dir):
     chk = seeded.checksum([got["o"], got["o_next"], got["s"], got["s_next"]])
     np.testing.assert_allclose(chk, float(fix["smac_greedy/o_checksum"]), rtol=1e-6)
     assert steps == int(fix["smac_greedy/steps"]) and list(wins) == list(fix["smac_greedy/wins"])
+
+
+@pytest.mark.parametrize("shape,E,T,eps", [("2s3z", 37, 8, 0.3), ("2s3z", 1024, 6, 0.5), ("2s3z", 2048, 5, 0.0), ("2s3z", 3000, 5, 1.0),
+                                           ("2s3z", 4096, 7, 0.2), ("2s3z", 4500, 4, 0.2), ("3s5z", 300, 6, 0.4), ("3s5z", 2048, 5, 0.1)])
+def test_split_rollout_decompositions_agree_bitwise(shape, E, T, eps):
+    """csrc/rollout_x6.hip (round 6: the recurrent team runs x W_ih and h W_hh down one accumulator chain, three barriers per lock-step,
+    up to five row tiles per workgroup) against csrc/rollout_x6_v1.hip (round 5: gate sums handed over through LDS, four barriers,
+    three tiles): the same additions in the same order, so every field of the record and the final hidden state agree BIT FOR BIT -
+    at one to five row tiles per workgroup, one and several rounds of workgroups, ragged last workgroups."""
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd import experiments
+    dims = {"2s3z": (5, 80, 120, 11), "3s5z": (8, 128, 216, 14)}[shape]
+    args = seeded.make_args(shape, "qmix", episode_limit=T, epsilon=eps, seed=31)
+    args.anneal_epsilon = 0.02
+    args.gemm_mode = "bf16x6"
+    mac, _ = _mac(args)
+    recs = []
+    for v1 in (0, 1):
+        with experiments.override(rollout_v1=v1):
+            w = RolloutWorker(SyntheticSMACEnv(E, *dims, T, seed=9, env0=3), mac, args)
+            out = []
+            for _ in range(2):                  # the second rollout continues the episode counter and the epsilon schedule
+                ep, rew, wins, steps = w.generate_episodes(E, evaluate=False)
+                out.append((ep.record, mac.hidden_states.clone(), rew, steps, w.epsilon))
+            recs.append(out)
+    for (ra, ha, rewa, sa, ea), (rb, hb, rewb, sb, eb) in zip(*recs):
+        for f in ("obs", "state", "avail", "u", "r", "term", "padded", "length", "won"):
+            assert torch.equal(getattr(ra, f), getattr(rb, f)), f
+        assert torch.equal(ha, hb) and rewa == rewb and sa == sb and ea == eb
+        assert int((ra.u >= 0).sum()) > 0

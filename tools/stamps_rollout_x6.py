@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Where a lock-step of the split rollout kernel (csrc/rollout_x6.hip) goes, per wave of workgroup 0 (diagnostic build
 `make -C marl_amd/csrc stamps`):  python tools/stamps_rollout_x6.py [envs]
-team R (waves 0-3): P1 recurrence | B1 | P2 fc1 | B2 | P3 x | B3 | P4 state + availability | B4
-team I (waves 4-7): P1 observations | B1 | P2 fc2 + choice | B2 | P3 env step, uniforms | B3 | P4 gate sums | B4"""
+team R (waves 0-3): A recurrence | B1 | B observations of slot t+2 (first part) | B2 | C rest + state + availability | B3
+team I (waves 4-7): A fc1 + hashes | B1 | B fc2 + choice | B2 | C x + env step | B3
+MARL_ROLLOUT_V1=1: the round-5 kernel (P1 | B1 | P2 | B2 | P3 | B3 | P4 | B4)"""
 import os, sys, ctypes
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["MARL_HIP_LIB"] = os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so")
@@ -14,7 +15,8 @@ import bench  # noqa: E402
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 lib = _lib.load()
 buf = torch.zeros(16 * 16, dtype=torch.int64, device="cuda")
-fn = lib.marl_debug_stamps_rollout_x6
+V1 = os.environ.get("MARL_ROLLOUT_V1") == "1"
+fn = lib.marl_debug_stamps_rollout_x6_v1 if V1 else lib.marl_debug_stamps_rollout_x6
 fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
 assert fn(buf.data_ptr()) == 0
 from marl_amd.controller.share_params import SharedMAC
@@ -29,4 +31,5 @@ for _ in range(2):
     buf.zero_()
     w.generate_episodes(E)
     torch.cuda.synchronize()
-show(buf.cpu().view(16, 16).numpy(), ["P1", "B1", "P2", "B2", "P3", "B3", "P4", "B4"], "split rollout", E, args.episode_limit)
+show(buf.cpu().view(16, 16).numpy(), ["P1", "B1", "P2", "B2", "P3", "B3", "P4", "B4"] if V1 else ["A", "B1", "B", "B2", "C", "B3"],
+     "split rollout" + (" (round-5 kernel)" if V1 else ""), E, args.episode_limit)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Whole-rollout kernels: fp32 MFMA (csrc/rollout_fused.hip) vs the bf16x6 split variant (csrc/rollout_x6.hip), 2s3z shape, T = 120.
+"""Whole-rollout kernels: fp32 MFMA (csrc/rollout_fused.hip) vs the bf16x6 split kernels (csrc/rollout_x6.hip, and its round-5 twin
+csrc/rollout_x6_v1.hip behind the rollout_v1 experiment switch), 2s3z shape, T = 120.
     [SHAPE=2s3z|3s5z] python tools/time_rollout.py [envs ...]"""
 import os, sys
 import torch
@@ -8,12 +9,14 @@ import bench
 from marl_amd.controller.share_params import SharedMAC
 from marl_amd.rollout import RolloutWorker
 from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+from marl_amd import experiments
 shape = os.environ.get("SHAPE", "2s3z")
 for envs in [int(x) for x in sys.argv[1:]] or [4096, 2048, 1024, 512]:
     recs = {}
-    for mode in ("f32", "bf16x6"):
+    for mode in ("f32", "x6_v1", "bf16x6"):
         args = bench.make_args("qmix", shape, 0)
-        args.gemm_mode = mode
+        args.gemm_mode = "f32" if mode == "f32" else "bf16x6"
+        experiments.set("rollout_v1", 1 if mode == "x6_v1" else 0)
         torch.manual_seed(0)
         mac = SharedMAC(args); mac.cuda()
         env = SyntheticSMACEnv(envs, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, args.episode_limit, seed=1)
