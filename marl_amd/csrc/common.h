@@ -10,8 +10,9 @@
 //   fwd_xs (1): the double-Q unroll reads the eval unroll's input-side gate sums;  fwd_dma (0): LDS-DMA observation tile of the
 //   saving unroll;  fwd_w2l (1): six prefetch registers / fc2 fragments in LDS for wide observations;  bwd_pipe_max_rt (4): row
 //   tiles up to which the pipelined BPTT runs;  wgrad_tall (1): LDS-staged tall weight-gradient kernel;  wide_res (1) / wide_res32
-//   (0): resident-weights forward of the wide-state QMIX mixer (16- / 32-row tiles);  rollout_v1 (0): the split whole-rollout kernel
-//   of round 5 (rollout_x6_v1.hip: four barriers per lock-step, at most three row tiles per workgroup) instead of rollout_x6.hip
+//   (0): resident-weights forward of the wide-state QMIX mixer (16- / 32-row tiles);  rollout_v1 (0 = by batch size): 1 forces the split
+//   whole-rollout kernel of round 5 (rollout_x6_v1.hip: four barriers per lock-step, at most three row tiles per workgroup), 2 the one
+//   of round 6 (rollout_x6.hip: three barriers, up to five tiles)
 struct MarlSwitches {
   int fwd_xs, fwd_dma, fwd_w2l, bwd_pipe_max_rt, wgrad_tall, wide_res, wide_res32, rollout_v1;
 };

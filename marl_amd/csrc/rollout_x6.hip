@@ -14,12 +14,11 @@
 // A lock-step, three LDS-only barriers; the dependent chain is  rec (R) | choice (I) | x (I), everything else rides beside it:
 //   A  R: gates(t) = bias + x(t) W_ih + h(t-1) W_hh, gate math, h(t) -> planes        I: pre(t+1) = fc1 of the slot-(t+1) planes; the hashes
 //                                                                                        of the steps to come (uniforms, slot prefixes)
-//   B  I: q(t) = fc2(h(t)) and the epsilon-greedy choice IN REGISTERS                  R: generate the observations of slot t+2 (record +
-//         (a row's 16 actions on a DPP row: max + three ballots)                          planes), first part
-//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step (reward / terminated / padded)
-//                                                                                     R: rest of the observations; state + availability of slot t+2
-// fc1 = (bias + W1[:, obs | id] in) - on the matrix cores, a step ahead - + W1[:, O + u], one column of fp32 weights added per row
-// once u is known (a table in LDS).  Availability lives in LDS as one bit mask per row and slot (four slots deep: no hazards).
+//   B  I: q(t) = fc2(h(t)) and the epsilon-greedy choice IN REGISTERS (a row's 16 actions on a DPP row: max + three ballots), every
+//         stage for all row tiles side by side                          R: slot t+2: state + availability (record, bit masks), observations part 1
+//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step      R: observations part 2 (record + input planes)
+// fc1 = (bias + W1[:, obs | id] in) - on the matrix cores - + W1[:, O + u], one column of fp32 weights added per row once u is known
+// (a table in LDS).  Availability lives in LDS as one bit mask per row and slot (a ring of four slots: no hazards).
 #include "x6.h"
 #include "synth_hash.h"
 #include "../../include/marl_hip.h"
@@ -38,6 +37,11 @@ constexpr int RNT = 512;
 constexpr int HP = 72;            // pitch (bf16) of the 64-wide planes
 
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef MARL_STAMPS
+#define ST_RESET() ST_NOW(st_prev_)
+#else
+#define ST_RESET()
+#endif
 #define X6_TERMS(OP) OP(m, m) OP(h, l) OP(l, h) OP(h, m) OP(m, h) OP(h, h)
 
 template <int CTRL>
@@ -130,14 +134,12 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   float* W1a = reinterpret_cast<float*>(Hp0 + 2 * XP_E);                   // [A + 1][64]: fc1 columns of the one-hot(last action) block; row A = zeros
   unsigned* avm = reinterpret_cast<unsigned*>(W1a + (A + 1) * H);          // [4 slots][rows] availability bit masks (bit k = action k)
   int* act = reinterpret_cast<int*>(avm + 4 * rows);                       // [rows]
-  int* rowe = act + rows;                                                  // [rows] local env of the row
-  int* rown = rowe + rows;                                                 // [rows] agent
-  int* elen = rown + rows;                                                 // [rows] episode length of the local env
-  unsigned* pfxO = reinterpret_cast<unsigned*>(elen + rows);               // [rows] hash prefix of the observations of the slot to generate
-  unsigned* pfxA = pfxO + rows;                                            // [rows] ... of its availability
-  unsigned* pfxS = pfxA + rows;                                            // [rows] ... of its state (per env: entries 0 .. EPW-1); entries rows/2 .. : the reward hash prefix of the NEXT step, per env
-  float* uex = reinterpret_cast<float*>(pfxS + rows);                      // [2 step parities][2][rows] explore / pick uniforms of a step's choice
-  int4* rmeta = reinterpret_cast<int4*>(uex + 4 * rows);                   // [rows] {obs offset of (b,0,n,0), avail offset, episode length, n}
+  unsigned* pfxO = reinterpret_cast<unsigned*>(act + rows);                // [2 slot parities][rows] hash prefix of a slot's observations
+  unsigned* pfxA = pfxO + 2 * rows;                                        // [2][rows] ... of its availability
+  unsigned* pfxS = pfxA + 2 * rows;                                        // [2][rows] ... of its state (per env: entries 0 .. EPW-1)
+  unsigned* pfxR = pfxS + 2 * rows;                                        // [2 step parities][rows / 2] the reward hash prefix of a step, per env
+  float* uex = reinterpret_cast<float*>(pfxR + rows);                      // [2 step parities][2][rows] explore / pick uniforms of a step's choice
+  int4* rmeta = reinterpret_cast<int4*>(uex + 4 * rows);                   // [rows] {obs offset of (b,0,n,0), avail offset, episode length, n | local env << 16}
   int4* emeta = rmeta + rows;                                              // [EPW] {state offset of (b,0,0), episode length, env in range, -}
   auto hpp = [&](int b) { return Hp0 + b * XP_E; };
 
@@ -146,25 +148,28 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   // (the host sizes RTC = ceil(EPW N / 16): every row tile holds valid rows)
   const int b0 = blockIdx.x * nenv_wg;
   const long row0 = (long)b0 * N;
+  const int lmin = T / 2 > 1 ? T / 2 : 1;
+  auto ep_len = [&](int b) {
+    const int L = lmin + (int)(hkey(a.seed, ST_LEN, (unsigned)(a.env0 + b), (unsigned)a.episode, 0u) % (unsigned)(T - lmin + 1));
+    return a.fixed_len ? T : L;
+  };
   for (int r = tid; r < rows; r += RNT) {
     long rho = row0 + (r < vrows ? r : vrows - 1);
     if (rho > a.R - 1) rho = a.R - 1;                    // clamp: duplicates of the last row
-    rowe[r] = (int)(rho / N) - b0;
-    rown[r] = (int)(rho % N);
+    const int b = (int)(rho / N), n = (int)(rho % N);
+    const int bn = b * (T + 1) * N + n;
+    rmeta[r] = make_int4(bn * O, bn * A, ep_len(b), n | ((b - b0) << 16));
     act[r] = -1;
   }
   for (int r = tid; r < 4 * rows; r += RNT) avm[r] = 0u;
-  const int lmin = T / 2 > 1 ? T / 2 : 1;
   for (int e = tid; e < nenv_wg; e += RNT) {
     int b = b0 + e; if (b > a.E - 1) b = a.E - 1;
-    const unsigned env = (unsigned)(a.env0 + b);
-    int L = lmin + (int)(hkey(a.seed, ST_LEN, env, (unsigned)a.episode, 0u) % (unsigned)(T - lmin + 1));
-    if (a.fixed_len) L = T;
-    elen[e] = L;
+    const int L = ep_len(b);
     a.length[b] = L;
-    const int won_ = (int)(hkey(a.seed, ST_WON, env, (unsigned)a.episode, 0u) & 1u);
+    const int won_ = (int)(hkey(a.seed, ST_WON, (unsigned)(a.env0 + b), (unsigned)a.episode, 0u) & 1u);
     a.won[b] = won_;
     if (a.stats && b0 + e < a.E) { a.stats[a.E + b] = (float)won_; a.stats[2L * a.E + b] = (float)L; }
+    emeta[e] = make_int4((b0 + e) * (T + 1) * (int)a.SL, L, b0 + e < a.E ? 1 : 0, 0);
   }
   // planes: zero everywhere (padding rows, pad columns, the one-hot block: its contribution comes from the W1a table), h(-1) = 0
   for (int e = tid; e < (IN_E + 3 * XP_E) / 2; e += RNT) reinterpret_cast<int*>(In0)[e] = 0;
@@ -173,42 +178,36 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     W1a[e] = (a.has_act && aa < A) ? a.W1[(long)j * a.I + O + aa] : 0.f;
   }
   __syncthreads();
-  for (int r = tid; r < vrows; r += RNT) {
-    const int el = rowe[r], n = rown[r];
-    const int bn = (b0 + el) * (T + 1) * N + n;
-    rmeta[r] = make_int4(bn * O, bn * A, elen[el], n);
-    if (a.has_id) In0[r * IP + (a.I - N) + n] = (short)0x3F80;      // agent id: bf16 1.0 in the hi plane
-  }
-  for (int el = tid; el < nenv_wg; el += RNT)
-    emeta[el] = make_int4((b0 + el) * (T + 1) * (int)a.SL, elen[el], b0 + el < a.E ? 1 : 0, 0);
+  if (a.has_id)
+    for (int r = tid; r < vrows; r += RNT) In0[r * IP + (a.I - N) + (rmeta[r].w & 0xffff)] = (short)0x3F80;      // agent id: bf16 1.0 in the hi plane
 
   // ---- the environment's slot t -> record (+ input planes / availability masks); flattened over (row, 4-column group) items,
-  // branch-free (rollout_fused.hip: gen_slot); `tl` / `nthr`: the threads that share the work
+  // branch-free (rollout_fused.hip: gen_slot); `tl` / `nthr`: the threads that share the work.  The slot's hash prefixes sit in the
+  // entry t & 1 of the prefix arrays (the other entry is being written for slot t + 1 meanwhile).
   const int O4 = O >> 2, S4 = (S + 3) >> 2;
   const float invO4 = 1.0f / (float)(O4 > 0 ? O4 : 1), invA = 1.0f / (float)A;
   const float invS4 = 1.0f / (float)(S4 > 0 ? S4 : 1), invS = 1.0f / (float)S;
   const bool svec = (a.SL & 3) == 0 && a.SL >= 4 * S4 && (reinterpret_cast<uintptr_t>(a.state) & 15) == 0;
   auto bits = [](float v) { return __builtin_bit_cast(unsigned, v); };
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  auto gen_prefix_obs = [&](int t, int r) {
+  auto gen_prefix = [&](int t, int r) {
     const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-    pfxO[r] = hprefix(a.seed, ST_OBS, (unsigned)(a.env0 + b0 + rowe[r]), tg);
-  };
-  auto gen_prefix_rest = [&](int t, int r) {
-    const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-    pfxA[r] = hprefix(a.seed, ST_AVAIL, (unsigned)(a.env0 + b0 + rowe[r]), tg);
-    if (r < nenv_wg) pfxS[r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg);
+    const unsigned env = (unsigned)(a.env0 + b0 + (rmeta[r].w >> 16));
+    pfxO[(t & 1) * rows + r] = hprefix(a.seed, ST_OBS, env, tg);
+    pfxA[(t & 1) * rows + r] = hprefix(a.seed, ST_AVAIL, env, tg);
+    if (r < nenv_wg) pfxS[(t & 1) * rows + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg);
   };
   // observation items e_lo <= e < e_hi of slot t (item = (row, 4-column group)), thread tl of nthr
   auto gen_obs = [&](int t, bool to_lds, int e_lo, int e_hi, int tl, int nthr) __attribute__((always_inline)) {
     const int tNO = t * N * O;
+    const unsigned* pO = pfxO + (t & 1) * rows;
     for (int e = e_lo + tl; e < e_hi; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invO4);
       const int k = 4 * (e - r * O4);
       const int4 mt = rmeta[r];
-      const unsigned po = pfxO[r];
+      const unsigned po = pO[r];
       const unsigned lm = t <= mt.z ? 0xffffffffu : 0u, fm = t < mt.z ? 0xffffffffu : 0u;
-      const unsigned idx = (unsigned)(mt.w * O + k);
+      const unsigned idx = (unsigned)((mt.w & 0xffff) * O + k);
       u32x4 v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = bits(2.0f * u01(hfin(po, idx + (unsigned)i)) - 1.0f) & lm;
@@ -230,12 +229,14 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   auto gen_rest = [&](int t, int tl, int nthr) __attribute__((always_inline)) {
     const int tNA = t * N * A, tS = t * (int)a.SL;
     unsigned* am = avm + (t & 3) * rows;
+    const unsigned* pA = pfxA + (t & 1) * rows;
+    const unsigned* pS = pfxS + (t & 1) * rows;
     for (int r = tl; r < rows; r += nthr) avm[((t + 1) & 3) * rows + r] = 0u;
     for (int e = tl; e < vrows * A; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invA);
       const int k = e - r * A;
       const int4 mt = rmeta[r];
-      const float uu = u01(hfin(pfxA[r], (unsigned)(mt.w * A + k)));
+      const float uu = u01(hfin(pA[r], (unsigned)((mt.w & 0xffff) * A + k)));
       const bool on = (t <= mt.z) & ((k == 0) | (uu < 0.7f));
       a.avail[(long)mt.y + tNA + k] = on ? 1.f : 0.f;
       if (on) atomicOr(am + r, 1u << k);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         const int el = (int)(((float)e + 0.5f) * invS4);
         const int k = 4 * (e - el * S4);
         const int4 mt = emeta[el];
-        const unsigned ps = pfxS[el];
+        const unsigned ps = pS[el];
         const unsigned lm = t <= mt.y ? 0xffffffffu : 0u;
         u32x4 v;
 #pragma unroll
@@ -258,34 +259,37 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         const int k = e - el * S;
         const int4 mt = emeta[el];
         const unsigned lm = t <= mt.y ? 0xffffffffu : 0u;
-        const unsigned v = bits(2.0f * u01(hfin(pfxS[el], (unsigned)k)) - 1.0f) & lm;
+        const unsigned v = bits(2.0f * u01(hfin(pS[el], (unsigned)k)) - 1.0f) & lm;
         if (mt.z) reinterpret_cast<unsigned*>(a.state)[(long)mt.x + tS + k] = v;
       }
     }
   };
+  // ---- prologue: slot 0 (record, planes, masks) -> x(0) (team I) -> slot 1 takes the input planes' place; the uniforms of the first choice
   const int n_oi = vrows * O4;                   // observation items of a slot
-  // ---- prologue: slot 0 (record, planes, masks) -> x(0) (team I); then slot 1 takes the input planes' place
   __syncthreads();
-  if (tid < rows) { gen_prefix_obs(0, tid); gen_prefix_rest(0, tid); }
+  if (tid < rows) {
+    gen_prefix(0, tid); gen_prefix(1, tid);
+    const int4 mt = rmeta[tid];
+    const unsigned env = (unsigned)(a.env0 + b0 + (mt.w >> 16)), tg0 = (unsigned)(a.episode * (T + 1));
+    uex[tid] = u01(hkey(a.rseed, ST_EXPLORE, env, tg0, (unsigned)(mt.w & 0xffff)));
+    uex[rows + tid] = u01(hkey(a.rseed, ST_PICK, env, tg0, (unsigned)(mt.w & 0xffff)));
+  }
   __syncthreads();
   gen_obs(0, true, 0, n_oi, tid, RNT);
   gen_rest(0, tid, RNT);
-  __syncthreads();
-  if (tid < rows) {       // prefixes of slot 1; uniforms of the first choice
-    gen_prefix_obs(1, tid); gen_prefix_rest(1, tid);
-    const unsigned env = (unsigned)(a.env0 + b0 + rowe[tid]), tg0 = (unsigned)(a.episode * (T + 1));
-    uex[tid] = u01(hkey(a.rseed, ST_EXPLORE, env, tg0, (unsigned)rown[tid]));
-    uex[rows + tid] = u01(hkey(a.rseed, ST_PICK, env, tg0, (unsigned)rown[tid]));
-  }
+  auto prologue_slot1 = [&]() __attribute__((always_inline)) {      // (behind P1: x(0) made, the input planes and slot 0's prefixes are free)
+    gen_obs(1, 1 < T, 0, n_oi, tid, RNT);
+    gen_rest(1, tid, RNT);
+  };
   const int KC1 = a.KI >> 5;
-  // (the reward prefixes live in the upper half of pfxS, double-buffered by step parity: EPW <= rows / 4 - always, unless N < 4)
-  const bool pre_r = 4 * nenv_wg <= rows;
+  // (the reward prefixes of the step to come are hashed a step ahead, off the env step's dependent chain: two parities of EPW entries)
+  const bool pre_r = 2 * nenv_wg <= rows;
   // epsilon of step t: a device vector, or the reference's per-step anneal (rollout.py:100-101) evaluated here in fp64
   float eps_next = a.eps ? a.eps[0] : (float)a.eps0;
   double eps_d = a.eps0;
 
   if (team == 0) {
-    // =============================== team R: the recurrence; beside the chain: the slots to come ===============================
+    // =============================== team R: the recurrence ===============================
     F3 wi[6], wh[6];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -299,11 +303,10 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 #pragma unroll
     for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
     // R's share of a slot's observation items before the choice barrier (team I needs ~the choice's time to get there)
-    const int oi_cut = (n_oi * 5) >> 3;
+    const int oi_cut = (n_oi * 6) >> 4;
     WG_BARRIER();                                  // P0: slot 0 in the planes, tables (team I: fc1, x(0))
     WG_BARRIER();                                  // P1: x(0), pre(0) taken: the input planes are free
-    gen_obs(1, 1 < T, 0, n_oi, tid, RNT / 2);      // slot 1 (team I: its hashes ran before P0)
-    gen_rest(1, tid, RNT / 2);
+    prologue_slot1();
     WG_BARRIER();                                  // P2
     ST_DECL(6);
     for (int t = 0; t < T; ++t) {
@@ -336,15 +339,16 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       ST_MARK(0);
       WG_BARRIER();                                // B1: h(t) planes | pre(t+1) taken: the input planes are free; prefixes of slot t+2
       ST_MARK(1);
-      // ---- B, C: slot t+2 (its observations feed fc1 in A of step t+1; its availability the choice of step t+2)
-      if (t + 2 <= T) gen_obs(t + 2, t + 2 < T, 0, oi_cut, tid, RNT / 2);
+      // ---- B, C (beside team I's choice and x): slot t+2 -> record; its observations -> input planes (fc1 reads them in A of step
+      // t+1), its availability -> bit masks (the choice of step t+2 reads them)
+      if (t + 2 <= T) {
+        gen_rest(t + 2, tid, RNT / 2);
+        gen_obs(t + 2, t + 2 < T, 0, oi_cut, tid, RNT / 2);
+      }
       ST_MARK(2);
       WG_BARRIER();                                // B2: act(t)
       ST_MARK(3);
-      if (t + 2 <= T) {
-        gen_obs(t + 2, t + 2 < T, oi_cut, n_oi, tid, RNT / 2);
-        gen_rest(t + 2, tid, RNT / 2);
-      }
+      if (t + 2 <= T) gen_obs(t + 2, t + 2 < T, oi_cut, n_oi, tid, RNT / 2);
       ST_MARK(4);
       WG_BARRIER();                                // B3: x(t+1) planes | slot t+2
       ST_MARK(5);
@@ -362,8 +366,9 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       }
     }
   } else {
-    // =============================== team I: fc1, fc2 + the choice, x, the environment's bookkeeping ===============================
+    // =============================== team I: the slots to come, fc1, fc2 + the choice, x, the environment's bookkeeping ===============================
     const int ti = tid - RNT / 2;
+    ST_DECL(8);
     F3 w1[NK1], w2[2];
 #pragma unroll
     for (int c = 0; c < NK1; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
@@ -389,22 +394,29 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         pre[rt] = (acc[0] + acc[1]) + acc[2];
       }
     };
-    // x = relu(pre + W1[:, O + last action]) -> planes (rows whose last action is "none": the zero row of the table)
+    // x = relu(pre + W1[:, O + last action]) -> planes (rows whose last action is "none": the zero row of the table); stage by stage
+    // over the row tiles: every LDS read of a stage is in flight before the first result is used
     auto xput = [&]() __attribute__((always_inline)) {
+      i32x4 aa[RTC];
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) aa[rt] = *reinterpret_cast<const i32x4*>(act + rt * 16 + 4 * q);
+      f32x4 wv[RTC];
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[rt][r] = W1a[(aa[rt][r] < 0 ? A : aa[rt][r]) * H + u];
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         f32x4 x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int aa = act[rt * 16 + 4 * q + r];
-          x[r] = fmaxf(__fadd_rn(pre[rt][r], W1a[(aa < 0 ? A : aa) * H + u]), 0.f);
-        }
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(__fadd_rn(pre[rt][r], wv[rt][r]), 0.f);
         put4(Xp0, HP, rows * HP, rt * 16 + 4 * q, u, x);
       }
     };
-    // ---- q = fc2(h) and the epsilon-greedy choice (share_params.py:66-70) of a row tile, in registers: lane (q, m) of the accumulator
-    // tile holds rows 4q + r of action m - a row's 16 actions sit on the 16 lanes of a DPP row.  Every wave of the team computes q of
-    // the tile (12 products) and makes the choice of its rows 4q + s (four rows in ONE pass of ballots).
+    // ---- q = fc2(h) and the epsilon-greedy choice (share_params.py:66-70), in registers: lane (q, m) of the accumulator tile holds
+    // rows 4q + r of action m - a row's 16 actions sit on the 16 lanes of a DPP row.  Every wave of the team computes q of every tile
+    // (12 products) and makes the choice of its rows 4q + s (four rows in ONE pass of ballots).  Stage by stage over the row tiles (the
+    // tiles' chains - products, DPP maxima, ballots - are independent: written side by side they hide each other's latencies).
     int c_rr[RTC], c_len[RTC], c_uoff[RTC];      // this lane's row of each tile: its index (clamped), episode length (-1: not a row), u offset
 #pragma unroll
     for (int rt = 0; rt < RTC; ++rt) {
@@ -413,53 +425,70 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       const int rr = valid ? row : vrows - 1;
       const int4 mt = rmeta[rr];
       c_rr[rt] = rr; c_len[rt] = valid ? mt.z : -1;
-      c_uoff[rt] = (b0 + rowe[rr]) * T * N + mt.w;
+      c_uoff[rt] = (b0 + (mt.w >> 16)) * T * N + (mt.w & 0xffff);
     }
-    auto choose = [&](int rt, int t, float eps) __attribute__((always_inline)) {
+    auto choose_all = [&](int t, float eps) __attribute__((always_inline)) {
       const int par = t & 1;
-      F3 hb[2];
+      unsigned avw[RTC]; float ue[RTC], up[RTC], qsel[RTC];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(par ^ 1) + rt * 16 * HP, HP, rows * HP, c, lane);
-      f32x4 ac[2] = {splat(bias_2), splat(0.f)};
+      for (int rt = 0; rt < RTC; ++rt) {
+        avw[rt] = avm[(t & 3) * rows + c_rr[rt]];
+        ue[rt] = uex[par * 2 * rows + c_rr[rt]];
+        up[rt] = uex[par * 2 * rows + rows + c_rr[rt]];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+        F3 hb[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(par ^ 1) + rt * 16 * HP, HP, rows * HP, c, lane);
+        f32x4 ac[2] = {splat(bias_2), splat(0.f)};
 #define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
-      X6_TERMS(OP)
+        X6_TERMS(OP)
 #undef OP
-      const f32x4 qv = ac[0] + ac[1];
-      const float qs = s == 0 ? qv[0] : s == 1 ? qv[1] : s == 2 ? qv[2] : qv[3];
-      const int rr = c_rr[rt], sh = 16 * q;
-      const bool on = m < A && ((avm[(t & 3) * rows + rr] >> m) & 1u) != 0u;
-      const float v = on ? qs : -3.0e38f;
-      const float mx = group_max16(v);
-      const unsigned am = (unsigned)(__ballot(on) >> sh) & 0xffffu;
-      const unsigned em = (unsigned)(__ballot(on && v == mx) >> sh) & 0xffffu;
-      const int navail = __popc(am);
-      int arg = em ? __ffs(em) - 1 : (am ? __ffs(am) - 1 : 0);
-      const bool explore = uex[par * 2 * rows + rr] < eps;
-      int kk = (int)floorf(uex[par * 2 * rows + rows + rr] * (float)navail);
-      if (kk > navail - 1) kk = navail - 1;
-      const bool sel = explore && on && __popc(am & ((1u << m) - 1u)) == kk;
-      const unsigned sm = (unsigned)(__ballot(sel) >> sh) & 0xffffu;
-      if (sm) arg = __ffs(sm) - 1;
-      if (!(t < c_len[rt])) arg = -1;
-      if (c_len[rt] >= 0 && m == 0) {
-        act[rt * 16 + 4 * q + s] = arg;
-        a.u[c_uoff[rt] + t * N] = arg;
+        const f32x4 qv = ac[0] + ac[1];
+        qsel[rt] = s == 0 ? qv[0] : s == 1 ? qv[1] : s == 2 ? qv[2] : qv[3];
+      }
+      ST_MARK(6);
+      const int sh = 16 * q;
+#pragma unroll
+      for (int rt = 0; rt < RTC; ++rt) {
+        const bool on = m < A && ((avw[rt] >> m) & 1u) != 0u;
+        const float v = on ? qsel[rt] : -3.0e38f;
+        const float mx = group_max16(v);
+        const unsigned am = (unsigned)(__ballot(on) >> sh) & 0xffffu;
+        const unsigned em = (unsigned)(__ballot(on && v == mx) >> sh) & 0xffffu;
+        const int navail = __popc(am);
+        int arg = em ? __ffs(em) - 1 : (am ? __ffs(am) - 1 : 0);
+        const bool explore = ue[rt] < eps;
+        int kk = (int)floorf(up[rt] * (float)navail);
+        if (kk > navail - 1) kk = navail - 1;
+        const bool sel = explore && on && __popc(am & ((1u << m) - 1u)) == kk;
+        const unsigned sm = (unsigned)(__ballot(sel) >> sh) & 0xffffu;
+        if (sm) arg = __ffs(sm) - 1;
+        if (!(t < c_len[rt])) arg = -1;
+        if (c_len[rt] >= 0 && m == 0) {
+          act[rt * 16 + 4 * q + s] = arg;
+          a.u[c_uoff[rt] + t * N] = arg;
+        }
       }
     };
-    // the uniforms of step t+1's choice and the hash prefixes of slot t+2 (+ the reward prefix of step t+1): items (kind, row), kind-major
+    // the uniforms of step t+1's choice, the hash prefixes of slot t+2 (team R generates it in B / C of this step), the reward prefix of
+    // step t+1: items (kind, row), kind-major
     auto hashes = [&](int t) __attribute__((always_inline)) {
       const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
+      float* ux = uex + ((t + 1) & 1) * 2 * rows;
+      const int pp = (t & 1) * rows;             // entry of slot t + 2
       for (int x = ti; x < 5 * rows; x += RNT / 2) {
         const int kind = x / rows, r = x - kind * rows;
-        const unsigned env = (unsigned)(a.env0 + b0 + rowe[r]), nn_ = (unsigned)rown[r];
-        float* ux = uex + ((t + 1) & 1) * 2 * rows;
+        const int w_ = rmeta[r].w;
+        const unsigned env = (unsigned)(a.env0 + b0 + (w_ >> 16)), nn_ = (unsigned)(w_ & 0xffff);
         if (kind == 0) ux[r] = u01(hkey(a.rseed, ST_EXPLORE, env, tg + 1u, nn_));
         else if (kind == 1) ux[rows + r] = u01(hkey(a.rseed, ST_PICK, env, tg + 1u, nn_));
-        else if (kind == 2) pfxO[r] = hprefix(a.seed, ST_OBS, env, tg + 2u);
-        else if (kind == 3) pfxA[r] = hprefix(a.seed, ST_AVAIL, env, tg + 2u);
-        else if (r < nenv_wg) pfxS[r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg + 2u);
-        else if (pre_r && r >= rows / 2 && r - rows / 2 < nenv_wg)      // the reward prefix of step t+1 (off the env step's dependent chain)
-          pfxS[rows / 2 + ((t + 1) & 1) * (rows / 4) + (r - rows / 2)] = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + r - rows / 2), tg + 1u);
+        else if (kind == 2) pfxO[pp + r] = hprefix(a.seed, ST_OBS, env, tg + 2u);
+        else if (kind == 3) pfxA[pp + r] = hprefix(a.seed, ST_AVAIL, env, tg + 2u);
+        else if (r < nenv_wg) pfxS[pp + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg + 2u);
+        else if (pre_r && r >= rows / 2 && r - rows / 2 < nenv_wg)      // the reward prefix of step t+1
+          pfxR[((t + 1) & 1) * (rows / 2) + (r - rows / 2)] = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + r - rows / 2), tg + 1u);
       }
     };
     // env step: lane -> (env, agent); the N rows of an environment sit in ONE wave, environments dealt to the four waves in turn
@@ -467,39 +496,40 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     const int es_n = lane - es_er * N, es_l0 = es_er * N;
     const int es_el = 4 * es_er + s;
     const bool es_has = es_er < es_epw && es_el < nenv_wg && b0 + es_el < a.E;
+    const int es_L = es_has ? emeta[es_el].y : 0;
     float ep_r = 0.f;
     WG_BARRIER();                                  // P0: slot 0 in the planes, tables
     fc1();
     xput();                                        // x(0): no last action
-    WG_BARRIER();                                  // P1: (team R: slot 1 -> the input planes)
+    WG_BARRIER();                                  // P1: x(0); the input planes are free
+    prologue_slot1();
     WG_BARRIER();                                  // P2
-    ST_DECL(6);
+    ST_RESET();
     for (int t = 0; t < T; ++t) {
       const float eps = eps_next;
       if (a.eps) { if (t + 1 < T) eps_next = a.eps[t + 1]; }
       else { eps_d = eps_d > a.eps_min ? eps_d - a.eps_anneal : eps_d; eps_next = (float)eps_d; }
       const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-      // ---- A: pre(t+1) from the planes of slot t+1; the hashes of the steps to come (they depend on nothing of this step; the uniforms
-      // go to the other parity's buffer, the slot prefixes were last read before B3 of step t-1)
+      // ---- A (beside the recurrence): pre(t+1) from the planes of slot t+1; the hashes of the steps to come
       if (t + 1 < T) fc1();
       hashes(t);
       ST_MARK(0);
       WG_BARRIER();                                // B1: h(t)
       ST_MARK(1);
       // ---- B: q(t) and the choice
-#pragma unroll
-      for (int rt = 0; rt < RTC; ++rt) choose(rt, t, eps);
+      choose_all(t, eps);
       ST_MARK(2);
       WG_BARRIER();                                // B2: act(t)
       ST_MARK(3);
       // ---- C: x(t+1); env step (reward / terminated / padded; fixed-order fp32 sum over agents)
       if (t + 1 < T) xput();
+      ST_MARK(7);
       if (es_has) {
-        const int L = elen[es_el];
+        const int L = es_L;
         const bool live = t < L;
         float term = 0.f;
         if (live) {
-          const unsigned pre_ = (pre_r && t > 0) ? pfxS[rows / 2 + (t & 1) * (rows / 4) + es_el]
+          const unsigned pre_ = (pre_r && t > 0) ? pfxR[(t & 1) * (rows / 2) + es_el]
                                                  : hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
           term = u01(hfin(pre_, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
         }
@@ -524,7 +554,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       WG_BARRIER();                                // B3: x(t+1)
       ST_MARK(5);
     }
-    ST_DUMP(6);
+    ST_DUMP(8);
     if (a.stats && es_has && es_n == 0) a.stats[b0 + es_el] = ep_r;
   }
 }
@@ -532,7 +562,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 // LDS bytes of a workgroup of RTC row tiles holding EPW environments
 static size_t rx6_lds(int rtc, int KI, int A, int epw) {
   const size_t rows = 16 * (size_t)rtc, IP = KI + 8;
-  return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)(A + 1) * H * 4 + 4 * rows * 4 /* avm */ + rows * (4 * 4 /* act rowe rown elen */ + 3 * 4 /* pfx */ + 4 * 4 /* uex */) +
+  return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)(A + 1) * H * 4 + 4 * rows * 4 /* avm */ + rows * (4 /* act */ + 7 * 4 /* pfx O A S x 2, R */ + 4 * 4 /* uex */) +
          rows * 16 /* rmeta */ + (size_t)epw * 16 /* emeta */;
 }
 // row tiles a workgroup may hold: five fc1 chunks (wide inputs) cost registers and LDS
@@ -560,7 +590,13 @@ extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned see
                                      float* r, float* term, float* padded, int* length, int* won, float* h_out,
                                      float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N,
                                      int O, int S, int A, int last_action, int reuse_network, void* stream) {
-  if (marl_switches()->rollout_v1 && marl_rollout_x6_v1_supported(N, O, A))
+  // which decomposition: this file's kernel pays where the round-5 one needs more than one round of workgroups (its three row tiles
+  // per workgroup - two for wide inputs - do not hold a CU's share of the batch); below that the two are level or the round-5 kernel
+  // is ahead (one tile per workgroup: 0.46 against 0.52 ms at 512 envs).  experiments: rollout_v1 = 1 / 2 forces the round-5 / this kernel
+  const int sw = marl_switches()->rollout_v1;
+  const int v1_epw_max = ((O + (last_action ? A : 0) + (reuse_network ? N : 0) + 31) / 32 * 32 > 96 ? 32 : 48) / (N > 0 ? N : 1);
+  const bool use_v1 = marl_rollout_x6_v1_supported(N, O, A) && (sw == 1 || (sw == 0 && (long)E <= 256L * v1_epw_max));
+  if (use_v1)
     return marl_rollout_x6_v1(w, seed, rseed, env0, episode, fixed_len, eps, obs, state, state_ld, avail, u, r, term, padded, length, won,
                               h_out, stats, eps0, eps_anneal, eps_min, E, T, N, O, S, A, last_action, reuse_network, stream);
   if (E <= 0 || T <= 0) return 0;

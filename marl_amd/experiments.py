@@ -11,7 +11,7 @@ library switches (environment variable -> name, default):
     MARL_BWD_PIPE_MAX_RT -> bwd_pipe_max_rt 4
     MARL_WGRAD_TALL -> wgrad_tall 1   LDS-staged tall weight-gradient kernel
     MARL_WIDE_RES -> wide_res 1, MARL_WIDE_RES32 -> wide_res32 0    resident-weights forward of the wide-state QMIX mixer
-    MARL_ROLLOUT_V1 -> rollout_v1 0   the round-5 split whole-rollout kernel (csrc/rollout_x6_v1.hip) instead of csrc/rollout_x6.hip
+    MARL_ROLLOUT_V1 -> rollout_v1 0   split whole-rollout kernel: 0 = by batch size, 1 = round 5 (csrc/rollout_x6_v1.hip), 2 = round 6 (csrc/rollout_x6.hip)
 host switches:
     MARL_BIG_PAIR -> big_pair 0       batches beyond the pair's tile cap: eval chain and target unroll in flight together (two streams)
     MARL_NO_PAIR -> no_pair 0         the eval and target unrolls back to back instead of side by side on two streams

@@ -334,7 +334,7 @@ def test_split_rollout_decompositions_agree_bitwise(shape, E, T, eps):
     args.gemm_mode = "bf16x6"
     mac, _ = _mac(args)
     recs = []
-    for v1 in (0, 1):
+    for v1 in (2, 1):           # 2 / 1: force this round's / the round-5 kernel (0 = the library picks by batch size)
         with experiments.override(rollout_v1=v1):
             w = RolloutWorker(SyntheticSMACEnv(E, *dims, T, seed=9, env0=3), mac, args)
             out = []

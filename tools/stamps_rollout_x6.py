@@ -16,6 +16,8 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 lib = _lib.load()
 buf = torch.zeros(16 * 16, dtype=torch.int64, device="cuda")
 V1 = os.environ.get("MARL_ROLLOUT_V1") == "1"
+if not V1:
+    os.environ["MARL_ROLLOUT_V1"] = "2"      # force this round's kernel at every batch size
 fn = lib.marl_debug_stamps_rollout_x6_v1 if V1 else lib.marl_debug_stamps_rollout_x6
 fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
 assert fn(buf.data_ptr()) == 0
@@ -31,5 +33,5 @@ for _ in range(2):
     buf.zero_()
     w.generate_episodes(E)
     torch.cuda.synchronize()
-show(buf.cpu().view(16, 16).numpy(), ["P1", "B1", "P2", "B2", "P3", "B3", "P4", "B4"] if V1 else ["A", "B1", "B", "B2", "C", "B3"],
+show(buf.cpu().view(16, 16).numpy(), ["P1", "B1", "P2", "B2", "P3", "B3", "P4", "B4"] if V1 else ["A", "B1", "B(choice)", "B2", "C(env)", "B3", "B(q)", "C(x)"],
      "split rollout" + (" (round-5 kernel)" if V1 else ""), E, args.episode_limit)

@@ -13,10 +13,10 @@ from marl_amd import experiments
 shape = os.environ.get("SHAPE", "2s3z")
 for envs in [int(x) for x in sys.argv[1:]] or [4096, 2048, 1024, 512]:
     recs = {}
-    for mode in ("f32", "x6_v1", "bf16x6"):
+    for mode in ("f32", "x6_v1", "x6_r6", "bf16x6"):
         args = bench.make_args("qmix", shape, 0)
         args.gemm_mode = "f32" if mode == "f32" else "bf16x6"
-        experiments.set("rollout_v1", 1 if mode == "x6_v1" else 0)
+        experiments.set("rollout_v1", {"x6_v1": 1, "x6_r6": 2}.get(mode, 0))      # forced round-5 / round-6 kernel; bf16x6 = the library's choice
         torch.manual_seed(0)
         mac = SharedMAC(args); mac.cuda()
         env = SyntheticSMACEnv(envs, args.n_agents, args.obs_shape, args.state_shape, args.n_actions, args.episode_limit, seed=1)
