@@ -12,11 +12,12 @@
 //   team I (waves 4-7, slice s):             fc1 (observation part) and fc2 fragments, the epsilon-greedy choice, the env step
 // No gate-sum buffer: 30 KB of LDS per row tile -> up to FIVE tiles per workgroup, the whole share of a CU in one round.
 // A lock-step, three LDS-only barriers; the dependent chain is  rec (R) | choice (I) | x (I), everything else rides beside it:
-//   A  R: gates(t) = bias + x(t) W_ih + h(t-1) W_hh, gate math, h(t) -> planes        I: pre(t+1) = fc1 of the slot-(t+1) planes; the hashes
-//                                                                                        of the steps to come (uniforms, slot prefixes)
+//   A  R: gates(t) = bias + x(t) W_ih + h(t-1) W_hh, gate math, h(t) -> planes (software-pipelined over the row tiles: a tile's gate
+//         math sits in the gaps of the next tile's products)            I: pre(t+1) = fc1 of the slot-(t+1) planes
 //   B  I: q(t) = fc2(h(t)) and the epsilon-greedy choice IN REGISTERS (a row's 16 actions on a DPP row: max + three ballots), every
 //         stage for all row tiles side by side                          R: slot t+2: state + availability (record, bit masks), observations part 1
-//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step      R: observations part 2 (record + input planes)
+//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step      R: observations part 2 (record + input planes); the hashes of the
+//                                                                          steps to come (one prefix per environment, stream and time)
 // fc1 = (bias + W1[:, obs | id] in) - on the matrix cores - + W1[:, O + u], one column of fp32 weights added per row once u is known
 // (a table in LDS).  Availability lives in LDS as one bit mask per row and slot (a ring of four slots: no hazards).
 #include "x6.h"
@@ -134,13 +135,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   float* W1a = reinterpret_cast<float*>(Hp0 + 2 * XP_E);                   // [A + 1][64]: fc1 columns of the one-hot(last action) block; row A = zeros
   unsigned* avm = reinterpret_cast<unsigned*>(W1a + (A + 1) * H);          // [4 slots][rows] availability bit masks (bit k = action k)
   int* act = reinterpret_cast<int*>(avm + 4 * rows);                       // [rows]
-  unsigned* pfxO = reinterpret_cast<unsigned*>(act + rows);                // [2 slot parities][rows] hash prefix of a slot's observations
-  unsigned* pfxA = pfxO + 2 * rows;                                        // [2][rows] ... of its availability
-  unsigned* pfxS = pfxA + 2 * rows;                                        // [2][rows] ... of its state (per env: entries 0 .. EPW-1)
-  unsigned* pfxR = pfxS + 2 * rows;                                        // [2 step parities][rows / 2] the reward hash prefix of a step, per env
-  float* uex = reinterpret_cast<float*>(pfxR + rows);                      // [2 step parities][2][rows] explore / pick uniforms of a step's choice
+  float* uex = reinterpret_cast<float*>(act + rows);                       // [2 step parities][2][rows] explore / pick uniforms of a step's choice
   int4* rmeta = reinterpret_cast<int4*>(uex + 4 * rows);                   // [rows] {obs offset of (b,0,n,0), avail offset, episode length, n | local env << 16}
   int4* emeta = rmeta + rows;                                              // [EPW] {state offset of (b,0,0), episode length, env in range, -}
+  // hash prefixes over (seed, stream, env, time): ONE per environment, stream and time - [6 streams][2 parities][EPW]:
+  // observations / availability / state of a slot (parity of the slot), reward / explore / pick of a step (parity of the step)
+  unsigned* P = reinterpret_cast<unsigned*>(emeta + a.EPW);
+  enum { K_OBS = 0, K_AVAIL, K_STATE, K_REWARD, K_EXPLORE, K_PICK };
   auto hpp = [&](int b) { return Hp0 + b * XP_E; };
 
   const int nenv_wg = a.EPW;
@@ -190,22 +191,23 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   const bool svec = (a.SL & 3) == 0 && a.SL >= 4 * S4 && (reinterpret_cast<uintptr_t>(a.state) & 15) == 0;
   auto bits = [](float v) { return __builtin_bit_cast(unsigned, v); };
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  auto gen_prefix = [&](int t, int r) {
-    const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-    const unsigned env = (unsigned)(a.env0 + b0 + (rmeta[r].w >> 16));
-    pfxO[(t & 1) * rows + r] = hprefix(a.seed, ST_OBS, env, tg);
-    pfxA[(t & 1) * rows + r] = hprefix(a.seed, ST_AVAIL, env, tg);
-    if (r < nenv_wg) pfxS[(t & 1) * rows + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg);
+  auto Pp = [&](int kind, int par) { return P + (kind * 2 + par) * nenv_wg; };
+  auto kstream = [](int kind) { return kind == K_OBS ? ST_OBS : kind == K_AVAIL ? ST_AVAIL : kind == K_STATE ? ST_STATE : kind == K_REWARD ? ST_REWARD : kind == K_EXPLORE ? ST_EXPLORE : ST_PICK; };
+  // prefix of (kind, local env el) at time index tt -> entry par
+  auto put_prefix = [&](int kind, int el, int tt, int par) {
+    const unsigned tg = (unsigned)(a.episode * (T + 1) + tt);
+    Pp(kind, par)[el] = hprefix(kind >= K_EXPLORE ? a.rseed : a.seed, (unsigned)kstream(kind), (unsigned)(a.env0 + b0 + el), tg);
   };
+  const float inv_nE = 1.0f / (float)nenv_wg, inv_rows = 1.0f / (float)rows;
   // observation items e_lo <= e < e_hi of slot t (item = (row, 4-column group)), thread tl of nthr
   auto gen_obs = [&](int t, bool to_lds, int e_lo, int e_hi, int tl, int nthr) __attribute__((always_inline)) {
     const int tNO = t * N * O;
-    const unsigned* pO = pfxO + (t & 1) * rows;
+    const unsigned* pO = Pp(K_OBS, t & 1);
     for (int e = e_lo + tl; e < e_hi; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invO4);
       const int k = 4 * (e - r * O4);
       const int4 mt = rmeta[r];
-      const unsigned po = pO[r];
+      const unsigned po = pO[mt.w >> 16];
       const unsigned lm = t <= mt.z ? 0xffffffffu : 0u, fm = t < mt.z ? 0xffffffffu : 0u;
       const unsigned idx = (unsigned)((mt.w & 0xffff) * O + k);
       u32x4 v;
@@ -229,14 +231,14 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   auto gen_rest = [&](int t, int tl, int nthr) __attribute__((always_inline)) {
     const int tNA = t * N * A, tS = t * (int)a.SL;
     unsigned* am = avm + (t & 3) * rows;
-    const unsigned* pA = pfxA + (t & 1) * rows;
-    const unsigned* pS = pfxS + (t & 1) * rows;
+    const unsigned* pA = Pp(K_AVAIL, t & 1);
+    const unsigned* pS = Pp(K_STATE, t & 1);
     for (int r = tl; r < rows; r += nthr) avm[((t + 1) & 3) * rows + r] = 0u;
     for (int e = tl; e < vrows * A; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invA);
       const int k = e - r * A;
       const int4 mt = rmeta[r];
-      const float uu = u01(hfin(pA[r], (unsigned)((mt.w & 0xffff) * A + k)));
+      const float uu = u01(hfin(pA[mt.w >> 16], (unsigned)((mt.w & 0xffff) * A + k)));
       const bool on = (t <= mt.z) & ((k == 0) | (uu < 0.7f));
       a.avail[(long)mt.y + tNA + k] = on ? 1.f : 0.f;
       if (on) atomicOr(am + r, 1u << k);
@@ -267,23 +269,46 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   // ---- prologue: slot 0 (record, planes, masks) -> x(0) (team I) -> slot 1 takes the input planes' place; the uniforms of the first choice
   const int n_oi = vrows * O4;                   // observation items of a slot
   __syncthreads();
-  if (tid < rows) {
-    gen_prefix(0, tid); gen_prefix(1, tid);
-    const int4 mt = rmeta[tid];
-    const unsigned env = (unsigned)(a.env0 + b0 + (mt.w >> 16)), tg0 = (unsigned)(a.episode * (T + 1));
-    uex[tid] = u01(hkey(a.rseed, ST_EXPLORE, env, tg0, (unsigned)(mt.w & 0xffff)));
-    uex[rows + tid] = u01(hkey(a.rseed, ST_PICK, env, tg0, (unsigned)(mt.w & 0xffff)));
+  for (int x = tid; x < 10 * nenv_wg; x += RNT) {      // slots 0, 1 (obs / avail / state) and steps 0, 1 (explore / pick)
+    const int j = (int)(((float)x + 0.5f) * inv_nE), el = x - j * nenv_wg;
+    if (j < 6) put_prefix(j % 3, el, j / 3, j / 3);
+    else put_prefix(K_EXPLORE + (j - 6) % 2, el, (j - 6) / 2, (j - 6) / 2);
   }
   __syncthreads();
+  for (int x = tid; x < 2 * rows; x += RNT) {           // the uniforms of the first choice
+    const int which = x >= rows ? 1 : 0, r = x - which * rows;
+    const int w_ = rmeta[r].w;
+    uex[which * rows + r] = u01(hfin(Pp(K_EXPLORE + which, 0)[w_ >> 16], (unsigned)(w_ & 0xffff)));
+  }
   gen_obs(0, true, 0, n_oi, tid, RNT);
   gen_rest(0, tid, RNT);
   auto prologue_slot1 = [&]() __attribute__((always_inline)) {      // (behind P1: x(0) made, the input planes and slot 0's prefixes are free)
     gen_obs(1, 1 < T, 0, n_oi, tid, RNT);
     gen_rest(1, tid, RNT);
+    for (int x = tid; x < 3 * nenv_wg; x += RNT) {      // slot 2 (the entries slot 0 left)
+      const int j = (int)(((float)x + 0.5f) * inv_nE);
+      put_prefix(j, x - j * nenv_wg, 2, 0);
+    }
+  };
+  // the hashes of the steps to come, ONE item per thread of a 256-thread team at the headline shape (6 EPW prefixes + 2 x rows uniforms):
+  // prefixes of slot t+3 (observations / availability / state: generated in B / C of step t+1), of step t+1's reward and step t+2's
+  // explore / pick draws; the uniforms of step t+1's choice from the explore / pick prefixes the previous call left
+  auto hashes = [&](int t, int tl, int nthr) __attribute__((always_inline)) {
+    const int nP = 6 * nenv_wg;
+    for (int x = tl; x < nP + 2 * rows; x += nthr) {
+      if (x < nP) {
+        const int kind = (int)(((float)x + 0.5f) * inv_nE), el = x - kind * nenv_wg;
+        if (kind < K_REWARD) put_prefix(kind, el, t + 3, (t + 1) & 1);
+        else if (kind == K_REWARD) put_prefix(kind, el, t + 1, (t + 1) & 1);
+        else put_prefix(kind, el, t + 2, t & 1);
+      } else {
+        const int j = x - nP, which = j >= rows ? 1 : 0, r = j - which * rows;
+        const int w_ = rmeta[r].w;
+        uex[((t + 1) & 1) * 2 * rows + which * rows + r] = u01(hfin(Pp(K_EXPLORE + which, (t + 1) & 1)[w_ >> 16], (unsigned)(w_ & 0xffff)));
+      }
+    }
   };
   const int KC1 = a.KI >> 5;
-  // (the reward prefixes of the step to come are hashed a step ahead, off the env step's dependent chain: two parities of EPW entries)
-  const bool pre_r = 2 * nenv_wg <= rows;
   // epsilon of step t: a device vector, or the reference's per-step anneal (rollout.py:100-101) evaluated here in fp64
   float eps_next = a.eps ? a.eps[0] : (float)a.eps0;
   double eps_d = a.eps0;
@@ -311,30 +336,49 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     ST_DECL(6);
     for (int t = 0; t < T; ++t) {
       const int par = t & 1;
-      // ---- A: gates(t) = bias + x(t) W_ih + h(t-1) W_hh (one accumulator chain per gate: bias, x chunks, h chunks), gate math, h(t)
+      // ---- A: gates(t) = bias + x(t) W_ih + h(t-1) W_hh (one accumulator chain per gate: bias, x chunks, h chunks), gate math, h(t).
+      // Software pipeline over the row tiles: the 72 products of tile rt are issued with the gate math of tile rt-1 between them
+      // (two accumulator sets; an operand chunk is read from LDS while the previous one multiplies) - written tile by tile the matrix
+      // pipe idled through every tile's gate math and the gate math waited for every tile's last product.
+      f32x4 G[2][4];
+      F3 fa = bfrag(Xp0, HP, rows * HP, 0, lane);
 #pragma unroll
-      for (int rt = 0; rt < RTC; ++rt) {
-        f32x4 ag[3] = {splat(bias_r), splat(bias_z), splat(bias_n)};
-        f32x4 ahn = splat(bias_hn);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const F3 xb = bfrag(Xp0 + rt * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int g = 0; g < 3; ++g) ag[g] = mm(xb.p_, wi[2 * g + c].q_, ag[g]);
+      for (int rt = 0; rt <= RTC; ++rt) {
+        if (rt < RTC) {
+          f32x4* g = G[rt & 1];
+          g[0] = splat(bias_r); g[1] = splat(bias_z); g[2] = splat(bias_n); g[3] = splat(bias_hn);
+          const F3 fb = bfrag(Xp0 + rt * 16 * HP, HP, rows * HP, 1, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int k = 0; k < 3; ++k) g[k] = mm(fa.p_, wi[2 * k].q_, g[k]);
+          X6_TERMS(OP)
+#undef OP
+          const F3 fc = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, 0, lane);
+#define OP(p_, q_) _Pragma("unroll") for (int k = 0; k < 3; ++k) g[k] = mm(fb.p_, wi[2 * k + 1].q_, g[k]);
+          X6_TERMS(OP)
+#undef OP
+          const F3 fd = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, 1, lane);
+#define OP(p_, q_) g[0] = mm(fc.p_, wh[0].q_, g[0]); g[1] = mm(fc.p_, wh[2].q_, g[1]); g[3] = mm(fc.p_, wh[4].q_, g[3]);
+          X6_TERMS(OP)
+#undef OP
+          if (rt + 1 < RTC) fa = bfrag(Xp0 + (rt + 1) * 16 * HP, HP, rows * HP, 0, lane);
+#define OP(p_, q_) g[0] = mm(fd.p_, wh[1].q_, g[0]); g[1] = mm(fd.p_, wh[3].q_, g[1]); g[3] = mm(fd.p_, wh[5].q_, g[3]);
           X6_TERMS(OP)
 #undef OP
         }
+        if (rt > 0) {
+          const f32x4* g = G[(rt - 1) & 1];
+          f32x4 hn;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const F3 hb = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, c, lane);
-#define OP(p_, q_) ag[0] = mm(hb.p_, wh[c].q_, ag[0]); ag[1] = mm(hb.p_, wh[2 + c].q_, ag[1]); ahn = mm(hb.p_, wh[4 + c].q_, ahn);
-          X6_TERMS(OP)
-#undef OP
+          for (int r = 0; r < 4; ++r) hn[r] = gru_h_x6(g[0][r], g[1][r], g[2][r], g[3][r], hreg[rt - 1][r]);
+          put4(hpp(par ^ 1), HP, rows * HP, (rt - 1) * 16 + 4 * q, u, hn);
+          hreg[rt - 1] = hn;
         }
-        f32x4 hn;
+        if (rt > 0 && rt < RTC) {      // the products of tile rt with the gate math of tile rt-1 in their gaps
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hn[r] = gru_h_x6(ag[0][r], ag[1][r], ag[2][r], ahn[r], hreg[rt][r]);
-        put4(hpp(par ^ 1), HP, rows * HP, rt * 16 + 4 * q, u, hn);
-        hreg[rt] = hn;
+          for (int i = 0; i < 72; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+        }
       }
       ST_MARK(0);
       WG_BARRIER();                                // B1: h(t) planes | pre(t+1) taken: the input planes are free; prefixes of slot t+2
@@ -349,6 +393,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       WG_BARRIER();                                // B2: act(t)
       ST_MARK(3);
       if (t + 2 <= T) gen_obs(t + 2, t + 2 < T, oi_cut, n_oi, tid, RNT / 2);
+      hashes(t, tid, RNT / 2);
       ST_MARK(4);
       WG_BARRIER();                                // B3: x(t+1) planes | slot t+2
       ST_MARK(5);
@@ -472,25 +517,6 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         }
       }
     };
-    // the uniforms of step t+1's choice, the hash prefixes of slot t+2 (team R generates it in B / C of this step), the reward prefix of
-    // step t+1: items (kind, row), kind-major
-    auto hashes = [&](int t) __attribute__((always_inline)) {
-      const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-      float* ux = uex + ((t + 1) & 1) * 2 * rows;
-      const int pp = (t & 1) * rows;             // entry of slot t + 2
-      for (int x = ti; x < 5 * rows; x += RNT / 2) {
-        const int kind = x / rows, r = x - kind * rows;
-        const int w_ = rmeta[r].w;
-        const unsigned env = (unsigned)(a.env0 + b0 + (w_ >> 16)), nn_ = (unsigned)(w_ & 0xffff);
-        if (kind == 0) ux[r] = u01(hkey(a.rseed, ST_EXPLORE, env, tg + 1u, nn_));
-        else if (kind == 1) ux[rows + r] = u01(hkey(a.rseed, ST_PICK, env, tg + 1u, nn_));
-        else if (kind == 2) pfxO[pp + r] = hprefix(a.seed, ST_OBS, env, tg + 2u);
-        else if (kind == 3) pfxA[pp + r] = hprefix(a.seed, ST_AVAIL, env, tg + 2u);
-        else if (r < nenv_wg) pfxS[pp + r] = hprefix(a.seed, ST_STATE, (unsigned)(a.env0 + b0 + r), tg + 2u);
-        else if (pre_r && r >= rows / 2 && r - rows / 2 < nenv_wg)      // the reward prefix of step t+1
-          pfxR[((t + 1) & 1) * (rows / 2) + (r - rows / 2)] = hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + r - rows / 2), tg + 1u);
-      }
-    };
     // env step: lane -> (env, agent); the N rows of an environment sit in ONE wave, environments dealt to the four waves in turn
     const int es_epw = 64 / N, es_er = lane / N;
     const int es_n = lane - es_er * N, es_l0 = es_er * N;
@@ -510,9 +536,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       if (a.eps) { if (t + 1 < T) eps_next = a.eps[t + 1]; }
       else { eps_d = eps_d > a.eps_min ? eps_d - a.eps_anneal : eps_d; eps_next = (float)eps_d; }
       const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-      // ---- A (beside the recurrence): pre(t+1) from the planes of slot t+1; the hashes of the steps to come
+      // ---- A (beside the recurrence): pre(t+1) from the planes of slot t+1
       if (t + 1 < T) fc1();
-      hashes(t);
       ST_MARK(0);
       WG_BARRIER();                                // B1: h(t)
       ST_MARK(1);
@@ -529,8 +554,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         const bool live = t < L;
         float term = 0.f;
         if (live) {
-          const unsigned pre_ = (pre_r && t > 0) ? pfxR[(t & 1) * (rows / 2) + es_el]
-                                                 : hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
+          const unsigned pre_ = t > 0 ? Pp(K_REWARD, t & 1)[es_el] : hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
           term = u01(hfin(pre_, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
         }
         float acc = 0.f;
@@ -562,8 +586,8 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 // LDS bytes of a workgroup of RTC row tiles holding EPW environments
 static size_t rx6_lds(int rtc, int KI, int A, int epw) {
   const size_t rows = 16 * (size_t)rtc, IP = KI + 8;
-  return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)(A + 1) * H * 4 + 4 * rows * 4 /* avm */ + rows * (4 /* act */ + 7 * 4 /* pfx O A S x 2, R */ + 4 * 4 /* uex */) +
-         rows * 16 /* rmeta */ + (size_t)epw * 16 /* emeta */;
+  return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)(A + 1) * H * 4 + 4 * rows * 4 /* avm */ + rows * (4 /* act */ + 4 * 4 /* uex */) +
+         rows * 16 /* rmeta */ + (size_t)epw * (16 /* emeta */ + 12 * 4 /* P */);
 }
 // row tiles a workgroup may hold: five fc1 chunks (wide inputs) cost registers and LDS
 static int rx6_max_tiles(int KI) { return KI > 96 ? 4 : 5; }

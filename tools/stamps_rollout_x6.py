@@ -17,7 +17,8 @@ lib = _lib.load()
 buf = torch.zeros(16 * 16, dtype=torch.int64, device="cuda")
 V1 = os.environ.get("MARL_ROLLOUT_V1") == "1"
 if not V1:
-    os.environ["MARL_ROLLOUT_V1"] = "2"      # force this round's kernel at every batch size
+    from marl_amd import experiments
+    experiments.set("rollout_v1", 2)         # force this round's kernel at every batch size
 fn = lib.marl_debug_stamps_rollout_x6_v1 if V1 else lib.marl_debug_stamps_rollout_x6
 fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
 assert fn(buf.data_ptr()) == 0
