@@ -13,11 +13,12 @@
 // No gate-sum buffer: 30 KB of LDS per row tile -> up to FIVE tiles per workgroup, the whole share of a CU in one round.
 // A lock-step, three LDS-only barriers; the dependent chain is  rec (R) | choice (I) | x (I), everything else rides beside it:
 //   A  R: gates(t) = bias + x(t) W_ih + h(t-1) W_hh, gate math, h(t) -> planes (software-pipelined over the row tiles: a tile's gate
-//         math sits in the gaps of the next tile's products)            I: pre(t+1) = fc1 of the slot-(t+1) planes
+//         math sits in the gaps of the next tile's products)            I: pre(t+1) = fc1 of the slot-(t+1) planes; state + availability of slot t+1
+//                                                                          (record, bit masks)
 //   B  I: q(t) = fc2(h(t)) and the epsilon-greedy choice IN REGISTERS (a row's 16 actions on a DPP row: max + three ballots), every
-//         stage for all row tiles side by side                          R: slot t+2: state + availability (record, bit masks), observations part 1
-//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step      R: observations part 2 (record + input planes); the hashes of the
-//                                                                          steps to come (one prefix per environment, stream and time)
+//         stage for all row tiles side by side                          R: observations of slot t+2 (record + input planes), part 1
+//   C  I: x(t+1) = relu(pre + W1[:, O + u(t)]) -> planes; env step      R: part 2; the hashes of the steps to come (one prefix per
+//                                                                          environment, stream and time)
 // fc1 = (bias + W1[:, obs | id] in) - on the matrix cores - + W1[:, O + u], one column of fp32 weights added per row once u is known
 // (a table in LDS).  Availability lives in LDS as one bit mask per row and slot (a ring of four slots: no hazards).
 #include "x6.h"
@@ -228,13 +229,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   };
   // state + availability of slot t: record, and the availability bit masks of the slot (ring entry t & 3: zero when this starts - the
   // entry of slot t + 1 is cleared here for the next call)
-  auto gen_rest = [&](int t, int tl, int nthr) __attribute__((always_inline)) {
+  auto gen_rest = [&](int t, int tl, int nthr, bool do_avail = true, bool do_state = true) __attribute__((always_inline)) {
     const int tNA = t * N * A, tS = t * (int)a.SL;
     unsigned* am = avm + (t & 3) * rows;
     const unsigned* pA = Pp(K_AVAIL, t & 1);
     const unsigned* pS = Pp(K_STATE, t & 1);
-    for (int r = tl; r < rows; r += nthr) avm[((t + 1) & 3) * rows + r] = 0u;
-    for (int e = tl; e < vrows * A; e += nthr) {
+    if (do_avail) for (int r = tl; r < rows; r += nthr) avm[((t + 1) & 3) * rows + r] = 0u;
+    if (do_avail) for (int e = tl; e < vrows * A; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * invA);
       const int k = e - r * A;
       const int4 mt = rmeta[r];
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       a.avail[(long)mt.y + tNA + k] = on ? 1.f : 0.f;
       if (on) atomicOr(am + r, 1u << k);
     }
+    if (!do_state) return;
     if (svec) {
       for (int e = tl; e < nenv_wg * S4; e += nthr) {
         const int el = (int)(((float)e + 0.5f) * invS4);
@@ -285,20 +287,20 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   auto prologue_slot1 = [&]() __attribute__((always_inline)) {      // (behind P1: x(0) made, the input planes and slot 0's prefixes are free)
     gen_obs(1, 1 < T, 0, n_oi, tid, RNT);
     gen_rest(1, tid, RNT);
-    for (int x = tid; x < 3 * nenv_wg; x += RNT) {      // slot 2 (the entries slot 0 left)
-      const int j = (int)(((float)x + 0.5f) * inv_nE);
-      put_prefix(j, x - j * nenv_wg, 2, 0);
-    }
+    for (int x = tid; x < 2 * nenv_wg; x += RNT)        // slot 2's observations and state (the entries slot 0 left)
+      put_prefix(x < nenv_wg ? K_OBS : K_STATE, x < nenv_wg ? x : x - nenv_wg, 2, 0);
   };
   // the hashes of the steps to come, ONE item per thread of a 256-thread team at the headline shape (6 EPW prefixes + 2 x rows uniforms):
-  // prefixes of slot t+3 (observations / availability / state: generated in B / C of step t+1), of step t+1's reward and step t+2's
-  // explore / pick draws; the uniforms of step t+1's choice from the explore / pick prefixes the previous call left
+  // prefixes of slot t+3's observations and state (team R generates them in B / C of step t+1), of slot t+2's availability (team I, A
+  // of step t+1), of step t+1's reward and step t+2's explore / pick draws; the uniforms of step t+1's choice from the explore / pick
+  // prefixes the previous call left
   auto hashes = [&](int t, int tl, int nthr) __attribute__((always_inline)) {
     const int nP = 6 * nenv_wg;
     for (int x = tl; x < nP + 2 * rows; x += nthr) {
       if (x < nP) {
         const int kind = (int)(((float)x + 0.5f) * inv_nE), el = x - kind * nenv_wg;
-        if (kind < K_REWARD) put_prefix(kind, el, t + 3, (t + 1) & 1);
+        if (kind == K_OBS || kind == K_STATE) put_prefix(kind, el, t + 3, (t + 1) & 1);
+        else if (kind == K_AVAIL) put_prefix(kind, el, t + 2, t & 1);
         else if (kind == K_REWARD) put_prefix(kind, el, t + 1, (t + 1) & 1);
         else put_prefix(kind, el, t + 2, t & 1);
       } else {
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 #pragma unroll
     for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
     // R's share of a slot's observation items before the choice barrier (team I needs ~the choice's time to get there)
-    const int oi_cut = (n_oi * 6) >> 4;
+    const int oi_cut = (n_oi * 9) >> 4;
     WG_BARRIER();                                  // P0: slot 0 in the planes, tables (team I: fc1, x(0))
     WG_BARRIER();                                  // P1: x(0), pre(0) taken: the input planes are free
     prologue_slot1();
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       // ---- B, C (beside team I's choice and x): slot t+2 -> record; its observations -> input planes (fc1 reads them in A of step
       // t+1), its availability -> bit masks (the choice of step t+2 reads them)
       if (t + 2 <= T) {
-        gen_rest(t + 2, tid, RNT / 2);
+        gen_rest(t + 2, tid, RNT / 2, false, true);
         gen_obs(t + 2, t + 2 < T, 0, oi_cut, tid, RNT / 2);
       }
       ST_MARK(2);
@@ -536,8 +538,10 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       if (a.eps) { if (t + 1 < T) eps_next = a.eps[t + 1]; }
       else { eps_d = eps_d > a.eps_min ? eps_d - a.eps_anneal : eps_d; eps_next = (float)eps_d; }
       const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
-      // ---- A (beside the recurrence): pre(t+1) from the planes of slot t+1
+      // ---- A (beside the recurrence): pre(t+1) from the planes of slot t+1; state + availability of slot t+1 (record, bit masks; slot 1's
+      // were made in the prologue)
       if (t + 1 < T) fc1();
+      if (t >= 1) gen_rest(t + 1, ti, RNT / 2, true, false);
       ST_MARK(0);
       WG_BARRIER();                                // B1: h(t)
       ST_MARK(1);

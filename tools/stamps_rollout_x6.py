@@ -6,7 +6,7 @@ team I (waves 4-7): A fc1 + hashes | B1 | B fc2 + choice | B2 | C x + env step |
 MARL_ROLLOUT_V1=1: the round-5 kernel (P1 | B1 | P2 | B2 | P3 | B3 | P4 | B4)"""
 import os, sys, ctypes
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MARL_HIP_LIB"] = os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so")
+os.environ.setdefault("MARL_HIP_LIB", os.path.join(HERE, "marl_amd", "libmarl_hip_stamps.so"))      # (a variant build: MARL_HIP_LIB=marl_amd/variants/...)
 sys.path.insert(0, HERE)
 import torch  # noqa: E402
 from marl_amd import _lib  # noqa: E402
