@@ -503,8 +503,13 @@ int marl_synth_rollout(const marl_agent_weights_t* w, unsigned seed, unsigned rs
  * "bf16x6"): same arguments, same environment, same epsilon-greedy choice, same record - the integer fields agree with
  * marl_synth_rollout wherever no two available actions' Q values lie within fp32 rounding of each other (the choice is an argmax).
  * fc1 is evaluated as (bias + W1[:, obs | id] in) + W1[:, O + last action]: the observation part on the matrix cores a step ahead,
- * the chosen action's column added in fp32.  Supported: H = 64, 1 <= A <= 16, O a multiple of 4, O + A + N <= 160, N <= 48. */
+ * the chosen action's column added in fp32.  Supported: H = 64, 1 <= A <= 16, O a multiple of 4, O + A + N <= 160, N <= 64. */
 int marl_synth_rollout_x6_supported(int N, int O, int A);
+/* How marl_synth_rollout_x6 runs a batch of E environments (two decompositions of the same arithmetic, picked by batch size:
+ * csrc/rollout_x6_v1.hip holds at most three row tiles of 16 (episode, agent) rows per workgroup, csrc/rollout_x6.hip up to five):
+ * plan[0] = decomposition (1 / 2), plan[1] = workgroups, plan[2] = row tiles per workgroup, plan[3] = environments per workgroup,
+ * plan[4] = fc1 chunks of 32 input columns.  What bench.py's roofline model counts the executed products by. */
+int marl_synth_rollout_x6_plan(int E, int N, int O, int A, int last_action, int reuse_network, int* plan);
 int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
                           int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                           float* r, float* term, float* padded, int* length, int* won, float* h_out,

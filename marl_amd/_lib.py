@@ -144,6 +144,7 @@ SIGNATURES = {
     "marl_synth_rollout_supported": (I, [I, I, I]),
     "marl_synth_rollout": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, D, D, D, I, I, I, I, I, I, I, I, P]),
     "marl_synth_rollout_x6_supported": (I, [I, I, I]),
+    "marl_synth_rollout_x6_plan": (I, [I, I, I, I, I, I, P]),
     "marl_synth_rollout_x6": (I, [AW, U, U, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, D, D, D, I, I, I, I, I, I, I, I, P]),
     "marl_hip_version": (C.c_char_p, []),
     "marl_experiment_set": (I, [C.c_char_p, I]),

@@ -596,6 +596,29 @@ static size_t rx6_lds(int rtc, int KI, int A, int epw) {
 // row tiles a workgroup may hold: five fc1 chunks (wide inputs) cost registers and LDS
 static int rx6_max_tiles(int KI) { return KI > 96 ? 4 : 5; }
 
+// environments per workgroup: one workgroup per CU while the batch fits one round (small batches spread over all CUs with partly
+// filled tiles); beyond that as few FULL rounds of 256 workgroups as five row tiles per workgroup allow, evenly filled (0: none fits)
+static int rx6_epw(int E, int N, int KI, int A) {
+  int epw_max = 16 * rx6_max_tiles(KI) / N;
+  while (epw_max > 1 && rx6_lds((epw_max * N + 15) / 16, KI, A, epw_max) > 160 * 1024) --epw_max;
+  if (epw_max < 1) return 0;
+  int epw = (E + 255) / 256;
+  if (epw > epw_max) {
+    const int rounds = (E + 256 * epw_max - 1) / (256 * epw_max);
+    epw = (E + 256 * rounds - 1) / (256 * rounds);
+    if (epw > epw_max) epw = epw_max;
+  }
+  return epw;
+}
+// which decomposition runs a batch: this file's kernel pays where the round-5 one needs more than one round of workgroups (its three
+// row tiles per workgroup - two for wide inputs - do not hold a CU's share of the batch); below that the two are level or the round-5
+// kernel is ahead (one tile per workgroup: 0.46 against 0.52 ms at 512 envs).  experiments: rollout_v1 = 1 / 2 forces one of them
+static bool rx6_use_v1(int E, int N, int O, int A, int last_action, int reuse_network) {
+  const int sw = marl_switches()->rollout_v1;
+  const int v1_epw_max = ((O + (last_action ? A : 0) + (reuse_network ? N : 0) + 31) / 32 * 32 > 96 ? 32 : 48) / (N > 0 ? N : 1);
+  return marl_rollout_x6_v1_supported(N, O, A) && (sw == 1 || (sw == 0 && (long)E <= 256L * v1_epw_max));
+}
+
 }  // namespace
 
 ST_DEFINE_SETTER(marl_debug_stamps_rollout_x6)
@@ -613,17 +636,37 @@ extern "C" int marl_synth_rollout_x6_supported(int N, int O, int A) {
   return rx6_lds((N + 15) / 16, KI, A, 1) <= 160 * 1024 ? 1 : 0;
 }
 
+// how marl_synth_rollout_x6 would run a batch (what bench.py's roofline model counts products by): plan[0] = decomposition (1: round 5,
+// rollout_x6_v1.hip; 2: round 6, this file), plan[1] = workgroups, plan[2] = row tiles of 16 (episode, agent) rows per workgroup,
+// plan[3] = environments per workgroup, plan[4] = fc1 chunks of 32 input columns.  Returns 0, or hipErrorInvalidValue for unsupported shapes
+extern "C" int marl_synth_rollout_x6_plan(int E, int N, int O, int A, int last_action, int reuse_network, int* plan) {
+  if (!plan || E <= 0 || !marl_synth_rollout_x6_supported(N, O, A)) return (int)hipErrorInvalidValue;
+  const int I = O + (last_action ? A : 0) + (reuse_network ? N : 0), KI = (I + 31) / 32 * 32;
+  int epw;
+  if (rx6_use_v1(E, N, O, A, last_action, reuse_network)) {
+    const int epw_max = (KI > 96 ? 32 : 48) / N;
+    epw = (E + 255) / 256;
+    if (epw > epw_max) {
+      const int rounds = (E + 256 * epw_max - 1) / (256 * epw_max);
+      epw = (E + 256 * rounds - 1) / (256 * rounds);
+      if (epw > epw_max) epw = epw_max;
+    }
+    plan[0] = 1;
+  } else {
+    epw = rx6_epw(E, N, KI, A);
+    if (epw < 1) return (int)hipErrorInvalidValue;
+    plan[0] = 2;
+  }
+  plan[1] = (E + epw - 1) / epw; plan[2] = (epw * N + 15) / 16; plan[3] = epw; plan[4] = KI > 96 ? 5 : 3;
+  return 0;
+}
+
 extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned seed, unsigned rseed, int env0, int episode,
                                      int fixed_len, const float* eps, float* obs, float* state, long state_ld, float* avail, int* u,
                                      float* r, float* term, float* padded, int* length, int* won, float* h_out,
                                      float* stats, double eps0, double eps_anneal, double eps_min, int E, int T, int N,
                                      int O, int S, int A, int last_action, int reuse_network, void* stream) {
-  // which decomposition: this file's kernel pays where the round-5 one needs more than one round of workgroups (its three row tiles
-  // per workgroup - two for wide inputs - do not hold a CU's share of the batch); below that the two are level or the round-5 kernel
-  // is ahead (one tile per workgroup: 0.46 against 0.52 ms at 512 envs).  experiments: rollout_v1 = 1 / 2 forces the round-5 / this kernel
-  const int sw = marl_switches()->rollout_v1;
-  const int v1_epw_max = ((O + (last_action ? A : 0) + (reuse_network ? N : 0) + 31) / 32 * 32 > 96 ? 32 : 48) / (N > 0 ? N : 1);
-  const bool use_v1 = marl_rollout_x6_v1_supported(N, O, A) && (sw == 1 || (sw == 0 && (long)E <= 256L * v1_epw_max));
+  const bool use_v1 = rx6_use_v1(E, N, O, A, last_action, reuse_network);
   if (use_v1)
     return marl_rollout_x6_v1(w, seed, rseed, env0, episode, fixed_len, eps, obs, state, state_ld, avail, u, r, term, padded, length, won,
                               h_out, stats, eps0, eps_anneal, eps_min, E, T, N, O, S, A, last_action, reuse_network, stream);
@@ -644,18 +687,9 @@ extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned see
   // record offsets are 32-bit element offsets inside the kernel
   if ((double)E * (T + 1) * N * (O > A ? O : A) >= 2147483648.0 || (double)E * (T + 1) * state_ld >= 2147483648.0)
     return (int)hipErrorInvalidValue;
-  // environments per workgroup: one workgroup per CU while the batch fits one round (small batches spread over all CUs with partly
-  // filled tiles); beyond that as few FULL rounds of 256 workgroups as five row tiles per workgroup allow, evenly filled
   const int nk1 = a.KI > 96 ? 5 : 3;
-  int epw_max = 16 * rx6_max_tiles(a.KI) / N;
-  while (epw_max > 1 && rx6_lds((epw_max * N + 15) / 16, a.KI, A, epw_max) > 160 * 1024) --epw_max;
-  if (epw_max < 1) return (int)hipErrorInvalidValue;
-  int epw = (E + 255) / 256;
-  if (epw > epw_max) {
-    const int rounds = (E + 256 * epw_max - 1) / (256 * epw_max);
-    epw = (E + 256 * rounds - 1) / (256 * rounds);
-    if (epw > epw_max) epw = epw_max;
-  }
+  const int epw = rx6_epw(E, N, a.KI, A);
+  if (epw < 1) return (int)hipErrorInvalidValue;
   a.EPW = epw;
   const int rtc = (epw * N + 15) / 16;
   const size_t lds = rx6_lds(rtc, a.KI, A, epw);

@@ -432,6 +432,13 @@ def synth_rollout_x6_supported(N, O, A):
     return bool(_lib.load().marl_synth_rollout_x6_supported(N, O, A))
 
 
+def synth_rollout_x6_plan(E, N, O, A, last_action=True, reuse_network=True):
+    """(decomposition 1 / 2, workgroups, row tiles per workgroup, environments per workgroup, fc1 chunks) of a split whole rollout"""
+    plan = (C.c_int * 5)()
+    check(_lib.load().marl_synth_rollout_x6_plan(E, N, O, A, 1 if last_action else 0, 1 if reuse_network else 0, plan), "marl_synth_rollout_x6_plan")
+    return tuple(plan)
+
+
 def synth_rollout(w, seed, rseed, env0, episode, fixed_len, eps, rec, h_out, E, T, N, O, S, A, last_action, reuse_network,
                   stats=None, eps_sched=None, x6=False):
     """eps: device (T,) epsilon per lock-step, or None with eps_sched = (eps0, anneal, eps_min): the per-step anneal of

@@ -347,3 +347,32 @@ def test_split_rollout_decompositions_agree_bitwise(shape, E, T, eps):
             assert torch.equal(getattr(ra, f), getattr(rb, f)), f
         assert torch.equal(ha, hb) and rewa == rewb and sa == sb and ea == eb
         assert int((ra.u >= 0).sum()) > 0
+
+
+@pytest.mark.parametrize("N,O,S,A,E,T", [(49, 40, 60, 5, 23, 6), (1, 8, 10, 3, 700, 5), (16, 64, 100, 16, 300, 5), (33, 100, 70, 5, 40, 4)])
+def test_split_rollout_edge_shapes_match_the_per_step_path(N, O, S, A, E, T):
+    """shapes only the round-6 split rollout kernel covers in one launch (an environment of up to 64 agents across several row tiles;
+    one-agent environments, 80 to a workgroup; 16 actions = a full DPP row): the whole-rollout record == the per-step kernels' record
+    (fp32 agent step; actions are argmaxes of well separated Q values here) and == the oracle's integer fields"""
+    from marl_amd.rollout import RolloutWorker
+    from marl_amd.env.synthetic_smac import SyntheticSMACEnv
+    from marl_amd import ops
+    import types
+    assert ops.synth_rollout_x6_supported(N, O, A)
+    args = seeded.make_args("2s3z", "qmix", episode_limit=T, epsilon=0.4, seed=5)
+    args.n_agents, args.obs_shape, args.state_shape, args.n_actions = N, O, S, A
+    args.anneal_epsilon = 0.03
+    args.gemm_mode = "bf16x6"
+    mac, agent = _mac(args)
+    w = RolloutWorker(SyntheticSMACEnv(E, N, O, S, A, T, seed=4, env0=1), mac, args)
+    ep, rew, wins, steps = w.generate_episodes(E)
+    w2 = RolloutWorker(SyntheticSMACEnv(E, N, O, S, A, T, seed=4, env0=1), mac, args)
+    w2.rollout_mode = "unfused"
+    ep2, rew2, wins2, steps2 = w2.generate_episodes(E)
+    for f in ("obs", "state", "avail", "u", "r", "term", "padded", "length", "won"):
+        assert torch.equal(getattr(ep.record, f), getattr(ep2.record, f)), f
+    assert steps == steps2 and wins == wins2
+    sy = orl.SynthSMAC(N, O, S, A, T, seed=4)
+    oep, orew, owins, osteps, _ = orl.batched_rollout(agent, args, sy, E, 0.4, rseed=5, env0=1)
+    np.testing.assert_array_equal(ep.numpy()["u"], oep["u"])
+    assert steps == osteps
