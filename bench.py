@@ -70,6 +70,64 @@ def learner_flops_per_transition(a, alg):
     raise ValueError(alg)
 
 
+# ---- what the split (bf16x6) kernels put on the matrix cores: wave-level MFMA instructions per launch, from each kernel's decomposition
+# (checked against SQ_INSTS_MFMA of the committed PMC passes by tests/test_roofline_model_cpu.py).  "k32" = v_mfma_f32_16x16x32_bf16
+# (16 384 FLOP), "k16" = v_mfma_f32_16x16x16_bf16 (8 192 FLOP); an fp32 product costs six of either.  Tile padding and redundant
+# products ARE counted here (this is what the pipe executes); `executed_flop` of a row counts the useful products only.
+MFMA_FLOP = {"k32": 16384.0, "k16": 8192.0}
+
+
+def mfma_flop(m):
+    return sum(MFMA_FLOP[k] * v for k, v in m.items())
+
+
+def bptt_x6_plan(rows):
+    """(two-tile workgroups, one-tile workgroups) of agent_bwd_x6_kernel for a batch of `rows` (episode, agent) rows
+    (csrc/agent_bwd_x6.hip: bx6_plan)"""
+    tiles = (rows + 15) // 16
+    if tiles <= 256:
+        return 0, tiles
+    n2 = tiles // 512 * 256
+    rem = tiles - 2 * n2
+    if n2 > 0 and 0 < rem <= 256:
+        return n2, rem
+    return (tiles + 1) // 2, 0
+
+
+def mfma_bptt_x6(B, T, N):
+    """per step a two-tile workgroup multiplies: team R  carry' = G W_hh and dx = G W_ih (6 k chunks x 2 tiles x 6 terms each, four slice
+    waves) = 576, team I  dW_ih, dW_hh (48 output tiles each) and dW_2 (4: the action dimension padded to 16) x 6 terms = 600 - all on the
+    32-deep instruction; a one-tile workgroup: 288 of those and its 600 reductions on the 16-deep one.  dq -> dh is not matrix work (the
+    loss reaches q through one or two (action, gradient) pairs per row)."""
+    n2, n1 = bptt_x6_plan(B * N)
+    return {"k32": T * (n2 * 1176 + n1 * 288), "k16": T * n1 * 600}
+
+
+def mfma_rollout_x6(plan, T):
+    """per lock-step and row tile: recurrence 4 slice waves x 72 (x W_ih + h W_hh: 3 gates x (2 + 2) chunks x 6 terms), fc1 4 x 6 NK1,
+    fc2 12 products by EVERY slice wave of a team (each makes the choice of its own rows): 288 + 24 NK1 + 48 - the same count in both
+    decompositions (ops.synth_rollout_x6_plan: workgroups, row tiles per workgroup incl. padding rows)"""
+    _, wgs, rtc, _, nk1 = plan
+    return {"k32": T * wgs * rtc * (288 + 24 * nk1 + 48), "k16": 0}
+
+
+def mfma_qmix_x6(rows, N, S, E, backward):
+    """per 16-row tile: hypernet GEMM [16 x S] x [S x (N E + 3 E)] on the 32-deep instruction (S padded to 32s) x 6 terms; the backward
+    recomputes it and adds dW = d(out)^T s on the 16-deep one (contraction over the tile's 16 rows: (N E + 3 E) / 16 x ceil(S / 16) output
+    tiles x 6 terms)"""
+    tiles = (rows + 15) // 16
+    cols = (N * E + 3 * E + 15) // 16
+    m = {"k32": tiles * cols * ((S + 31) // 32) * 6, "k16": 0}
+    if backward:
+        m["k16"] = tiles * cols * ((S + 31) // 32 * 2) * 6
+    return m
+
+
+def mfma_unroll_x6(B, T, N, nk1=3):
+    """plain / saving unroll: per step and row tile 4 x (36 recurrence + 36 input gates + 6 NK1 fc1) + 48 fc2"""
+    return {"k32": T * ((B * N + 15) // 16) * (288 + 24 * nk1 + 48), "k16": 0}
+
+
 class KernelTimers:
     """HIP-event timing of the C-ABI calls of the hot path inside the timed region, on the stream each one is launched
     on (events are recorded on torch's CURRENT stream at the call, which is the side stream for the forked launches).
@@ -102,15 +160,20 @@ class KernelTimers:
             m = fwd(ar, kw)          # same arguments as agent_unroll_fwd; the kernel is agent_fwd_x6_kernel (csrc/agent_x6.hip)
             if m is None:
                 return None
-            return (m[0].replace("agent_fwd_kernel", "agent_fwd_x6_kernel") + " fp32 products as six bf16 MFMA products", "agent_fwd_x6") + m[2:]
+            mf = mfma_unroll_x6(ar[12], ar[13], ar[14], 3 if I <= 96 else 5 if I <= 160 else 7) if kw.get("gi_in") is None else None
+            return (m[0].replace("agent_fwd_kernel", "agent_fwd_x6_kernel") + " fp32 products as six bf16 MFMA products", "agent_fwd_x6") + m[2:] + (True, mf)
 
         def bwd(ar, kw):
             B, T, N_, A_ = ar[8], ar[9], ar[10], ar[11]
             rows = B * T * N_
             f = (8 * 3 * H * H + 4 * A_ * H) * rows   # dx, dh_prev, dW_ih, dW_hh (2*192*64 each) + dq->dh and dW_2 (2*A*64 each)
             if kw.get("x6"):      # csrc/agent_bwd_x6.hip (opt-in gemm_mode)
+                # useful products: dx, carry', dW_ih, dW_hh (2 * 192 * 64 each) and dW_2 (2 * A * 64) on the matrix cores; dq -> dh is one or
+                # two sparse (action, gradient) pairs per row on the vector unit (2 * 64 each)
+                pairs = 2 if (len(ar) > 14 and ar[14] is not None) or kw.get("dq_idx2") is not None else 1
+                fx = (8 * 3 * H * H + 2 * A_ * H + pairs * 2 * H) * rows
                 return ("agent_bwd_x6_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2, fp32 products as six bf16 MFMA products)", "agent_bwd_x6_kernel",
-                        f, f, 4.0 * rows * (10 * H + H))
+                        fx, f, 4.0 * rows * (10 * H + H), True, mfma_bptt_x6(B, T, N_))
             return ("agent_bwd_kernel (BPTT: delta pass + dW_ih / dW_hh / dW_2)", "agent_bwd_kernel", f, f, 4.0 * rows * (10 * H + H))
 
         def wgrad(ar, kw):
@@ -131,7 +194,8 @@ class KernelTimers:
                 f = 2.0 * rows * S_ * (N_ * E_ + 3 * E_) * mult
                 if kw.get("x6"):      # the split variant: template arguments <BWD, 8 waves, LOSS, X6 = true>
                     name = "qmix_fused_kernel<%s, 8, %s, true>" % ("true" if mult > 1 else "false", "true" if loss else "false")
-                    return (label + ", fp32 products as six bf16 MFMA products", name, f, f, 4.0 * rows * (S_ + N_ + 1), True)
+                    return (label + ", fp32 products as six bf16 MFMA products", name, f, f, 4.0 * rows * (S_ + N_ + 1), True,
+                            mfma_qmix_x6(rows, N_, S_, E_, mult > 1))
                 return (label, roc, f, f, 4.0 * rows * (S_ + N_ + 1))
             return m
 
@@ -175,7 +239,8 @@ class KernelTimers:
             f = float(Fa) * E_ * T_ * N_
             by = 4.0 * E_ * (T_ + 1) * (N_ * O + S + N_ * A)
             if kw.get("x6"):      # csrc/rollout_x6.hip: the agent step as bf16x6 split products
-                return ("synth_rollout_x6_kernel (whole rollout, T lock-steps; fp32 products as six bf16 MFMA products)", "synth_rollout_x6_kernel", f, f, by, True)
+                return ("synth_rollout_x6_kernel (whole rollout, T lock-steps; fp32 products as six bf16 MFMA products)", "synth_rollout_x6_kernel", f, f, by, True,
+                        mfma_rollout_x6(ops.synth_rollout_x6_plan(E_, N_, O, A), T_))
             return ("synth_rollout_kernel (whole rollout, T lock-steps)", "synth_rollout_kernel", f, f, by)
 
         self.models = {"agent_unroll_fwd": fwd, "agent_unroll_fwd_x6": fwd_x6, "agent_unroll_bwd": bwd, "linear_wgrad": wgrad, "linear": lin,
@@ -209,7 +274,8 @@ class KernelTimers:
             r = orig(*a, **k)
             e1.record()
             self.rec.setdefault(m[0], {"roc": m[1], "ev": [], "exec": m[2], "alg": m[3], "bytes": m[4], "call": name,
-                                       "x6": ("x6" in m[1]) or (len(m) > 5 and bool(m[5]))})["ev"].append((e0, e1))
+                                       "x6": ("x6" in m[1]) or (len(m) > 5 and bool(m[5])),
+                                       "mfma": m[6] if len(m) > 6 else None})["ev"].append((e0, e1))
             return r
         setattr(self.ops, name, timed)
 
@@ -224,6 +290,9 @@ class KernelTimers:
             e = {"name": label, "rocprof_name": r["roc"], "call": r["call"], "x6": r["x6"], "launches_timed": len(ms), "ms": avg, "total_ms": float(np.sum(ms)),
                  "executed_flop": r["exec"], "algorithmic_flop": r["alg"], "tflops": tf, "frac": tf / PEAK_F32_TFLOPS,
                  "algorithmic_bytes": r["bytes"], "hbm_gb": None, "hbm_frac": None}
+            if r.get("mfma"):      # what the matrix cores execute for it (padding and redundant products included), fp32-equivalent
+                e["mfma_instr_model"] = r["mfma"]
+                e["mfma_flop"] = mfma_flop(r["mfma"]) / 6.0
             rows.append(e)
         rows.sort(key=lambda e: -e["total_ms"])
         return rows
@@ -772,6 +841,10 @@ def roofline_object(kern, pmc, pmc_path, steps):
             e["hbm_frac"] = hit["hbm_bytes_per_launch"] / (e["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
             if "SQ_INSTS_MFMA" in hit and not e["x6"]:
                 e["mfma_flop_pmc"] = hit["SQ_INSTS_MFMA"] * 2048.0      # v_mfma_f32_16x16x4_f32: 2048 FLOP per wave-instruction
+            if "SQ_INSTS_MFMA" in hit and e.get("mfma_instr_model"):
+                e["mfma_instr_pmc"] = hit["SQ_INSTS_MFMA"]              # against sum(mfma_instr_model): the model's instruction count
+            if "mfma_busy_frac" in hit:
+                e["mfma_busy_frac"] = hit["mfma_busy_frac"]
     roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
     if not kern:
         return roof
@@ -785,7 +858,8 @@ def roofline_object(kern, pmc, pmc_path, steps):
         if e["x6"]:
             e["frac"] = e["tflops"] / (PEAK_BF16_TFLOPS / 6.0)
             e["peak"] = PEAK_BF16_TFLOPS / 6.0
-    roof["kernels"] = [{k: e.get(k) for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "peak", "hbm_gb", "hbm_frac")}
+    roof["kernels"] = [{k: e.get(k) for k in ("name", "rocprof_name", "launches_timed", "ms", "executed_flop", "frac", "peak", "hbm_gb", "hbm_frac",
+                                              "mfma_flop", "mfma_instr_model", "mfma_instr_pmc", "mfma_busy_frac")}
                        for e in kern[:6]]
     if d["x6"]:
         roof.update(peak=PEAK_BF16_TFLOPS / 6.0, frac=d["tflops"] / (PEAK_BF16_TFLOPS / 6.0),
