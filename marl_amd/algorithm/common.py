@@ -215,7 +215,7 @@ def agent_backward(mac, db, which, saved, hs, dq, dhs, buf, dq_idx=None, dq_val=
              "rnn.bias_ih": ag.rnn.bias_ih.grad, "rnn.bias_hh": ag.rnn.bias_hh.grad,
              "fc2.weight": ag.fc2.weight.grad, "fc2.bias": ag.fc2.bias.grad}
     # opt-in args.gemm_mode = "bf16x6": the split BPTT kernel (csrc/agent_bwd_x6.hip; one workgroup per 16 rows up to 256 row tiles,
-    # per 32 rows beyond) - faster than the fp32 kernels at every size measured (profiles/r04_unroll_x6_times.txt)
+    # per 32 rows beyond) - faster than the fp32 kernels at every size measured (profiles/archive/r04_unroll_x6_times.txt)
     from ..network import mixer as _mixer
     x6 = (getattr(args, "gemm_mode", _mixer.DEFAULT_GEMM_MODE) == "bf16x6" and dq is None and dq_idx is not None
           and (B * N + 31) // 32 >= experiments.get("x6_bwd_min_wg") and ops.agent_unroll_bwd_x6_supported(B, T, N, A))
@@ -314,7 +314,7 @@ class PairedUnroll:
     # software-pipelined kernel; beyond that ~1.3 + 2.1 per tile (5.5 at 2, 7.6 at 3, 11.7 at 5)
     def _step_us(self, rt):
         if self.x6:
-            # agent_fwd_x6_kernel (profiles/r04_unroll_x6_times.txt: 0.18 / 0.33 / 1.04 ms per 120 steps at 1 / 2 / 5 row tiles per CU;
+            # agent_fwd_x6_kernel (profiles/archive/r04_unroll_x6_times.txt: 0.18 / 0.33 / 1.04 ms per 120 steps at 1 / 2 / 5 row tiles per CU;
             # it holds one or two tiles per workgroup and runs more in rounds of workgroups)
             return 1.5 if rt <= 1 else 2.75 if rt <= 2 else 1.74 * rt
         return 3.3 if rt <= 1 else 1.3 + 2.1 * rt

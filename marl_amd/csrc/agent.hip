@@ -16,7 +16,7 @@
 //     backward pass needs are written once, one 16-byte store per lane and plane (tile layout, below).
 // LDS tile pitches of THIS file: +4 floats.  The +8 of common.h halves the bank-conflict share of the b128 fragment reads
 // (tools/lds_pitch.py) but is time-neutral on 2s3z-sized tiles and COSTS the wide ones: QMIX on MMM2 / 1024 envs 159.6 -> 169.2
-// updates/s with +4 here, QTRAN-base 3s5z 282 -> 284, QMIX 2s3z within +-0.3 % (same box, alternating: profiles/r03_prescale_ab.txt, 8).
+// updates/s with +4 here, QTRAN-base 3s5z 282 -> 284, QMIX 2s3z within +-0.3 % (same box, alternating: profiles/archive/r03_prescale_ab.txt, 8).
 #ifndef MARL_PAD_H
 #define MARL_PAD_H 4
 #define MARL_PAD_K 4
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(FNT, 2) void agent_fwd_kernel(FwdArgs a) {
         flip_u(t + 1 < a.T ? t + 1 : a.T - 1);
         if (team == 1) {                          // observations of step t+1 and actions of step t+2, in flight during the gates
           // waves 4-7 are the younger half of the workgroup and lose the issue arbitration against their SIMD partners'
-          // MFMA streams (profiles/r03_phase_probe.txt): without the priority the ~40 address instructions per DMA crawl
+          // MFMA streams (profiles/archive/r03_phase_probe.txt): without the priority the ~40 address instructions per DMA crawl
           // through the partners' gate phase (stamps: 45 % of a step for nine DMAs)
           __builtin_amdgcn_s_setprio(3);
           dma_fill(t + 1 < a.T ? t + 1 : a.T - 1, ws, 4);
@@ -1825,7 +1825,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
   // switch fwd_dma = 1: the activation-saving unroll fills its observation tile by LDS-DMA (DMA kernels).  OFF by
   // default - measured slower (2s3z / 4096 envs 1.75 vs 1.62 ms; MMM2 / 1024 envs 2.98 ms at three row tiles per workgroup vs
   // 2.24 ms at two through registers): the issuing waves spend a third of every step in the nine to eleven DMA issues
-  // (profiles/r03_stamps_dma.txt), although a wave alone issues such a DMA every ~100 cycles (profiles/r03_dma_probe.txt)
+  // (profiles/archive/r03_stamps_dma.txt), although a wave alone issues such a DMA every ~100 cycles (profiles/archive/r03_dma_probe.txt)
   const int dma_mode = marl_switches()->fwd_dma;
   const bool xs_req = a.vload && gi_in && !saved && T >= 2 && !xs_off;      // the launch reads stored input-side sums
   if (a.vload && !xs_req) {   // the workgroup keeps one step's obs tile (rows * O/4 float4) in NLDW * 512 registers
@@ -1840,7 +1840,7 @@ extern "C" int marl_agent_unroll_fwd(const marl_agent_weights_t* w, const float*
     const bool w2l_off = !marl_switches()->fwd_w2l;      // A/B switch
     // (only where it makes the launch a single round of workgroups: beside the target unroll under the pair schedule -
     // cu_budget 128 - three tiles per workgroup were SLOWER than two, 2.57 vs 2.24 ms at MMM2 / 1024 envs; alone on the chip
-    // 1.25 vs 1.75 ms, profiles/r03_mmm2_schedules.txt)
+    // 1.25 vs 1.75 ms, profiles/archive/r03_mmm2_schedules.txt)
     const int cap6 = (6 * FNT) / (16 * (O / 4));
     if (saved && !dma && T > 1 && A > 16 && cap2 < want && cap2 < 8 && want <= cap6 && !w2l_off) { w2l = true; cap2 = cap6; }
     if (cap2 < want && cap2 < 8 && T > 1 && O % 8 == 0 && !saved) {  // wide observations: the registers hold one column

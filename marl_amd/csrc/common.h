@@ -24,8 +24,8 @@ extern "C" const MarlSwitches* marl_switches(void);      // optim.hip
 // ds_read_b128 per lane (row m, columns 4q..4q+3 of a 16-chunk); gfx950 serves that instruction in four groups of 16 lanes over
 // 64 banks, and a pitch of 8 (mod 16) floats spreads every group over all banks (the usual "+4" is a 2-way conflict on every
 // such read; tools/lds_pitch.py), while the accumulator-layout accesses (row 4q+i, column m: ds_read/write_b32) become 2-way -
-// free for the writes, and the reads are few.  It halves the conflict share the counters show (profiles/r03_pmc_pitch8.json)
-// and is time-neutral on 2s3z-sized tiles (profiles/r03_ab_variants.txt).
+// free for the writes, and the reads are few.  It halves the conflict share the counters show (profiles/archive/r03_pmc_pitch8.json)
+// and is time-neutral on 2s3z-sized tiles (profiles/archive/r03_ab_variants.txt).
 #ifndef MARL_PAD_H
 #define MARL_PAD_H 8
 #endif
@@ -126,7 +126,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 #define MARL_NLOG2E (-1.4426950408889634f)
 #define MARL_2LOG2E (2.8853900817779268f)
 #define MARL_INV_2LOG2E (0.34657359027997264f)
-// Measured (same box, alternating, profiles/r03_prescale_ab.txt): the rollout kernel gains 1.5 % from this; of the learner's unroll
+// Measured (same box, alternating, profiles/archive/r03_prescale_ab.txt): the rollout kernel gains 1.5 % from this; of the learner's unroll
 // kernels the two-action-tile instantiations (AC = 2: MMM2, 18 actions) gain 10 % and the one-tile ones (2s3z, 3s5z) LOSE 2 % (the
 // saving unroll also has to un-scale the plane it stores for BPTT) - those use gru_point_plain().  GRU_PRE: agent.hip decides by AC.
 // -DMARL_NO_PRESCALE: plain form everywhere (A/B).

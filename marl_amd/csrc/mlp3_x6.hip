@@ -6,10 +6,10 @@
 // Every fp32 operand element is split EXACTLY into three bf16 terms, a = hi + mid + lo (round-to-nearest each: 8 + 8 + 8 significand
 // bits), and a product a.b is the six bf16 products  mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi  accumulated in fp32 by
 // v_mfma_f32_16x16x32_bf16 (smallest first); the dropped terms (mid.lo, lo.mid, lo.lo) are <= 2^-24 of |a.b|.  Measured against fp64:
-// error / output scale 4.7e-7 at K = 64 where the fp32 MFMA has 6.8e-7 (profiles/r03_bf16x3_probe.txt).  Six such MFMAs cover a
+// error / output scale 4.7e-7 at K = 64 where the fp32 MFMA has 6.8e-7 (profiles/archive/r03_bf16x3_probe.txt).  Six such MFMAs cover a
 // 16 x 16 x 32 block in ~100 pipe cycles; the eight v_mfma_f32_16x16x4_f32 of the same block take 256.
 //
-// Layouts (checked with integer data by tools/probe/x6_layout_probe.hip, profiles/r04_x6_layout_probe.txt):
+// Layouts (checked with integer data by tools/probe/x6_layout_probe.hip, profiles/archive/r04_x6_layout_probe.txt):
 //   * v_mfma_f32_16x16x32_bf16: lane (g = l >> 4, i = l & 15) holds A[i][slot j] and B[slot j][i], j = 0..7; D register r =
 //     C[4g + r][i].  The slot -> k assignment is free as long as both operands use the same one.
 //   * transposed formulation (as mlp3_fused.hip): out^T[feature][row] = W[feature][k] in^T[k][row]; the WEIGHTS are the A operand

@@ -1,5 +1,6 @@
 """bench.py prints ONE final stdout line the driver can parse from an 8 KB tail: the compact line is built from a canned
-full result (a committed round-4 run with thirteen legs, 34 KB) and must stay under 8 KB with the headline objects intact."""
+full result (tests/golden/bench_full_canned.json: a round-4 run with thirteen legs, 34 KB) and must stay under 8 KB with the headline
+objects intact."""
 import json
 import os
 import sys
@@ -9,13 +10,16 @@ sys.path.insert(0, ROOT)
 
 
 def _canned():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_full_line.json")))
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_canned.json")))
     # what this round's bench adds to a full result
     d["config"]["gemm_mode"] = "bf16x6"
     d["f32_mfma_twin"] = {"what": "x" * 200, "value": 5.2e7, "unit": "env-steps/s", "ms_per_step": 9.4, "dtype": "f32", "last_loss": 0.2,
                           "learner_updates_per_sec": 134.0, "roofline": dict(d["roofline"])}
     for c in d["configs"]:
         c["segments_updates_per_sec"] = [c["learner_updates_per_sec"]] * 3
+    for r in (d["roofline"], d["f32_mfma_twin"]["roofline"]):      # round 6: what the matrix cores execute, by model and by counter
+        for k in r.get("kernels", []):
+            k.update(mfma_flop=2.466e11, mfma_instr_model={"k32": 80000000, "k16": 18432000}, mfma_instr_pmc=99532800.0, mfma_busy_frac=0.45)
     return d
 
 

@@ -3,7 +3,7 @@
 # unpacks that commit into _abtree/<commit>/ (git-ignored, but shipped to the GPU box by gpurun), builds its library there, and prints the
 # gpurun line that alternates its bench.py with the current tree's in ONE call.  Box-to-box spread of the same binary is +-3 % per
 # step: a comparison across calls cannot see a 1-2 % change (round 3: the pre-scaled gate math cost the headline 1 % and went
-# unnoticed for most of the round - profiles/r03_prescale_ab.txt).  Remove _abtree/ afterwards.
+# unnoticed for most of the round - profiles/archive/r03_prescale_ab.txt).  Remove _abtree/ afterwards.
 set -e
 C=${1:?commit}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
