@@ -44,6 +44,9 @@ constexpr int HP = 72;            // pitch (bf16) of the 64-wide planes
 #else
 #define ST_RESET()
 #endif
+#ifndef OI_CUT_16
+#define OI_CUT_16 9      // sixteenths of a slot's observation items team R generates before the choice barrier (A/B builds)
+#endif
 #define X6_TERMS(OP) OP(m, m) OP(h, l) OP(l, h) OP(h, m) OP(m, h) OP(h, h)
 
 template <int CTRL>
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   short* Hp0 = Xp0 + XP_E;                                                 // [2][3][rows][HP] h by step parity
   float* W1a = reinterpret_cast<float*>(Hp0 + 2 * XP_E);                   // [A + 1][64]: fc1 columns of the one-hot(last action) block; row A = zeros
   unsigned* avm = reinterpret_cast<unsigned*>(W1a + (A + 1) * H);          // [4 slots][rows] availability bit masks (bit k = action k)
-  int* act = reinterpret_cast<int*>(avm + 4 * rows);                       // [rows]
+  int* act = reinterpret_cast<int*>(avm + 4 * rows);                       // [rows] chosen action (-1: none)
   float* uex = reinterpret_cast<float*>(act + rows);                       // [2 step parities][2][rows] explore / pick uniforms of a step's choice
   int4* rmeta = reinterpret_cast<int4*>(uex + 4 * rows);                   // [rows] {obs offset of (b,0,n,0), avail offset, episode length, n | local env << 16}
   int4* emeta = rmeta + rows;                                              // [EPW] {state offset of (b,0,0), episode length, env in range, -}
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 #pragma unroll
     for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
     // R's share of a slot's observation items before the choice barrier (team I needs ~the choice's time to get there)
-    const int oi_cut = (n_oi * 9) >> 4;
+    const int oi_cut = (n_oi * OI_CUT_16) >> 4;
     WG_BARRIER();                                  // P0: slot 0 in the planes, tables (team I: fc1, x(0))
     WG_BARRIER();                                  // P1: x(0), pre(0) taken: the input planes are free
     prologue_slot1();
