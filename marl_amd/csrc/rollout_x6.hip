@@ -94,6 +94,15 @@ __device__ __forceinline__ void put4(short* pl, int pitch, int ps, int row0, int
     p[k * ps + 3 * pitch] = (short)((unsigned)d[k][1] >> 16);
   }
 }
+// accumulator tile of a TRANSPOSED product (weights as the A operand: lane (q, m) holds columns col0 .. col0 + 3 of row `row`) -> planes:
+// one 8-byte write per plane (the row-major products' put4 above needs four 2-byte writes per plane)
+__device__ __forceinline__ void put4t(short* pl, int pitch, int ps, int row, int col0, const f32x4& v) {
+  const F3h f = split4(v);
+  short* p = pl + row * pitch + col0;
+  *reinterpret_cast<i32x2*>(p) = f.h;
+  *reinterpret_cast<i32x2*>(p + ps) = f.m;
+  *reinterpret_cast<i32x2*>(p + 2 * ps) = f.l;
+}
 __device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
 // the gate math of agent_x6.hip (every fused / unfused operation spelled out)
 __device__ __forceinline__ float gru_h_x6(float ar, float az, float ain, float ahn, float hp) {
@@ -328,7 +337,15 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         wi[2 * g + c] = wfrag(a.Wih, H, g * H + 16 * s, 3 * H, H, c, lane);
         wh[2 * g + c] = wfrag(a.Whh, H, g * H + 16 * s, 3 * H, H, c, lane);
       }
-    const float bias_r = a.bih[u] + a.bhh[u], bias_z = a.bih[H + u] + a.bhh[H + u], bias_n = a.bih[2 * H + u], bias_hn = a.bhh[2 * H + u];
+    // the products run TRANSPOSED (weights as the A operand): lane (q, m) holds hidden units 16 s + 4 q + r (r = 0..3) of row m - four
+    // consecutive columns of one row of the planes
+    const int u4 = 16 * s + 4 * q;
+    f32x4 bias_r, bias_z, bias_n, bias_hn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bias_r[r] = a.bih[u4 + r] + a.bhh[u4 + r]; bias_z[r] = a.bih[H + u4 + r] + a.bhh[H + u4 + r];
+      bias_n[r] = a.bih[2 * H + u4 + r]; bias_hn[r] = a.bhh[2 * H + u4 + r];
+    }
     f32x4 hreg[RTC];
 #pragma unroll
     for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
@@ -351,21 +368,21 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       for (int rt = 0; rt <= RTC; ++rt) {
         if (rt < RTC) {
           f32x4* g = G[rt & 1];
-          g[0] = splat(bias_r); g[1] = splat(bias_z); g[2] = splat(bias_n); g[3] = splat(bias_hn);
+          g[0] = bias_r; g[1] = bias_z; g[2] = bias_n; g[3] = bias_hn;
           const F3 fb = bfrag(Xp0 + rt * 16 * HP, HP, rows * HP, 1, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int k = 0; k < 3; ++k) g[k] = mm(fa.p_, wi[2 * k].q_, g[k]);
+#define OP(p_, q_) _Pragma("unroll") for (int k = 0; k < 3; ++k) g[k] = mm(wi[2 * k].q_, fa.p_, g[k]);
           X6_TERMS(OP)
 #undef OP
           const F3 fc = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, 0, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int k = 0; k < 3; ++k) g[k] = mm(fb.p_, wi[2 * k + 1].q_, g[k]);
+#define OP(p_, q_) _Pragma("unroll") for (int k = 0; k < 3; ++k) g[k] = mm(wi[2 * k + 1].q_, fb.p_, g[k]);
           X6_TERMS(OP)
 #undef OP
           const F3 fd = bfrag(hpp(par) + rt * 16 * HP, HP, rows * HP, 1, lane);
-#define OP(p_, q_) g[0] = mm(fc.p_, wh[0].q_, g[0]); g[1] = mm(fc.p_, wh[2].q_, g[1]); g[3] = mm(fc.p_, wh[4].q_, g[3]);
+#define OP(p_, q_) g[0] = mm(wh[0].q_, fc.p_, g[0]); g[1] = mm(wh[2].q_, fc.p_, g[1]); g[3] = mm(wh[4].q_, fc.p_, g[3]);
           X6_TERMS(OP)
 #undef OP
           if (rt + 1 < RTC) fa = bfrag(Xp0 + (rt + 1) * 16 * HP, HP, rows * HP, 0, lane);
-#define OP(p_, q_) g[0] = mm(fd.p_, wh[1].q_, g[0]); g[1] = mm(fd.p_, wh[3].q_, g[1]); g[3] = mm(fd.p_, wh[5].q_, g[3]);
+#define OP(p_, q_) g[0] = mm(wh[1].q_, fd.p_, g[0]); g[1] = mm(wh[3].q_, fd.p_, g[1]); g[3] = mm(wh[5].q_, fd.p_, g[3]);
           X6_TERMS(OP)
 #undef OP
         }
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
           f32x4 hn;
 #pragma unroll
           for (int r = 0; r < 4; ++r) hn[r] = gru_h_x6(g[0][r], g[1][r], g[2][r], g[3][r], hreg[rt - 1][r]);
-          put4(hpp(par ^ 1), HP, rows * HP, (rt - 1) * 16 + 4 * q, u, hn);
+          put4t(hpp(par ^ 1), HP, rows * HP, (rt - 1) * 16 + m, u4, hn);
           hreg[rt - 1] = hn;
         }
         if (rt > 0 && rt < RTC) {      // the products of tile rt with the gate math of tile rt-1 in their gaps
@@ -407,12 +424,9 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     if (a.h_out) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * q + r;
-          const long rho = row0 + row;
-          if (row < vrows && rho < a.R) a.h_out[rho * H + u] = hreg[rt][r];
-        }
+        const int row = rt * 16 + m;
+        const long rho = row0 + row;
+        if (row < vrows && rho < a.R) *reinterpret_cast<f32x4*>(a.h_out + rho * H + u4) = hreg[rt];
       }
     }
   } else {
@@ -424,20 +438,22 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     for (int c = 0; c < NK1; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
 #pragma unroll
     for (int c = 0; c < 2; ++c) w2[c] = wfrag(a.W2, H, 0, A, H, c, lane);
-    const float bias_1 = a.b1[u], bias_2 = m < A ? a.b2[m] : 0.f;
+    const int u4 = 16 * s + 4 * q;                 // fc1 runs transposed like the recurrence: lane (q, m) = units u4 .. u4 + 3 of row m
+    const f32x4 bias_1 = {a.b1[u4], a.b1[u4 + 1], a.b1[u4 + 2], a.b1[u4 + 3]};
+    const float bias_2 = m < A ? a.b2[m] : 0.f;
     f32x4 pre[RTC];
     // pre = bias + W1[:, obs | id] in  of every row tile from the input planes (three accumulator chains, chunk c on chain c % 3)
     auto fc1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
-        f32x4 acc[3] = {splat(bias_1), splat(0.f), splat(0.f)};
+        f32x4 acc[3] = {bias_1, splat(0.f), splat(0.f)};
 #pragma unroll
         for (int c0 = 0; c0 < NK1; c0 += 3) {
           F3 xi[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c)
             if (c0 + c < NK1) xi[c] = bfrag(In0 + rt * 16 * IP, IP, rows * IP, c0 + c < KC1 ? c0 + c : 0, lane);
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c0 + c < NK1) acc[c] = mm(xi[c].p_, w1[c0 + c].q_, acc[c]);
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c0 + c < NK1) acc[c] = mm(w1[c0 + c].q_, xi[c].p_, acc[c]);
           X6_TERMS(OP)
 #undef OP
         }
@@ -447,20 +463,18 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     // x = relu(pre + W1[:, O + last action]) -> planes (rows whose last action is "none": the zero row of the table); stage by stage
     // over the row tiles: every LDS read of a stage is in flight before the first result is used
     auto xput = [&]() __attribute__((always_inline)) {
-      i32x4 aa[RTC];
+      int aa[RTC];
 #pragma unroll
-      for (int rt = 0; rt < RTC; ++rt) aa[rt] = *reinterpret_cast<const i32x4*>(act + rt * 16 + 4 * q);
+      for (int rt = 0; rt < RTC; ++rt) aa[rt] = act[rt * 16 + m];
       f32x4 wv[RTC];
 #pragma unroll
-      for (int rt = 0; rt < RTC; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wv[rt][r] = W1a[(aa[rt][r] < 0 ? A : aa[rt][r]) * H + u];
+      for (int rt = 0; rt < RTC; ++rt) wv[rt] = *reinterpret_cast<const f32x4*>(W1a + (aa[rt] < 0 ? A : aa[rt]) * H + u4);
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = fmaxf(__fadd_rn(pre[rt][r], wv[rt][r]), 0.f);
-        put4(Xp0, HP, rows * HP, rt * 16 + 4 * q, u, x);
+        put4t(Xp0, HP, rows * HP, rt * 16 + m, u4, x);
       }
     };
     // ---- q = fc2(h) and the epsilon-greedy choice (share_params.py:66-70), in registers: lane (q, m) of the accumulator tile holds
