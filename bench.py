@@ -108,7 +108,7 @@ def mfma_rollout_x6(plan, T):
     fc2 12 products by EVERY slice wave of a team (each makes the choice of its own rows): 288 + 24 NK1 + 48 - the same count in both
     decompositions (ops.synth_rollout_x6_plan: workgroups, row tiles per workgroup incl. padding rows)"""
     _, wgs, rtc, _, nk1 = plan
-    return {"k32": T * wgs * rtc * (288 + 24 * nk1 + 48), "k16": 0}
+    return {"k32": T * wgs * rtc * (288 + 24 * nk1 + 48 * (2 if nk1 == 7 else 1)), "k16": 0}      # (seven chunks: two action tiles of fc2)
 
 
 def mfma_qmix_x6(rows, N, S, E, backward):

@@ -132,7 +132,7 @@ struct RX6Args {
   long R;
 };
 
-template <int RTC, int NK1>
+template <int RTC, int NK1, int AC = 1>      // row tiles per workgroup, fc1 chunks of 32 input columns, action tiles of 16 (fc2 / the choice)
 __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,6 +154,9 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   // hash prefixes over (seed, stream, env, time): ONE per environment, stream and time - [6 streams][2 parities][EPW]:
   // observations / availability / state of a slot (parity of the slot), reward / explore / pick of a step (parity of the step)
   unsigned* P = reinterpret_cast<unsigned*>(emeta + a.EPW);
+  // (two action tiles: the fc2 fragments live in LDS - [2 tiles x 2 k chunks][3 planes][64 lanes] 16 bytes, the same for every wave -
+  // team I's registers hold seven fc1 chunks there)
+  i32x4* W2f = reinterpret_cast<i32x4*>(reinterpret_cast<char*>(P) + ((12 * a.EPW * 4 + 15) & ~15));
   enum { K_OBS = 0, K_AVAIL, K_STATE, K_REWARD, K_EXPLORE, K_PICK };
   auto hpp = [&](int b) { return Hp0 + b * XP_E; };
 
@@ -327,6 +330,10 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
   float eps_next = a.eps ? a.eps[0] : (float)a.eps0;
   double eps_d = a.eps0;
 
+  if (AC == 2 && wave < 4) {
+    const F3 f = wfrag(a.W2, H, 16 * (wave >> 1), A, H, wave & 1, lane);
+    W2f[(wave * 3 + 0) * 64 + lane] = f.h; W2f[(wave * 3 + 1) * 64 + lane] = f.m; W2f[(wave * 3 + 2) * 64 + lane] = f.l;
+  }
   if (team == 0) {
     // =============================== team R: the recurrence ===============================
     F3 wi[6], wh[6];
@@ -433,14 +440,17 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     // =============================== team I: the slots to come, fc1, fc2 + the choice, x, the environment's bookkeeping ===============================
     const int ti = tid - RNT / 2;
     ST_DECL(8);
-    F3 w1[NK1], w2[2];
+    F3 w1[NK1], w2[1][2];      // (w2: one action tile; two tiles read their fragments from LDS)
 #pragma unroll
     for (int c = 0; c < NK1; ++c) w1[c] = c < KC1 ? wfrag(a.W1, a.I, 16 * s, H, a.I, c, lane) : F3{};
 #pragma unroll
-    for (int c = 0; c < 2; ++c) w2[c] = wfrag(a.W2, H, 0, A, H, c, lane);
+    for (int c = 0; c < 2; ++c)
+      if constexpr (AC == 1) w2[0][c] = wfrag(a.W2, H, 0, A, H, c, lane);
     const int u4 = 16 * s + 4 * q;                 // fc1 runs transposed like the recurrence: lane (q, m) = units u4 .. u4 + 3 of row m
     const f32x4 bias_1 = {a.b1[u4], a.b1[u4 + 1], a.b1[u4 + 2], a.b1[u4 + 3]};
-    const float bias_2 = m < A ? a.b2[m] : 0.f;
+    float bias_2[AC];
+#pragma unroll
+    for (int at = 0; at < AC; ++at) bias_2[at] = 16 * at + m < A ? a.b2[16 * at + m] : 0.f;
     f32x4 pre[RTC];
     // pre = bias + W1[:, obs | id] in  of every row tile from the input planes (three accumulator chains, chunk c on chain c % 3)
     auto fc1 = [&]() __attribute__((always_inline)) {
@@ -458,6 +468,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 #undef OP
         }
         pre[rt] = (acc[0] + acc[1]) + acc[2];
+        if constexpr (NK1 == 7) __builtin_amdgcn_sched_barrier(0);      // (84 registers of fc1 fragments: one tile's input fragments at a time)
       }
     };
     // x = relu(pre + W1[:, O + last action]) -> planes (rows whose last action is "none": the zero row of the table); stage by stage
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     }
     auto choose_all = [&](int t, float eps) __attribute__((always_inline)) {
       const int par = t & 1;
-      unsigned avw[RTC]; float ue[RTC], up[RTC], qsel[RTC];
+      unsigned avw[RTC]; float ue[RTC], up[RTC], qsel[RTC][AC];
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
         avw[rt] = avm[(t & 3) * rows + c_rr[rt]];
@@ -505,29 +516,50 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         F3 hb[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) hb[c] = bfrag(hpp(par ^ 1) + rt * 16 * HP, HP, rows * HP, c, lane);
-        f32x4 ac[2] = {splat(bias_2), splat(0.f)};
-#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, w2[c].q_, ac[c]);
-        X6_TERMS(OP)
+#pragma unroll
+        for (int at = 0; at < AC; ++at) {
+          f32x4 ac[2] = {splat(bias_2[at]), splat(0.f)};
+          F3 wq[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if constexpr (AC == 1) wq[c] = w2[0][c];
+            else { const i32x4* f = W2f + (at * 2 + c) * 3 * 64 + lane; wq[c].h = f[0]; wq[c].m = f[64]; wq[c].l = f[128]; }
+          }
+#define OP(p_, q_) _Pragma("unroll") for (int c = 0; c < 2; ++c) ac[c] = mm(hb[c].p_, wq[c].q_, ac[c]);
+          X6_TERMS(OP)
 #undef OP
-        const f32x4 qv = ac[0] + ac[1];
-        qsel[rt] = s == 0 ? qv[0] : s == 1 ? qv[1] : s == 2 ? qv[2] : qv[3];
+          const f32x4 qv = ac[0] + ac[1];
+          qsel[rt][at] = s == 0 ? qv[0] : s == 1 ? qv[1] : s == 2 ? qv[2] : qv[3];
+          if constexpr (AC == 2) __builtin_amdgcn_sched_barrier(0);      // (seven fc1 chunks live in this team's registers: one tile's fragments at a time)
+        }
       }
       ST_MARK(6);
       const int sh = 16 * q;
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
-        const bool on = m < A && ((avw[rt] >> m) & 1u) != 0u;
-        const float v = on ? qsel[rt] : -3.0e38f;
-        const float mx = group_max16(v);
-        const unsigned am = (unsigned)(__ballot(on) >> sh) & 0xffffu;
-        const unsigned em = (unsigned)(__ballot(on && v == mx) >> sh) & 0xffffu;
+        // a lane holds the row's actions m (and 16 + m with two action tiles); masks over the row's actions are 16 bits per tile
+        bool on[AC]; float v[AC], mx = -3.0e38f;
+        unsigned am = 0u, em = 0u;
+#pragma unroll
+        for (int at = 0; at < AC; ++at) {
+          on[at] = 16 * at + m < A && ((avw[rt] >> (16 * at + m)) & 1u) != 0u;
+          v[at] = on[at] ? qsel[rt][at] : -3.0e38f;
+          mx = fmaxf(mx, group_max16(v[at]));
+          am |= ((unsigned)(__ballot(on[at]) >> sh) & 0xffffu) << (16 * at);
+        }
+#pragma unroll
+        for (int at = 0; at < AC; ++at) em |= ((unsigned)(__ballot(on[at] && v[at] == mx) >> sh) & 0xffffu) << (16 * at);
         const int navail = __popc(am);
         int arg = em ? __ffs(em) - 1 : (am ? __ffs(am) - 1 : 0);
         const bool explore = ue[rt] < eps;
         int kk = (int)floorf(up[rt] * (float)navail);
         if (kk > navail - 1) kk = navail - 1;
-        const bool sel = explore && on && __popc(am & ((1u << m) - 1u)) == kk;
-        const unsigned sm = (unsigned)(__ballot(sel) >> sh) & 0xffffu;
+        unsigned sm = 0u;
+#pragma unroll
+        for (int at = 0; at < AC; ++at) {
+          const bool sel = explore && on[at] && __popc(am & ((1u << (16 * at + m)) - 1u)) == kk;
+          sm |= ((unsigned)(__ballot(sel) >> sh) & 0xffffu) << (16 * at);
+        }
         if (sm) arg = __ffs(sm) - 1;
         if (!(t < c_len[rt])) arg = -1;
         if (c_len[rt] >= 0 && m == 0) {
@@ -608,10 +640,10 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
 static size_t rx6_lds(int rtc, int KI, int A, int epw) {
   const size_t rows = 16 * (size_t)rtc, IP = KI + 8;
   return 3 * rows * IP * 2 + 3 * 3 * rows * HP * 2 + (size_t)(A + 1) * H * 4 + 4 * rows * 4 /* avm */ + rows * (4 /* act */ + 4 * 4 /* uex */) +
-         rows * 16 /* rmeta */ + (size_t)epw * (16 /* emeta */ + 12 * 4 /* P */);
+         rows * 16 /* rmeta */ + (size_t)epw * (16 /* emeta */ + 12 * 4 /* P */) + 16 + (KI > 160 ? 12 * 1024 : 0) /* W2f */;
 }
-// row tiles a workgroup may hold: five fc1 chunks (wide inputs) cost registers and LDS
-static int rx6_max_tiles(int KI) { return KI > 96 ? 4 : 5; }
+// row tiles a workgroup may hold: five / seven fc1 chunks (wide inputs) cost registers and LDS
+static int rx6_max_tiles(int KI) { return KI > 160 ? 3 : KI > 96 ? 4 : 5; }
 
 // environments per workgroup: one workgroup per CU while the batch fits one round (small batches spread over all CUs with partly
 // filled tiles); beyond that as few FULL rounds of 256 workgroups as five row tiles per workgroup allow, evenly filled (0: none fits)
@@ -640,13 +672,13 @@ static bool rx6_use_v1(int E, int N, int O, int A, int last_action, int reuse_ne
 
 ST_DEFINE_SETTER(marl_debug_stamps_rollout_x6)
 
-// shapes the split rollout covers: H = 64, <= 16 actions, observation width a multiple of 4, input width <= 160 (three / five fc1
-// chunks: 2s3z- and 3s5z-sized agents), whole environments in at most five (wide inputs: four) row tiles; an environment's agents in
-// one wave
+// shapes the split rollout covers: H = 64, observation width a multiple of 4, input width <= 224 (three / five / seven fc1 chunks:
+// 2s3z-, 3s5z- and MMM2-sized agents), <= 16 actions up to 160 input columns and <= 32 beyond (two action tiles of fc2 and of the
+// choice), whole environments in at most five (wide inputs: four / three) row tiles; an environment's agents in one wave
 extern "C" int marl_synth_rollout_x6_supported(int N, int O, int A) {
-  if (A < 1 || A > 16 || N < 1 || O < 4 || (O & 3)) return 0;
+  if (A < 1 || N < 1 || O < 4 || (O & 3)) return 0;
   const int I = O + A + N;
-  if (I > 160) return 0;
+  if (I > 224 || A > (I > 160 ? 32 : 16)) return 0;
   const int KI = (I + 31) / 32 * 32;
   const int mt = rx6_max_tiles(KI);
   if (N > 16 * mt || N > 64) return 0;                   // a whole environment in one workgroup; its agents on one wave (env step)
@@ -674,7 +706,7 @@ extern "C" int marl_synth_rollout_x6_plan(int E, int N, int O, int A, int last_a
     if (epw < 1) return (int)hipErrorInvalidValue;
     plan[0] = 2;
   }
-  plan[1] = (E + epw - 1) / epw; plan[2] = (epw * N + 15) / 16; plan[3] = epw; plan[4] = KI > 96 ? 5 : 3;
+  plan[1] = (E + epw - 1) / epw; plan[2] = (epw * N + 15) / 16; plan[3] = epw; plan[4] = KI > 160 ? 7 : KI > 96 ? 5 : 3;
   return 0;
 }
 
@@ -704,7 +736,7 @@ extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned see
   // record offsets are 32-bit element offsets inside the kernel
   if ((double)E * (T + 1) * N * (O > A ? O : A) >= 2147483648.0 || (double)E * (T + 1) * state_ld >= 2147483648.0)
     return (int)hipErrorInvalidValue;
-  const int nk1 = a.KI > 96 ? 5 : 3;
+  const int nk1 = a.KI > 160 ? 7 : a.KI > 96 ? 5 : 3;
   const int epw = rx6_epw(E, N, a.KI, A);
   if (epw < 1) return (int)hipErrorInvalidValue;
   a.EPW = epw;
@@ -716,7 +748,8 @@ extern "C" int marl_synth_rollout_x6(const marl_agent_weights_t* w, unsigned see
 #define RX6_PICK(NK_) (rtc == 1 ? (const void*)synth_rollout_x6_kernel<1, NK_> : rtc == 2 ? (const void*)synth_rollout_x6_kernel<2, NK_> \
                        : rtc == 3 ? (const void*)synth_rollout_x6_kernel<3, NK_> : (const void*)synth_rollout_x6_kernel<4, NK_>)
   if (nk1 == 3) fn = rtc == 5 ? (const void*)synth_rollout_x6_kernel<5, 3> : RX6_PICK(3);
-  else fn = RX6_PICK(5);
+  else if (nk1 == 5) fn = RX6_PICK(5);
+  else fn = rtc == 1 ? (const void*)synth_rollout_x6_kernel<1, 7, 2> : rtc == 2 ? (const void*)synth_rollout_x6_kernel<2, 7, 2> : (const void*)synth_rollout_x6_kernel<3, 7, 2>;
 #undef RX6_PICK
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;

@@ -81,11 +81,13 @@ def test_split_kernel_capability_predicates():
     assert fwd(512, 120, 5, 192, 11) == 1 and fwd(512, 120, 5, 200, 11) == 0      # O <= 192: three prefetch registers per thread of one team
     assert fwd(512, 120, 8, 128, 16) == 1 and fwd(512, 120, 8, 128, 17) == 0      # 152 / 153 input columns: one action tile up to 160 columns
     assert fwd(512, 120, 10, 176, 32) == 1 and fwd(512, 120, 10, 176, 33) == 0    # wider than 160: two action tiles, 32 actions at most
-    # the split whole-rollout kernel: 2s3z- and 3s5z-sized agents (<= 160 input columns, <= 16 actions, whole environments in at most
-    # five - wide inputs: four - row tiles of 16 rows, an environment's agents on one wave)
+    # the split whole-rollout kernel: 2s3z-, 3s5z- and MMM2-sized agents (<= 224 input columns; <= 16 actions up to 160 columns, <= 32
+    # beyond: two action tiles; whole environments in at most five - wide inputs: four / three - row tiles of 16 rows, an environment's
+    # agents on one wave)
     rx6 = lib.marl_synth_rollout_x6_supported
     assert rx6(5, 80, 11) == 1 and rx6(8, 128, 14) == 1 and rx6(2, 4, 3) == 1 and rx6(49, 40, 5) == 1 and rx6(33, 100, 5) == 1
-    assert rx6(10, 176, 18) == 0 and rx6(5, 80, 17) == 0 and rx6(5, 82, 11) == 0 and rx6(65, 40, 5) == 0 and rx6(64, 40, 5) == 1
+    assert rx6(10, 176, 18) == 1 and rx6(4, 180, 32) == 1 and rx6(4, 180, 33) == 0 and rx6(10, 200, 18) == 0
+    assert rx6(5, 80, 17) == 0 and rx6(5, 82, 11) == 0 and rx6(65, 40, 5) == 0 and rx6(64, 40, 5) == 1 and rx6(49, 176, 18) == 0
     # ... and how a batch runs: the round-5 decomposition (three row tiles per workgroup) while the batch fits one round of workgroups,
     # the round-6 one (five tiles) beyond - (decomposition, workgroups, row tiles, environments per workgroup, fc1 chunks)
     import ctypes
@@ -96,7 +98,8 @@ def test_split_kernel_capability_predicates():
     assert plan(512, 5, 80, 11) == (1, 256, 1, 2, 3) and plan(2304, 5, 80, 11) == (1, 256, 3, 9, 3)
     assert plan(4096, 5, 80, 11) == (2, 256, 5, 16, 3) and plan(8192, 5, 80, 11) == (2, 512, 5, 16, 3)
     assert plan(2048, 8, 128, 14) == (2, 256, 4, 8, 5) and plan(100, 49, 40, 5) == (2, 100, 4, 1, 3)
-    assert lib.marl_synth_rollout_x6_plan(512, 10, 176, 18, 1, 1, (ctypes.c_int * 5)()) != 0
+    assert plan(1024, 10, 176, 18) == (2, 256, 3, 4, 7) and plan(2048, 10, 176, 18) == (2, 512, 3, 4, 7)      # MMM2: three tiles at most
+    assert lib.marl_synth_rollout_x6_plan(512, 10, 200, 18, 1, 1, (ctypes.c_int * 5)()) != 0
     # the fused-head split pair: the padded input width must leave a free column in its last 64-column block
     m3 = lambda k, n3=1: lib.marl_mlp3_x6_supported(__import__("ctypes").byref(_src_cpu(k)), k, 64, 64, n3, 10)
     assert m3(112) == 1 and m3(120) == 1 and m3(175) == 1 and m3(188) == 1

@@ -349,10 +349,12 @@ def test_split_rollout_decompositions_agree_bitwise(shape, E, T, eps):
         assert int((ra.u >= 0).sum()) > 0
 
 
-@pytest.mark.parametrize("N,O,S,A,E,T", [(49, 40, 60, 5, 23, 6), (1, 8, 10, 3, 700, 5), (16, 64, 100, 16, 300, 5), (33, 100, 70, 5, 40, 4)])
+@pytest.mark.parametrize("N,O,S,A,E,T", [(49, 40, 60, 5, 23, 6), (1, 8, 10, 3, 700, 5), (16, 64, 100, 16, 300, 5), (33, 100, 70, 5, 40, 4),
+                                         (10, 176, 322, 18, 37, 6), (10, 176, 322, 18, 1024, 4), (4, 180, 50, 32, 300, 5), (7, 152, 64, 16, 200, 5)])
 def test_split_rollout_edge_shapes_match_the_per_step_path(N, O, S, A, E, T):
     """shapes only the round-6 split rollout kernel covers in one launch (an environment of up to 64 agents across several row tiles;
-    one-agent environments, 80 to a workgroup; 16 actions = a full DPP row): the whole-rollout record == the per-step kernels' record
+    one-agent environments, 80 to a workgroup; 16 actions = a full DPP row; MMM2-sized agents: seven fc1 chunks and TWO action tiles -
+    18 and 32 actions; 175 input columns and 16 actions): the whole-rollout record == the per-step kernels' record
     (fp32 agent step; actions are argmaxes of well separated Q values here) and == the oracle's integer fields"""
     from marl_amd.rollout import RolloutWorker
     from marl_amd.env.synthetic_smac import SyntheticSMACEnv
