@@ -123,9 +123,11 @@ def mfma_qmix_x6(rows, N, S, E, backward):
     return m
 
 
-def mfma_unroll_x6(B, T, N, nk1=3):
-    """plain / saving unroll: per step and row tile 4 x (36 recurrence + 36 input gates + 6 NK1 fc1) + 48 fc2"""
-    return {"k32": T * ((B * N + 15) // 16) * (288 + 24 * nk1 + 48), "k16": 0}
+def mfma_unroll_x6(B, T, N, nk1=3, r6=False):
+    """plain / saving unroll: per step and row tile 4 x (36 recurrence + 36 input gates + 6 NK1 fc1) + 48 fc2 (agent_x6.hip: fc2 by one
+    wave per tile, 12 products on each of its two k-chunk chains x 2... = 48); the round-6 plain unroll (agent_x6p.hip) 288 + 72 + 12"""
+    per = 288 + 24 * nk1 + (12 if r6 else 48)
+    return {"k32": T * ((B * N + 15) // 16) * per, "k16": 0}
 
 
 class KernelTimers:
@@ -160,7 +162,9 @@ class KernelTimers:
             m = fwd(ar, kw)          # same arguments as agent_unroll_fwd; the kernel is agent_fwd_x6_kernel (csrc/agent_x6.hip)
             if m is None:
                 return None
-            mf = mfma_unroll_x6(ar[12], ar[13], ar[14], 3 if I <= 96 else 5 if I <= 160 else 7) if kw.get("gi_in") is None else None
+            r6 = ar[11] is None and kw.get("gi_in") is None and ar[9] is None and \
+                ops.agent_unroll_x6_plain_r6(ar[12], ar[13], ar[14], O, A, cu_budget=kw.get("cu_budget", 0))      # (saved, gi_in, hs all absent)
+            mf = mfma_unroll_x6(ar[12], ar[13], ar[14], 3 if I <= 96 else 5 if I <= 160 else 7, r6) if kw.get("gi_in") is None else None
             return (m[0].replace("agent_fwd_kernel", "agent_fwd_x6_kernel") + " fp32 products as six bf16 MFMA products", "agent_fwd_x6") + m[2:] + (True, mf)
 
         def bwd(ar, kw):

@@ -306,6 +306,12 @@ int marl_mlp3_bwd_saved(const marl_mlp3_weights_t* w, const marl_src_t* x, const
  * widest instantiation); T >= 4; B T N 256 < 2^32 (32-bit offsets): 2s3z-, 3s5z- and MMM2-sized agents; beyond 96 input columns one row
  * tile per workgroup.  The entry point also wants obs on a 16-byte boundary.  The caller uses marl_agent_unroll_fwd otherwise. */
 int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A, int last_action, int reuse_network);
+/* 1 when a NON-SAVING launch of marl_agent_unroll_fwd_x6 on this batch (saved = gi_in = hs = NULL: the target network's unroll and the
+ * double-Q continuation of reference q_learner.py:104-110) runs on the round-6 decomposition (csrc/agent_x6p.hip: the recurrent team
+ * multiplies x W_ih and h W_hh in one chain, five row tiles per workgroup, two barriers per step): whole-chip launches (cu_budget 0 /
+ * 256) of more than 512 row tiles of 2s3z-sized agents (<= 96 input columns, <= 16 actions).  The learner then keeps no input-side
+ * gate sums (gi_out / gi_in) for that batch. */
+int marl_agent_unroll_x6_plain_r6(int B, int T, int N, int O, int A, int last_action, int reuse_network, int cu_budget);
 int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                              const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                              const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T, int N,

@@ -74,6 +74,7 @@ SIGNATURES = {
     "marl_agent_unroll_fwd": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P, P]),
     "marl_agent_unroll_reuse_supported": (I, [I, I, I, I, I, I]),
     "marl_agent_unroll_x6_supported": (I, [I, I, I, I, I, I, I]),
+    "marl_agent_unroll_x6_plain_r6": (I, [I, I, I, I, I, I, I, I]),
     "marl_agent_unroll_fwd_x6": (I, [AW, P, L, I, P, L, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P, P]),
     "marl_agent_bwd_workspace": (SZ, [I, I, I]),
     "marl_agent_unroll_bwd_x6_supported": (I, [I, I, I, I, I]),

@@ -120,6 +120,8 @@ class QLearner(ResumeMixin, SpeculativeBatchMixin):
             shifted = on is oc and on_bs == oc_bs and on_t0 == oc_t0 + 1
             split = self.pair.chain_split(B * N, T, a.obs_shape)
             from .. import experiments
+            # (the continuation keeps reading the eval pass's input-side gate sums at every batch size: 0.55 ms at 4096 envs against
+            # 0.97 ms for a plain unroll in the round-6 decomposition, csrc/agent_x6p.hip - which the TARGET unroll below runs on)
             if shifted and ((self.eval_net.unroll_x6(B, T, oc) and experiments.get("fwd_xs") != 0) or
                             ops.agent_unroll_reuse_supported(B, T, N, a.obs_shape, A, split[0] if split else 256)):
                 gi = g("gi", ops.saved_shape(T, B, N, planes=3))

@@ -23,6 +23,12 @@
 #include <cstdlib>
 #include "../../include/marl_hip.h"
 
+// the plain unroll in the round-6 decomposition (agent_x6p.hip): row tiles per workgroup (0: not its launch), and its launch
+int marl_agent_x6p_tiles(int B, int T, int N, int O, int A, int last_action, int reuse_network, int cu_budget);
+int marl_agent_x6p_launch(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0, const int* ufed, long u_bs, int u_t0,
+                          const int* ep_len, const int* ep_map, const float* h0, float* q, float* h_last, int B, int T, int N, int O, int A,
+                          int last_action, int reuse_network, int tpw, void* stream);
+
 namespace {
 
 constexpr int H = 64;
@@ -567,6 +573,14 @@ extern "C" int marl_agent_unroll_x6_supported(int B, int T, int N, int O, int A,
   return 1;
 }
 
+// 1 when a NON-SAVING split unroll of this batch (no activations kept, no gate sums read, no hidden states written) runs on the
+// round-6 decomposition (agent_x6p.hip): the caller then keeps no input-side gate sums for a double-Q continuation to read - that
+// pass recomputes its input side faster than the hand-over kernel reads it, and the saving pass stores a third less
+extern "C" int marl_agent_unroll_x6_plain_r6(int B, int T, int N, int O, int A, int last_action, int reuse_network, int cu_budget) {
+  return marl_agent_unroll_x6_supported(B, T, N, O, A, last_action, reuse_network) &&
+         marl_agent_x6p_tiles(B, T, N, O, A, last_action, reuse_network, cu_budget) ? 1 : 0;
+}
+
 extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const float* obs, long obs_bs, int obs_t0,
                                         const int* ufed, long u_bs, int u_t0, const int* ep_len, const int* ep_map,
                                         const float* h0, float* q, float* hs, float* h_last, float* saved, int B, int T, int N,
@@ -576,6 +590,11 @@ extern "C" int marl_agent_unroll_fwd_x6(const marl_agent_weights_t* w, const flo
   if (w->H != H || cu_budget < 0 || cu_budget > 256 || !marl_agent_unroll_x6_supported(B, T, N, O, A, last_action, reuse_network))
     return (int)hipErrorInvalidValue;
   if (saved && gi_in) return (int)hipErrorInvalidValue;      // a launch stores the input-side sums or reads them
+  if (!saved && !gi_in && !hs) {                             // a plain unroll of a large batch: the round-6 decomposition (agent_x6p.hip)
+    const int tpw = marl_agent_x6p_tiles(B, T, N, O, A, last_action, reuse_network, cu_budget);
+    if (tpw) return marl_agent_x6p_launch(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, ep_len, ep_map, h0, q, h_last, B, T, N, O, A, last_action,
+                                          reuse_network, tpw, stream);
+  }
   if ((reinterpret_cast<uintptr_t>(obs) & 15) || (h0 && (reinterpret_cast<uintptr_t>(h0) & 3)) || (saved && (reinterpret_cast<uintptr_t>(saved) & 15)) ||
       (gi_out && (reinterpret_cast<uintptr_t>(gi_out) & 15)) || (gi_in && (reinterpret_cast<uintptr_t>(gi_in) & 15)))
     return (int)hipErrorInvalidValue;

@@ -12,9 +12,10 @@
 //   tiles up to which the pipelined BPTT runs;  wgrad_tall (1): LDS-staged tall weight-gradient kernel;  wide_res (1) / wide_res32
 //   (0): resident-weights forward of the wide-state QMIX mixer (16- / 32-row tiles);  rollout_v1 (0 = by batch size): 1 forces the split
 //   whole-rollout kernel of round 5 (rollout_x6_v1.hip: four barriers per lock-step, at most three row tiles per workgroup), 2 the one
-//   of round 6 (rollout_x6.hip: three barriers, up to five tiles)
+//   of round 6 (rollout_x6.hip: three barriers, up to five tiles);  unroll_r6 (1): non-saving split unrolls of large batches on
+//   agent_x6p.hip (the round-6 decomposition: five row tiles per workgroup, two barriers per step)
 struct MarlSwitches {
-  int fwd_xs, fwd_dma, fwd_w2l, bwd_pipe_max_rt, wgrad_tall, wide_res, wide_res32, rollout_v1;
+  int fwd_xs, fwd_dma, fwd_w2l, bwd_pipe_max_rt, wgrad_tall, wide_res, wide_res32, rollout_v1, unroll_r6;
 };
 extern "C" const MarlSwitches* marl_switches(void);      // optim.hip
 

@@ -103,13 +103,13 @@ extern "C" int marl_adam_step(float* p, const float* g, float* m, float* v, long
 }
 
 // ---- experiment switches (common.h: MarlSwitches) ----------------------------------------------------------------------------
-static MarlSwitches g_switches = {1, 0, 1, 4, 1, 1, 0, 0};
+static MarlSwitches g_switches = {1, 0, 1, 4, 1, 1, 0, 0, 1};
 extern "C" const MarlSwitches* marl_switches(void) { return &g_switches; }
 static int* switch_slot(const char* name) {
   if (!name) return nullptr;
   struct { const char* n; int* p; } tab[] = {{"fwd_xs", &g_switches.fwd_xs}, {"fwd_dma", &g_switches.fwd_dma}, {"fwd_w2l", &g_switches.fwd_w2l},
                                              {"bwd_pipe_max_rt", &g_switches.bwd_pipe_max_rt}, {"wgrad_tall", &g_switches.wgrad_tall},
-                                             {"wide_res", &g_switches.wide_res}, {"wide_res32", &g_switches.wide_res32}, {"rollout_v1", &g_switches.rollout_v1}};
+                                             {"wide_res", &g_switches.wide_res}, {"wide_res32", &g_switches.wide_res32}, {"rollout_v1", &g_switches.rollout_v1}, {"unroll_r6", &g_switches.unroll_r6}};
   for (auto& t : tab)
     if (!strcmp(t.n, name)) return t.p;
   return nullptr;

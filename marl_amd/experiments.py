@@ -11,6 +11,7 @@ library switches (environment variable -> name, default):
     MARL_BWD_PIPE_MAX_RT -> bwd_pipe_max_rt 4
     MARL_WGRAD_TALL -> wgrad_tall 1   LDS-staged tall weight-gradient kernel
     MARL_WIDE_RES -> wide_res 1, MARL_WIDE_RES32 -> wide_res32 0    resident-weights forward of the wide-state QMIX mixer
+    MARL_UNROLL_R6 -> unroll_r6 1     non-saving split unrolls of more than 512 row tiles on csrc/agent_x6p.hip (0: csrc/agent_x6.hip everywhere)
     MARL_ROLLOUT_V1 -> rollout_v1 0   split whole-rollout kernel: 0 = by batch size, 1 = round 5 (csrc/rollout_x6_v1.hip), 2 = round 6 (csrc/rollout_x6.hip)
 host switches:
     MARL_BIG_PAIR -> big_pair 0       batches beyond the pair's tile cap: eval chain and target unroll in flight together (two streams)
@@ -27,7 +28,7 @@ import contextlib
 import os
 import warnings
 
-LIB_DEFAULTS = {"fwd_xs": 1, "fwd_dma": 0, "fwd_w2l": 1, "bwd_pipe_max_rt": 4, "wgrad_tall": 1, "wide_res": 1, "wide_res32": 0, "rollout_v1": 0}
+LIB_DEFAULTS = {"fwd_xs": 1, "fwd_dma": 0, "fwd_w2l": 1, "bwd_pipe_max_rt": 4, "wgrad_tall": 1, "wide_res": 1, "wide_res32": 0, "rollout_v1": 0, "unroll_r6": 1}
 HOST_DEFAULTS = {"big_pair": 0, "no_pair": 0, "no_chain": 0, "chain_split": None, "mlp3_keep": 1, "x6_bwd_min_wg": 1, "force_reducer": 0}
 
 

@@ -177,11 +177,17 @@ def agent_unroll_x6_supported(B, T, N, O, A, last_action=True, reuse_network=Tru
     return bool(_lib.load().marl_agent_unroll_x6_supported(B, T, N, O, A, 1 if last_action else 0, 1 if reuse_network else 0))
 
 
+def agent_unroll_x6_plain_r6(B, T, N, O, A, last_action=True, reuse_network=True, cu_budget=0):
+    """a non-saving split unroll of this batch runs on csrc/agent_x6p.hip (the round-6 decomposition): no gate sums are kept for it"""
+    return bool(_lib.load().marl_agent_unroll_x6_plain_r6(B, T, N, O, A, 1 if last_action else 0, 1 if reuse_network else 0, int(cu_budget)))
+
+
 def agent_unroll_fwd_x6(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_last, saved, B, T, N, O, A, last_action=True,
                         reuse_network=True, ep_len=None, ep_map=None, cu_budget=0, gi_out=None, gi_in=None):
     """the unroll on the bf16x6 split kernels (csrc/agent_x6.hip; opt-in args.gemm_mode = "bf16x6"): same arguments as
     agent_unroll_fwd, same `saved` layout (the fp32 BPTT kernel reads it); gi_out / gi_in hold plain sums here, so a storing and a
     reading launch must both be this one"""
+    assert obs.numel() < 2 ** 30 and (ufed is None or ufed.numel() < 2 ** 30)       # (csrc/agent_x6p.hip addresses both with 32-bit byte offsets)
     check(_lib.load().marl_agent_unroll_fwd_x6(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
                                                _p(_i32(ep_map)) if ep_map is not None else None, _p(h0), _p(_f32(q)), _p(hs),
                                                _p(h_last), _p(saved), B, T, N, O, A, 1 if last_action else 0,

@@ -579,6 +579,55 @@ def test_agent_unroll_shifted_storage(dev):
         close(q, q_ref, 1e-4)
 
 
+@pytest.mark.parametrize("B,T,with_h0,ragged,ut0", [(1700, 6, True, True, 0), (2100, 5, False, True, -1), (4096, 4, True, False, 0),
+                                                     (4100, 4, True, True, 0), (9000, 4, False, True, 0), (2621, 7, True, True, -1)])
+def test_agent_unroll_x6_plain_round6_decomposition(dev, B, T, with_h0, ragged, ut0):
+    """csrc/agent_x6p.hip (non-saving split unrolls of more than 512 row tiles: the recurrent team runs x W_ih + h W_hh down one
+    accumulator chain, three to five row tiles per workgroup, two barriers per step) against the CPU oracle at the unroll bound (1e-4)
+    and beside csrc/agent_x6.hip on the same inputs (unroll_r6 = 0; the two differ only in where the last action's fc1 column is added):
+    (T+1)-slot storage read through an episode map, the shifted / unshifted fed action, ragged episode lengths, a carried hidden state,
+    three / four / five tiles per workgroup, several rounds of workgroups, a partial last workgroup."""
+    from marl_amd import ops, experiments
+    args, p_np, _, _, _ = _agent_case("2s3z", B, T, dev, with_h0=with_h0)
+    N, O, A = args.n_agents, args.obs_shape, args.n_actions
+    assert ops.agent_unroll_x6_plain_r6(B, T, N, O, A) and not ops.agent_unroll_x6_plain_r6(B, T, N, O, A, cu_budget=128)
+    assert not ops.agent_unroll_x6_plain_r6(1600, T, N, O, A)            # 500 row tiles: one round of two-tile workgroups of agent_x6.hip
+    rng = np.random.default_rng(B + T)
+    E = B + 2
+    store = rng.standard_normal((E, T + 1, N, O)).astype(np.float32)
+    u = rng.integers(-1, A, size=(B, T, N))
+    emap = rng.permutation(E)[:B]
+    lens = rng.integers(1, T + 1, size=B) if ragged else np.full(B, T)
+    lens[0] = T
+    h0 = (rng.standard_normal((B * N, 64)).astype(np.float32) * 0.3) if with_h0 else None
+    w = ops.agent_weights({k: cu(v, dev) for k, v in p_np.items()})
+    sd, ud, ed, ld = cu(store, dev), cu(u, dev, torch.int32), cu(emap, dev, torch.int32), cu(lens, dev, torch.int32)
+    t0 = 1 if ut0 == 0 else 0
+    outs = {}
+    for r6 in (1, 0):
+        with experiments.override(unroll_r6=r6):
+            assert ops.agent_unroll_x6_plain_r6(B, T, N, O, A) == bool(r6)
+            q, hl = torch.full((B, T, N, A), 9.0, device=dev), torch.full((B * N, 64), 9.0, device=dev)
+            ops.agent_unroll_fwd_x6(w, sd, (T + 1) * N, t0, ud, T * N, ut0, cu(h0, dev) if h0 is not None else None, q, None, hl, None,
+                                    B, T, N, O, A, ep_len=ld, ep_map=ed)
+            outs[r6] = (q.cpu(), hl.cpu())
+    obs = store[emap][:, t0:t0 + T].copy()
+    for b in range(B):
+        obs[b, lens[b]:] = 0          # steps t >= ep_len feed zeros
+    ufed = u.copy()
+    if ut0 == -1:
+        ufed[:, 1:] = u[:, :-1]; ufed[:, 0] = -1
+    with torch.no_grad():
+        _, q_ref, _, hl_ref = _oracle_unroll(args, p_np, obs, ufed, h0)
+    for r6 in (1, 0):
+        close(outs[r6][0], q_ref, 1e-4, msg="q (unroll_r6 = %d)" % r6)
+        close(outs[r6][1], hl_ref, 1e-4, msg="h_last (unroll_r6 = %d)" % r6)
+    close(outs[1][0], outs[0][0], 2e-5, msg="the two split unrolls")
+    e6 = float((outs[1][0].double() - q_ref.double()).abs().max())
+    e5 = float((outs[0][0].double() - q_ref.double()).abs().max())
+    print("plain unroll B=%d T=%d: max |q - oracle|: agent_x6p %.2e, agent_x6 %.2e" % (B, T, e6, e5))
+
+
 @pytest.mark.parametrize("shape,B,T,cus", [("2s3z", 37, 5, 4), ("2s3z", 700, 6, 48), ("3s5z", 40, 4, 8), ("2s3z", 9, 2, 2),
                                             ("2s3z", 37, 5, 16), ("2s3z", 300, 7, 256), ("3s5z", 21, 4, 64),
                                             ("MMM2", 60, 4, 16), ("MMM2", 1000, 3, 256), ("MMM2", 30, 5, 128)])

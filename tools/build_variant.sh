@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../marl_amd/csrc"
 make -j8 > /dev/null
 mkdir -p build/v_$NAME ../variants
 OBJS=""
-for f in gemm agent mixers optim rollout rollout_fused rollout_x6 rollout_x6_v1 qmix_fused mlp3_fused qtran_fused qmix_wide mlp3_x6 agent_x6 agent_bwd_x6; do
+for f in gemm agent mixers optim rollout rollout_fused rollout_x6 rollout_x6_v1 qmix_fused mlp3_fused qtran_fused qmix_wide mlp3_x6 agent_x6 agent_x6p agent_bwd_x6; do
   if echo " $FILES " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC $FLAGS -c -o build/v_$NAME/$f.o $f.hip &
     OBJS="$OBJS build/v_$NAME/$f.o"

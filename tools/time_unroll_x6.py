@@ -25,8 +25,14 @@ for B in [int(x) for x in sys.argv[1:]] or [4096, 1024, 512]:
     hl = torch.zeros(B * N, 64, device=dev)
     cus = int(os.environ.get("CUS", "0"))
     f32, x6 = ops.agent_unroll_fwd, ops.agent_unroll_fwd_x6
+    from marl_amd import experiments
+    def x6_r5(*a_, **k_):            # the round-5 plain kernel (csrc/agent_x6.hip) where the library would pick csrc/agent_x6p.hip
+        with experiments.override(unroll_r6=0):
+            x6(*a_, **k_)
     legs = [("fp32 MFMA        ", lambda: f32(w, obs, (T + 1) * N, 1, u, T * N, 0, None, q, None, None, None, B, T, N, O, A, cu_budget=cus)),
+            ("bf16x6 (agent_x6)", lambda: x6_r5(w, obs, (T + 1) * N, 1, u, T * N, 0, None, q6, None, None, None, B, T, N, O, A, cu_budget=cus)),
             ("bf16x6           ", lambda: x6(w, obs, (T + 1) * N, 1, u, T * N, 0, None, q6, None, None, None, B, T, N, O, A, cu_budget=cus)),
+            ("bf16x6 saving -gi", lambda: x6(w, obs, (T + 1) * N, 0, u, T * N, -1, None, q6, None, hl, saved, B, T, N, O, A, cu_budget=cus)),
             ("fp32 MFMA saving ", lambda: f32(w, obs, (T + 1) * N, 0, u, T * N, -1, None, q, None, hl, saved, B, T, N, O, A, cu_budget=cus, gi_out=gi)),
             ("bf16x6 saving    ", lambda: x6(w, obs, (T + 1) * N, 0, u, T * N, -1, None, q6, None, hl, saved, B, T, N, O, A, cu_budget=cus, gi_out=gi6)),
             ("fp32 MFMA reading", lambda: f32(w, obs, (T + 1) * N, 1, u, T * N, 0, hl, q, None, None, None, B, T, N, O, A, cu_budget=cus, gi_in=gi)),
