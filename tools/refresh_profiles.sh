@@ -59,7 +59,11 @@ python3 tools/time_unroll_x6.py 4096 1024 512 256 > $OUT/${TAG}_unroll_x6_times.
 SHAPE=3s5z python3 tools/time_unroll_x6.py 512 2048 >> $OUT/${TAG}_unroll_x6_times.txt 2>&1
 SHAPE=MMM2 python3 tools/time_unroll_x6.py 1024 >> $OUT/${TAG}_unroll_x6_times.txt 2>&1
 python3 tools/time_qmix.py 4096 1024 512 > $OUT/${TAG}_qmix_times.txt 2>&1
-python3 tools/time_rollout.py > $OUT/${TAG}_rollout_times.txt 2>&1
+python3 tools/time_rollout.py 2>&1 | grep -v "Init\|amdgpu" > $OUT/${TAG}_rollout_times.txt
+( echo "== 3s5z"; SHAPE=3s5z python3 tools/time_rollout.py 2048 1536 512; echo "== MMM2"; SHAPE=MMM2 python3 tools/time_rollout.py 1024 ) 2>&1 | grep -v "Init\|amdgpu" >> $OUT/${TAG}_rollout_times.txt
+( echo "== whole rollout, round-6 kernel (csrc/rollout_x6.hip)"; python3 tools/stamps_rollout_x6.py 4096; python3 tools/stamps_rollout_x6.py 2048
+  echo "== whole rollout, round-5 kernel (csrc/rollout_x6_v1.hip)"; MARL_ROLLOUT_V1=1 python3 tools/stamps_rollout_x6.py 4096; MARL_ROLLOUT_V1=1 python3 tools/stamps_rollout_x6.py 512
+  echo "== plain unroll, round-6 decomposition (csrc/agent_x6p.hip)"; python3 tools/stamps_unroll_x6p.py 4096; python3 tools/stamps_unroll_x6p.py 2048 ) 2>&1 | grep -v "Init\|amdgpu" > $OUT/${TAG}_stamps.txt
 fi
 if want rates; then
 ( for a in "--alg qmix --envs 512" "--alg qmix --envs 4096" "--alg qplex --envs 512" "--alg qplex --envs 4096"; do for w in 1 100000; do
@@ -71,6 +75,9 @@ fi
 if want shards; then
 for e in 512 1024 2048 4096; do python3 bench.py --envs $e --gemm-mode f32 --no-cpu-baseline --no-configs --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('envs_per_gpu=%d gemm_mode=f32 hip_graph=%s : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['envs_per_gpu'], d['config']['hip_graph'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"; done > $OUT/${TAG}_shard_steps.txt
 for e in 512 1024 2048 4096; do python3 bench.py --envs $e --gemm-mode bf16x6 --no-twin --no-cpu-baseline --no-configs --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('envs_per_gpu=%d gemm_mode=bf16x6 hip_graph=%s : ms_per_step %.3f env-steps/s %.2f M  learner updates/s %.1f  rollout M env-steps/s %.1f' % (d['config']['envs_per_gpu'], d['config']['hip_graph'], d['ms_per_step'], d['value']/1e6, d['learner_updates_per_sec'], d['rollout_env_steps_per_sec']/1e6))"; done >> $OUT/${TAG}_shard_steps.txt
+fi
+if want shards; then   # what a world-1 RCCL reducer (two collectives + the agreed-length read-back per update) adds to a 512-env step
+( for r in 0 1; do echo -n "envs_per_gpu=512 force_reducer=$r : "; MARL_FORCE_REDUCER=$r python3 bench.py --envs 512 --no-twin --no-cpu-baseline --no-configs --steps 60 --warmup 10 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('ms_per_step %.3f learner updates/s %.1f' % (d['ms_per_step'], d['learner_updates_per_sec']))"; done ) > $OUT/${TAG}_reducer_world1.txt 2>&1
 fi
 if want soak; then
 for e in 4096 512; do python3 bench.py --envs $e --no-twin --no-cpu-baseline --no-configs --steps 2000 --warmup 20 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('soak: envs=%d steps=%d ms_per_step %.3f env-steps/s %.2f M (timed %.1f s)' % (d['config']['global_envs'], d['steps'], d['ms_per_step'], d['value']/1e6, d['ms_per_step']*d['steps']/1e3))"; done > $OUT/${TAG}_soak.txt

@@ -27,7 +27,7 @@ for name in ("_bench_line.json", "_bench_full.json", "_bench_profiled_line.json"
         line = [l for l in open(src).read().splitlines() if l.startswith("{")][-1].strip()      # (stdout also carries the host classes' prints)
         json.loads(line)
         open(os.path.join(P, tag + name), "w").write(line + "\n")
-for name in ("_mlp3_times.txt", "_rollout_times.txt", "_unroll_x6_times.txt", "_bptt_x6_ab.txt", "_learner_rates.txt", "_shard_steps.txt", "_soak.txt", "_qmix_times.txt"):
+for name in ("_mlp3_times.txt", "_rollout_times.txt", "_stamps.txt", "_reducer_world1.txt", "_unroll_x6_times.txt", "_bptt_x6_ab.txt", "_learner_rates.txt", "_shard_steps.txt", "_soak.txt", "_qmix_times.txt"):
     cp(os.path.join(G, tag + name), os.path.join(P, tag + name))
 vf = os.path.join(G, tag + "_lib_version.txt")
 ver = open(vf).read().strip() if os.path.exists(vf) else None
