@@ -937,7 +937,12 @@ def main():
     dev = torch.device("cuda", local)
     from marl_amd.hostutil import pin_to_gpu_numa
     numa = pin_to_gpu_numa(local)            # one process per GPU, on the CPUs of that GPU's NUMA node (two-socket hosts)
-    if world > 1:
+    from marl_amd import experiments
+    forced = world == 1 and experiments.get("force_reducer") == 1
+    if forced:      # MARL_FORCE_REDUCER=1 on one GPU: a world-1 RCCL group, so every update pays its collectives (what they cost at N = 1)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         import torch.distributed as dist
         backend = os.environ.get("MARL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
