@@ -47,7 +47,7 @@ def test_rollout_model_matches_the_counters():
     k, f = _pmc()
     hit = [(n, v) for n, v in k.items() if n.startswith("synth_rollout_x6_kernel<")]
     assert len(hit) == 1
-    rtc, nk1 = [int(x) for x in re.search(r"<(\d+), (\d+)>", hit[0][0]).groups()]
+    rtc, nk1 = [int(x) for x in re.search(r"<(\d+), (\d+)", hit[0][0]).groups()]      # <row tiles, fc1 chunks[, action tiles]>
     lib = _lib.load()
     try:
         plans = []
