@@ -165,6 +165,8 @@ class KernelTimers:
             r6 = ar[11] is None and kw.get("gi_in") is None and ar[9] is None and \
                 ops.agent_unroll_x6_plain_r6(ar[12], ar[13], ar[14], O, A, cu_budget=kw.get("cu_budget", 0))      # (saved, gi_in, hs all absent)
             mf = mfma_unroll_x6(ar[12], ar[13], ar[14], 3 if I <= 96 else 5 if I <= 160 else 7, r6) if kw.get("gi_in") is None else None
+            if r6:      # csrc/agent_x6p.hip: the plain unroll in the round-6 decomposition (five row tiles per workgroup, two barriers per step)
+                return ("agent_fwd_x6p_kernel[plain: target unroll, round-6 decomposition] fp32 products as six bf16 MFMA products", "agent_fwd_x6p_kernel") + m[2:] + (True, mf)
             return (m[0].replace("agent_fwd_kernel", "agent_fwd_x6_kernel") + " fp32 products as six bf16 MFMA products", "agent_fwd_x6") + m[2:] + (True, mf)
 
         def bwd(ar, kw):
@@ -660,7 +662,9 @@ def compact_line(out, limit=LINE_LIMIT):
                      "launches_timed", "flop_per_launch", "bytes_per_launch"))
     if isinstance(r.get("kernel"), str):
         r["kernel"] = r["kernel"][:96]
-    r["kernels"] = [dict(_pick(e, ("rocprof_name", "launches_timed", "ms", "frac", "hbm_gb")), name=e["name"][:64]) for e in (roof.get("kernels") or [])[:6]]
+    r["kernels"] = [dict(_pick(e, ("rocprof_name", "launches_timed", "ms", "frac", "hbm_gb", "mfma_busy_frac", "mfma_instr_pmc")), name=e["name"][:64],
+                         **({"mfma_instr_model": sum(e["mfma_instr_model"].values())} if e.get("mfma_instr_model") else {}))
+                    for e in (roof.get("kernels") or [])[:6]]
     if "algorithmic_rate" in roof:
         r["algorithmic_tflops_unrolls"] = roof["algorithmic_rate"]["tflops"]
     line["roofline"] = r
