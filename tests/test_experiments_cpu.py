@@ -64,3 +64,21 @@ def test_graph_policy_from_args_and_split_step_model():
     assert f32.chain_split(512 * 5, 120, 80) == (160, 96)              # the fp32 kernels' chain schedule at the 512-env shard
     assert x6._step_us(1) < f32._step_us(1) and x6._step_us(5) < f32._step_us(5)
     assert x6.chain_split(4096 * 5, 120, 80) is None and f32.chain_split(4096 * 5, 120, 80) is None      # large batches: plain schedule
+
+
+def test_get_answers_library_switches_from_the_library_and_set_bumps_the_generation():
+    """a C-ABI caller may flip a library switch through marl_experiment_set directly - the host's decisions read the
+    library's table, not a Python mirror; every experiments.set() moves the generation a captured hipGraph schedule is keyed by."""
+    from marl_amd import experiments, _lib
+    lib = _lib.load()
+    try:
+        assert experiments.get("fwd_xs") == 1 and experiments.get("rollout_v1") == 0 and experiments.get("unroll_r6") == 1
+        assert lib.marl_experiment_set(b"fwd_xs", 0) == 0
+        assert experiments.get("fwd_xs") == 0                     # not the value this module last wrote
+        g0 = experiments.generation
+        with experiments.override(rollout_v1=2, big_pair=1):
+            assert lib.marl_experiment_get(b"rollout_v1") == 2 and experiments.get("big_pair") == 1 and experiments.generation > g0
+        assert lib.marl_experiment_get(b"rollout_v1") == 0 and experiments.get("big_pair") == 0
+        assert lib.marl_experiment_set(b"no_such_switch", 1) != 0
+    finally:
+        lib.marl_experiment_set(b"fwd_xs", 1)
