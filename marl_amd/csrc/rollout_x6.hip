@@ -325,6 +325,45 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       }
     }
   };
+  // env step (reward / terminated / padded; fixed-order fp32 sum over agents): lane -> (env, agent); the N rows of an environment sit in
+  // ONE wave, environments dealt to the four slice waves of a team in turn.  Team I's up from three row tiles per workgroup (beside its
+  // x, while team R generates observations); team R's at one or two tiles, where team R has nothing else left in phase C and the step
+  // is a chain of latencies (stamps at one tile: the two waves that carry the environments were the last at the barrier by 1 400 cycles)
+  constexpr bool ENV_R = RTC <= 2;
+  const int es_epw = 64 / N, es_er = lane / N;
+  const int es_n = lane - es_er * N, es_l0 = es_er * N;
+  const int es_el = 4 * es_er + s;
+  const bool es_has = es_er < es_epw && es_el < nenv_wg && b0 + es_el < a.E;
+  const int es_L = es_has ? emeta[es_el].y : 0;
+  float ep_r = 0.f;
+  auto env_step = [&](int t) __attribute__((always_inline)) {
+    if (es_has) {
+      const unsigned tg = (unsigned)(a.episode * (T + 1) + t);
+      const int L = es_L;
+      const bool live = t < L;
+      float term = 0.f;
+      if (live) {
+        const unsigned pre_ = t > 0 ? Pp(K_REWARD, t & 1)[es_el] : hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
+        term = u01(hfin(pre_, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
+      }
+      float acc = 0.f;
+      for (int n0 = 0; n0 < N; n0 += 4) {          // four shuffles in flight; the sum stays in agent order
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __shfl(term, (es_l0 + n0 + k) & 63, 64);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = n0 + k < N ? acc + v[k] : acc;
+      }
+      if (es_n == 0) {
+        const long o = (long)(b0 + es_el) * T + t;
+        const float rew = live ? acc * (1.0f / (float)N) : 0.f;
+        ep_r = ep_r + rew;
+        a.r[o] = rew;
+        a.term[o] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
+        a.padded[o] = live ? 0.f : 1.f;
+      }
+    }
+  };
   const int KC1 = a.KI >> 5;
   // epsilon of step t: a device vector, or the reference's per-step anneal (rollout.py:100-101) evaluated here in fp64
   float eps_next = a.eps ? a.eps[0] : (float)a.eps0;
@@ -358,6 +397,7 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
     for (int rt = 0; rt < RTC; ++rt) hreg[rt] = splat(0.f);
     // R's share of a slot's observation items before the choice barrier (team I needs ~the choice's time to get there)
     const int oi_cut = (n_oi * OI_CUT_16) >> 4;
+    auto rot = [&](int w) { return (tid + 64 * w) & (RNT / 2 - 1); };      // this thread's index with the team's waves rotated by w
     WG_BARRIER();                                  // P0: slot 0 in the planes, tables (team I: fc1, x(0))
     WG_BARRIER();                                  // P1: x(0), pre(0) taken: the input planes are free
     prologue_slot1();
@@ -414,20 +454,24 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       ST_MARK(1);
       // ---- B, C (beside team I's choice and x): slot t+2 -> record; its observations -> input planes (fc1 reads them in A of step
       // t+1), its availability -> bit masks (the choice of step t+2 reads them)
+      // (the item loops of the different jobs start at different waves - rot(): with few items, one or two row tiles per workgroup,
+      // every job would otherwise land on wave 0, which shares its SIMD with team I's first wave)
       if (t + 2 <= T) {
-        gen_rest(t + 2, tid, RNT / 2, false, true);
+        gen_rest(t + 2, rot(3), RNT / 2, false, true);
         gen_obs(t + 2, t + 2 < T, 0, oi_cut, tid, RNT / 2);
       }
       ST_MARK(2);
       WG_BARRIER();                                // B2: act(t)
       ST_MARK(3);
-      if (t + 2 <= T) gen_obs(t + 2, t + 2 < T, oi_cut, n_oi, tid, RNT / 2);
-      hashes(t, tid, RNT / 2);
+      if (ENV_R) env_step(t);
+      if (t + 2 <= T) gen_obs(t + 2, t + 2 < T, oi_cut, n_oi, rot(1), RNT / 2);
+      hashes(t, rot(2), RNT / 2);
       ST_MARK(4);
       WG_BARRIER();                                // B3: x(t+1) planes | slot t+2
       ST_MARK(5);
     }
     ST_DUMP(6);
+    if (ENV_R && a.stats && es_has && es_n == 0) a.stats[b0 + es_el] = ep_r;
     if (a.h_out) {
 #pragma unroll
       for (int rt = 0; rt < RTC; ++rt) {
@@ -568,13 +612,6 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
         }
       }
     };
-    // env step: lane -> (env, agent); the N rows of an environment sit in ONE wave, environments dealt to the four waves in turn
-    const int es_epw = 64 / N, es_er = lane / N;
-    const int es_n = lane - es_er * N, es_l0 = es_er * N;
-    const int es_el = 4 * es_er + s;
-    const bool es_has = es_er < es_epw && es_el < nenv_wg && b0 + es_el < a.E;
-    const int es_L = es_has ? emeta[es_el].y : 0;
-    float ep_r = 0.f;
     WG_BARRIER();                                  // P0: slot 0 in the planes, tables
     fc1();
     xput();                                        // x(0): no last action
@@ -602,37 +639,13 @@ __global__ __launch_bounds__(RNT, 2) void synth_rollout_x6_kernel(RX6Args a) {
       // ---- C: x(t+1); env step (reward / terminated / padded; fixed-order fp32 sum over agents)
       if (t + 1 < T) xput();
       ST_MARK(7);
-      if (es_has) {
-        const int L = es_L;
-        const bool live = t < L;
-        float term = 0.f;
-        if (live) {
-          const unsigned pre_ = t > 0 ? Pp(K_REWARD, t & 1)[es_el] : hprefix(a.seed, ST_REWARD, (unsigned)(a.env0 + b0 + es_el), tg);
-          term = u01(hfin(pre_, (unsigned)(es_n * A + act[es_el * N + es_n]))) - 0.5f;
-        }
-        float acc = 0.f;
-        for (int n0 = 0; n0 < N; n0 += 4) {          // four shuffles in flight; the sum stays in agent order
-          float v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = __shfl(term, (es_l0 + n0 + k) & 63, 64);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc = n0 + k < N ? acc + v[k] : acc;
-        }
-        if (es_n == 0) {
-          const long o = (long)(b0 + es_el) * T + t;
-          const float rew = live ? acc * (1.0f / (float)N) : 0.f;
-          ep_r = ep_r + rew;
-          a.r[o] = rew;
-          a.term[o] = live ? (t + 1 >= L ? 1.f : 0.f) : 1.f;
-          a.padded[o] = live ? 0.f : 1.f;
-        }
-      }
+      if (!ENV_R) env_step(t);
       ST_MARK(4);
       WG_BARRIER();                                // B3: x(t+1)
       ST_MARK(5);
     }
     ST_DUMP(8);
-    if (a.stats && es_has && es_n == 0) a.stats[b0 + es_el] = ep_r;
+    if (!ENV_R && a.stats && es_has && es_n == 0) a.stats[b0 + es_el] = ep_r;
   }
 }
 
@@ -659,13 +672,13 @@ static int rx6_epw(int E, int N, int KI, int A) {
   }
   return epw;
 }
-// which decomposition runs a batch: this file's kernel pays where the round-5 one needs more than one round of workgroups (its three
-// row tiles per workgroup - two for wide inputs - do not hold a CU's share of the batch); below that the two are level or the round-5
-// kernel is ahead (one tile per workgroup: 0.46 against 0.52 ms at 512 envs).  experiments: rollout_v1 = 1 / 2 forces one of them
+// which decomposition runs a batch: the round-5 kernel where it holds ONE row tile per workgroup (0.46 against 0.47 ms at 512 envs: a
+// lock-step is a chain of latencies there, and its four short phases carry them better), this file's kernel from two tiles on (1024
+// envs 0.67 / 0.68, 2048 envs 0.91 / 0.95, 4096 envs 1.44 / 1.90 ms).  experiments: rollout_v1 = 1 / 2 forces one of them
 static bool rx6_use_v1(int E, int N, int O, int A, int last_action, int reuse_network) {
   const int sw = marl_switches()->rollout_v1;
-  const int v1_epw_max = ((O + (last_action ? A : 0) + (reuse_network ? N : 0) + 31) / 32 * 32 > 96 ? 32 : 48) / (N > 0 ? N : 1);
-  return marl_rollout_x6_v1_supported(N, O, A) && (sw == 1 || (sw == 0 && (long)E <= 256L * v1_epw_max));
+  const int v1_epw_one_tile = 16 / (N > 0 ? N : 1);
+  return marl_rollout_x6_v1_supported(N, O, A) && (sw == 1 || (sw == 0 && v1_epw_one_tile >= 1 && (long)E <= 256L * v1_epw_one_tile));
 }
 
 }  // namespace

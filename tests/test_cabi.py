@@ -88,14 +88,15 @@ def test_split_kernel_capability_predicates():
     assert rx6(5, 80, 11) == 1 and rx6(8, 128, 14) == 1 and rx6(2, 4, 3) == 1 and rx6(49, 40, 5) == 1 and rx6(33, 100, 5) == 1
     assert rx6(10, 176, 18) == 1 and rx6(4, 180, 32) == 1 and rx6(4, 180, 33) == 0 and rx6(10, 200, 18) == 0
     assert rx6(5, 80, 17) == 0 and rx6(5, 82, 11) == 0 and rx6(65, 40, 5) == 0 and rx6(64, 40, 5) == 1 and rx6(49, 176, 18) == 0
-    # ... and how a batch runs: the round-5 decomposition (three row tiles per workgroup) while the batch fits one round of workgroups,
-    # the round-6 one (five tiles) beyond - (decomposition, workgroups, row tiles, environments per workgroup, fc1 chunks)
+    # ... and how a batch runs: the round-5 decomposition while it holds one row tile per workgroup, the round-6 one (up to five tiles)
+    # beyond - (decomposition, workgroups, row tiles, environments per workgroup, fc1 chunks)
     import ctypes
     def plan(E, N, O, A):
         out = (ctypes.c_int * 5)()
         assert lib.marl_synth_rollout_x6_plan(E, N, O, A, 1, 1, out) == 0
         return tuple(out)
-    assert plan(512, 5, 80, 11) == (1, 256, 1, 2, 3) and plan(2304, 5, 80, 11) == (1, 256, 3, 9, 3)
+    assert plan(512, 5, 80, 11) == (1, 256, 1, 2, 3) and plan(768, 5, 80, 11) == (1, 256, 1, 3, 3) and plan(1024, 5, 80, 11) == (2, 256, 2, 4, 3)
+    assert plan(2304, 5, 80, 11) == (2, 256, 3, 9, 3)
     assert plan(4096, 5, 80, 11) == (2, 256, 5, 16, 3) and plan(8192, 5, 80, 11) == (2, 512, 5, 16, 3)
     assert plan(2048, 8, 128, 14) == (2, 256, 4, 8, 5) and plan(100, 49, 40, 5) == (2, 100, 4, 1, 3)
     assert plan(1024, 10, 176, 18) == (2, 256, 3, 4, 7) and plan(2048, 10, 176, 18) == (2, 512, 3, 4, 7)      # MMM2: three tiles at most
