@@ -187,7 +187,9 @@ def agent_unroll_fwd_x6(w, obs, obs_bs, obs_t0, ufed, u_bs, u_t0, h0, q, hs, h_l
     """the unroll on the bf16x6 split kernels (csrc/agent_x6.hip; opt-in args.gemm_mode = "bf16x6"): same arguments as
     agent_unroll_fwd, same `saved` layout (the fp32 BPTT kernel reads it); gi_out / gi_in hold plain sums here, so a storing and a
     reading launch must both be this one"""
-    assert obs.numel() < 2 ** 30 and (ufed is None or ufed.numel() < 2 ** 30)       # (csrc/agent_x6p.hip addresses both with 32-bit byte offsets)
+    if saved is None and gi_in is None and hs is None and agent_unroll_x6_plain_r6(B, T, N, O, A, last_action, reuse_network, cu_budget):
+        # csrc/agent_x6p.hip addresses the observations and the fed actions with 32-bit byte offsets against a uniform base
+        assert obs.numel() < 2 ** 30 and (ufed is None or ufed.numel() < 2 ** 30), "observation storage beyond 4 GB: set MARL_UNROLL_R6=0"
     check(_lib.load().marl_agent_unroll_fwd_x6(C.byref(w), _p(_f32(obs)), obs_bs, obs_t0, _p(ufed), u_bs, u_t0, _p(ep_len),
                                                _p(_i32(ep_map)) if ep_map is not None else None, _p(h0), _p(_f32(q)), _p(hs),
                                                _p(h_last), _p(saved), B, T, N, O, A, 1 if last_action else 0,
