@@ -711,6 +711,9 @@ def compact_line(out, limit=LINE_LIMIT):
     return txt
 
 
+LINE_OUT = None              # main(): the process's real stdout (it points sys.stdout at stderr for everything but the line)
+
+
 def emit(out):
     """full result -> bench_full.json beside this script (and gpurun_out/ when it exists) and stderr; the compact line -> stdout, LAST"""
     out["full"] = "bench_full.json"
@@ -724,7 +727,7 @@ def emit(out):
                 pass
     print("[bench full] " + full, file=sys.stderr, flush=True)
     sys.stdout.flush()
-    print(compact_line(out), flush=True)
+    print(compact_line(out), file=LINE_OUT or sys.stdout, flush=True)
 
 
 class Pipeline:
@@ -931,6 +934,11 @@ def main():
         # initialised HIP must never be replaced by exec)
         sys.exit(self_launch(o.gpus))
 
+    # stdout carries the ONE JSON line and nothing else: what the classes print as the reference's do ('Init RolloutWorker',
+    # rollout.py:135) goes to stderr from here on
+    global LINE_OUT
+    LINE_OUT = sys.stdout
+    sys.stdout = sys.stderr
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

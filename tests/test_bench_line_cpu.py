@@ -61,6 +61,7 @@ def test_emit_prints_the_compact_line_last_and_writes_the_full_result(tmp_path, 
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     bench.emit(_canned())
     cap = capsys.readouterr()
+    assert len(cap.out.strip().splitlines()) == 1           # stdout: the line and nothing else
     last = cap.out.strip().splitlines()[-1]
     assert len(last) < 8192 and json.loads(last)["full"] == "bench_full.json"
     assert "[bench full]" in cap.err
