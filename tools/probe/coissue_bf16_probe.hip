@@ -111,6 +111,75 @@ __global__ __launch_bounds__(256 * WPS) void blocked(int nm, unsigned long long*
   if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
 }
 
+
+// the same questions for v_mfma_f32_32x32x16_bf16 (twice the FLOP of a 16x16x32 per instruction, 16 accumulator registers)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int PER, int WPS>
+__global__ __launch_bounds__(256 * WPS) void own32(int nm, unsigned long long* out, float* sink) {
+  unsigned long long t0, t1;
+  __syncthreads();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  f32x16 a0, a1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  bf8 x, y;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x[j] = (__bf16)(float)(threadIdx.x + j); y[j] = (__bf16)1.0f; }
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)threadIdx.x + (float)k;
+  auto work = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], 1.0001f, 0.5f);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int i = 0; i < nm; i += 2) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); work();
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); work();
+  }
+  float keep = a0[0] + a1[1] + a0[15] + a1[14];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) keep += v[k];
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  if (keep == 12345.678f) sink[0] = keep;
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
+}
+template <int PER, int WPS, int BLK>
+__global__ __launch_bounds__(256 * WPS) void blocked32(int nm, unsigned long long* out, float* sink) {
+  unsigned long long t0, t1;
+  __syncthreads();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  f32x16 a0, a1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  bf8 x, y;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x[j] = (__bf16)(float)(threadIdx.x + j); y[j] = (__bf16)1.0f; }
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)threadIdx.x + (float)k;
+  const bool second = WPS > 1 && (threadIdx.x >> 8) & 1;
+  for (int i = 0; i < nm; i += BLK) {
+    if (!second || i > 0) {
+#pragma unroll
+      for (int b = 0; b < BLK; b += 2) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < BLK * PER; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], 1.0001f, 0.5f);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float keep = a0[0] + a1[1] + a0[15] + a1[14];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) keep += v[k];
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  if (keep == 12345.678f) sink[0] = keep;
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
+}
+
 static unsigned long long* out; static float* sink;
 template <int PER, int WPS> void run_own() {
   unsigned long long h[16];
@@ -130,6 +199,24 @@ template <int PER, int WPS, int BLK, int PRIO = 0> void run_blocked() {
   printf("  blocks of %d MFMAs then %d v_fma_f32, %d wave(s) per SIMD (second staggered)%s: %.1f cycles per MFMA of the slowest wave (%.1f per SIMD-MFMA)\n",
          BLK, BLK * PER, WPS, PRIO == 1 ? ", vector blocks at s_setprio(3)" : PRIO == 2 ? ", MFMA blocks at s_setprio(3)" : "", mx / 4096.0, mx / 4096.0 / WPS);
 }
+template <int PER, int WPS> void run_own32() {
+  unsigned long long h[16];
+  own32<PER, WPS><<<256, 256 * WPS>>>(2048, out, sink);
+  own32<PER, WPS><<<256, 256 * WPS>>>(2048, out, sink);
+  (void)hipMemcpy(h, out, 8 * 4 * WPS, hipMemcpyDeviceToHost);
+  unsigned long long mx = 0; for (int i = 0; i < 4 * WPS; ++i) mx = h[i] > mx ? h[i] : mx;
+  printf("  32x32x16: interleaved, %d wave(s) per SIMD, %d v_fma_f32 after each MFMA: %.1f cycles per MFMA of the slowest wave (%.1f per SIMD-MFMA = %.1f per 16x16x32 of work)\n",
+         WPS, PER, mx / 2048.0, mx / 2048.0 / WPS, mx / 2048.0 / WPS / 2);
+}
+template <int PER, int WPS, int BLK> void run_blocked32() {
+  unsigned long long h[16];
+  blocked32<PER, WPS, BLK><<<256, 256 * WPS>>>(2048, out, sink);
+  blocked32<PER, WPS, BLK><<<256, 256 * WPS>>>(2048, out, sink);
+  (void)hipMemcpy(h, out, 8 * 4 * WPS, hipMemcpyDeviceToHost);
+  unsigned long long mx = 0; for (int i = 0; i < 4 * WPS; ++i) mx = h[i] > mx ? h[i] : mx;
+  printf("  32x32x16: blocks of %d MFMAs then %d v_fma_f32, %d wave(s) per SIMD (second staggered): %.1f per SIMD-MFMA = %.1f per 16x16x32 of work\n",
+         BLK, BLK * PER, WPS, mx / 2048.0 / WPS, mx / 2048.0 / WPS / 2);
+}
 int main() {
   (void)hipMalloc(&out, 256); (void)hipMalloc(&sink, 4);
   unsigned long long h[8];
@@ -148,5 +235,8 @@ int main() {
   run_blocked<4, 1, 24>(); run_blocked<4, 2, 24>(); run_blocked<2, 2, 24>(); run_blocked<4, 2, 96>();
   run_blocked<4, 2, 24, 1>(); run_blocked<4, 2, 24, 2>(); run_blocked<4, 2, 96, 1>(); run_blocked<4, 2, 96, 2>();
   run_blocked<6, 2, 24>(); run_blocked<6, 2, 24, 1>(); run_blocked<6, 2, 24, 2>();
+  run_own32<0, 1>(); run_own32<2, 1>(); run_own32<4, 1>(); run_own32<6, 1>(); run_own32<8, 1>(); run_own32<12, 1>();
+  run_own32<0, 2>(); run_own32<4, 2>(); run_own32<6, 2>(); run_own32<8, 2>(); run_own32<12, 2>();
+  run_blocked32<8, 1, 12>(); run_blocked32<8, 2, 12>(); run_blocked32<4, 2, 12>(); run_blocked32<12, 2, 12>();
   return 0;
 }
