@@ -235,6 +235,7 @@ int main() {
   run_blocked<4, 1, 24>(); run_blocked<4, 2, 24>(); run_blocked<2, 2, 24>(); run_blocked<4, 2, 96>();
   run_blocked<4, 2, 24, 1>(); run_blocked<4, 2, 24, 2>(); run_blocked<4, 2, 96, 1>(); run_blocked<4, 2, 96, 2>();
   run_blocked<6, 2, 24>(); run_blocked<6, 2, 24, 1>(); run_blocked<6, 2, 24, 2>();
+  run_blocked<4, 3, 24>(); run_blocked<4, 4, 24>(); run_blocked<6, 3, 24>(); run_blocked<6, 4, 24>(); run_blocked<2, 4, 24>();
   run_own32<0, 1>(); run_own32<2, 1>(); run_own32<4, 1>(); run_own32<6, 1>(); run_own32<8, 1>(); run_own32<12, 1>();
   run_own32<0, 2>(); run_own32<4, 2>(); run_own32<6, 2>(); run_own32<8, 2>(); run_own32<12, 2>();
   run_blocked32<8, 1, 12>(); run_blocked32<8, 2, 12>(); run_blocked32<4, 2, 12>(); run_blocked32<12, 2, 12>();
