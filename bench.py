@@ -377,7 +377,7 @@ def pmc_traffic(pmc, e):
     return hit[0] if len(hit) == 1 else None
 
 
-def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=12, warmup=6, ktimed=4):
+def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=12, warmup=6, ktimed=4, rewarm=10):
     """One learner-update leg of another BASELINE configuration at its per-GPU shard size (after the contract's timed
     region; record already in HBM): updates/s, transitions/s, the whole-update fraction of the fp32 MFMA peak (SURVEY 8d
     FLOP per transition) and the executed-FLOP roofline of the kernel the update spends the most time in."""
@@ -428,6 +428,13 @@ def config_leg(label, alg, shape, envs, mixer_dtype, gemm_mode="f32", updates=12
             # rate: `updates` updates with no per-kernel events (their ~20 event records per update cost a small shard 4-15 %), three
             # such segments: the MEDIAN is the leg's rate and all three are on the line (the small shards are bound by the host's
             # launch path and a segment now and then runs 10-15 % slow with unchanged kernel times: tools/leg_seq.py)
+            # the device idled through the collection above (and the leg's setup): a small shard's updates keep getting faster for
+            # ~15 updates after an idle stretch (3.0 -> 2.6 ms at QPLEX 512 envs, tools/leg_updates.py), and without these untimed
+            # updates the first timed segment ran 5-8 % low on every box
+            for i in range(rewarm):
+                train(warmup + i)
+            torch.cuda.synchronize()
+            warmup += rewarm
             segs = []
             for seg in range(3):
                 t0 = time.perf_counter()
