@@ -47,6 +47,8 @@ def test_visible_gpus_never_touches_the_runtime(monkeypatch):
     import bench
     import torch
     monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("must not ask the runtime")))
+    for k in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):      # (a GPU box's lease sets one of them)
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
     assert bench.visible_gpus() == 3
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")          # HIP_ indexes into the ROCR_ set: both lists bound the count
